@@ -1,0 +1,196 @@
+"""TEST INFRASTRUCTURE ONLY.  Pins oracle/deft_oracle.py against the reference's
+own modules and writes the golden fixtures under tests/golden/.
+
+Runs ONLY in the build container (needs /root/reference):
+
+    python oracle/make_golden.py
+
+What is pinned here (reference modules imported unchanged via ref_import.py):
+  * DLASeg forward (dla.py:758-817, base_model.py:111-132) incl. all 13 FeatureMaps
+    -- with the reference's DeformConv/IDAUp/DLAUp code driving `dcn_v2.DCN`
+       bound to the oracle's DCN restatement (DCNv2 itself stays UNPINNED: its
+       source is not in /root/reference).
+  * AFE_module.forward_feature_extracter / forward_stacker_features (AFE.py:88-160)
+  * model.decode.generic_decode (decode.py:102) on sigmoid'ed heads
+  * KalmanFilterLSTM.predict (kalman_filter_lstm.py:65-78)
+  * utils.image.convert_detection (image.py:391-412)
+The script asserts oracle == reference (max-abs <= 2e-5 on floats, exact on
+indices) and stores the REFERENCE outputs as the fixtures.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import deft_oracle as O  # noqa: E402
+import ref_import  # noqa: E402
+
+GOLD = os.path.join(HERE, "..", "tests", "golden")
+
+
+class OracleDCN(torch.nn.Module):
+    """Stands in for the un-vendored `dcn_v2.DCN` (ctor per dla.py:652-660)."""
+
+    def __init__(self, cin, cout, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super().__init__()
+        assert tuple(kernel_size) == (3, 3) and stride == 1 and padding == 1 and dilation == 1
+        self.weight = torch.nn.Parameter(torch.zeros(cout, cin, 3, 3))
+        self.bias = torch.nn.Parameter(torch.zeros(cout))
+        self.conv_offset_mask = torch.nn.Conv2d(cin, 27, 3, 1, 1)
+
+    def forward(self, x):
+        return O.dcn_v2_forward(x, self.conv_offset_mask.weight, self.conv_offset_mask.bias,
+                                self.weight, self.bias)
+
+
+def maxabs(a, b):
+    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+
+
+def sample_map(t, n=64, seed=0):
+    """Deterministic sparse sample of a tensor (keeps fixtures small)."""
+    flat = t.reshape(-1)
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, flat.numel(), (n,), generator=g)
+    return idx.numpy(), flat[idx].numpy()
+
+
+def run(dataset, H, W, tag):
+    torch.set_grad_enabled(False)
+    model, opt = ref_import.build_reference_model(dataset, OracleDCN)
+    sd = O.synth_state_dict(dataset)
+    missing = model.load_state_dict(sd, strict=True)
+    print(tag, "state_dict loaded strict:", missing)
+    model.eval()
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0))
+    # reference .cuda() calls are gated on torch.cuda.is_available() (False here)
+    ref_out, ref_maps = model(x)
+    ref_out = ref_out[-1]
+    ora_out, ora_maps = O.dlaseg_forward(x, sd, dataset)
+    fix = {"H": H, "W": W}
+    for k in range(13):
+        d = maxabs(ref_maps[k], ora_maps[k])
+        print("  fmap %2d %s maxabs %.3e  (|ref| max %.3f)" % (k, tuple(ref_maps[k].shape), d, ref_maps[k].abs().max()))
+        assert d <= 2e-5 * max(1.0, float(ref_maps[k].abs().max()))
+        idx, val = sample_map(ref_maps[k], 96, seed=k)
+        fix["fmap%d_idx" % k] = idx; fix["fmap%d_val" % k] = val
+        fix["fmap%d_sum" % k] = np.float64(ref_maps[k].double().sum())
+        fix["fmap%d_abs" % k] = np.float64(ref_maps[k].double().abs().sum())
+    for h in ref_out:
+        d = maxabs(ref_out[h], ora_out[h])
+        print("  head %s maxabs %.3e" % (h, d))
+        assert d <= 2e-5 * max(1.0, float(ref_out[h].abs().max()))
+        idx, val = sample_map(ref_out[h], 128, seed=100)
+        fix["head_%s_idx" % h] = idx; fix["head_%s_val" % h] = val
+    # ---- decode (detector.py:486-494 + decode.py:102) ----
+    from model.decode import generic_decode
+    sg = ref_out["hm"].sigmoid()
+    npk = int((torch.nn.functional.max_pool2d(sg, 3, 1, 1) == sg).sum())
+    K = 100 if npk >= 150 else max(4, min(20, npk // 2))
+    print("  peaks %d -> K %d" % (npk, K))
+    ref_sig = {k: v.clone() for k, v in ref_out.items()}
+    ref_sig["hm"] = ref_sig["hm"].sigmoid_()
+    if "dep" in ref_sig:
+        ref_sig["dep"] = 1.0 / (ref_sig["dep"].sigmoid() + 1e-6) - 1.0
+    ref_dets = generic_decode(ref_sig, K=K, opt=opt)
+    ora_dets = O.generic_decode(O.sigmoid_output(ora_out), K=K)
+    # the oracle's own path must reproduce the reference's indices bit-exactly
+    hw = (H // 4) * (W // 4)
+    ref_inds = (ref_dets["ys"] * (W // 4) + ref_dets["xs"]).long()
+    assert torch.equal(ref_inds, ora_dets["inds"]), "top-k indices differ (oracle vs reference)"
+    for k in ["scores", "clses", "xs", "ys", "bboxes", "tracking"]:
+        d = maxabs(ref_dets[k], ora_dets[k])
+        print("  dets %s maxabs %.3e" % (k, d))
+        assert d <= 1e-4
+        fix["det_" + k] = ref_dets[k].numpy()
+    fix["det_inds"] = ref_inds.numpy(); fix["det_K"] = K
+    gap = (ref_dets["scores"][0, :-1] - ref_dets["scores"][0, 1:]).min()
+    print("  min adjacent top-k score gap %.3e" % float(gap))
+    # ---- embeddings (AFE.py:88) ----
+    N = 12
+    g = torch.Generator().manual_seed(2)
+    centers = (torch.rand(1, N, 1, 1, 2, generator=g) * 2 - 1)
+    centers[0, 0] = torch.tensor([-1.0, -1.0]); centers[0, 1] = torch.tensor([1.0, 1.0])  # border cases
+    centers[0, 2] = torch.tensor([0.9999, -0.9999])
+    ref_emb = model.AFE.forward_feature_extracter(ref_maps, centers)
+    ora_emb = O.afe_extract(ora_maps, centers, sd)
+    d = maxabs(ref_emb, ora_emb)
+    print("  embed %s maxabs %.3e" % (tuple(ref_emb.shape), d))
+    assert d <= 2e-5 * max(1.0, float(ref_emb.abs().max()))
+    fix["emb_centers"] = centers.numpy(); fix["emb"] = ref_emb.numpy()
+    # ---- affinity (AFE.py:110) ----
+    D = ref_emb.shape[2]
+    g = torch.Generator().manual_seed(5)
+    for n, (P, Q) in enumerate([(5, 7), (12, 12), (1, 3), (9, 2)]):
+        xp = torch.randn(1, P, D, generator=g).abs() * 3.0
+        xn = torch.randn(1, Q, D, generator=g).abs() * 3.0
+        ref_a = model.AFE.forward_stacker_features(xp, xn, False)
+        ora_a = O.afe_affinity(xp, xn, sd, opt.max_object)
+        d = maxabs(ref_a, ora_a)
+        print("  affinity %dx%d maxabs %.3e range [%.4f, %.4f]" % (P, Q, d, ref_a.min(), ref_a.max()))
+        assert d <= 1e-6
+        fix["aff%d_xp" % n] = xp.numpy(); fix["aff%d_xn" % n] = xn.numpy(); fix["aff%d" % n] = ref_a
+    # embeddings-driven affinity (realistic magnitudes)
+    ref_a = model.AFE.forward_stacker_features(ref_emb[:, :7], ref_emb[:, 5:], False)
+    ora_a = O.afe_affinity(ora_emb[:, :7], ora_emb[:, 5:], sd, opt.max_object)
+    assert maxabs(ref_a, ora_a) <= 1e-5
+    fix["aff_emb"] = ref_a
+    np.savez_compressed(os.path.join(GOLD, "forward_%s.npz" % tag), **fix)
+    return model
+
+
+def run_lstm(dataset):
+    from utils.tracking_utils.kalman_filter_lstm import KalmanFilterLSTM
+    opt = ref_import.make_opt(dataset)
+    kf = KalmanFilterLSTM(opt)
+    lsd = O.synth_lstm_state_dict(dataset)
+    kf.model.load_state_dict(lsd, strict=True)
+    kf.model.eval()
+    nin = lsd["lstm.weight_ih_l0"].shape[1]
+    T, steps = 6, 4
+    g = torch.Generator().manual_seed(7)
+    h = torch.zeros(T, 128); c = torch.zeros(T, 128)
+    xs = torch.randn(steps, T, nin, generator=g)
+    fix = {"xs": xs.numpy()}
+    with torch.no_grad():
+        hr = h.clone(); cr = c.clone()
+        for s in range(steps):
+            ho, co, po = O.lstm_predict(h, c, xs[s], lsd)
+            preds = []
+            for t in range(T):
+                hn, cn, pr = kf.predict(hr[t].view(1, 1, 128), cr[t].view(1, 1, 128), xs[s, t].view(1, 1, nin))
+                hr[t] = hn.view(128); cr[t] = cn.view(128)
+                preds.append(np.stack([pr[i + 1] for i in range(kf.MAX_dis_fut)]))
+            preds = np.stack(preds)
+            d = max(maxabs(hr, ho), maxabs(cr, co), maxabs(preds, po))
+            print("  lstm[%s] step %d maxabs %.3e" % (dataset, s, d))
+            assert d <= 2e-6
+            h, c = ho, co
+            fix["h%d" % s] = hr.numpy().copy(); fix["c%d" % s] = cr.numpy().copy(); fix["p%d" % s] = preds
+    np.savez_compressed(os.path.join(GOLD, "lstm_%s.npz" % dataset), **fix)
+
+
+def run_convert_detection():
+    from utils.image import convert_detection
+    g = np.random.RandomState(3)
+    boxes = g.rand(9, 4) * 400
+    boxes[:, 2:] += boxes[:, :2]
+    ref = convert_detection(boxes.copy(), 608.0, 1088.0)
+    ora = O.convert_detection(boxes.copy(), 608.0, 1088.0)
+    assert torch.equal(ref, ora)
+    np.savez_compressed(os.path.join(GOLD, "convert_detection.npz"), boxes=boxes, centers=ref.numpy())
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    run("mot", 128, 160, "mot_128x160")
+    run("mot", 224, 384, "mot_224x384")
+    run("nuscenes", 96, 128, "nuscenes_96x128")
+    run_lstm("mot")
+    run_lstm("nuscenes")
+    run_convert_detection()
+    print("golden fixtures written to", os.path.abspath(GOLD))
