@@ -1,0 +1,564 @@
+// Non-GEMM kernels of the DEFT hot path for gfx950: layout adapters, pooling,
+// transposed-conv upsample + skip add, peak extraction / top-K, sparse heads,
+// box decode, sparse embedding head, dual-softmax affinity tail, batched LSTM step.
+// All HBM-bound or tiny: coalesced float4 NHWC traffic, LDS staging, wave shuffles.
+#include <cstdarg>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void deft_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* deft_last_error(void) { return g_err; }
+extern "C" int deft_version(void) { return DEFT_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------
+// layout adapters
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int N, int C, int HW, int ldy) {
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (long long)N * HW) return;
+    const int n = (int)(pix / HW);
+    const int hw = (int)(pix - (long long)n * HW);
+    const float* xp = x + (size_t)n * C * HW + hw;
+    float* yp = y + (size_t)pix * ldy;
+    for (int c = 0; c < ldy; ++c) yp[c] = c < C ? xp[(size_t)c * HW] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int N, int C, int HW, int ldx) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * C * HW) return;
+    const int hw = (int)(i % HW);
+    const long long t = i / HW;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    y[i] = x[((size_t)n * HW + hw) * ldx + c];
+}
+
+extern "C" int deft_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ldy, void* stream) {
+    DEFT_CHECK(x && y && ldy >= C, -1, "deft_nchw_to_nhwc: bad arguments");
+    const long long tot = (long long)N * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H * W, ldy);
+    DEFT_CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+extern "C" int deft_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int ldx, void* stream) {
+    DEFT_CHECK(x && y && ldx >= C, -1, "deft_nhwc_to_nchw: bad arguments");
+    const long long tot = (long long)N * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H * W, ldx);
+    DEFT_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// MaxPool2d(2,2)   (dla.py:266-267)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         int N, int H, int W, int C4, int ldx, int ldy) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int OH = H >> 1, OW = W >> 1;
+    if (i >= (long long)N * OH * OW * C4) return;
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const float* p = x + ((size_t)(n * H + 2 * oy) * W + 2 * ox) * ldx + 4 * c4;
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + ldx);
+    const float4 c = *(const float4*)(p + (size_t)W * ldx), d = *(const float4*)(p + (size_t)W * ldx + ldx);
+    float4 r;
+    r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+    r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+    r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    *(float4*)(y + ((size_t)(n * OH + oy) * OW + ox) * ldy + 4 * c4) = r;
+}
+
+extern "C" int deft_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, int ldx, int ldy, void* stream) {
+    DEFT_CHECK(x && y && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (H & 1) == 0 && (W & 1) == 0, -1,
+               "deft_maxpool2x2: need C,ld %% 4 == 0 and even H,W (got C=%d H=%d W=%d)", C, H, W);
+    const long long tot = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C / 4, ldx, ldy);
+    DEFT_CHECK_LAUNCH("maxpool2x2");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// depthwise ConvTranspose2d(k=2f, stride f, pad f/2) + skip   (dla.py:677-699)
+// out[oy] gathers in[iy]*w[ky] with ky = oy + f/2 - iy*f in [0,2f): two rows, two cols.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ wup,
+                                                           const float* __restrict__ skip, float* __restrict__ y,
+                                                           int N, int H, int W, int C4, int f, int ldx, int lds, int ldy) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int OH = H * f, OW = W * f;
+    if (i >= (long long)N * OH * OW * C4) return;
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const int k2 = 2 * f, kk = k2 * k2;
+    const int py = oy + f / 2, px = ox + f / 2;
+    const int iy1 = py / f, ix1 = px / f;            // tap ky1 = py - iy1*f in [0,f)
+    const int ky1 = py - iy1 * f, kx1 = px - ix1 * f;
+    const size_t o = ((size_t)(n * OH + oy) * OW + ox);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int iy = iy1 - 1 + a, ky = ky1 + f - a * f;   // a=0: (iy1-1, ky1+f); a=1: (iy1, ky1)
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ix = ix1 - 1 + b, kx = kx1 + f - b * f;
+            if (ix < 0 || ix >= W) continue;
+            const float4 v = *(const float4*)(x + ((size_t)(n * H + iy) * W + ix) * ldx + 4 * c4);
+            const float* wp = wup + (size_t)(4 * c4) * kk + ky * k2 + kx;
+            acc[0] += v.x * wp[0];
+            acc[1] += v.y * wp[kk];
+            acc[2] += v.z * wp[2 * kk];
+            acc[3] += v.w * wp[3 * kk];
+        }
+    }
+    const float4 s = *(const float4*)(skip + o * lds + 4 * c4);
+    *(float4*)(y + o * ldy + 4 * c4) = make_float4(acc[0] + s.x, acc[1] + s.y, acc[2] + s.z, acc[3] + s.w);
+}
+
+extern "C" int deft_upsample_add(const float* x, const float* wup, const float* skip, float* y,
+                                 int N, int H, int W, int C, int f, int ldx, int lds, int ldy, void* stream) {
+    DEFT_CHECK(x && wup && skip && y && (C & 3) == 0 && f >= 2 && (f & 1) == 0, -1, "deft_upsample_add: bad arguments (C=%d f=%d)", C, f);
+    DEFT_CHECK((ldx & 3) == 0 && (lds & 3) == 0 && (ldy & 3) == 0, -2, "deft_upsample_add: ld %% 4 != 0");
+    const long long tot = (long long)N * H * f * W * f * (C / 4);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, wup, skip, y, N, H, W, C / 4, f, ldx, lds, ldy);
+    DEFT_CHECK_LAUNCH("upsample_add");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// sigmoid + 3x3 NMS + candidate compaction   (detector.py:488, utils.py:69-74)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void hm_peaks_kernel(const float* __restrict__ hm, int N, int H, int W, int C, int ld,
+                                                       float* __restrict__ cs, int* __restrict__ ci, int* __restrict__ cc, int cap) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * C) return;
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const float* base = hm + (size_t)n * H * W * ld + c;
+    const float s = sigmoidf_(base[(size_t)(y * W + x) * ld]);
+    bool peak = true;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if ((dy | dx) != 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                peak = peak && (sigmoidf_(base[(size_t)(yy * W + xx) * ld]) <= s);
+        }
+    if (peak) {
+        const int pos = atomicAdd(&cc[n], 1);
+        if (pos < cap) {
+            cs[(size_t)n * cap + pos] = s;
+            ci[(size_t)n * cap + pos] = c * H * W + y * W + x;
+        }
+    }
+}
+
+extern "C" int deft_hm_peaks(const float* hm, int N, int H, int W, int C, int ld,
+                             float* cand_score, int* cand_idx, int* cand_count, int cap, void* stream) {
+    DEFT_CHECK(hm && cand_score && cand_idx && cand_count && cap > 0 && ld >= C, -1, "deft_hm_peaks: bad arguments");
+    const long long tot = (long long)N * H * W * C;
+    hipLaunchKernelGGL(hm_peaks_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, hm, N, H, W, C, ld, cand_score, cand_idx, cand_count, cap);
+    DEFT_CHECK_LAUNCH("hm_peaks");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// top-K of the candidates: 64-bit keys (score bits : ~index) are all distinct, so a
+// 6-pass MSB radix select finds the K-th key exactly; the K survivors are bitonic
+// sorted in LDS (descending score, ascending index on ties).   (utils.py:89-104)
+// ---------------------------------------------------------------------------
+#define TOPK_MAXK 512
+
+__device__ __forceinline__ unsigned long long topk_key(float s, int idx) {
+    return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ cs, const int* __restrict__ ci,
+                                                   const int* __restrict__ cc, int cap, int K, int HW,
+                                                   float* __restrict__ out_s, int* __restrict__ out_i, int* __restrict__ out_c) {
+    __shared__ int hist[2048];
+    __shared__ unsigned long long sel[TOPK_MAXK];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_kth, s_nsel;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    int cnt = cc[n];
+    if (cnt > cap) cnt = cap;
+    const float* s = cs + (size_t)n * cap;
+    const int* ix = ci + (size_t)n * cap;
+    for (int i = tid; i < TOPK_MAXK; i += 256) sel[i] = 0ull;
+    if (tid == 0) { s_prefix = 0ull; s_kth = K; s_nsel = 0; }
+    __syncthreads();
+    if (cnt > K) {
+        // passes of 11,11,11,11,11,9 bits from the top
+        int hi = 64;
+        for (int pass = 0; pass < 6; ++pass) {
+            const int bits = pass < 5 ? 11 : 9;
+            const int lo = hi - bits;
+            for (int i = tid; i < 2048; i += 256) hist[i] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            for (int i = tid; i < cnt; i += 256) {
+                const unsigned long long key = topk_key(s[i], ix[i]);
+                if (pass == 0 || (key >> hi) == prefix) atomicAdd(&hist[(int)((key >> lo) & ((1u << bits) - 1))], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int kth = s_kth, b = (1 << bits) - 1;
+                for (; b > 0; --b) {
+                    if (hist[b] >= kth) break;
+                    kth -= hist[b];
+                }
+                s_kth = kth;
+                s_prefix = (prefix << bits) | (unsigned long long)b;
+            }
+            __syncthreads();
+            hi = lo;
+        }
+    }
+    const unsigned long long thr = (cnt > K) ? s_prefix : 0ull;
+    for (int i = tid; i < cnt; i += 256) {
+        const unsigned long long key = topk_key(s[i], ix[i]);
+        if (key >= thr) {
+            const int pos = atomicAdd(&s_nsel, 1);
+            if (pos < TOPK_MAXK) sel[pos] = key;
+        }
+    }
+    __syncthreads();
+    // bitonic sort, descending, TOPK_MAXK slots
+    for (int k = 2; k <= TOPK_MAXK; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < TOPK_MAXK; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = sel[i], b = sel[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { sel[i] = b; sel[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int k = tid; k < K; k += 256) {
+        const unsigned long long key = sel[k];
+        float sc = 0.f; int ind = 0, cls = 0;
+        if (key != 0ull) {
+            sc = __uint_as_float((unsigned)(key >> 32));
+            const unsigned full = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+            cls = (int)(full / (unsigned)HW);
+            ind = (int)(full - (unsigned)cls * (unsigned)HW);
+        }
+        out_s[(size_t)n * K + k] = sc;
+        out_i[(size_t)n * K + k] = ind;
+        out_c[(size_t)n * K + k] = cls;
+    }
+}
+
+extern "C" int deft_topk(const float* cand_score, const int* cand_idx, const int* cand_count,
+                         int N, int cap, int K, int HW, float* out_score, int* out_ind, int* out_cls, void* stream) {
+    DEFT_CHECK(cand_score && cand_idx && cand_count && out_score && out_ind && out_cls, -1, "deft_topk: null pointer");
+    DEFT_CHECK(K > 0 && K <= TOPK_MAXK && HW > 0, -2, "deft_topk: K=%d must be in 1..%d", K, TOPK_MAXK);
+    hipLaunchKernelGGL(topk_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, cand_score, cand_idx, cand_count, cap, K, HW, out_score, out_ind, out_cls);
+    DEFT_CHECK_LAUNCH("topk");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// regression heads at the K peaks only   (base_model.py:37-66 + utils.py:32-36)
+// ---------------------------------------------------------------------------
+#define HP_PPB 4      // peaks per block
+#define HP_MAXK 576   // 9 * 64
+
+__global__ __launch_bounds__(256) void heads_at_peaks_kernel(const float* __restrict__ feat, int H, int W, int Cf, int ld,
+                                                             const int* __restrict__ inds, int K,
+                                                             const float* __restrict__ w0t, const float* __restrict__ b0,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             const int* __restrict__ head_of, int nheads, int Ctot,
+                                                             float* __restrict__ out) {
+    __shared__ float patch[HP_PPB][HP_MAXK];
+    __shared__ float hid[HP_PPB][256];
+    const int tid = threadIdx.x, n = blockIdx.y, k0 = blockIdx.x * HP_PPB;
+    const int KK = 9 * Cf;
+    for (int i = tid; i < HP_PPB * KK; i += 256) {
+        const int pk = i / KK, kk = i - pk * KK;
+        const int tap = kk / Cf, c = kk - tap * Cf;
+        float v = 0.f;
+        if (k0 + pk < K) {
+            const int ind = inds[(size_t)n * K + k0 + pk];
+            const int y = ind / W + tap / 3 - 1, x = ind % W + tap % 3 - 1;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = feat[((size_t)(n * H + y) * W + x) * ld + c];
+        }
+        patch[pk][kk] = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int h = 0; h < nheads; ++h) {
+        float acc[HP_PPB];
+        const float bb = b0[h * 256 + tid];
+#pragma unroll
+        for (int q = 0; q < HP_PPB; ++q) acc[q] = bb;
+        const float* wp = w0t + (size_t)h * KK * 256 + tid;
+        for (int kk = 0; kk < KK; ++kk) {
+            const float w = wp[(size_t)kk * 256];
+#pragma unroll
+            for (int q = 0; q < HP_PPB; ++q) acc[q] += w * patch[q][kk];
+        }
+#pragma unroll
+        for (int q = 0; q < HP_PPB; ++q) hid[q][tid] = fmaxf(acc[q], 0.f);
+        __syncthreads();
+        // wave w finishes peak w: out[c] = b2[c] + sum_o w2[c][o] * hid[w][o]
+        for (int c = 0; c < Ctot; ++c) {
+            if (head_of[c] != h) continue;
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part += w2[(size_t)c * 256 + lane + 64 * q] * hid[wave][lane + 64 * q];
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0 && k0 + wave < K) out[((size_t)n * K + k0 + wave) * Ctot + c] = part + b2[c];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int deft_heads_at_peaks(const float* feat, int N, int H, int W, int Cf, int ld,
+                                   const int* inds, int K, const float* w0t, const float* b0,
+                                   const float* w2, const float* b2, const int* head_of,
+                                   int nheads, int Ctot, float* out, void* stream) {
+    DEFT_CHECK(feat && inds && w0t && b0 && w2 && b2 && head_of && out, -1, "deft_heads_at_peaks: null pointer");
+    DEFT_CHECK(9 * Cf <= HP_MAXK && nheads > 0 && Ctot > 0 && K > 0, -2, "deft_heads_at_peaks: Cf=%d too large or empty", Cf);
+    hipLaunchKernelGGL(heads_at_peaks_kernel, dim3(deft_cdiv(K, HP_PPB), N), dim3(256), 0, (hipStream_t)stream,
+                       feat, H, W, Cf, ld, inds, K, w0t, b0, w2, b2, head_of, nheads, Ctot, out);
+    DEFT_CHECK_LAUNCH("heads_at_peaks");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// box assembly   (decode.py:118-196)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_boxes_kernel(const int* __restrict__ inds, const float* __restrict__ heads,
+                                                           int NK, int Wm, int Ctot, int off_reg, int off_wh, int off_ltrb,
+                                                           float* __restrict__ cts, float* __restrict__ bboxes) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NK) return;
+    const int ind = inds[i];
+    const float ys0 = (float)(ind / Wm), xs0 = (float)(ind % Wm);
+    const float* hv = heads + (size_t)i * Ctot;
+    cts[2 * i] = xs0; cts[2 * i + 1] = ys0;
+    float xs = xs0 + 0.5f, ys = ys0 + 0.5f;
+    if (off_reg >= 0) { xs = xs0 + hv[off_reg]; ys = ys0 + hv[off_reg + 1]; }
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (off_wh >= 0) {
+        const float w = fmaxf(hv[off_wh], 0.f), h = fmaxf(hv[off_wh + 1], 0.f);
+        b0 = xs - w / 2; b1 = ys - h / 2; b2 = xs + w / 2; b3 = ys + h / 2;
+    }
+    if (off_ltrb >= 0) {
+        b0 = xs0 + hv[off_ltrb]; b1 = ys0 + hv[off_ltrb + 1]; b2 = xs0 + hv[off_ltrb + 2]; b3 = ys0 + hv[off_ltrb + 3];
+    }
+    bboxes[4 * i] = b0; bboxes[4 * i + 1] = b1; bboxes[4 * i + 2] = b2; bboxes[4 * i + 3] = b3;
+}
+
+extern "C" int deft_decode_boxes(const int* inds, const float* heads, int N, int K, int Wm, int Ctot,
+                                 int off_reg, int off_wh, int off_ltrb_amodal, float* cts, float* bboxes, void* stream) {
+    DEFT_CHECK(inds && heads && cts && bboxes && Wm > 0, -1, "deft_decode_boxes: bad arguments");
+    hipLaunchKernelGGL(decode_boxes_kernel, dim3(deft_cdiv(N * K, 256)), dim3(256), 0, (hipStream_t)stream,
+                       inds, heads, N * K, Wm, Ctot, off_reg, off_wh, off_ltrb_amodal, cts, bboxes);
+    DEFT_CHECK_LAUNCH("decode_boxes");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// sparse embedding head for one feature map   (AFE.py:162-188)
+// ---------------------------------------------------------------------------
+#define EM_MAXC 512
+
+__global__ __launch_bounds__(256) void embed_map_kernel(const float* __restrict__ fmap, int H, int W, int C, int ld,
+                                                        const float* __restrict__ wsel_t, const float* __restrict__ bsel, int Co,
+                                                        const float* __restrict__ centers, int ndet,
+                                                        float* __restrict__ out, int ldo, int col_off) {
+    __shared__ __attribute__((aligned(16))) float patch[16 * EM_MAXC];
+    __shared__ float vals[4][64];
+    const int tid = threadIdx.x, i = blockIdx.x, n = blockIdx.y;
+    const float gx = centers[((size_t)n * ndet + i) * 2], gy = centers[((size_t)n * ndet + i) * 2 + 1];
+    // grid_sample: unnormalise (align_corners=False), clip to the border, bilinear corners
+    float fx = ((gx + 1.f) * W - 1.f) / 2.f, fy = ((gy + 1.f) * H - 1.f) / 2.f;
+    fx = fminf((float)(W - 1), fmaxf(fx, 0.f));
+    fy = fminf((float)(H - 1), fmaxf(fy, 0.f));
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int C4 = C >> 2;
+    for (int t = tid; t < 16 * C4; t += 256) {
+        const int pos = t / C4, c4 = t - pos * C4;
+        const int py = y0 - 1 + (pos >> 2), px = x0 - 1 + (pos & 3);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W)
+            v = *(const float4*)(fmap + ((size_t)(n * H + py) * W + px) * ld + 4 * c4);
+        *(float4*)&patch[pos * C + 4 * c4] = v;
+    }
+    __syncthreads();
+    if (tid < 4 * Co) {
+        const int q = tid / Co, o = tid - q * Co;
+        const int qy = q >> 1, qx = q & 1;
+        float acc = bsel[o];
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* pp = &patch[((qy + tap / 3) * 4 + (qx + tap % 3)) * C];
+            const float* wp = wsel_t + (size_t)tap * C * Co + o;
+            for (int c = 0; c < C; ++c) acc += wp[(size_t)c * Co] * pp[c];
+        }
+        vals[q][o] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    if (tid < Co) {
+        const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+        const float nw = (x1f - fx) * (y1f - fy), ne = (fx - x0f) * (y1f - fy);
+        const float sw = (x1f - fx) * (fy - y0f), se = (fx - x0f) * (fy - y0f);
+        const bool xin = x0 + 1 <= W - 1, yin = y0 + 1 <= H - 1;
+        float r = vals[0][tid] * nw;
+        if (xin) r += vals[1][tid] * ne;
+        if (yin) r += vals[2][tid] * sw;
+        if (xin && yin) r += vals[3][tid] * se;
+        out[((size_t)n * ndet + i) * ldo + col_off + tid] = r;
+    }
+}
+
+extern "C" int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, int ld,
+                              const float* wsel_t, const float* bsel, int Co,
+                              const float* centers, int ndet, float* out, int ldo, int col_off, void* stream) {
+    DEFT_CHECK(fmap && wsel_t && bsel && centers && out, -1, "deft_embed_map: null pointer");
+    DEFT_CHECK(C <= EM_MAXC && (C & 3) == 0 && (ld & 3) == 0 && Co <= 64 && Co > 0, -2, "deft_embed_map: C=%d (<=%d, %%4) Co=%d (<=64)", C, EM_MAXC, Co);
+    if (ndet <= 0) return 0;
+    hipLaunchKernelGGL(embed_map_kernel, dim3(ndet, Nf), dim3(256), 0, (hipStream_t)stream,
+                       fmap, H, W, C, ld, wsel_t, bsel, Co, centers, ndet, out, ldo, col_off);
+    DEFT_CHECK_LAUNCH("embed_map");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// affinity tail: final 64->1 + ReLU, dual softmax with analytic padding   (AFE.py:119-150)
+// ---------------------------------------------------------------------------
+#define AF_MAXOBJ 112   // 112*112*4 B = 49 KB of LDS (opts.py:339 max_object = 100)
+
+__global__ __launch_bounds__(256) void affinity_finish_kernel(const float* __restrict__ h4, int ldh, int C4,
+                                                              const float* __restrict__ w5, float b5,
+                                                              const int* __restrict__ row_start, int Q, int max_object,
+                                                              float* __restrict__ out) {
+    __shared__ float E[AF_MAXOBJ * AF_MAXOBJ];
+    __shared__ float rs[AF_MAXOBJ], csum[AF_MAXOBJ];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int t0 = row_start[f], P = row_start[f + 1] - t0;
+    const float e1 = expf(1.f);
+    for (int p = tid; p < P * Q; p += 256) {
+        const float* hp = h4 + ((size_t)t0 * Q + p) * ldh;
+        float acc = b5;
+        for (int k = 0; k < C4; k += 4) {
+            const float4 v = *(const float4*)(hp + k);
+            acc += v.x * w5[k] + v.y * w5[k + 1] + v.z * w5[k + 2] + v.w * w5[k + 3];
+        }
+        E[p] = expf(fmaxf(acc, 0.f));
+    }
+    __syncthreads();
+    if (tid < P) {
+        float s = 0.f;
+        for (int j = 0; j < Q; ++j) s += E[tid * Q + j];
+        rs[tid] = s + (float)(max_object - Q) + e1;
+    }
+    if (tid < Q) {
+        float s = 0.f;
+        for (int i = 0; i < P; ++i) s += E[i * Q + tid];
+        csum[tid] = s + (float)(max_object - P) + e1;
+    }
+    __syncthreads();
+    for (int p = tid; p < P * (Q + 1); p += 256) {
+        const int i = p / (Q + 1), j = p - i * (Q + 1);
+        float v;
+        if (j < Q) {
+            const float e = E[i * Q + j];
+            v = fmaxf(e / rs[i], e / csum[j]);
+        } else {
+            v = e1 / rs[i];
+        }
+        out[(size_t)(t0 + i) * (Q + 1) + j] = v;
+    }
+}
+
+extern "C" int deft_affinity_finish(const float* h4, int ldh, int C4, const float* w5, float b5,
+                                    const int* row_start, int F, int Q, int max_object, float* out, void* stream) {
+    DEFT_CHECK(h4 && w5 && row_start && out, -1, "deft_affinity_finish: null pointer");
+    DEFT_CHECK(Q > 0 && Q <= AF_MAXOBJ && max_object <= AF_MAXOBJ && Q <= max_object && (C4 & 3) == 0 && (ldh & 3) == 0, -2,
+               "deft_affinity_finish: Q=%d max_object=%d must be <= %d", Q, max_object, AF_MAXOBJ);
+    if (F <= 0) return 0;
+    hipLaunchKernelGGL(affinity_finish_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, h4, ldh, C4, w5, b5, row_start, Q, max_object, out);
+    DEFT_CHECK_LAUNCH("affinity_finish");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// batched single-step LSTM + 2 Linears   (kalman_filter_lstm.py:9-29, 65-78)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict__ x, float* __restrict__ h, float* __restrict__ c,
+                                                        int nin, int nout,
+                                                        const float* __restrict__ wih_t, const float* __restrict__ whh_t,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ w1_t, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2_t, const float* __restrict__ b2,
+                                                        float* __restrict__ pred) {
+    __shared__ float xin[32], hin[128], gates[512], hnew[128], o1[64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (tid < nin) xin[tid] = x[(size_t)t * nin + tid];
+    if (tid < 128) hin[tid] = h[(size_t)t * 128 + tid];
+    __syncthreads();
+    float acc = bias[tid];
+    for (int k = 0; k < nin; ++k) acc += wih_t[k * 512 + tid] * xin[k];
+    for (int k = 0; k < 128; ++k) acc += whh_t[k * 512 + tid] * hin[k];
+    gates[tid] = acc;
+    __syncthreads();
+    if (tid < 128) {
+        const float ig = sigmoidf_(gates[tid]), fg = sigmoidf_(gates[128 + tid]);
+        const float gg = tanhf(gates[256 + tid]), og = sigmoidf_(gates[384 + tid]);
+        const float cn = fg * c[(size_t)t * 128 + tid] + ig * gg;
+        const float hn = og * tanhf(cn);
+        c[(size_t)t * 128 + tid] = cn;
+        h[(size_t)t * 128 + tid] = hn;
+        hnew[tid] = hn;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float a = b1[tid];
+        for (int k = 0; k < 128; ++k) a += w1_t[k * 64 + tid] * hnew[k];
+        o1[tid] = a;
+    }
+    __syncthreads();
+    if (tid < nout) {
+        float a = b2[tid];
+        for (int k = 0; k < 64; ++k) a += w2_t[k * nout + tid] * o1[k];
+        pred[(size_t)t * nout + tid] = a;
+    }
+}
+
+extern "C" int deft_lstm_step(const float* x, float* h, float* c, int T, int nin, int nout,
+                              const float* wih_t, const float* whh_t, const float* bias,
+                              const float* w1_t, const float* b1, const float* w2_t, const float* b2,
+                              float* pred, void* stream) {
+    DEFT_CHECK(x && h && c && wih_t && whh_t && bias && w1_t && b1 && w2_t && b2 && pred, -1, "deft_lstm_step: null pointer");
+    DEFT_CHECK(nin > 0 && nin <= 32 && nout > 0 && nout <= 64, -2, "deft_lstm_step: nin=%d (<=32) nout=%d (<=64)", nin, nout);
+    if (T <= 0) return 0;
+    hipLaunchKernelGGL(lstm_step_kernel, dim3(T), dim3(512), 0, (hipStream_t)stream, x, h, c, nin, nout, wih_t, whh_t, bias, w1_t, b1, w2_t, b2, pred);
+    DEFT_CHECK_LAUNCH("lstm_step");
+    return 0;
+}

@@ -1,0 +1,512 @@
+"""Static execution plans that drive libdeft_hip.so for DEFT's per-frame hot path.
+
+Host logic only: weight packing (reference state_dict keys -> MFMA-friendly
+layouts), buffer planning (NHWC fp32, concat-by-stride), and the ordered list of
+C-ABI calls for one batch of frames.  All arithmetic happens in the HIP library;
+torch is used for device memory and streams.  Reference anchors:
+
+  DlaSegPlan      dla.py:758-817 (DLASeg.img2feats), :400-411 (DLA.forward),
+                  :271-284 (Tree), :693-735 (IDAUp/DLAUp), base_model.py:111-132
+  detect()        detector.py:486-494, decode.py:102-196, utils.py:69-104
+  AfePlan         AFE.py:88-213
+  LstmPlan        kalman_filter_lstm.py:65-78
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import hiplib
+from .hiplib import GemmDesc, ptr
+
+BN_EPS = 1e-5
+
+HEADS = {   # opts.py:500-520 + experiments/*.sh
+    "mot": {"hm": 1, "reg": 2, "wh": 2, "tracking": 2, "ltrb_amodal": 4},
+    "kitti_tracking": {"hm": 3, "reg": 2, "wh": 2, "tracking": 2},
+    "nuscenes": {"hm": 10, "reg": 2, "wh": 2, "tracking": 2, "dep": 1, "rot": 8, "dim": 3, "amodel_offset": 2},
+}
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+class View:
+    """A channel slice [c0, c0+C) of an NHWC buffer [N,H,W,ld]."""
+
+    def __init__(self, buf, N, H, W, C, ld, c0=0):
+        self.buf, self.N, self.H, self.W, self.C, self.ld, self.c0 = buf, N, H, W, C, ld, c0
+
+    @property
+    def addr(self):
+        return self.buf.data_ptr() + 4 * self.c0
+
+    def sub(self, c0, C):
+        return View(self.buf, self.N, self.H, self.W, C, self.ld, self.c0 + c0)
+
+    def to_nchw(self):
+        """Debug/test view (torch indexing, not on the hot path)."""
+        return self.buf.view(self.N, self.H, self.W, self.ld)[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2).contiguous()
+
+
+def _bn_fold(sd, p):
+    """Eval BatchNorm as y = x*alpha + beta, computed like ATen's CPU kernel."""
+    invstd = 1.0 / torch.sqrt(sd[p + ".running_var"].float() + BN_EPS)
+    alpha = invstd * sd[p + ".weight"].float()
+    beta = sd[p + ".bias"].float() - sd[p + ".running_mean"].float() * alpha
+    return alpha, beta
+
+
+def pack_conv_weight(w, cin_pad=None):
+    """[Co,Ci,KH,KW] -> [CoPad(128)][Kpad(32)] with k = (r*KW+s)*CiPad + c."""
+    Co, Ci, KH, KW = w.shape
+    cp = Ci if cin_pad is None else cin_pad
+    t = torch.zeros(Co, KH, KW, cp, dtype=torch.float32)
+    t[..., :Ci] = w.float().permute(0, 2, 3, 1)
+    K = KH * KW * cp
+    out = torch.zeros(_rup(Co, 128), _rup(K, 32), dtype=torch.float32)
+    out[:Co, :K] = t.reshape(Co, K)
+    return out, K
+
+
+class _Plan:
+    """Common machinery: device buffers + an ordered list of bound C-ABI calls."""
+
+    def __init__(self, device, lib=None):
+        self.device = torch.device(device)
+        self.lib = lib if lib is not None else hiplib.get_lib()
+        self.ops = []          # (kind, name, callable, flops)
+        self._keep = []        # tensors / descriptors kept alive
+        self.profile = None    # when set to a list, run() appends (name, kind, flops, ms)
+
+    def dev(self, t):
+        t = t.contiguous().to(self.device)
+        self._keep.append(t)
+        return t
+
+    def alloc(self, N, H, W, C, ld=None):
+        ld = _rup(C, 4) if ld is None else ld
+        buf = torch.zeros(N * H * W * ld, dtype=torch.float32, device=self.device)
+        self._keep.append(buf)
+        return View(buf, N, H, W, C, ld)
+
+    def _stream(self):
+        return hiplib.stream_ptr(self.device)
+
+    def add(self, kind, name, fn, flops=0.0):
+        self.ops.append((kind, name, fn, flops))
+
+    def run(self):
+        if self.profile is None:
+            for _, _, fn, _ in self.ops:
+                fn()
+            return
+        for kind, name, fn, flops in self.ops:
+            if self.device.type == "cuda":
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record()
+                self.profile.append((name, kind, flops, e0, e1))
+            else:
+                fn()
+
+    # ---- op builders -------------------------------------------------------
+    def gemm(self, entry, name, desc, flops):
+        self._keep.append(desc)
+        lib, ref = self.lib, C.byref(desc)
+        self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
+
+    def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0):
+        OH = (x.H + 2 * pad - KH) // stride + 1
+        OW = (x.W + 2 * pad - KW) // stride + 1
+        if out is None:
+            out = self.alloc(x.N, OH, OW, Cout)
+        assert (out.N, out.H, out.W, out.C) == (x.N, OH, OW, Cout), (name, out.H, out.W, out.C, OH, OW, Cout)
+        if res is not None:
+            assert (res.H, res.W, res.C) == (OH, OW, Cout), name
+        d = GemmDesc()
+        d.x = x.addr; d.x2 = None; d.w = w_packed.data_ptr()
+        d.scale = scale.data_ptr() if scale is not None else None
+        d.shift = shift.data_ptr() if shift is not None else None
+        d.res = res.addr if res is not None else None
+        d.y = out.addr
+        d.N, d.H, d.W, d.Cin, d.ldx = x.N, x.H, x.W, x.C, x.ld
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = OH, OW, Cout, out.ld, (res.ld if res is not None else 0)
+        d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+        d.Ktot, d.Kpad = K, w_packed.shape[1]
+        d.cin_log2 = int(math.log2(x.C)) if KH * KW > 1 else 0
+        d.M = x.N * OH * OW
+        d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = tile
+        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * Cout * KH * KW * x.C)
+        return out
+
+    def maxpool(self, name, x, out=None):
+        if out is None:
+            out = self.alloc(x.N, x.H // 2, x.W // 2, x.C)
+        lib = self.lib
+        a = (C.c_void_p(x.addr), C.c_void_p(out.addr), x.N, x.H, x.W, x.C, x.ld, out.ld)
+        self.add("deft_maxpool2x2", name, lambda: lib.call("deft_maxpool2x2", *a, self._stream()))
+        return out
+
+    def upsample_add(self, name, x, wup, skip, f):
+        out = self.alloc(x.N, x.H * f, x.W * f, x.C)
+        assert (skip.H, skip.W, skip.C) == (out.H, out.W, out.C), name
+        lib = self.lib
+        a = (C.c_void_p(x.addr), ptr(wup), C.c_void_p(skip.addr), C.c_void_p(out.addr),
+             x.N, x.H, x.W, x.C, f, x.ld, skip.ld, out.ld)
+        self.add("deft_upsample_add", name, lambda: lib.call("deft_upsample_add", *a, self._stream()))
+        return out
+
+
+class DlaSegPlan(_Plan):
+    """DLA-34 + DLAUp/IDAUp (DCNv2) + heads + decode for a fixed (N, H, W)."""
+
+    def __init__(self, sd, N, H, W, dataset="mot", K=100, device="cuda", lib=None, dense_heads=False):
+        super().__init__(device, lib)
+        assert H % 32 == 0 and W % 32 == 0, "DLA-34 needs H, W divisible by 32"
+        self.sd, self.N, self.H, self.W, self.K = sd, N, H, W, K
+        self.heads = HEADS[dataset]
+        self.dataset = dataset
+        self._wcache = {}
+        self.image = torch.zeros(N, 3, H, W, dtype=torch.float32, device=self.device)
+        x4 = self.alloc(N, H, W, 4)
+        lib = self.lib
+        a = (ptr(self.image), C.c_void_p(x4.addr), N, 3, H, W, 4)
+        self.add("deft_nchw_to_nhwc", "image", lambda: lib.call("deft_nchw_to_nhwc", *a, self._stream()))
+        self._build_base(x4)
+        self._build_neck()
+        self._build_heads(dense_heads)
+
+    # ---- weights -----------------------------------------------------------
+    def _conv_bn(self, name, x, wkey, bnkey, KH, stride, pad, relu, out=None, res=None, cin_pad=None):
+        if wkey not in self._wcache:
+            wp, K = pack_conv_weight(self.sd[wkey + ".weight"], cin_pad)
+            alpha, beta = _bn_fold(self.sd, bnkey)
+            self._wcache[wkey] = (self.dev(wp), K, self.dev(alpha), self.dev(beta))
+        wp, K, alpha, beta = self._wcache[wkey]
+        Cout = self.sd[wkey + ".weight"].shape[0]
+        return self.conv(name, x, wp, K, KH, KH, stride, pad, Cout, alpha, beta, relu, out=out, res=res)
+
+    def _block(self, p, x, stride, residual, out):
+        """BasicBlock dla.py:73-87."""
+        cout = self.sd[p + ".conv1.weight"].shape[0]
+        t = self._conv_bn(p + ".conv1", x, p + ".conv1", p + ".bn1", 3, stride, 1, True)
+        return self._conv_bn(p + ".conv2", t, p + ".conv2", p + ".bn2", 3, 1, 1, True, out=out, res=residual)
+
+    def _tree1(self, p, x, cin, cout, stride, level_root, cat=None, bottom=None, out=None):
+        """Tree(levels=1) dla.py:271-284; `cat` = the Root's concat buffer
+        [x2 | x1 | children...] (children already written when passed in)."""
+        N = x.N
+        oh, ow = x.H // stride, x.W // stride
+        if cat is None:
+            cat = self.alloc(N, oh, ow, 2 * cout + (cin if level_root else 0))
+        if bottom is None:
+            if stride > 1:
+                bottom = self.maxpool(p + ".downsample", x, out=cat.sub(2 * cout, cin) if level_root else None)
+            else:
+                bottom = x
+        if (p + ".project.0.weight") in self.sd:
+            residual = self._conv_bn(p + ".project", bottom, p + ".project.0", p + ".project.1", 1, 1, 0, False)
+        else:
+            residual = bottom
+        x1 = self._block(p + ".tree1", x, stride, residual, cat.sub(cout, cout))
+        self._block(p + ".tree2", x1, 1, x1, cat.sub(0, cout))
+        root_in = View(cat.buf, cat.N, cat.H, cat.W, cat.C, cat.ld, cat.c0)
+        return self._conv_bn(p + ".root", root_in, p + ".root.conv", p + ".root.bn", 1, 1, 0, True, out=out)
+
+    def _tree2(self, p, x, cin, cout):
+        """Tree(levels=2, stride 2, level_root=True) dla.py:271-284.  The outer
+        project(bottom) is dead compute in the reference and skipped."""
+        oh, ow = x.H // 2, x.W // 2
+        cat = self.alloc(x.N, oh, ow, 2 * cout + cin + cout)       # [b2 | b1 | bottom | x1]
+        bottom = self.maxpool(p + ".downsample", x, out=cat.sub(2 * cout, cin))
+        x1 = self._tree1(p + ".tree1", x, cin, cout, 2, False, bottom=bottom, out=cat.sub(2 * cout + cin, cout))
+        return self._tree1(p + ".tree2", x1, cout, cout, 1, False, cat=cat, bottom=x1)
+
+    def _build_base(self, x4):
+        b = self._conv_bn("base_layer", x4, "base.base_layer.0", "base.base_layer.1", 7, 1, 3, True, cin_pad=4)
+        y0 = self._conv_bn("level0", b, "base.level0.0", "base.level0.1", 3, 1, 1, True)
+        y1 = self._conv_bn("level1", y0, "base.level1.0", "base.level1.1", 3, 2, 1, True)
+        y2 = self._tree1("base.level2", y1, 32, 64, 2, False)
+        y3 = self._tree2("base.level3", y2, 64, 128)
+        y4 = self._tree2("base.level4", y3, 128, 256)
+        y5 = self._tree1("base.level5", y4, 256, 512, 2, True)
+        self.base = [y0, y1, y2, y3, y4, y5]
+
+    def _deform(self, p, x):
+        """DeformConv dla.py:646-665: DCN (offset conv + modulated gather GEMM) -> BN -> ReLU."""
+        sd = self.sd
+        cin = x.C
+        cout = sd[p + ".conv.weight"].shape[0]
+        key = p + ".conv"
+        if key not in self._wcache:
+            wo, Ko = pack_conv_weight(sd[p + ".conv.conv_offset_mask.weight"])
+            wm, Km = pack_conv_weight(sd[p + ".conv.weight"])
+            alpha, beta = _bn_fold(sd, p + ".actf.0")
+            shift = sd[p + ".conv.bias"].float() * alpha + beta
+            self._wcache[key] = (self.dev(wo), Ko, self.dev(sd[p + ".conv.conv_offset_mask.bias"].float()),
+                                 self.dev(wm), Km, self.dev(alpha), self.dev(shift))
+        wo, Ko, bo, wm, Km, alpha, shift = self._wcache[key]
+        om = self.alloc(x.N, x.H, x.W, 27, ld=32)
+        self.conv(p + ".offset", x, wo, Ko, 3, 3, 1, 1, 27, None, bo, False, out=om)
+        out = self.alloc(x.N, x.H, x.W, cout)
+        d = GemmDesc()
+        d.x = x.addr; d.x2 = om.addr; d.w = wm.data_ptr()
+        d.scale = alpha.data_ptr(); d.shift = shift.data_ptr(); d.res = None; d.y = out.addr
+        d.N, d.H, d.W, d.Cin, d.ldx = x.N, x.H, x.W, cin, x.ld
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = x.H, x.W, cout, out.ld, 0
+        d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
+        d.Ktot, d.Kpad = Km, wm.shape[1]
+        d.cin_log2 = int(math.log2(cin))
+        d.M = x.N * x.H * x.W
+        d.relu = 1; d.Q = 0; d.ldom = om.ld; d.tile = 0
+        self.gemm("deft_dcn_v2_nhwc", p + ".dcn", d, 2.0 * d.M * cout * 9 * cin)
+        return out
+
+    def _ida_up(self, layers, p, startp, endp):
+        """IDAUp.forward dla.py:693-699."""
+        for i in range(startp + 1, endp):
+            k = i - startp
+            wkey = p + ".up_%d.weight" % k
+            if wkey not in self._wcache:
+                w = self.sd[wkey].float()
+                self._wcache[wkey] = (self.dev(w.reshape(w.shape[0], -1)), w.shape[2] // 2)
+            wup, f = self._wcache[wkey]
+            t = self._deform(p + ".proj_%d" % k, layers[i])
+            u = self.upsample_add(p + ".up_%d" % k, t, wup, layers[i - 1], f)
+            layers[i] = self._deform(p + ".node_%d" % k, u)
+
+    def _build_neck(self):
+        layers = list(self.base)
+        out = [layers[-1]]                                   # DLAUp.forward dla.py:728-735
+        for i in range(len(layers) - 2 - 1):
+            self._ida_up(layers, "dla_up.ida_%d" % i, len(layers) - i - 2, len(layers))
+            out.insert(0, layers[-1])
+        y = [out[0], out[1], out[2]]                         # img2feats dla.py:795-799 (clones are views here)
+        self._ida_up(y, "ida_up", 0, 3)
+        self.fmaps = list(self.base) + out + y
+        self.feat = y[-1]
+
+    # ---- heads + decode ------------------------------------------------------
+    def _build_heads(self, dense_heads):
+        sd, N, K = self.sd, self.N, self.K
+        h, w = self.feat.H, self.feat.W
+        self.out_h, self.out_w = h, w
+        self.dense = {}
+        names = ["hm"] + ([k for k in self.heads if k != "hm"] if dense_heads else [])
+        for hd in names:
+            c = self.heads[hd]
+            w0, K0 = pack_conv_weight(sd[hd + ".0.weight"])
+            w1, K1 = pack_conv_weight(sd[hd + ".2.weight"])
+            hid = self.conv(hd + ".0", self.feat, self.dev(w0), K0, 3, 3, 1, 1, 256, None, self.dev(sd[hd + ".0.bias"].float()), True)
+            self.dense[hd] = self.conv(hd + ".2", hid, self.dev(w1), K1, 1, 1, 1, 0, c, None, self.dev(sd[hd + ".2.bias"].float()), False)
+        hm = self.dense["hm"]
+        chm = self.heads["hm"]
+        lib = self.lib
+        cap = h * w * chm
+        self.cand_s = torch.zeros(N * cap, dtype=torch.float32, device=self.device)
+        self.cand_i = torch.zeros(N * cap, dtype=torch.int32, device=self.device)
+        self.cand_n = torch.zeros(N, dtype=torch.int32, device=self.device)
+        self.scores = torch.zeros(N, K, dtype=torch.float32, device=self.device)
+        self.inds = torch.zeros(N, K, dtype=torch.int32, device=self.device)
+        self.clses = torch.zeros(N, K, dtype=torch.int32, device=self.device)
+        self.add("zero", "cand_count", lambda: self.cand_n.zero_())
+        a = (C.c_void_p(hm.addr), N, h, w, chm, hm.ld, ptr(self.cand_s), ptr(self.cand_i), ptr(self.cand_n), cap)
+        self.add("deft_hm_peaks", "hm_peaks", lambda: lib.call("deft_hm_peaks", *a, self._stream()))
+        b = (ptr(self.cand_s), ptr(self.cand_i), ptr(self.cand_n), N, cap, K, h * w, ptr(self.scores), ptr(self.inds), ptr(self.clses))
+        self.add("deft_topk", "topk", lambda: lib.call("deft_topk", *b, self._stream()))
+        # regression heads only at the K peaks
+        reg = [k for k in self.heads if k != "hm"]
+        self.reg_heads = reg
+        self.reg_off = {}
+        off = 0
+        for k in reg:
+            self.reg_off[k] = off
+            off += self.heads[k]
+        Ctot = off
+        self.Ctot = Ctot
+        Cf = self.feat.C
+        w0t = torch.stack([sd[k + ".0.weight"].float().permute(2, 3, 1, 0).reshape(9 * Cf, 256) for k in reg])   # [nh][(r,s,c)][256]
+        b0 = torch.stack([sd[k + ".0.bias"].float() for k in reg])
+        w2 = torch.cat([sd[k + ".2.weight"].float().reshape(self.heads[k], 256) for k in reg])
+        b2 = torch.cat([sd[k + ".2.bias"].float() for k in reg])
+        head_of = torch.tensor([i for i, k in enumerate(reg) for _ in range(self.heads[k])], dtype=torch.int32)
+        w0t, b0, w2, b2, head_of = map(self.dev, (w0t, b0, w2, b2, head_of))
+        self.head_vals = torch.zeros(N, K, Ctot, dtype=torch.float32, device=self.device)
+        self.cts = torch.zeros(N, K, 2, dtype=torch.float32, device=self.device)
+        self.bboxes = torch.zeros(N, K, 4, dtype=torch.float32, device=self.device)
+        c_ = (C.c_void_p(self.feat.addr), N, h, w, Cf, self.feat.ld, ptr(self.inds), K, ptr(w0t), ptr(b0), ptr(w2), ptr(b2),
+              ptr(head_of), len(reg), Ctot, ptr(self.head_vals))
+        self.add("deft_heads_at_peaks", "heads_at_peaks", lambda: lib.call("deft_heads_at_peaks", *c_, self._stream()),
+                 2.0 * N * K * len(reg) * (9 * Cf * 256) + 2.0 * N * K * Ctot * 256)
+        d_ = (ptr(self.inds), ptr(self.head_vals), N, K, w, Ctot, self.reg_off.get("reg", -1), self.reg_off.get("wh", -1),
+              self.reg_off.get("ltrb_amodal", -1), ptr(self.cts), ptr(self.bboxes))
+        self.add("deft_decode_boxes", "decode_boxes", lambda: lib.call("deft_decode_boxes", *d_, self._stream()))
+
+    # ---- public --------------------------------------------------------------
+    def forward(self, images):
+        """images [N,3,H,W] fp32 (detector.py:150).  Runs backbone + neck + hm head + decode.
+        Results stay on the device: self.scores/inds/clses/cts/bboxes/head_vals, self.fmaps."""
+        self.image.copy_(images, non_blocking=True)
+        self.run()
+        return self
+
+    def dets(self):
+        """generic_decode's dict (decode.py:102-196) for the heads present; device tensors."""
+        r = {"scores": self.scores, "clses": self.clses.float(), "inds": self.inds.long(),
+             "xs": self.cts[..., 0], "ys": self.cts[..., 1], "cts": self.cts, "bboxes": self.bboxes}
+        if "ltrb_amodal" in self.reg_off:
+            r["bboxes_amodal"] = self.bboxes
+        for k in ("tracking", "dep", "rot", "dim", "amodel_offset"):
+            if k in self.reg_off:
+                o = self.reg_off[k]
+                r[k] = self.head_vals[..., o:o + self.heads[k]]
+        return r
+
+    def flops(self):
+        return sum(f for _, _, _, f in self.ops)
+
+
+class AfePlan(_Plan):
+    """Embedding extraction at detection centres + pairwise affinity (AFE.py:88-213)."""
+
+    def __init__(self, sd, max_object=100, device="cuda", lib=None):
+        super().__init__(device, lib)
+        self.max_object = max_object
+        nsel = 13
+        self.sel = []
+        off = 0
+        for k in range(nsel):
+            w = sd["AFE.selector.%d.weight" % k].float()          # [Co,C,3,3]
+            Co, Cc = w.shape[0], w.shape[1]
+            wt = w.permute(2, 3, 1, 0).reshape(9 * Cc, Co)        # [(r,s,c)][Co]
+            self.sel.append((self.dev(wt), self.dev(sd["AFE.selector.%d.bias" % k].float()), Co, Cc, off))
+            off += Co
+        self.D = D = off
+        # ---- pair MLP, separable first layer with both BatchNorms folded in fp64 ----
+        a0, b0 = [t.double() for t in _bn_fold(sd, "AFE.stacker2_bn")]
+        W1 = sd["AFE.final_net.0.weight"].double().reshape(512, 2 * D)
+        bias1 = sd["AFE.final_net.0.bias"].double()
+        a1, b1 = [t.double() for t in _bn_fold(sd, "AFE.final_net.1")]
+        W1a, W1b = W1[:, :D], W1[:, D:]
+        Ua = (W1a * a0.view(1, D)) * a1.view(512, 1)                              # U' = x_hist @ Ua^T
+        Vb = (W1b * a0.view(1, D)) * a1.view(512, 1)                              # V' = x_cur @ Vb^T + cb
+        cb = a1 * (bias1 + W1a @ b0 + W1b @ b0) + b1
+        Kd = _rup(D, 32)
+
+        def pack(Wm):
+            out = torch.zeros(_rup(Wm.shape[0], 128), Kd, dtype=torch.float32)
+            out[:Wm.shape[0], :D] = Wm.float()
+            return out
+        self.Ua, self.Vb, self.cb, self.Kd = self.dev(pack(Ua)), self.dev(pack(Vb)), self.dev(cb.float()), Kd
+        self.layers = []
+        for i, bn in ((3, True), (6, True), (9, False)):
+            w = sd["AFE.final_net.%d.weight" % i].float()
+            wp, K = pack_conv_weight(w)
+            bias = sd["AFE.final_net.%d.bias" % i].float()
+            if bn:
+                al, be = _bn_fold(sd, "AFE.final_net.%d" % (i + 1))
+                scale, shift = al, bias * al + be
+            else:
+                scale, shift = None, bias
+            self.layers.append((self.dev(wp), K, w.shape[0], self.dev(scale) if scale is not None else None, self.dev(shift)))
+        self.w5 = self.dev(sd["AFE.final_net.11.weight"].float().reshape(-1))
+        self.b5 = float(sd["AFE.final_net.11.bias"].float().item())
+
+    def extract(self, fmaps, centers):
+        """fmaps: 13 Views (DlaSegPlan.fmaps); centers [Nf, ndet, 2] (x,y in [-1,1], as
+        convert_detection image.py:391-412 produces) -> embeddings [Nf, ndet, D]."""
+        Nf, ndet = centers.shape[0], centers.shape[1]
+        centers = centers.to(self.device, torch.float32).contiguous()
+        out = torch.empty(Nf, ndet, self.D, dtype=torch.float32, device=self.device)
+        s = self._stream()
+        for fm, (wt, b, Co, Cc, off) in zip(fmaps, self.sel):
+            assert fm.C == Cc and fm.N == Nf
+            self.lib.call("deft_embed_map", C.c_void_p(fm.addr), Nf, fm.H, fm.W, fm.C, fm.ld, ptr(wt), ptr(b), Co,
+                          ptr(centers), ndet, ptr(out), self.D, off, s)
+        return out
+
+    def _lin(self, x, M, Cin, ldx, wp, Kpad, Cout, scale, shift, relu, y, ldy):
+        d = GemmDesc()
+        d.x = x.data_ptr(); d.x2 = None; d.w = wp.data_ptr()
+        d.scale = scale.data_ptr() if scale is not None else None
+        d.shift = shift.data_ptr() if shift is not None else None
+        d.res = None; d.y = y.data_ptr()
+        d.N, d.H, d.W, d.Cin, d.ldx = M, 1, 1, Cin, ldx
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, Cout, ldy, 0
+        d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+        d.Ktot, d.Kpad, d.cin_log2, d.M = Cin, Kpad, 0, M
+        d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0
+        self.lib.call("deft_conv2d_nhwc", C.byref(d), self._stream())
+
+    def affinity(self, hist, cur):
+        """hist: list of [P_f, D] embeddings of F stored frames; cur [Q, D].
+        Returns the F matrices [P_f, Q+1] of forward_stacker_features (AFE.py:110-160,
+        fill_up_column=False) as one device tensor [sum P_f, Q+1] plus the row offsets."""
+        dev, D, Kd = self.device, self.D, self.Kd
+        Q = cur.shape[0]
+        starts = [0]
+        for hx in hist:
+            assert hx.shape[0] <= self.max_object
+            starts.append(starts[-1] + hx.shape[0])
+        T = starts[-1]
+        assert 0 < Q <= self.max_object and T > 0
+        xh = torch.zeros(T, Kd, dtype=torch.float32, device=dev)
+        xh[:, :D] = torch.cat([hx.to(dev, torch.float32) for hx in hist], 0)
+        xc = torch.zeros(Q, Kd, dtype=torch.float32, device=dev)
+        xc[:, :D] = cur.to(dev, torch.float32)
+        U = torch.empty(T, 512, dtype=torch.float32, device=dev)
+        V = torch.empty(Q, 512, dtype=torch.float32, device=dev)
+        self._lin(xh, T, Kd, Kd, self.Ua, Kd, 512, None, None, False, U, 512)
+        self._lin(xc, Q, Kd, Kd, self.Vb, Kd, 512, None, self.cb, False, V, 512)
+        M = T * Q
+        (w2, K2, c2, s2, t2), (w3, K3, c3, s3, t3), (w4, K4, c4, s4, t4) = self.layers
+        h2 = torch.empty(M, c2, dtype=torch.float32, device=dev)
+        d = GemmDesc()
+        d.x = U.data_ptr(); d.x2 = V.data_ptr(); d.w = w2.data_ptr()
+        d.scale = s2.data_ptr(); d.shift = t2.data_ptr(); d.res = None; d.y = h2.data_ptr()
+        d.N, d.H, d.W, d.Cin, d.ldx = M, 1, 1, 512, 512
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, c2, c2, 0
+        d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+        d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
+        d.relu = 1; d.Q = Q; d.ldom = 0; d.tile = 0
+        self.lib.call("deft_pair_layer", C.byref(d), self._stream())
+        h3 = torch.empty(M, c3, dtype=torch.float32, device=dev)
+        self._lin(h2, M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, h3, c3)
+        h4 = torch.empty(M, c4, dtype=torch.float32, device=dev)
+        self._lin(h3, M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, h4, c4)
+        out = torch.empty(T, Q + 1, dtype=torch.float32, device=dev)
+        rs = torch.tensor(starts, dtype=torch.int32, device=dev)
+        self.lib.call("deft_affinity_finish", ptr(h4), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(rs), len(hist), Q,
+                      self.max_object, ptr(out), self._stream())
+        return out, starts
+
+    @staticmethod
+    def affinity_flops(T, Q, D):
+        return 2.0 * (T + Q) * D * 512 + 2.0 * T * Q * (512 * 256 + 256 * 128 + 128 * 64 + 64)
+
+
+class LstmPlan(_Plan):
+    """Batched KalmanFilterLSTM.predict (kalman_filter_lstm.py:65-78)."""
+
+    def __init__(self, lsd, device="cuda", lib=None):
+        super().__init__(device, lib)
+        self.nin = lsd["lstm.weight_ih_l0"].shape[1]
+        self.nout = lsd["out2.weight"].shape[0]
+        self.wih_t = self.dev(lsd["lstm.weight_ih_l0"].float().t())
+        self.whh_t = self.dev(lsd["lstm.weight_hh_l0"].float().t())
+        self.bias = self.dev(lsd["lstm.bias_ih_l0"].float() + lsd["lstm.bias_hh_l0"].float())
+        self.w1_t = self.dev(lsd["out1.weight"].float().t())
+        self.b1 = self.dev(lsd["out1.bias"].float())
+        self.w2_t = self.dev(lsd["out2.weight"].float().t())
+        self.b2 = self.dev(lsd["out2.bias"].float())
+
+    def step(self, x, h, c):
+        """x [T,nin]; h,c [T,128] updated IN PLACE; returns pred [T, nout//4, 4]."""
+        T = x.shape[0]
+        x = x.to(self.device, torch.float32).contiguous()
+        assert h.is_contiguous() and c.is_contiguous() and h.device == self.device
+        pred = torch.empty(T, self.nout, dtype=torch.float32, device=self.device)
+        self.lib.call("deft_lstm_step", ptr(x), ptr(h), ptr(c), T, self.nin, self.nout, ptr(self.wih_t), ptr(self.whh_t),
+                      ptr(self.bias), ptr(self.w1_t), ptr(self.b1), ptr(self.w2_t), ptr(self.b2), ptr(pred), self._stream())
+        return pred.view(T, -1, 4)

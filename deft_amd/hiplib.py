@@ -1,0 +1,107 @@
+"""ctypes binding of libdeft_hip.so (include/deft_hip.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  `get_lib()`
+raises if deft_amd/lib/libdeft_hip.so (built by `python -m deft_amd.build` /
+__graft_entry__.build()) is missing.  The unit tests may hand an explicitly
+built emulator object (tests/hipemu) to `load(path)`; nothing in this package
+ever selects it.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdeft_hip.so")
+
+c_fp = C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    """Mirror of DeftGemmDesc (include/deft_hip.h)."""
+    _fields_ = [
+        ("x", c_fp), ("x2", c_fp), ("w", c_fp), ("scale", c_fp), ("shift", c_fp), ("res", c_fp), ("y", c_fp),
+        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("ldx", C.c_int),
+        ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int), ("ldy", C.c_int), ("ldr", C.c_int),
+        ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("Ktot", C.c_int), ("Kpad", C.c_int), ("cin_log2", C.c_int), ("M", C.c_int),
+        ("relu", C.c_int), ("Q", C.c_int), ("ldom", C.c_int), ("tile", C.c_int),
+    ]
+
+
+_SIGS = {
+    "deft_version": (C.c_int, []),
+    "deft_last_error": (C.c_char_p, []),
+    "deft_conv2d_nhwc": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "deft_dcn_v2_nhwc": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "deft_pair_layer": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "deft_nchw_to_nhwc": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
+    "deft_nhwc_to_nchw": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
+    "deft_maxpool2x2": (C.c_int, [c_fp, c_fp] + [C.c_int] * 6 + [c_fp]),
+    "deft_upsample_add": (C.c_int, [c_fp] * 4 + [C.c_int] * 8 + [c_fp]),
+    "deft_hm_peaks": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp] * 3 + [C.c_int, c_fp]),
+    "deft_topk": (C.c_int, [c_fp] * 3 + [C.c_int] * 4 + [c_fp] * 3 + [c_fp]),
+    "deft_heads_at_peaks": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, C.c_int] + [c_fp] * 5 + [C.c_int] * 2 + [c_fp, c_fp]),
+    "deft_decode_boxes": (C.c_int, [c_fp, c_fp] + [C.c_int] * 7 + [c_fp] * 3),
+    "deft_embed_map": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp]),
+    "deft_affinity_finish": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_float, c_fp] + [C.c_int] * 3 + [c_fp, c_fp]),
+    "deft_lstm_step": (C.c_int, [c_fp] * 3 + [C.c_int] * 3 + [c_fp] * 8 + [c_fp]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+class DeftHipError(RuntimeError):
+    pass
+
+
+class HipLib:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise DeftHipError(
+                "HIP extension missing: %s -- run `python -m deft_amd.build` "
+                "(hipcc --offload-arch=gfx950); deft_amd has no CPU fallback" % path)
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self.cdll, name)          # AttributeError if a symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        v = self.cdll.deft_version()
+        if v != 1:
+            raise DeftHipError("libdeft_hip ABI version %d, expected 1" % v)
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise DeftHipError("%s failed (%d): %s" % (name, rc, self.cdll.deft_last_error().decode()))
+
+
+_lib = None
+
+
+def load(path):
+    """Load a specific shared object (tests use this with the emulator build)."""
+    global _lib
+    _lib = HipLib(path)
+    return _lib
+
+
+def get_lib():
+    global _lib
+    if _lib is None:
+        _lib = HipLib(LIB_PATH)
+    return _lib
+
+
+def ptr(t):
+    """Device (or, under the test emulator, host) address of a tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.dtype in (torch.float32, torch.int32), t.dtype
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    if device.type == "cuda":
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return None

@@ -1,0 +1,145 @@
+/* deft_hip.h -- C ABI of libdeft_hip.so: the MI355X (gfx950) kernels behind DEFT's
+ * per-frame hot path.  Plain pointers and sizes only; every pointer is DEVICE memory
+ * owned by the caller (PyTorch-ROCm tensors in the Python host), every call is
+ * asynchronous on `stream` (a hipStream_t passed as void*), returns 0 on success or
+ * a negative code with text in deft_last_error().  The library allocates nothing.
+ *
+ * Tensors are fp32 NHWC: element (n,y,x,c) of a map lives at
+ *     base[((n*H + y)*W + x)*ld + c],   ld >= C, ld % 4 == 0
+ * (ld lets a producer write straight into a channel slice of a concat buffer --
+ * DLA's Root nodes, dla.py:199-207, never materialise torch.cat).
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to the reference repo MedChaabane/DEFT).
+ */
+#ifndef DEFT_HIP_H
+#define DEFT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEFT_ABI_VERSION 1
+
+/* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
+typedef struct DeftGemmDesc {
+    const float* x;      /* conv/dcn: input map NHWC.  pair: U' [T][ldx]                    */
+    const float* x2;     /* dcn: offset/mask map [M][ldom] (ch 2k=dy_k, 2k+1=dx_k, 18+k=mask
+                            logit).  pair: V' [Q][ldx].  conv: unused                        */
+    const float* w;      /* packed weights [CoutPad][Kpad], k = (r*KW+s)*Cin + c, zero padded */
+    const float* scale;  /* per-Cout epilogue scale (NULL = 1)  -- folded BatchNorm gamma/std */
+    const float* shift;  /* per-Cout epilogue shift (NULL = 0)  -- folded bias / BN beta      */
+    const float* res;    /* optional residual map added before ReLU (NULL = none)            */
+    float* y;            /* output NHWC / [M][ldy]                                            */
+    int N, H, W, Cin, ldx;        /* input geometry                                          */
+    int OH, OW, Cout, ldy, ldr;   /* output geometry, residual pixel stride                  */
+    int KH, KW, stride, pad;
+    int Ktot, Kpad;               /* KH*KW*Cin and its multiple-of-32 padding                */
+    int cin_log2;                 /* log2(Cin) when KH*KW > 1 (Cin must be a power of two)   */
+    int M;                        /* GEMM rows: N*OH*OW (conv/dcn) or T*Q (pair)             */
+    int relu;                     /* apply max(.,0) last                                     */
+    int Q;                        /* pair: number of current-frame objects                   */
+    int ldom;                     /* dcn: pixel stride of x2                                 */
+    int tile;                     /* 0 = auto; else (BM<<16)|BN to force a tile config       */
+} DeftGemmDesc;
+
+int deft_version(void);
+const char* deft_last_error(void);
+
+/* Conv2d (+folded BatchNorm, +residual, +ReLU) as an FP32-MFMA implicit GEMM.
+ * Replaces every nn.Conv2d/BatchNorm2d/ReLU triple of DLA-34 and the heads:
+ * dla.py:47-87 (BasicBlock), :184-207 (Root), :301-345 (base/levels),
+ * base_model.py:37-66 (heads), AFE.py:331-347 (final_net 1x1 stack). */
+int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream);
+
+/* DCNv2 main contraction: bilinear offset gather * sigmoid(mask) fused into the
+ * A-operand loader (no global im2col buffer), then +bias/BN/ReLU epilogue.
+ * Replaces dcn_v2.DCN.forward (third-party CharlesShang/DCNv2, imported at
+ * dla.py:25-29, constructed dla.py:652-660, called dla.py:663) together with
+ * DeformConv.actf (dla.py:649-651).  x2 is produced by deft_conv2d_nhwc with the
+ * conv_offset_mask weights (Cout 27 -> ld 32). */
+int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream);
+
+/* Pair-MLP layer 2 of the affinity estimator: A[(i,j)][k] = relu(U'[i][k]+V'[j][k])
+ * generated on the fly (the separable form of final_net.0+BN+ReLU over the PxQ grid).
+ * Replaces AFE_module.forward_stacker2 + the first two blocks of forward_final
+ * (AFE.py:190-213) without materialising the [1,832,100,100] tensor. */
+int deft_pair_layer(const DeftGemmDesc* d, void* stream);
+
+/* [N,C,H,W] -> NHWC with channel padding to ld (zeros), and back.  Boundary
+ * adapters for detector.py:150 (images) and for handing FeatureMaps out as NCHW. */
+int deft_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ldy, void* stream);
+int deft_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int ldx, void* stream);
+
+/* MaxPool2d(2,2) -- Tree.downsample, dla.py:266-267, 273. */
+int deft_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, int ldx, int ldy, void* stream);
+
+/* Depthwise ConvTranspose2d(k=2f, stride f, pad f/2) + skip add:
+ * y = up(x) + skip  -- IDAUp.forward dla.py:696-699 (`upsample(project(l[i])) + l[i-1]`).
+ * x is [N,H,W,C]; skip and y are [N,f*H,f*W,C]; wup is the module's weight [C][2f*2f]. */
+int deft_upsample_add(const float* x, const float* wup, const float* skip, float* y,
+                      int N, int H, int W, int C, int f, int ldx, int lds, int ldy, void* stream);
+
+/* sigmoid + 3x3 peak NMS + candidate compaction (detector.py:488, utils.py:69-74).
+ * hm: logits NHWC [N,H,W,C] (ld).  For every (n) appends (score, c*H*W + y*W + x)
+ * of every local maximum to cand_*[n*cap ...]; cand_count[n] must be zeroed by the
+ * caller (hipMemsetAsync) before the call. */
+int deft_hm_peaks(const float* hm, int N, int H, int W, int C, int ld,
+                  float* cand_score, int* cand_idx, int* cand_count, int cap, void* stream);
+
+/* top-K over the candidates, descending score, ties by ascending index
+ * (utils.py:89-104 `_topk`: per-class top-K then top-K of the union == global top-K).
+ * Outputs per frame: score[K], ind[K] (= y*W+x), cls[K].  Missing entries (fewer
+ * than K peaks) get score 0, ind 0, cls 0. */
+int deft_topk(const float* cand_score, const int* cand_idx, const int* cand_count,
+              int N, int cap, int K, int HW, float* out_score, int* out_ind, int* out_cls, void* stream);
+
+/* Regression heads evaluated ONLY at the K peak pixels (they are only ever gathered
+ * there: decode.py:120-196 via utils.py:32-36): for head h, 3x3(64->256)+bias+ReLU
+ * then 1x1(256->c_h)+bias.  w0t [nheads][9*Cf][256] (k=(r*3+s)*Cf+c), b0 [nheads][256],
+ * w2 [Ctot][256], b2 [Ctot], head_of [Ctot] (which hidden vector an output uses).
+ * out [N][K][Ctot]. */
+int deft_heads_at_peaks(const float* feat, int N, int H, int W, int Cf, int ld,
+                        const int* inds, int K, const float* w0t, const float* b0,
+                        const float* w2, const float* b2, const int* head_of,
+                        int nheads, int Ctot, float* out, void* stream);
+
+/* Box assembly of generic_decode (decode.py:118-196): from (ind, head values) to
+ * xs, ys, bboxes.  off_* are channel offsets into `heads` rows (-1 = head absent).
+ * cts [N][K][2], bboxes [N][K][4]. */
+int deft_decode_boxes(const int* inds, const float* heads, int N, int K, int Wm, int Ctot,
+                      int off_reg, int off_wh, int off_ltrb_amodal,
+                      float* cts, float* bboxes, void* stream);
+
+/* Embedding head for one feature map: ReLU(3x3 selector conv) evaluated only at the
+ * 4 bilinear neighbours of each detection centre, then the grid_sample blend
+ * (bilinear, padding_mode=border, align_corners=False).  Replaces
+ * AFE_module.forward_selector_stacker1 (AFE.py:162-188) for one (map, selector) pair.
+ * fmap NHWC [Nf,H,W,C]; wsel_t [9*C][Co] (k=(r*3+s)*C+c); centers [Nf][ndet][2] (x,y in
+ * [-1,1]); out[(n*ndet+i)*ldo + col_off + o]. */
+int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, int ld,
+                   const float* wsel_t, const float* bsel, int Co,
+                   const float* centers, int ndet, float* out, int ldo, int col_off, void* stream);
+
+/* Tail of the affinity estimator for F history frames against one current frame:
+ * x = relu(h4 . w5 + b5) per pair, then the dual softmax with the analytic padding
+ * terms ((max_object - n) * e^0 + e^1) and the max/unmatched-column assembly
+ * (AFE.py:119-150).  h4 [T*Q][ldh] (pairs ordered (t,j)), row_start [F+1] prefix of
+ * history object counts (T = row_start[F]); out [T][Q+1]. */
+int deft_affinity_finish(const float* h4, int ldh, int C4, const float* w5, float b5,
+                         const int* row_start, int F, int Q, int max_object,
+                         float* out, void* stream);
+
+/* One LSTM step + two Linears for T tracks at once.  Replaces the per-track
+ * KalmanFilterLSTM.predict (kalman_filter_lstm.py:65-78).  wih_t [nin][512],
+ * whh_t [128][512] (transposed), bias [512] (= b_ih + b_hh), w1_t [128][64], b1 [64],
+ * w2_t [64][nout], b2 [nout].  x [T][nin]; h,c [T][128] updated in place; pred [T][nout]. */
+int deft_lstm_step(const float* x, float* h, float* c, int T, int nin, int nout,
+                   const float* wih_t, const float* whh_t, const float* bias,
+                   const float* w1_t, const float* b1, const float* w2_t, const float* b2,
+                   float* pred, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFT_HIP_H */

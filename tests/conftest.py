@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU emulation test")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """libdeft_emu.so: the unmodified HIP sources compiled against the SIMT emulator
+    (tests/hipemu).  Test infrastructure only -- the product never loads it."""
+    import subprocess
+    from deft_amd import hiplib
+    so = os.path.join(ROOT, "tests", "hipemu", "_build", "libdeft_emu.so")
+    srcs = [os.path.join(ROOT, "deft_amd", "csrc", f) for f in ("igemm.hip", "ops.hip", "common.h")]
+    srcs += [os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "deft_hip.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh")])
+    return hiplib.HipLib(so)
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    import torch
+    from deft_amd import hiplib
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return hiplib.get_lib()      # raises loudly if libdeft_hip.so is missing

@@ -1,0 +1,242 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny single-process SIMT emulator that lets the
+// UNMODIFIED HIP sources in deft_amd/csrc be compiled for the host (clang++,
+// -I tests/hipemu shadows <hip/hip_runtime.h>) and executed on CPU pointers, so
+// kernel indexing / MFMA fragment logic can be unit-tested in the GPU-less build
+// container.  It is NOT a fallback: the product loader (deft_amd/hiplib.py) only
+// ever loads libdeft_hip.so built by hipcc for gfx950; this header is reachable
+// from tests/ alone (tests/hipemu/build_emu.sh -> tests/hipemu/_build/libdeft_emu.so).
+//
+// Model: one fiber (ucontext) per GPU thread, blocks run one after another.
+// Wave-level collectives (MFMA, shuffles) rendezvous the 64 lanes of a wave;
+// __syncthreads() rendezvous the block.  MFMA lane<->element maps follow
+// /opt/skills/guides/cdna_hip_programming.md §3 (gfx950):
+//   32x32x2 f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+//                 D reg r -> row=(r&3)+8*(r>>2)+4*(l>>5), col=l&31
+//   16x16x4 f32 : A[l&15][k=l>>4],  B[k=l>>4][l&15], D reg r -> row=(l>>4)*4+r, col=l&15
+// and accumulate as a k-ordered fmaf chain (bit-exact with the hardware).
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct int2 { int x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+
+namespace hipemu {
+enum Yield { Y_NONE = 0, Y_WAVE = 1, Y_BLOCK = 2, Y_DONE = 3 };
+struct State {
+    dim3 tid, bid, bdim, gdim;
+    int lane = 0, wave = 0;
+    ucontext_t sched, *cur = nullptr;
+    int yield_code = 0;
+    // wave exchange buffers: [parity][slot][lane]
+    float xf[2][2][64];
+    int parity = 0;
+};
+inline State& S() { static State s; return s; }
+inline void yield(int code) {
+    State& s = S();
+    s.yield_code = code;
+    swapcontext(s.cur, &s.sched);
+}
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    int state = Y_NONE;
+};
+inline std::function<void()>& body() { static std::function<void()> f; return f; }
+inline void trampoline() {
+    body()();
+    yield(Y_DONE);
+}
+
+inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, dim3 bid) {
+    State& s = S();
+    const int nthr = block.x * block.y * block.z;
+    static std::vector<Fiber> fibers;
+    if ((int)fibers.size() < nthr) fibers.resize(nthr);
+    body() = fn;
+    for (int t = 0; t < nthr; ++t) {
+        Fiber& f = fibers[t];
+        if (f.stack.empty()) f.stack.resize(256 * 1024);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        f.state = Y_NONE;
+    }
+    const int nwave = (nthr + 63) / 64;
+    std::vector<int> wparity(nwave, 0);
+    auto resume = [&](int t) {
+        Fiber& f = fibers[t];
+        s.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        s.bid = bid; s.bdim = block; s.gdim = grid;
+        s.lane = t & 63; s.wave = t >> 6;
+        s.parity = wparity[t >> 6];
+        s.cur = &f.ctx;
+        swapcontext(&s.sched, &f.ctx);
+        f.state = s.yield_code;
+    };
+    for (;;) {
+        int done = 0;
+        for (int w = 0; w < nwave; ++w) {
+            const int t0 = w * 64, t1 = (t0 + 64 < nthr) ? t0 + 64 : nthr;
+            for (;;) {
+                for (int t = t0; t < t1; ++t)
+                    if (fibers[t].state == Y_NONE) resume(t);
+                int nw = 0, nb = 0, nd = 0;
+                for (int t = t0; t < t1; ++t) {
+                    nw += fibers[t].state == Y_WAVE;
+                    nb += fibers[t].state == Y_BLOCK;
+                    nd += fibers[t].state == Y_DONE;
+                }
+                if (nw == t1 - t0) {            // whole wave at a wave collective -> release
+                    wparity[w] ^= 1;
+                    for (int t = t0; t < t1; ++t) fibers[t].state = Y_NONE;
+                    continue;
+                }
+                if (nw != 0) {
+                    fprintf(stderr, "hipemu: divergent wave collective (wave %d: %d at op, %d at barrier, %d done)\n", w, nw, nb, nd);
+                    abort();
+                }
+                break;                          // all lanes at block barrier or done
+            }
+        }
+        int nb = 0;
+        for (int t = 0; t < nthr; ++t) { nb += fibers[t].state == Y_BLOCK; done += fibers[t].state == Y_DONE; }
+        if (done == nthr) return;
+        if (nb + done != nthr) { fprintf(stderr, "hipemu: scheduler stuck\n"); abort(); }
+        for (int t = 0; t < nthr; ++t)
+            if (fibers[t].state == Y_BLOCK) fibers[t].state = Y_NONE;
+    }
+}
+
+template <typename F>
+inline void launch(F&& fn, dim3 grid, dim3 block) {
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) run_block(fn, grid, block, dim3(x, y, z));
+}
+
+// wave exchange: deposit up to two floats, rendezvous, then read any lane's deposit
+inline void exchange(float a, float b, const float*& ra, const float*& rb) {
+    State& s = S();
+    const int p = s.parity ^ 1;               // buffer for THIS op (parity flips on release)
+    const int lane = s.lane;
+    s.xf[p][0][lane] = a;
+    s.xf[p][1][lane] = b;
+    yield(Y_WAVE);
+    ra = S().xf[p][0];
+    rb = S().xf[p][1];
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::S().tid)
+#define blockIdx (hipemu::S().bid)
+#define blockDim (hipemu::S().bdim)
+#define gridDim (hipemu::S().gdim)
+static const int warpSize = 64;
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
+
+static inline void __syncthreads() { hipemu::yield(hipemu::Y_BLOCK); }
+
+typedef float __attribute__((ext_vector_type(16))) hipemu_f32x16;
+typedef float __attribute__((ext_vector_type(4))) hipemu_f32x4;
+
+static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+    const float *A, *B;
+    const int lane = hipemu::S().lane;
+    hipemu::exchange(a, b, A, B);
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(A[row + 32 * k], B[col + 32 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+    const float *A, *B;
+    const int lane = hipemu::S().lane;
+    hipemu::exchange(a, b, A, B);
+    const int col = lane & 15, q = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = q * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(A[row + 16 * k], B[col + 16 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+static inline float __shfl_xor(float v, int mask, int = 64) {
+    const float *A, *B; const int lane = hipemu::S().lane;
+    hipemu::exchange(v, 0.f, A, B);
+    return A[(lane ^ mask) & 63];
+}
+static inline float __shfl_down(float v, int d, int = 64) {
+    const float *A, *B; const int lane = hipemu::S().lane;
+    hipemu::exchange(v, 0.f, A, B);
+    return A[lane + d < 64 ? lane + d : lane];
+}
+static inline float __shfl(float v, int src, int = 64) {
+    const float *A, *B;
+    hipemu::exchange(v, 0.f, A, B);
+    return A[src & 63];
+}
+static inline int __shfl_xor(int v, int mask, int = 64) {
+    float f; memcpy(&f, &v, 4); f = __shfl_xor(f, mask); memcpy(&v, &f, 4); return v;
+}
+static inline int __shfl_down(int v, int d, int = 64) {
+    float f; memcpy(&f, &v, 4); f = __shfl_down(f, d); memcpy(&v, &f, 4); return v;
+}
+static inline int __shfl(int v, int src, int = 64) {
+    float f; memcpy(&f, &v, 4); f = __shfl(f, src); memcpy(&v, &f, 4); return v;
+}
+static inline unsigned __shfl_xor(unsigned v, int mask, int = 64) { return (unsigned)__shfl_xor((int)v, mask); }
+static inline unsigned __shfl_down(unsigned v, int d, int = 64) { return (unsigned)__shfl_down((int)v, d); }
+
+template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}

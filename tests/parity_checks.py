@@ -1,0 +1,296 @@
+"""Parity checks shared by the CPU-emulator tests (-m "not gpu") and the real
+MI355X tests (-m gpu).  Every check drives the C ABI (through deft_amd.engine /
+deft_amd.hiplib) and compares with the oracle (oracle/deft_oracle.py) or with a
+plain torch fp32 op on the same seeded inputs.  Tolerances are written here:
+  * integer / index outputs: exact
+  * floats: max-abs <= 1e-3 (BASELINE.json north_star), most checks far tighter
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import deft_oracle as O
+from deft_amd import engine
+
+TOL = 1e-3
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def T(bm, bn):
+    return (bm << 16) | bn
+
+
+def maxabs(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def fill_view(v, x_nchw):
+    v.buf.view(v.N, v.H, v.W, v.ld)[..., v.c0:v.c0 + x_nchw.shape[1]] = x_nchw.permute(0, 2, 3, 1).to(v.buf.device)
+
+
+# ---------------------------------------------------------------------------
+def check_conv(lib, device, N, H, W, Ci, Co, k, stride, pad, tile, res=False, relu=True, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    plan = engine._Plan(device, lib)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (Ci * k * k) ** 0.5)
+    scale = torch.rand(Co, generator=g) + 0.5
+    shift = torch.randn(Co, generator=g)
+    cp = (Ci + 3) // 4 * 4
+    xv = plan.alloc(N, H, W, cp)
+    fill_view(xv, x)
+    wp, K = engine.pack_conv_weight(w, cp)
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W + 2 * pad - k) // stride + 1
+    rv = r = None
+    if res:
+        r = torch.randn(N, Co, OH, OW, generator=g)
+        rv = plan.alloc(N, OH, OW, Co)
+        fill_view(rv, r)
+    out = plan.conv("c", xv, plan.dev(wp), K, k, k, stride, pad, Co, plan.dev(scale), plan.dev(shift), relu, res=rv, tile=tile)
+    plan.run()
+    ref = F.conv2d(x, w, None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    err = maxabs(out.to_nchw(), ref)
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), ("conv", N, H, W, Ci, Co, k, stride, tile, err)
+    return err
+
+
+def check_concat_conv(lib, device):
+    """Root-style 1x1 conv reading a channel-concat buffer in place, output written
+    into a channel slice of another buffer (dla.py:199-207)."""
+    g = torch.Generator().manual_seed(3)
+    plan = engine._Plan(device, lib)
+    N, H, W = 1, 6, 9
+    a = torch.randn(N, 64, H, W, generator=g); b = torch.randn(N, 32, H, W, generator=g)
+    cat = plan.alloc(N, H, W, 96)
+    fill_view(cat.sub(0, 64), a); fill_view(cat.sub(64, 32), b)
+    w = torch.randn(48, 96, 1, 1, generator=g) * 0.1
+    wp, K = engine.pack_conv_weight(w)
+    dst = plan.alloc(N, H, W, 80)
+    out = plan.conv("root", cat, plan.dev(wp), K, 1, 1, 1, 0, 48, None, None, False, out=dst.sub(16, 48))
+    # and a conv that reads only the slice b
+    w2 = torch.randn(16, 32, 3, 3, generator=g) * 0.1
+    wp2, K2 = engine.pack_conv_weight(w2)
+    out2 = plan.conv("slice", cat.sub(64, 32), plan.dev(wp2), K2, 3, 3, 1, 1, 16, None, None, False, out=dst.sub(0, 16))
+    plan.run()
+    assert maxabs(out.to_nchw(), F.conv2d(torch.cat([a, b], 1), w)) <= 2e-5
+    assert maxabs(out2.to_nchw(), F.conv2d(b, w2, None, 1, 1)) <= 2e-5
+    assert float(dst.buf.view(N, H, W, 80)[..., 64:].abs().max()) == 0.0   # untouched slice
+
+
+def check_dcn(lib, device, N, H, W, Ci, Co, tile=0, seed=0, big_offsets=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w_off = torch.randn(27, Ci, 3, 3, generator=g) * ((2.0 if big_offsets else 0.5) / (Ci * 9) ** 0.5)
+    b_off = torch.randn(27, generator=g) * (3.0 if big_offsets else 0.5)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * (1.0 / (Ci * 9) ** 0.5)
+    b = torch.randn(Co, generator=g) * 0.1
+    sd = {"d.conv.weight": w, "d.conv.bias": b, "d.conv.conv_offset_mask.weight": w_off,
+          "d.conv.conv_offset_mask.bias": b_off, "d.actf.0.weight": torch.rand(Co, generator=g) + 0.5,
+          "d.actf.0.bias": torch.randn(Co, generator=g) * 0.2, "d.actf.0.running_mean": torch.randn(Co, generator=g) * 0.2,
+          "d.actf.0.running_var": torch.rand(Co, generator=g) + 0.5}
+    plan = engine.DlaSegPlan.__new__(engine.DlaSegPlan)
+    engine._Plan.__init__(plan, device, lib)
+    plan.sd = sd; plan._wcache = {}
+    xv = plan.alloc(N, H, W, Ci)
+    fill_view(xv, x)
+    if tile:
+        out = _deform_tiled(plan, "d", xv, tile)
+    else:
+        out = plan._deform("d", xv)
+    plan.run()
+    ref = O.deform_conv(x, sd, "d")
+    err = maxabs(out.to_nchw(), ref)
+    assert err <= 5e-5 * max(1.0, float(ref.abs().max())), ("dcn", N, H, W, Ci, Co, err)
+    return err
+
+
+def _deform_tiled(plan, p, xv, tile):
+    out = plan._deform(p, xv)
+    kind, name, fn, fl = plan.ops[-1]
+    plan._keep[-1].tile = tile      # last kept object is the dcn descriptor
+    return out
+
+
+def check_pool_upsample(lib, device):
+    g = torch.Generator().manual_seed(1)
+    plan = engine._Plan(device, lib)
+    N, H, W, Cc = 2, 6, 10, 8
+    x = torch.randn(N, Cc, H, W, generator=g)
+    xv = plan.alloc(N, H, W, Cc); fill_view(xv, x)
+    mp = plan.maxpool("mp", xv)
+    outs = []
+    for f in (2, 4):
+        wup = torch.rand(Cc, 1, 2 * f, 2 * f, generator=g)
+        skip = torch.randn(N, Cc, H * f, W * f, generator=g)
+        sv = plan.alloc(N, H * f, W * f, Cc); fill_view(sv, skip)
+        up = plan.upsample_add("up", xv, plan.dev(wup.reshape(Cc, -1)), sv, f)
+        outs.append((up, F.conv_transpose2d(x, wup, None, stride=f, padding=f // 2, groups=Cc) + skip))
+    plan.run()
+    assert maxabs(mp.to_nchw(), F.max_pool2d(x, 2, 2)) == 0.0
+    for up, ref in outs:
+        assert maxabs(up.to_nchw(), ref) <= 1e-5
+
+
+def check_layout(lib, device):
+    import ctypes as C
+    from deft_amd.hiplib import ptr, stream_ptr
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 5, 7, generator=g).to(device)
+    y = torch.full((2, 5, 7, 4), 9.0, device=device)
+    lib.call("deft_nchw_to_nhwc", ptr(x), ptr(y), 2, 3, 5, 7, 4, stream_ptr(torch.device(device)))
+    assert torch.equal(y[..., :3].cpu(), x.permute(0, 2, 3, 1).cpu()) and float(y[..., 3].abs().max()) == 0.0
+    z = torch.empty(2, 3, 5, 7, device=device)
+    lib.call("deft_nhwc_to_nchw", ptr(y), ptr(z), 2, 3, 5, 7, 4, stream_ptr(torch.device(device)))
+    assert torch.equal(z.cpu(), x.cpu())
+
+
+# ---------------------------------------------------------------------------
+def check_forward(lib, device, dataset, H, W, golden_tag=None, N=1, sd=None):
+    """Whole DLA-34 + DCN + heads + decode vs the oracle (and the golden fixture)."""
+    sd = sd if sd is not None else O.synth_state_dict(dataset)
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0))
+    xs = x if N == 1 else torch.cat([x] + [torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(10 + i)) for i in range(N - 1)])
+    with torch.no_grad():
+        ora_out, ora_maps = O.dlaseg_forward(xs, sd, dataset)
+    gold = np.load(os.path.join(GOLD, "forward_%s.npz" % golden_tag)) if golden_tag else None
+    if gold is not None:
+        K = int(gold["det_K"])
+    else:   # torch.topk's order among the zero (non-peak) entries is arbitrary: keep K <= #peaks
+        sg = torch.sigmoid(ora_out["hm"])
+        npk = min(int(((F.max_pool2d(sg, 3, 1, 1) == sg)[n]).sum()) for n in range(N))
+        K = max(1, min(100 if npk >= 150 else 20, npk - 1))
+    plan = engine.DlaSegPlan(sd, N, H, W, dataset, K=K, device=device, lib=lib, dense_heads=True)
+    plan.forward(xs.to(device))
+    report = {}
+    for k in range(13):
+        got = plan.fmaps[k].to_nchw().cpu()
+        err = maxabs(got, ora_maps[k])
+        scale = max(1.0, float(ora_maps[k].abs().max()))
+        report["fmap%d" % k] = err
+        assert err <= 1e-4 * scale, ("fmap", k, err, scale)
+        if gold is not None:
+            ref = torch.from_numpy(gold["fmap%d_val" % k])
+            assert maxabs(got[0:1].reshape(-1)[torch.from_numpy(gold["fmap%d_idx" % k])], ref) <= 1e-4 * scale
+    for h in plan.dense:
+        got = plan.dense[h].to_nchw().cpu()
+        err = maxabs(got, ora_out[h])
+        report["head_" + h] = err
+        assert err <= 1e-4 * max(1.0, float(ora_out[h].abs().max())), ("head", h, err)
+    # decode: bit-exact top-k indices, floats within TOL
+    ora_d = O.generic_decode(O.sigmoid_output(ora_out), K=K)
+    d = {k: v.cpu() for k, v in plan.dets().items()}
+    assert torch.equal(d["inds"], ora_d["inds"]), "top-k indices differ from the oracle"
+    assert torch.equal(d["clses"], ora_d["clses"])
+    for k in ["scores", "xs", "ys", "bboxes", "tracking"] + [k for k in ("dep", "rot", "dim", "amodel_offset") if k in ora_d]:
+        ref = ora_d[k]
+        if k == "dep":      # sigmoid transform is applied by Detector (detector.py:491-493); compare raw gather
+            ref = O._gather_at(ora_out["dep"], ora_d["inds"])
+        err = maxabs(d[k], ref)
+        report["det_" + k] = err
+        assert err <= TOL, ("dets", k, err)
+    if gold is not None:
+        assert torch.equal(d["inds"][0:1], torch.from_numpy(gold["det_inds"])), "top-k indices differ from the golden fixture"
+        for k in ["scores", "bboxes", "tracking"]:
+            assert maxabs(d[k][0:1], torch.from_numpy(gold["det_" + k])) <= TOL
+    return plan, report, (ora_out, ora_maps)
+
+
+def check_embed(lib, device, plan, ora_maps, sd, golden_tag=None, ndet=12):
+    afe = engine.AfePlan(sd, 100, device, lib)
+    if golden_tag:
+        gold = np.load(os.path.join(GOLD, "forward_%s.npz" % golden_tag))
+        centers = torch.from_numpy(gold["emb_centers"])            # [1,n,1,1,2]
+    else:
+        centers = torch.rand(1, ndet, 1, 1, 2, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    n = centers.shape[1]
+    Nf = plan.N
+    cs = centers.view(1, n, 2).repeat(Nf, 1, 1)
+    emb = afe.extract(plan.fmaps, cs).cpu()
+    for f in range(Nf):
+        ref = O.afe_extract([m[f:f + 1] for m in ora_maps], centers, sd)
+        err = maxabs(emb[f:f + 1], ref)
+        assert err <= 1e-4 * max(1.0, float(ref.abs().max())), ("embed", f, err)
+    if golden_tag and Nf >= 1:
+        assert maxabs(emb[0:1], torch.from_numpy(gold["emb"])) <= 1e-4 * max(1.0, float(np.abs(gold["emb"]).max()))
+    return afe, emb
+
+
+def check_affinity(lib, device, sd, shapes=((5, 7), (12, 12), (1, 3), (9, 2)), golden_tag=None, afe=None, scale=3.0):
+    afe = afe or engine.AfePlan(sd, 100, device, lib)
+    D = afe.D
+    g = torch.Generator().manual_seed(5)
+    worst = 0.0
+    gold = np.load(os.path.join(GOLD, "forward_%s.npz" % golden_tag)) if golden_tag else None
+    for n, (P, Q) in enumerate(shapes):
+        xp = torch.randn(1, P, D, generator=g).abs() * scale
+        xn = torch.randn(1, Q, D, generator=g).abs() * scale
+        out, starts = afe.affinity([xp[0]], xn[0])
+        ref = torch.from_numpy(O.afe_affinity(xp, xn, sd, 100))
+        err = maxabs(out, ref)
+        worst = max(worst, err)
+        assert out.shape == (P, Q + 1) and err <= 1e-4, ("affinity", P, Q, err)
+        if gold is not None:
+            assert maxabs(out, torch.from_numpy(gold["aff%d" % n])) <= 1e-4
+    # several history frames of different sizes in ONE call (tracker.py:76-90 batched)
+    hist = [torch.randn(p, D, generator=g).abs() * scale for p in (4, 9, 1, 6)]
+    cur = torch.randn(8, D, generator=g).abs() * scale
+    out, starts = afe.affinity(hist, cur)
+    for f, hx in enumerate(hist):
+        ref = torch.from_numpy(O.afe_affinity(hx.unsqueeze(0), cur.unsqueeze(0), sd, 100))
+        err = maxabs(out[starts[f]:starts[f + 1]], ref)
+        worst = max(worst, err)
+        assert err <= 1e-4, ("affinity batched", f, err)
+    return worst
+
+
+def check_lstm(lib, device, dataset="mot"):
+    lsd = O.synth_lstm_state_dict(dataset)
+    gold = np.load(os.path.join(GOLD, "lstm_%s.npz" % dataset))
+    lp = engine.LstmPlan(lsd, device, lib)
+    xs = torch.from_numpy(gold["xs"])
+    Tn = xs.shape[1]
+    h = torch.zeros(Tn, 128, device=device); c = torch.zeros(Tn, 128, device=device)
+    ho = torch.zeros(Tn, 128); co = torch.zeros(Tn, 128)
+    for s in range(xs.shape[0]):
+        pred = lp.step(xs[s], h, c)
+        ho, co, po = O.lstm_predict(ho, co, xs[s], lsd)
+        for a, b in ((h, ho), (c, co), (pred, po), (h, torch.from_numpy(gold["h%d" % s])),
+                     (c, torch.from_numpy(gold["c%d" % s])), (pred, torch.from_numpy(gold["p%d" % s]))):
+            assert maxabs(a, b) <= 1e-5, ("lstm", s)
+
+
+def check_topk_edge_cases(lib, device):
+    """Fewer peaks than K, multi-class maps, exact ties (ascending-index tie break)."""
+    import ctypes as C
+    from deft_amd.hiplib import ptr, stream_ptr
+    dev = torch.device(device)
+    N, H, W, Cc, K = 2, 12, 16, 3, 16
+    g = torch.Generator().manual_seed(4)
+    hm = torch.randn(N, Cc, H, W, generator=g)
+    hm[1] = -3.0                       # a flat map: every pixel is a (tied) peak
+    hm[1, 0, 3, 5] = 2.0
+    hv = torch.zeros(N, H, W, 4); hv[..., :Cc] = hm.permute(0, 2, 3, 1)
+    hv = hv.to(dev)
+    cap = H * W * Cc
+    cs = torch.zeros(N * cap, device=dev); ci = torch.zeros(N * cap, dtype=torch.int32, device=dev)
+    cn = torch.zeros(N, dtype=torch.int32, device=dev)
+    sc = torch.zeros(N, K, device=dev); ind = torch.zeros(N, K, dtype=torch.int32, device=dev); cl = torch.zeros(N, K, dtype=torch.int32, device=dev)
+    s = stream_ptr(dev)
+    lib.call("deft_hm_peaks", ptr(hv), N, H, W, Cc, 4, ptr(cs), ptr(ci), ptr(cn), cap, s)
+    lib.call("deft_topk", ptr(cs), ptr(ci), ptr(cn), N, cap, K, H * W, ptr(sc), ptr(ind), ptr(cl), s)
+    ref = O.generic_decode({"hm": torch.sigmoid(hm)}, K=K)
+    # frame 0: generic random map -> exact agreement with the oracle
+    assert torch.equal(ind[0].cpu().long(), ref["inds"][0]) and torch.equal(cl[0].cpu().float(), ref["clses"][0])
+    assert maxabs(sc[0], ref["scores"][0]) <= 1e-6
+    # frame 1: the single real peak first, then ties resolved by ascending (class, index)
+    assert int(ind[1, 0]) == 3 * W + 5 and int(cl[1, 0]) == 0
+    tied = [(int(cl[1, k]), int(ind[1, k])) for k in range(1, K)]
+    assert tied == sorted(tied) and len(set(tied)) == K - 1
+    assert abs(float(sc[1, 1]) - float(torch.sigmoid(torch.tensor(-3.0)))) <= 1e-6

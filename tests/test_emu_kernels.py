@@ -1,0 +1,68 @@
+"""CPU tests (-m "not gpu"): the UNMODIFIED HIP kernels, compiled against the SIMT
+emulator in tests/hipemu, checked through the C ABI against the oracle.  These
+validate indexing / fragment layouts / host packing before GPU time is spent; the
+real-hardware parity tests are in test_gpu_parity.py."""
+import pytest
+import torch
+
+import parity_checks as pc
+from parity_checks import T
+
+
+@pytest.mark.parametrize("args", [
+    (1, 8, 12, 16, 16, 3, 1, 1, T(128, 32)),
+    (2, 9, 7, 3, 16, 7, 1, 3, T(128, 32)),          # image layer: Cin 3 padded to 4, 7x7
+    (1, 10, 12, 32, 64, 3, 2, 1, T(64, 64)),
+    (1, 10, 12, 64, 64, 3, 1, 1, T(128, 64)),
+    (1, 6, 10, 448, 128, 1, 1, 0, T(128, 128)),     # Root over a 448-ch concat
+    (1, 6, 10, 64, 200, 1, 1, 0, T(64, 128)),       # Cout not a tile multiple
+    (1, 16, 16, 16, 40, 3, 1, 1, 0),                # auto tile
+    (3, 4, 4, 128, 27, 3, 1, 1, 0),                 # offset/mask conv shape, M < BM
+])
+def test_conv(emu_lib, args):
+    pc.check_conv(emu_lib, "cpu", *args, res=(args[4] % 3 == 1), relu=(args[3] != 448))
+
+
+def test_concat_conv(emu_lib):
+    pc.check_concat_conv(emu_lib, "cpu")
+
+
+@pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (2, 5, 6, 128, 64, 0), (1, 6, 6, 64, 160, T(64, 128))])
+def test_dcn(emu_lib, args):
+    pc.check_dcn(emu_lib, "cpu", *args[:5], tile=args[5])
+
+
+def test_dcn_big_offsets(emu_lib):
+    # offsets of several pixels: samples leave the image, all four zero-padding branches hit
+    pc.check_dcn(emu_lib, "cpu", 1, 6, 8, 64, 64, big_offsets=True, seed=3)
+
+
+def test_pool_upsample(emu_lib):
+    pc.check_pool_upsample(emu_lib, "cpu")
+
+
+def test_layout(emu_lib):
+    pc.check_layout(emu_lib, "cpu")
+
+
+def test_topk_edge_cases(emu_lib):
+    pc.check_topk_edge_cases(emu_lib, "cpu")
+
+
+@pytest.mark.parametrize("dataset", ["mot", "nuscenes"])
+def test_lstm(emu_lib, dataset):
+    pc.check_lstm(emu_lib, "cpu", dataset)
+
+
+def test_affinity(emu_lib):
+    import deft_oracle as O
+    pc.check_affinity(emu_lib, "cpu", O.synth_state_dict("mot"), golden_tag="mot_128x160")
+
+
+@pytest.mark.slow
+def test_forward_embed_mot(emu_lib):
+    """Whole path on a 64x96 frame (emulated): backbone+DCN neck+heads+decode+embedding."""
+    import deft_oracle as O
+    sd = O.synth_state_dict("mot")
+    plan, rep, (ora_out, ora_maps) = pc.check_forward(emu_lib, "cpu", "mot", 64, 96, sd=sd)
+    pc.check_embed(emu_lib, "cpu", plan, ora_maps, sd)
