@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""Benchmark of DEFT's per-frame hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+
+A "step" = one batch of B synthetic 1088x608 frames per GPU through
+DLA-34 + DCNv2 neck + hm head + decode (K=100) + sparse regression heads +
+embedding head (100 detections) + 100x500 affinity (5 history frames x 100).
+Inputs are resident in HBM when the timed region starts.  With N>1 (launched by
+torch.distributed.run, one rank per GPU) consecutive frames are sharded over the
+ranks and one RCCL all-gather of the embedding records per step provides the
+cross-rank history (deft_amd/pipeline.py); `value` is whole-job frames/s.
+
+Extra objects in the JSON line:
+  roofline      the implicit-GEMM kernel family (conv + DCNv2 launches of the step),
+                algorithmic FLOPs (2*M*Cout*K of each conv, no padding) / measured
+                launch time (HIP events on the launch stream) vs the FP32-MFMA peak.
+  cpu_baseline  the oracle (PyTorch-CPU restatement pinned against the reference
+                modules) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+H, W, KDET, HIST = 608, 1088, 100, 5
+
+
+def cpu_baseline(frames=3):
+    """kind=port: oracle/deft_oracle.py on the host cores (GPU not used)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import deft_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = O.synth_state_dict("mot")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 3, H, W, generator=g)
+    hist = [torch.rand(1, KDET, 416, generator=g) * 3 for _ in range(HIST)]
+    t_all = []
+    with torch.no_grad():
+        for it in range(frames + 1):
+            t0 = time.time()
+            out, maps = O.dlaseg_forward(x, sd, "mot")
+            dets = O.generic_decode(O.sigmoid_output(out), K=KDET)
+            b = dets["bboxes"][0]
+            c = torch.stack([(b[:, 0] + b[:, 2]) / (W / 4) - 1, (b[:, 1] + b[:, 3]) / (H / 4) - 1], 1).view(1, KDET, 1, 1, 2)
+            emb = O.afe_extract(maps, c, sd)
+            for hx in hist:
+                O.afe_affinity(hx, emb, sd, 100)
+            if it > 0:
+                t_all.append(time.time() - t0)
+    t = sorted(t_all)[len(t_all) // 2]
+    return {"value": round(1.0 / t, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d frames of 1088x608 (median; DLA-34+DCNv2+decode+embed(100)+5x(100x100) affinity), 1 warm-up" % frames}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from deft_amd import hiplib, synth
+    from deft_amd.pipeline import HipCompute, FramePipeline
+    lib = hiplib.get_lib()                      # no fallback: raises if the HIP extension is missing
+    sd = synth.synth_state_dict("mot")
+    B = args.batch
+    comp = HipCompute(sd, B, H, W, "mot", K=KDET, device=dev, lib=lib)
+    pipe = FramePipeline(comp, B, KDET, comp.D, history=HIST, device=dev)
+    g = torch.Generator().manual_seed(1000 + rank)
+    images = torch.randn(B, 3, H, W, generator=g).to(dev)      # resident in HBM before timing
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.step(images)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step(images)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = args.steps * B * world
+    fps = frames / dt
+
+    # ---- roofline of the dominant kernel family: one profiled step, HIP events per launch ----
+    roof = None
+    if rank == 0:
+        prof = []
+        comp.plan.profile = prof
+        comp.plan.forward(images)
+        torch.cuda.synchronize()
+        comp.plan.profile = None
+        gemm_ms = sum(e0.elapsed_time(e1) for (_, kind, _, e0, e1) in prof if kind in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc"))
+        gemm_fl = sum(fl for (_, kind, fl, _, _) in prof if kind in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc"))
+        n_launch = sum(1 for p in prof if p[1] in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc"))
+        all_ms = sum(e0.elapsed_time(e1) for (_, _, _, e0, e1) in prof)
+        ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "kernel": "igemm_kernel<*> (fp32 MFMA implicit GEMM: conv + DCNv2 loaders)",
+                "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
+                "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3)}
+        by = {}
+        for (name, kind, fl, e0, e1) in prof:
+            by.setdefault(kind, [0.0, 0]); by[kind][0] += e0.elapsed_time(e1); by[kind][1] += 1
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
+            json.dump({"by_kind_ms_launches": by,
+                       "ops": [(n, k, fl, e0.elapsed_time(e1)) for (n, k, fl, e0, e1) in prof]}, f)
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {"metric": "frames/sec (detect+embed+affinity) at 1088x608", "value": round(fps, 3), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "MOT17 1088x608 DLA-34 + DCNv2 + 100x500 affinity (BASELINE configs[1])",
+                          "frames_per_step_per_gpu": B, "detections": KDET, "history_frames": HIST,
+                          "parallelism": "frames sharded dp%d, 1 all-gather/step" % world},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -353,8 +353,9 @@ extern "C" int deft_heads_at_peaks(const float* feat, int N, int H, int W, int C
 // box assembly   (decode.py:118-196)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void decode_boxes_kernel(const int* __restrict__ inds, const float* __restrict__ heads,
-                                                           int NK, int Wm, int Ctot, int off_reg, int off_wh, int off_ltrb,
-                                                           float* __restrict__ cts, float* __restrict__ bboxes) {
+                                                           int NK, int Wm, int Hm, int Ctot, int off_reg, int off_wh, int off_ltrb,
+                                                           float* __restrict__ cts, float* __restrict__ bboxes,
+                                                           float* __restrict__ centers) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NK) return;
     const int ind = inds[i];
@@ -372,13 +373,18 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const int* __restrict
         b0 = xs0 + hv[off_ltrb]; b1 = ys0 + hv[off_ltrb + 1]; b2 = xs0 + hv[off_ltrb + 2]; b3 = ys0 + hv[off_ltrb + 3];
     }
     bboxes[4 * i] = b0; bboxes[4 * i + 1] = b1; bboxes[4 * i + 2] = b2; bboxes[4 * i + 3] = b3;
+    if (centers) {   // convert_detection: (2*x1/w + (x2-x1)/w) - 1
+        centers[2 * i] = (2.f * (b0 / (float)Wm) + (b2 - b0) / (float)Wm) - 1.f;
+        centers[2 * i + 1] = (2.f * (b1 / (float)Hm) + (b3 - b1) / (float)Hm) - 1.f;
+    }
 }
 
-extern "C" int deft_decode_boxes(const int* inds, const float* heads, int N, int K, int Wm, int Ctot,
-                                 int off_reg, int off_wh, int off_ltrb_amodal, float* cts, float* bboxes, void* stream) {
+extern "C" int deft_decode_boxes(const int* inds, const float* heads, int N, int K, int Wm, int Hm, int Ctot,
+                                 int off_reg, int off_wh, int off_ltrb_amodal, float* cts, float* bboxes, float* centers,
+                                 void* stream) {
     DEFT_CHECK(inds && heads && cts && bboxes && Wm > 0, -1, "deft_decode_boxes: bad arguments");
     hipLaunchKernelGGL(decode_boxes_kernel, dim3(deft_cdiv(N * K, 256)), dim3(256), 0, (hipStream_t)stream,
-                       inds, heads, N * K, Wm, Ctot, off_reg, off_wh, off_ltrb_amodal, cts, bboxes);
+                       inds, heads, N * K, Wm, Hm, Ctot, off_reg, off_wh, off_ltrb_amodal, cts, bboxes, centers);
     DEFT_CHECK_LAUNCH("decode_boxes");
     return 0;
 }

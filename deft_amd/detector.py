@@ -1,0 +1,64 @@
+"""Host-side mirror of the reference `Detector` for the kernel path (detector.py:72-344).
+
+Same names / argument meaning as the reference for the seam this package replaces:
+`Detector(opt)`, `.process(images, ...) -> (output, dets, FeatureMaps)`,
+`.img_height/.img_width`, `.reset_tracking(opt)`.  The forward, sigmoid, decode and the
+regression heads run as ONE plan of HIP launches (deft_amd.engine.DlaSegPlan) with a
+single D2H copy of the K detection records, instead of the reference's four
+`torch.cuda.synchronize()` points (detector.py:188, 534, 541, 545).
+"""
+import numpy as np
+import torch
+
+from . import engine, hiplib
+
+
+class Detector(object):
+    def __init__(self, opt, state_dict=None):
+        """opt: the reference's argparse namespace (opts.py); fields used: dataset, K,
+        max_object, gpus (gpus[0] >= 0 -> cuda).  state_dict: DLASeg weights with the
+        reference's key names (what model.load_model returns, model.py:40-121)."""
+        if state_dict is None:
+            ck = torch.load(opt.load_model, map_location="cpu")
+            state_dict = {k[7:] if k.startswith("module.") else k: v for k, v in ck["state_dict"].items()}  # model.py:49-53
+        self.opt = opt
+        self.device = torch.device("cuda" if getattr(opt, "gpus", [0])[0] >= 0 else "cpu")
+        if self.device.type != "cuda":
+            raise hiplib.DeftHipError("deft_amd.Detector needs an MI355X (no CPU path)")
+        self.lib = hiplib.get_lib()
+        self.sd = state_dict
+        self.dataset = opt.dataset
+        self.K = getattr(opt, "K", 100)
+        self._plans = {}
+        self.afe = engine.AfePlan(state_dict, getattr(opt, "max_object", 100), self.device, self.lib)
+        self.img_height = 100          # detector.py:108-109
+        self.img_width = 100
+        self.pre_images = None
+
+    def _plan(self, N, H, W):
+        key = (N, H, W)
+        if key not in self._plans:
+            self._plans[key] = engine.DlaSegPlan(self.sd, N, H, W, self.dataset, K=self.K, device=self.device, lib=self.lib)
+        return self._plans[key]
+
+    def process(self, images, pre_images=None, pre_hms=None, pre_inds=None, return_time=False):
+        """detector.py:530-551.  images [N,3,H,W] fp32.  Returns (output, dets, FeatureMaps):
+        output = {"hm": dense sigmoid'ed map as an NHWC View}, dets = generic_decode's dict as
+        numpy (one D2H), FeatureMaps = the 13 NHWC Views consumed by AFE (tracker.py:826)."""
+        assert pre_images is None and pre_hms is None, "DEFT inference never passes pre_img/pre_hm (detector.py:153,162)"
+        N, _, H, W = images.shape
+        plan = self._plan(N, H, W)
+        plan.forward(images.to(self.device, non_blocking=True))
+        d = plan.dets()
+        if "dep" in d:      # _sigmoid_output, detector.py:491-493, applied at the K peaks
+            d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
+        dets = {k: v.detach().cpu().numpy() for k, v in d.items()}
+        output = {"hm": plan.dense["hm"], "pre_inds": pre_inds}
+        if return_time:
+            import time
+            return output, dets, time.time(), plan.fmaps
+        return output, dets, plan.fmaps
+
+    def reset_tracking(self, opt):
+        """detector.py:677-686 (tracker state is owned by deft_amd.tracker)."""
+        self.pre_images = None

@@ -335,12 +335,13 @@ class DlaSegPlan(_Plan):
         self.head_vals = torch.zeros(N, K, Ctot, dtype=torch.float32, device=self.device)
         self.cts = torch.zeros(N, K, 2, dtype=torch.float32, device=self.device)
         self.bboxes = torch.zeros(N, K, 4, dtype=torch.float32, device=self.device)
+        self.centers = torch.zeros(N, K, 2, dtype=torch.float32, device=self.device)
         c_ = (C.c_void_p(self.feat.addr), N, h, w, Cf, self.feat.ld, ptr(self.inds), K, ptr(w0t), ptr(b0), ptr(w2), ptr(b2),
               ptr(head_of), len(reg), Ctot, ptr(self.head_vals))
         self.add("deft_heads_at_peaks", "heads_at_peaks", lambda: lib.call("deft_heads_at_peaks", *c_, self._stream()),
                  2.0 * N * K * len(reg) * (9 * Cf * 256) + 2.0 * N * K * Ctot * 256)
-        d_ = (ptr(self.inds), ptr(self.head_vals), N, K, w, Ctot, self.reg_off.get("reg", -1), self.reg_off.get("wh", -1),
-              self.reg_off.get("ltrb_amodal", -1), ptr(self.cts), ptr(self.bboxes))
+        d_ = (ptr(self.inds), ptr(self.head_vals), N, K, w, h, Ctot, self.reg_off.get("reg", -1), self.reg_off.get("wh", -1),
+              self.reg_off.get("ltrb_amodal", -1), ptr(self.cts), ptr(self.bboxes), ptr(self.centers))
         self.add("deft_decode_boxes", "decode_boxes", lambda: lib.call("deft_decode_boxes", *d_, self._stream()))
 
     # ---- public --------------------------------------------------------------

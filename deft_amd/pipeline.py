@@ -1,0 +1,75 @@
+"""Frame pipeline: detect -> embed -> (exchange) -> affinity, one batch of frames per step.
+
+This is the data-parallel form of `Detector.run` + `FeatureRecorder.update`
+(detector.py:112-344, tracker.py:59-90): whole frames are independent through
+detection, decode and embedding extraction, and the affinity of frame t against its
+history depends only on embeddings (tracker.py:76-90 reads `all_features` only).
+With world_size > 1 consecutive frames of the stream are sharded over the ranks and
+ONE all-gather of fixed-size embedding records per step (RCCL over xGMI) gives every
+rank the history its own frames need; there is no other cross-GPU state.
+
+`compute` is injected so the CPU/gloo tests can drive the exchange logic with a
+stand-in; the product default (HipCompute) calls the HIP library and nothing else.
+"""
+import torch
+import torch.distributed as dist
+
+from . import engine
+
+
+class HipCompute:
+    """detect+embed and affinity on the local GPU through libdeft_hip.so."""
+
+    def __init__(self, sd, batch, H, W, dataset="mot", K=100, max_object=100, device="cuda", lib=None):
+        self.plan = engine.DlaSegPlan(sd, batch, H, W, dataset, K=K, device=device, lib=lib)
+        self.afe = engine.AfePlan(sd, max_object, device, lib)
+        self.D = self.afe.D
+        self.K = K
+
+    def detect_embed(self, images):
+        p = self.plan
+        p.forward(images)
+        return self.afe.extract(p.fmaps, p.centers)          # [batch, K, D]
+
+    def affinity(self, hist, cur):
+        return self.afe.affinity(hist, cur)[0]
+
+
+class FramePipeline:
+    def __init__(self, compute, batch, K, D, history=5, device="cuda", group=None):
+        self.c, self.batch, self.K, self.D, self.history = compute, batch, K, D, history
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # ring of the last `history` frames of the GLOBAL stream order, then this step's frames
+        self.tail = torch.zeros(history, K, D, dtype=torch.float32, device=self.device)
+        self.tail_valid = 0
+        self.gathered = torch.zeros(self.world * batch, K, D, dtype=torch.float32, device=self.device)
+
+    def step(self, images):
+        """images [batch,3,H,W]: this rank's frames  (global frame index within the step =
+        rank*batch + b).  Returns the list (one per local frame) of affinity blocks
+        [sum_f P_f, Q+1] against the up-to-`history` preceding frames of the stream."""
+        emb = self.c.detect_embed(images)                                   # [batch,K,D]
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered, emb.contiguous(), group=self.group)
+            allf = self.gathered
+        else:
+            allf = emb
+        ring = torch.cat([self.tail[self.history - self.tail_valid:], allf], 0) if self.tail_valid else allf
+        base = self.tail_valid + self.rank * self.batch
+        outs = []
+        for b in range(self.batch):
+            g = base + b
+            lo = max(0, g - self.history)
+            if g == lo:
+                outs.append(None)                                           # very first frame: no history
+                continue
+            hist = [ring[t] for t in range(lo, g)]
+            outs.append(self.c.affinity(hist, ring[g]))
+        n = ring.shape[0]
+        keep = min(self.history, n)
+        self.tail[self.history - keep:] = ring[n - keep:]
+        self.tail_valid = keep
+        return outs

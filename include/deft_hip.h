@@ -106,10 +106,12 @@ int deft_heads_at_peaks(const float* feat, int N, int H, int W, int Cf, int ld,
 
 /* Box assembly of generic_decode (decode.py:118-196): from (ind, head values) to
  * xs, ys, bboxes.  off_* are channel offsets into `heads` rows (-1 = head absent).
- * cts [N][K][2], bboxes [N][K][4]. */
-int deft_decode_boxes(const int* inds, const float* heads, int N, int K, int Wm, int Ctot,
+ * cts [N][K][2], bboxes [N][K][4].  centers (nullable) [N][K][2]: box centres mapped
+ * to [-1,1] by the output-map size (Wm x Hm) -- convert_detection (image.py:391-412)
+ * for boxes expressed in output-map pixels. */
+int deft_decode_boxes(const int* inds, const float* heads, int N, int K, int Wm, int Hm, int Ctot,
                       int off_reg, int off_wh, int off_ltrb_amodal,
-                      float* cts, float* bboxes, void* stream);
+                      float* cts, float* bboxes, float* centers, void* stream);
 
 /* Embedding head for one feature map: ReLU(3x3 selector conv) evaluated only at the
  * 4 bilinear neighbours of each detection centre, then the grid_sample blend

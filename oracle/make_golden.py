@@ -25,6 +25,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
 import deft_oracle as O  # noqa: E402
 import ref_import  # noqa: E402
 
