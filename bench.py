@@ -34,18 +34,22 @@ FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 H, W, KDET, HIST = 608, 1088, 100, 5
 
 
-def cpu_baseline(frames=3):
-    """kind=port: oracle/deft_oracle.py on the host cores (GPU not used)."""
+def cpu_baseline(frames=3, budget_s=25.0):
+    """kind=port: oracle/deft_oracle.py on the host cores (GPU not used).  Bounded: stops
+    after `budget_s` seconds of CPU work (at least one timed frame)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import deft_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncpu, 32)))     # ATen's CPU convs stop scaling (and thrash) far below 256 threads
     sd = O.synth_state_dict("mot")
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 3, H, W, generator=g)
     hist = [torch.rand(1, KDET, 416, generator=g) * 3 for _ in range(HIST)]
     t_all = []
     with torch.no_grad():
-        for it in range(frames + 1):
+        O.dlaseg_forward(torch.randn(1, 3, 128, 160, generator=g), sd, "mot")       # small warm-up (thread pool, allocator)
+        t_begin = time.time()
+        for it in range(frames):
             t0 = time.time()
             out, maps = O.dlaseg_forward(x, sd, "mot")
             dets = O.generic_decode(O.sigmoid_output(out), K=KDET)
@@ -54,11 +58,12 @@ def cpu_baseline(frames=3):
             emb = O.afe_extract(maps, c, sd)
             for hx in hist:
                 O.afe_affinity(hx, emb, sd, 100)
-            if it > 0:
-                t_all.append(time.time() - t0)
+            t_all.append(time.time() - t0)
+            if time.time() - t_begin > budget_s:
+                break
     t = sorted(t_all)[len(t_all) // 2]
     return {"value": round(1.0 / t, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d frames of 1088x608 (median; DLA-34+DCNv2+decode+embed(100)+5x(100x100) affinity), 1 warm-up" % frames}
+            "sample": "%d frame(s) of 1088x608, median (DLA-34+DCNv2+decode+embed(100)+5x(100x100) affinity), small warm-up, %d threads" % (len(t_all), torch.get_num_threads())}
 
 
 def main():
@@ -110,31 +115,33 @@ def main():
     frames = args.steps * B * world
     fps = frames / dt
 
-    # ---- roofline of the dominant kernel family: one profiled step, HIP events per launch ----
+    # ---- roofline of the dominant kernel family: one profiled step, HIP events per launch
+    #      (torch events on the stream every kernel is launched on) ----
     roof = None
     if rank == 0:
         prof = []
-        comp.plan.profile = prof
-        comp.plan.forward(images)
+        lib.profile = prof
+        pipe.step(images)
         torch.cuda.synchronize()
-        comp.plan.profile = None
-        gemm_ms = sum(e0.elapsed_time(e1) for (_, kind, _, e0, e1) in prof if kind in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc"))
-        gemm_fl = sum(fl for (_, kind, fl, _, _) in prof if kind in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc"))
-        n_launch = sum(1 for p in prof if p[1] in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc"))
-        all_ms = sum(e0.elapsed_time(e1) for (_, _, _, e0, e1) in prof)
+        lib.profile = None
+        GEMM = ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer")
+        gemm_ms = sum(e0.elapsed_time(e1) for (k, _, e0, e1) in prof if k in GEMM)
+        gemm_fl = sum(fl for (k, fl, _, _) in prof if k in GEMM)
+        n_launch = sum(1 for p in prof if p[0] in GEMM)
+        all_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1) in prof)
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
-                "kernel": "igemm_kernel<*> (fp32 MFMA implicit GEMM: conv + DCNv2 loaders)",
+                "kernel": "igemm_kernel<*> (fp32 MFMA implicit GEMM: conv / DCNv2 / pair loaders)",
                 "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
+                "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                 "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3)}
         by = {}
-        for (name, kind, fl, e0, e1) in prof:
-            by.setdefault(kind, [0.0, 0]); by[kind][0] += e0.elapsed_time(e1); by[kind][1] += 1
+        for (k, fl, e0, e1) in prof:
+            by.setdefault(k, [0.0, 0, 0.0]); by[k][0] += e0.elapsed_time(e1); by[k][1] += 1; by[k][2] += fl
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
-            json.dump({"by_kind_ms_launches": by,
-                       "ops": [(n, k, fl, e0.elapsed_time(e1)) for (n, k, fl, e0, e1) in prof]}, f)
+            json.dump({"by_entry_ms_launches_flops": by, "calls": [(k, fl, e0.elapsed_time(e1)) for (k, fl, e0, e1) in prof]}, f)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:

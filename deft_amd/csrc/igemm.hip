@@ -63,9 +63,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
         r0[i] = ROW_INVALID; r1[i] = 0; r2[i] = 0;
         if (m < p.M) {
             if (MODE == MODE_PAIR) {
-                const int u = m / p.Q;
+                int u = m / p.Q;
+                int j = m - u * p.Q;
+                if (p.Tper > 0) {       // batched: (current frame c, history row t, object j)
+                    const int c = u / p.Tper;
+                    u = p.u0 + c * p.du + (u - c * p.Tper);
+                    j = p.v0 + c * p.dv + j;
+                }
                 r0[i] = u * p.ldx;
-                r1[i] = (m - u * p.Q) * p.ldx;
+                r1[i] = j * p.ldx;
             } else {
                 const int ohw = p.OH * p.OW;
                 const int n = m / ohw;
@@ -98,9 +104,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
                 const int iy = r0[i] + r, ix = r1[i] + s;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    v = *(const float4*)(p.x + (size_t)(r2[i] + iy * p.W + ix) * p.ldx + c);
+                const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                // unconditional load from a clamped (always valid) address + select: no branch per load
+                const int pix = ok ? r2[i] + iy * p.W + ix : 0;
+                float4 v = *(const float4*)(p.x + (size_t)pix * p.ldx + (ok ? c : 0));
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 va[i] = v;
             }
         } else if (MODE == MODE_DCN) {
@@ -221,22 +229,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 
     // epilogue: D reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31);
     // the 32 lanes of a half-wave write 32 consecutive channels of one pixel (128 B).
+    // Residual loads are hoisted out of the per-element path (one uniform branch, 16
+    // loads in flight) -- a per-element `if (res)` makes hipcc wait vmcnt(0) per load.
+    const bool has_res = p.res != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (co >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[co] : 1.f;
-        const float sh = p.shift ? p.shift[co] : 0.f;
+        const bool cok = co < p.Cout;
+        const int coc = cok ? co : p.Cout - 1;
+        const float sc = p.scale ? p.scale[coc] : 1.f;
+        const float sh = p.shift ? p.shift[coc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float v = acc[i][j][r] * sc + sh;
-                    if (p.res) v += p.res[(size_t)m * p.ldr + co];
+            for (int q = 0; q < 4; ++q) {       // 4 rows at a time keeps the epilogue's VGPR footprint small
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (has_res) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        int m = mb + t + 8 * q;
+                        m = m < p.M ? m : p.M - 1;
+                        rv[t] = p.res[(size_t)m * p.ldr + coc];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = mb + t + 8 * q;
+                    float v = acc[i][j][4 * q + t] * sc + sh + rv[t];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[(size_t)m * p.ldy + co] = v;
+                    if (cok && m < p.M) p.y[(size_t)m * p.ldy + co] = v;
                 }
             }
         }

@@ -116,7 +116,8 @@ class _Plan:
         lib, ref = self.lib, C.byref(desc)
         self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
 
-    def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0):
+    def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0,
+             true_cin=None):
         OH = (x.H + 2 * pad - KH) // stride + 1
         OW = (x.W + 2 * pad - KW) // stride + 1
         if out is None:
@@ -137,7 +138,9 @@ class _Plan:
         d.cin_log2 = int(math.log2(x.C)) if KH * KW > 1 else 0
         d.M = x.N * OH * OW
         d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = tile
-        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * Cout * KH * KW * x.C)
+        cin = x.C if true_cin is None else true_cin
+        d.flop_k = KH * KW * cin
+        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * Cout * KH * KW * cin)
         return out
 
     def maxpool(self, name, x, out=None):
@@ -185,7 +188,8 @@ class DlaSegPlan(_Plan):
             self._wcache[wkey] = (self.dev(wp), K, self.dev(alpha), self.dev(beta))
         wp, K, alpha, beta = self._wcache[wkey]
         Cout = self.sd[wkey + ".weight"].shape[0]
-        return self.conv(name, x, wp, K, KH, KH, stride, pad, Cout, alpha, beta, relu, out=out, res=res)
+        return self.conv(name, x, wp, K, KH, KH, stride, pad, Cout, alpha, beta, relu, out=out, res=res,
+                         true_cin=self.sd[wkey + ".weight"].shape[1])
 
     def _block(self, p, x, stride, residual, out):
         """BasicBlock dla.py:73-87."""
@@ -482,6 +486,51 @@ class AfePlan(_Plan):
                       self.max_object, ptr(out), self._stream())
         return out, starts
 
+    def affinity_ring(self, ring, g0, Bc, hist):
+        """Batched steady-state form used by the frame pipeline.  ring [R, K, D]: embeddings of
+        consecutive frames of one stream (every frame K objects); current frames are ring[g0+c],
+        c < Bc, each scored against ring[g0+c-hist : g0+c] (tracker.py:76-90 for `hist` stored
+        frames).  U'/V' are computed once per ring frame; one pair-GEMM chain covers all
+        Bc*hist frame pairs.  Returns [Bc, hist*K, K+1]."""
+        R, K, D = ring.shape
+        assert ring.is_contiguous() and D == self.D and D == self.Kd and g0 - hist >= 0 and g0 + Bc <= R
+        assert K <= self.max_object
+        key = (R, K, Bc, hist)
+        if not hasattr(self, "_ring"):
+            self._ring = {}
+        if key not in self._ring:
+            dev = self.device
+            (w2, K2, c2, s2, t2), (w3, K3, c3, s3, t3), (w4, K4, c4, s4, t4) = self.layers
+            M = Bc * hist * K * K
+            buf = {"U": torch.empty(R * K, 512, dtype=torch.float32, device=dev),
+                   "V": torch.empty(R * K, 512, dtype=torch.float32, device=dev),
+                   "h2": torch.empty(M, c2, dtype=torch.float32, device=dev),
+                   "h3": torch.empty(M, c3, dtype=torch.float32, device=dev),
+                   "h4": torch.empty(M, c4, dtype=torch.float32, device=dev),
+                   "out": torch.empty(Bc, hist * K, K + 1, dtype=torch.float32, device=dev),
+                   "rs": torch.arange(0, Bc * hist + 1, dtype=torch.int32, device=dev) * K}
+            self._ring[key] = buf
+        b = self._ring[key]
+        (w2, K2, c2, s2, t2), (w3, K3, c3, s3, t3), (w4, K4, c4, s4, t4) = self.layers
+        self._lin(ring, R * K, D, D, self.Ua, self.Kd, 512, None, None, False, b["U"], 512)
+        self._lin(ring, R * K, D, D, self.Vb, self.Kd, 512, None, self.cb, False, b["V"], 512)
+        M = Bc * hist * K * K
+        d = GemmDesc()
+        d.x = b["U"].data_ptr(); d.x2 = b["V"].data_ptr(); d.w = w2.data_ptr()
+        d.scale = s2.data_ptr(); d.shift = t2.data_ptr(); d.res = None; d.y = b["h2"].data_ptr()
+        d.N, d.H, d.W, d.Cin, d.ldx = M, 1, 1, 512, 512
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, c2, c2, 0
+        d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+        d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
+        d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0
+        d.Tper, d.u0, d.du, d.v0, d.dv = hist * K, (g0 - hist) * K, K, g0 * K, K
+        self.lib.call("deft_pair_layer", C.byref(d), self._stream())
+        self._lin(b["h2"], M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, b["h3"], c3)
+        self._lin(b["h3"], M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, b["h4"], c4)
+        self.lib.call("deft_affinity_finish", ptr(b["h4"]), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(b["rs"]),
+                      Bc * hist, K, self.max_object, ptr(b["out"]), self._stream())
+        return b["out"]
+
     @staticmethod
     def affinity_flops(T, Q, D):
         return 2.0 * (T + Q) * D * 512 + 2.0 * T * Q * (512 * 256 + 256 * 128 + 128 * 64 + 64)
@@ -506,7 +555,7 @@ class LstmPlan(_Plan):
         """x [T,nin]; h,c [T,128] updated IN PLACE; returns pred [T, nout//4, 4]."""
         T = x.shape[0]
         x = x.to(self.device, torch.float32).contiguous()
-        assert h.is_contiguous() and c.is_contiguous() and h.device == self.device
+        assert h.is_contiguous() and c.is_contiguous() and h.device.type == self.device.type
         pred = torch.empty(T, self.nout, dtype=torch.float32, device=self.device)
         self.lib.call("deft_lstm_step", ptr(x), ptr(h), ptr(c), T, self.nin, self.nout, ptr(self.wih_t), ptr(self.whh_t),
                       ptr(self.bias), ptr(self.w1_t), ptr(self.b1), ptr(self.w2_t), ptr(self.b2), ptr(pred), self._stream())

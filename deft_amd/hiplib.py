@@ -18,7 +18,9 @@ c_fp = C.c_void_p
 
 
 class GemmDesc(C.Structure):
-    """Mirror of DeftGemmDesc (include/deft_hip.h)."""
+    """Mirror of DeftGemmDesc (include/deft_hip.h).  `flop_k` (python-side only) overrides
+    Ktot in the algorithmic FLOP count when input channels are padding (the 3->4 image)."""
+    flop_k = 0
     _fields_ = [
         ("x", c_fp), ("x2", c_fp), ("w", c_fp), ("scale", c_fp), ("shift", c_fp), ("res", c_fp), ("y", c_fp),
         ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("ldx", C.c_int),
@@ -26,6 +28,7 @@ class GemmDesc(C.Structure):
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("Ktot", C.c_int), ("Kpad", C.c_int), ("cin_log2", C.c_int), ("M", C.c_int),
         ("relu", C.c_int), ("Q", C.c_int), ("ldom", C.c_int), ("tile", C.c_int),
+        ("Tper", C.c_int), ("u0", C.c_int), ("du", C.c_int), ("v0", C.c_int), ("dv", C.c_int),
     ]
 
 
@@ -70,10 +73,23 @@ class HipLib:
         if v != 1:
             raise DeftHipError("libdeft_hip ABI version %d, expected 1" % v)
 
+    profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1) per call
+
     def call(self, name, *args):
+        prof = self.profile
+        if prof is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
             raise DeftHipError("%s failed (%d): %s" % (name, rc, self.cdll.deft_last_error().decode()))
+        if prof is not None:
+            e1.record()
+            fl = 0.0
+            if name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer"):
+                d = args[0]._obj
+                fl = 2.0 * d.M * d.Cout * (d.flop_k if d.flop_k else d.Ktot)
+            prof.append((name, fl, e0, e1))
 
 
 _lib = None

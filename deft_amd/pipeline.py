@@ -34,6 +34,9 @@ class HipCompute:
     def affinity(self, hist, cur):
         return self.afe.affinity(hist, cur)[0]
 
+    def affinity_ring(self, ring, g0, Bc, hist):
+        return self.afe.affinity_ring(ring, g0, Bc, hist)
+
 
 class FramePipeline:
     def __init__(self, compute, batch, K, D, history=5, device="cuda", group=None):
@@ -60,7 +63,11 @@ class FramePipeline:
         ring = torch.cat([self.tail[self.history - self.tail_valid:], allf], 0) if self.tail_valid else allf
         base = self.tail_valid + self.rank * self.batch
         outs = []
-        for b in range(self.batch):
+        if base >= self.history and hasattr(self.c, "affinity_ring"):
+            # steady state: every local frame has `history` predecessors -> one batched chain
+            blk = self.c.affinity_ring(ring.contiguous(), base, self.batch, self.history)
+            outs = [blk[b] for b in range(self.batch)]
+        for b in range(self.batch if not outs else 0):
             g = base + b
             lo = max(0, g - self.history)
             if g == lo:

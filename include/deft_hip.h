@@ -41,6 +41,10 @@ typedef struct DeftGemmDesc {
     int Q;                        /* pair: number of current-frame objects                   */
     int ldom;                     /* dcn: pixel stride of x2                                 */
     int tile;                     /* 0 = auto; else (BM<<16)|BN to force a tile config       */
+    /* pair, batched form (Tper > 0): rows are (c, t, j) with c = m / (Tper*Q) the current
+     * frame, t its history row, j its object; U' row = u0 + c*du + t, V' row = v0 + c*dv + j.
+     * Tper == 0: rows are (t, j), U' row = t, V' row = j.                                   */
+    int Tper, u0, du, v0, dv;
 } DeftGemmDesc;
 
 int deft_version(void);

@@ -1,0 +1,90 @@
+"""GPU micro-benchmark of the implicit-GEMM kernel on the layer shapes of config B.
+    python tools/bench_igemm.py [batch]
+Prints ms and TFLOP/s per (shape, tile).  Tuning aid, not part of the product path."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from deft_amd import engine, hiplib  # noqa: E402
+
+T = lambda bm, bn: (bm << 16) | bn
+lib = hiplib.get_lib()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+
+
+def timeit(plan, n=20):
+    for _ in range(3):
+        plan.run()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        plan.run()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def conv_case(name, H, W, Ci, Co, k, stride, tiles):
+    for tile in tiles:
+        plan = engine._Plan("cuda", lib)
+        cp = (Ci + 3) // 4 * 4
+        xv = plan.alloc(B, H, W, cp)
+        xv.buf.normal_()
+        w = torch.randn(Co, Ci, k, k) * 0.05
+        wp, K = engine.pack_conv_weight(w, cp)
+        sc = plan.dev(torch.rand(Co) + 0.5); sh = plan.dev(torch.randn(Co))
+        try:
+            plan.conv("c", xv, plan.dev(wp), K, k, k, stride, k // 2, Co, sc, sh, True, tile=tile)
+            ms = timeit(plan)
+        except Exception as e:  # unsupported tile
+            print("%-28s tile %3dx%-3d  -- %s" % (name, tile >> 16, tile & 0xffff, str(e)[:60])); continue
+        fl = plan.ops[-1][3]
+        print("%-28s tile %3dx%-3d  %7.3f ms  %6.1f TF/s" % (name, tile >> 16, tile & 0xffff, ms, fl / ms / 1e9), flush=True)
+
+
+def dcn_case(name, H, W, Ci, Co, tiles):
+    import parity_checks as pc
+    for tile in tiles:
+        g = torch.Generator().manual_seed(0)
+        sd = {"d.conv.weight": torch.randn(Co, Ci, 3, 3, generator=g) * 0.05, "d.conv.bias": torch.zeros(Co),
+              "d.conv.conv_offset_mask.weight": torch.randn(27, Ci, 3, 3, generator=g) * 0.01,
+              "d.conv.conv_offset_mask.bias": torch.randn(27, generator=g) * 0.5,
+              "d.actf.0.weight": torch.ones(Co), "d.actf.0.bias": torch.zeros(Co),
+              "d.actf.0.running_mean": torch.zeros(Co), "d.actf.0.running_var": torch.ones(Co)}
+        plan = engine.DlaSegPlan.__new__(engine.DlaSegPlan)
+        engine._Plan.__init__(plan, "cuda", lib)
+        plan.sd = sd; plan._wcache = {}
+        xv = plan.alloc(B, H, W, Ci); xv.buf.normal_()
+        plan._deform("d", xv)
+        plan._keep[-1].tile = tile
+        off_op, dcn_op = plan.ops[-2], plan.ops[-1]
+        plan.ops = [off_op]; ms_off = timeit(plan)
+        plan.ops = [dcn_op]
+        try:
+            ms = timeit(plan)
+        except Exception as e:
+            print("%-28s tile %3dx%-3d  -- %s" % (name, tile >> 16, tile & 0xffff, str(e)[:60])); continue
+        print("%-28s tile %3dx%-3d  %7.3f ms  %6.1f TF/s   (offset conv %6.3f ms %5.1f TF/s)" % (
+            name, tile >> 16, tile & 0xffff, ms, dcn_op[3] / ms / 1e9, ms_off, off_op[3] / ms_off / 1e9), flush=True)
+
+
+ALL = [T(128, 128), T(128, 64), T(64, 64), T(64, 128)]
+conv_case("base 7x7 4->16 @608x1088", 608, 1088, 3, 16, 7, 1, [T(128, 32)])
+conv_case("level0 3x3 16->16 @608", 608, 1088, 16, 16, 3, 1, [T(128, 32)])
+conv_case("level1 3x3s2 16->32", 608, 1088, 16, 32, 3, 2, [T(128, 32)])
+conv_case("3x3 64->64 @152x272", 152, 272, 64, 64, 3, 1, [T(128, 64), T(64, 64)])
+conv_case("3x3 128->128 @76x136", 76, 136, 128, 128, 3, 1, ALL)
+conv_case("3x3 256->256 @38x68", 38, 68, 256, 256, 3, 1, ALL)
+conv_case("3x3 512->512 @19x34", 19, 34, 512, 512, 3, 1, ALL)
+conv_case("1x1 1280->512 @19x34", 19, 34, 1280, 512, 1, 1, ALL)
+conv_case("1x1 448->128 @76x136", 76, 136, 448, 128, 1, 1, ALL)
+conv_case("head 3x3 64->256 @152x272", 152, 272, 64, 256, 3, 1, ALL)
+conv_case("head 1x1 256->1", 152, 272, 256, 1, 1, 1, [T(128, 32)])
+dcn_case("dcn 64->64 @152x272", 152, 272, 64, 64, [T(64, 64)])
+dcn_case("dcn 128->64 @76x136", 76, 136, 128, 64, [T(64, 64)])
+dcn_case("dcn 128->128 @76x136", 76, 136, 128, 128, [T(64, 64), T(64, 128)])
+dcn_case("dcn 256->256 @38x68", 38, 68, 256, 256, [T(64, 64), T(64, 128)])
+dcn_case("dcn 512->256 @19x34", 19, 34, 512, 256, [T(64, 64), T(64, 128)])
