@@ -25,4 +25,10 @@ void deft_set_error(const char* fmt, ...);
         }                                                                    \
     } while (0)
 
+// Dynamic LDS, 16-byte aligned base (ds_read/write_b128).  Kernels that use it declare no
+// static __shared__ objects, so the dynamic region starts at offset 0 (guide G17).
+#ifndef DEFT_DYN_LDS      /* the unit-test SIMT emulator pre-defines this hook */
+#define DEFT_DYN_LDS(type, var) extern __shared__ __attribute__((aligned(16))) type var[]
+#endif
+
 static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -22,7 +22,13 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 #define LDS_STRIDE 36
 #define ROW_INVALID (-(1 << 28))
 
-template <int BM, int BN, int WM, int WN, int MODE>
+// dynamic-LDS layout (floats): As[NSTAGE][BM*36] | Bs[NSTAGE][BN*36] | DCN sampling params [2][BM*12]
+template <int BM, int BN, int NSTAGE, int MODE>
+constexpr int igemm_lds_floats() {
+    return NSTAGE * (BM + BN) * LDS_STRIDE + (MODE == MODE_DCN ? 2 * BM * 12 : 0);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
 __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, int ntiles) {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
@@ -30,9 +36,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
     constexpr int GB = BN / 32;  // float4 groups per thread, B tile
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
+    static_assert(MODE != MODE_DCN || NSTAGE == 2, "the DCN loader is written for the 2-stage loop");
 
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_STRIDE];
+    DEFT_DYN_LDS(float, smem);
+    float* const As = smem;
+    float* const Bs = smem + NSTAGE * BM * LDS_STRIDE;
+    float* const prm = Bs + NSTAGE * BN * LDS_STRIDE;   // DCN only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,13 +91,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                     r0[i] = oy * p.stride - p.pad;
                     r1[i] = ox * p.stride - p.pad;
                 } else {
-                    r0[i] = oy;
-                    r1[i] = ox;
+                    r0[i] = 0;
                 }
                 r2[i] = n * p.H * p.W;
             }
         }
     }
+
+    // DCN: one thread per tile row computes the bilinear sampling record of (row, tap) once
+    // per tap -- upstream DCNv2 modulated_deformable_im2col + dmcn_im2col_bilinear semantics --
+    // into prm[tap&1][row][12] = {4 pixel offsets, 4 corner weights, sigmoid(mask)}.
+    auto dcn_params = [&](int tap) {
+        if (tid < BM) {
+            const int m = m0 + tid;
+            int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mask = 0.f;
+            if (m < p.M) {
+                const int hw = p.H * p.W;
+                const int rem = m - (m / hw) * hw;
+                const int oy = rem / p.W, ox = rem - oy * p.W;
+                const float* om = p.x2 + (size_t)m * p.ldom;
+                const float dy = om[2 * tap], dx = om[2 * tap + 1], ml = om[18 + tap];
+                const int r = tap / 3, s = tap - 3 * r;
+                const float h_im = (float)(oy - 1 + r) + dy;
+                const float w_im = (float)(ox - 1 + s) + dx;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                    const float hl = floorf(h_im), wl = floorf(w_im);
+                    const float lh = h_im - hl, lw = w_im - wl;
+                    const float hh = 1.f - lh, hw_ = 1.f - lw;
+                    const int h_low = (int)hl, w_low = (int)wl;
+                    const int h_high = h_low + 1, w_high = w_low + 1;
+                    mask = 1.f / (1.f + expf(-ml));
+                    if (h_low >= 0 && w_low >= 0) { o1 = h_low * p.W + w_low; w1 = hh * hw_; }
+                    if (h_low >= 0 && w_high <= p.W - 1) { o2 = h_low * p.W + w_high; w2 = hh * lw; }
+                    if (h_high <= p.H - 1 && w_low >= 0) { o3 = h_high * p.W + w_low; w3 = lh * hw_; }
+                    if (h_high <= p.H - 1 && w_high <= p.W - 1) { o4 = h_high * p.W + w_high; w4 = lh * lw; }
+                }
+            }
+            float* pr = prm + ((tap & 1) * BM + tid) * 12;
+            *(float4*)(pr) = make_float4(__int_as_float(o1), __int_as_float(o2), __int_as_float(o3), __int_as_float(o4));
+            *(float4*)(pr + 4) = make_float4(w1, w2, w3, w4);
+            *(float4*)(pr + 8) = make_float4(mask, 0.f, 0.f, 0.f);
+        }
+    };
 
     auto load_a = [&](int kc, float4* va) {
         const int kflat = kc + g * 4;
@@ -112,42 +157,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                 va[i] = v;
             }
         } else if (MODE == MODE_DCN) {
-            // upstream DCNv2 modulated_deformable_im2col + dmcn_im2col_bilinear semantics
             const int c = kflat & (p.Cin - 1);
             const int tap = kflat >> p.cin_log2;  // 0..8 (Kpad == Ktot since Cin % 32 == 0)
-            const int r = tap / 3, s = tap - 3 * r;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r0[i] != ROW_INVALID) {
-                    const float* om = p.x2 + (size_t)(m0 + rbase + 32 * i) * p.ldom;
-                    const float dy = om[2 * tap], dx = om[2 * tap + 1], ml = om[18 + tap];
-                    const float h_im = (float)(r0[i] - 1 + r) + dy;
-                    const float w_im = (float)(r1[i] - 1 + s) + dx;
-                    if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-                        const float hl = floorf(h_im), wl = floorf(w_im);
-                        const float lh = h_im - hl, lw = w_im - wl;
-                        const float hh = 1.f - lh, hw = 1.f - lw;
-                        const int h_low = (int)hl, w_low = (int)wl;
-                        const int h_high = h_low + 1, w_high = w_low + 1;
-                        const float mask = 1.f / (1.f + expf(-ml));
-                        const float* base = p.x + (size_t)r2[i] * p.ldx + c;
-                        float4 v1 = v, v2 = v, v3 = v, v4 = v;
-                        if (h_low >= 0 && w_low >= 0)
-                            v1 = *(const float4*)(base + (size_t)(h_low * p.W + w_low) * p.ldx);
-                        if (h_low >= 0 && w_high <= p.W - 1)
-                            v2 = *(const float4*)(base + (size_t)(h_low * p.W + w_high) * p.ldx);
-                        if (h_high <= p.H - 1 && w_low >= 0)
-                            v3 = *(const float4*)(base + (size_t)(h_high * p.W + w_low) * p.ldx);
-                        if (h_high <= p.H - 1 && w_high <= p.W - 1)
-                            v4 = *(const float4*)(base + (size_t)(h_high * p.W + w_high) * p.ldx);
-                        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-                        v.x = (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * mask;
-                        v.y = (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * mask;
-                        v.z = (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * mask;
-                        v.w = (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * mask;
-                    }
-                }
+                const float* pr = prm + ((tap & 1) * BM + rbase + 32 * i) * 12;
+                const float4 po = *(const float4*)pr;          // invalid corners: offset 0, weight 0
+                const float4 pw = *(const float4*)(pr + 4);
+                const float mask = pr[8];
+                const float* base = p.x + (size_t)r2[i] * p.ldx + c;
+                const float4 v1 = *(const float4*)(base + (size_t)__float_as_int(po.x) * p.ldx);
+                const float4 v2 = *(const float4*)(base + (size_t)__float_as_int(po.y) * p.ldx);
+                const float4 v3 = *(const float4*)(base + (size_t)__float_as_int(po.z) * p.ldx);
+                const float4 v4 = *(const float4*)(base + (size_t)__float_as_int(po.w) * p.ldx);
+                float4 v;
+                v.x = (pw.x * v1.x + pw.y * v2.x + pw.z * v3.x + pw.w * v4.x) * mask;
+                v.y = (pw.x * v1.y + pw.y * v2.y + pw.z * v3.y + pw.w * v4.y) * mask;
+                v.z = (pw.x * v1.z + pw.y * v2.z + pw.z * v3.z + pw.w * v4.z) * mask;
+                v.w = (pw.x * v1.w + pw.y * v2.w + pw.z * v3.w + pw.w * v4.w) * mask;
                 va[i] = v;
             }
         } else {
@@ -171,6 +198,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
         for (int i = 0; i < GB; ++i)
             vb[i] = *(const float4*)(p.w + (size_t)(n0 + rbase + 32 * i) * p.Kpad + kc + g * 4);
     };
+    auto store_ab = [&](int stage, const float4* va, const float4* vb) {
+        float* as = As + stage * BM * LDS_STRIDE;
+        float* bs = Bs + stage * BN * LDS_STRIDE;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) *(float4*)&as[(rbase + 32 * i) * LDS_STRIDE + g * 4] = va[i];
+#pragma unroll
+        for (int i = 0; i < GB; ++i) *(float4*)&bs[(rbase + 32 * i) * LDS_STRIDE + g * 4] = vb[i];
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -182,27 +217,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 
     float4 va[GA], vb[GB];
     const int nk = p.Kpad >> 5;
-    load_a(0, va);
-    load_b(0, vb);
-
     const int frow = lane & 31;        // row of the 32-row MFMA tile this lane feeds
     const int fk = (lane >> 5) * 16;   // first of this lane's 16 k-values in the chunk
+    float a[TM][16], b[TN][16];
 
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // all waves finished reading the previous chunk
-#pragma unroll
-        for (int i = 0; i < GA; ++i) *(float4*)&As[(rbase + 32 * i) * LDS_STRIDE + g * 4] = va[i];
-#pragma unroll
-        for (int i = 0; i < GB; ++i) *(float4*)&Bs[(rbase + 32 * i) * LDS_STRIDE + g * 4] = vb[i];
-        __syncthreads();
-        if (kt + 1 < nk) {  // next chunk's global loads stay in flight under the MFMAs
-            load_a((kt + 1) << 5, va);
-            load_b((kt + 1) << 5, vb);
-        }
-        float a[TM][16], b[TN][16];
+    auto read_frags = [&](int stage) {
+        const float* as = As + stage * BM * LDS_STRIDE;
+        const float* bs = Bs + stage * BN * LDS_STRIDE;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const float4* ap = (const float4*)&As[((wm * TM + i) * 32 + frow) * LDS_STRIDE + fk];
+            const float4* ap = (const float4*)&as[((wm * TM + i) * 32 + frow) * LDS_STRIDE + fk];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 t = ap[q];
@@ -211,13 +235,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float4* bp = (const float4*)&Bs[((wn * TN + j) * 32 + frow) * LDS_STRIDE + fk];
+            const float4* bp = (const float4*)&bs[((wn * TN + j) * 32 + frow) * LDS_STRIDE + fk];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 t = bp[q];
                 b[j][4 * q + 0] = t.x; b[j][4 * q + 1] = t.y; b[j][4 * q + 2] = t.z; b[j][4 * q + 3] = t.w;
             }
         }
+    };
+    auto mfma_chunk = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
@@ -225,6 +251,61 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+    };
+
+    if (NSTAGE == 1) {
+        // one LDS stage, two barriers per chunk; next chunk's global loads fly under the MFMAs
+        load_a(0, va);
+        load_b(0, vb);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();  // all waves finished reading the previous chunk
+            store_ab(0, va, vb);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                load_a((kt + 1) << 5, va);
+                load_b((kt + 1) << 5, vb);
+            }
+            read_frags(0);
+            mfma_chunk();
+        }
+    } else {
+        // two LDS stages, ONE barrier per chunk.  Iteration kt: read fragments of chunk kt,
+        // park chunk kt+1 (registers, loaded one iteration ago) in the other stage, issue the
+        // global loads of chunk kt+2, then the MFMAs of chunk kt.  The stage written at kt was
+        // last read at kt-1 (barrier in between); it is read at kt+1 (barrier in between).
+        const int cpt = (MODE == MODE_DCN) ? (p.Cin >> 5) : 1;   // chunks per tap (DCN)
+        if (MODE == MODE_DCN) {
+            // sampling records whose first chunk is 0,1,2 must exist before the first loads
+            for (int c0 = 0; c0 <= 2 && c0 < nk; ++c0)
+                if (c0 % cpt == 0) dcn_params(c0 / cpt);
+            __syncthreads();
+        }
+        load_a(0, va);
+        load_b(0, vb);
+        store_ab(0, va, vb);
+        if (nk > 1) {
+            load_a(32, va);
+            load_b(32, vb);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            read_frags(cur);
+            if (kt + 1 < nk) store_ab(cur ^ 1, va, vb);
+            if (MODE == MODE_DCN) {
+                // record of the tap whose first chunk is kt+3: visible after this iteration's
+                // barrier, first used by load_a(kt+3) in iteration kt+1; the other parity buffer
+                // (tap-1) is still being read by this iteration's load_a(kt+2).
+                const int c3 = kt + 3;
+                if (c3 < nk && c3 % cpt == 0) dcn_params(c3 / cpt);
+            }
+            if (kt + 2 < nk) {
+                load_a((kt + 2) << 5, va);
+                load_b((kt + 2) << 5, vb);
+            }
+            mfma_chunk();
+            __syncthreads();
+        }
     }
 
     // epilogue: D reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31);
@@ -265,13 +346,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
 static int launch_igemm(const DeftGemmDesc& d, hipStream_t s) {
     const int mtiles = deft_cdiv(d.M, BM), ntiles = deft_cdiv(d.Cout, BN);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE>), dim3(mtiles * ntiles), dim3(256), 0, s, d,
+    constexpr int lds_bytes = igemm_lds_floats<BM, BN, NSTAGE, MODE>() * 4;
+    static bool attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
+    if (lds_bytes > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MODE, NSTAGE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        DEFT_CHECK(e == hipSuccess, -101, "igemm: hipFuncSetAttribute(%d B LDS) failed: %s", lds_bytes, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, NSTAGE>), dim3(mtiles * ntiles), dim3(256), lds_bytes, s, d,
                        mtiles, ntiles);
     DEFT_CHECK_LAUNCH("igemm");
     return 0;
+}
+
+// `tile` knob: bits 0-15 BN, bits 16-29 BM, bit 30 = force the 1-stage (2-barrier) loop
+template <int MODE>
+static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage, hipStream_t s) {
+    if (MODE != MODE_DCN && one_stage) {
+        constexpr int M1 = (MODE == MODE_DCN) ? MODE_CONV : MODE;
+        if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, M1, 1>(d, s);
+        if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, M1, 1>(d, s);
+        if (bm == 128 && bn == 32) return launch_igemm<128, 32, 4, 1, M1, 1>(d, s);
+        if (bm == 64 && bn == 64) return launch_igemm<64, 64, 2, 2, M1, 1>(d, s);
+        if (bm == 64 && bn == 128) return launch_igemm<64, 128, 2, 2, M1, 1>(d, s);
+    } else {
+        if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, MODE, 2>(d, s);
+        if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, MODE, 2>(d, s);
+        if (bm == 128 && bn == 32) return launch_igemm<128, 32, 4, 1, MODE, 2>(d, s);
+        if (bm == 64 && bn == 64) return launch_igemm<64, 64, 2, 2, MODE, 2>(d, s);
+        if (bm == 64 && bn == 128) return launch_igemm<64, 128, 2, 2, MODE, 2>(d, s);
+    }
+    DEFT_CHECK(false, -15, "igemm: unsupported tile %dx%d", bm, bn);
+    return -15;
 }
 
 static int check_common(const DeftGemmDesc* d, const char* who) {
@@ -297,21 +407,16 @@ extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->M == d->N * d->OH * d->OW, -13, "deft_conv2d_nhwc: M != N*OH*OW");
     DEFT_CHECK(d->ldx >= d->Cin, -14, "deft_conv2d_nhwc: ldx < Cin");
     hipStream_t s = (hipStream_t)stream;
-    int bm = d->tile >> 16, bn = d->tile & 0xffff;
-    if (d->tile == 0) {
+    int bm = (d->tile >> 16) & 0x3fff, bn = d->tile & 0xffff;
+    const bool one_stage = (d->tile >> 30) & 1;
+    if (bm == 0) {
         const long long m128 = deft_cdiv(d->M, 128);
         if (d->Cout <= 32) { bm = 128; bn = 32; }
         else if (d->Cout > 64 && m128 * deft_cdiv(d->Cout, 128) >= FILL_BLOCKS) { bm = 128; bn = 128; }
         else if (m128 * deft_cdiv(d->Cout, 64) >= FILL_BLOCKS) { bm = 128; bn = 64; }
         else { bm = 64; bn = 64; }
     }
-    if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, MODE_CONV>(*d, s);
-    if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, MODE_CONV>(*d, s);
-    if (bm == 128 && bn == 32) return launch_igemm<128, 32, 4, 1, MODE_CONV>(*d, s);
-    if (bm == 64 && bn == 64) return launch_igemm<64, 64, 2, 2, MODE_CONV>(*d, s);
-    if (bm == 64 && bn == 128) return launch_igemm<64, 128, 2, 2, MODE_CONV>(*d, s);
-    DEFT_CHECK(false, -15, "deft_conv2d_nhwc: unsupported tile %dx%d", bm, bn);
-    return -15;
+    return dispatch_igemm<MODE_CONV>(*d, bm, bn, one_stage, s);
 }
 
 extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
@@ -323,15 +428,13 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->Ktot == 9 * d->Cin && d->Kpad == d->Ktot, -23, "deft_dcn_v2_nhwc: Ktot/Kpad mismatch");
     DEFT_CHECK(d->OH == d->H && d->OW == d->W && d->M == d->N * d->H * d->W, -24, "deft_dcn_v2_nhwc: geometry mismatch");
     hipStream_t s = (hipStream_t)stream;
-    int bm = d->tile >> 16, bn = d->tile & 0xffff;
-    if (d->tile == 0) {
+    int bm = (d->tile >> 16) & 0x3fff, bn = d->tile & 0xffff;
+    const bool one_stage = (d->tile >> 30) & 1;
+    if (bm == 0) {
         bm = 64;
         bn = (d->Cout > 64 && (long long)deft_cdiv(d->M, 64) * deft_cdiv(d->Cout, 128) >= FILL_BLOCKS) ? 128 : 64;
     }
-    if (bm == 64 && bn == 64) return launch_igemm<64, 64, 2, 2, MODE_DCN>(*d, s);
-    if (bm == 64 && bn == 128) return launch_igemm<64, 128, 2, 2, MODE_DCN>(*d, s);
-    DEFT_CHECK(false, -25, "deft_dcn_v2_nhwc: unsupported tile %dx%d", bm, bn);
-    return -25;
+    return dispatch_igemm<MODE_DCN>(*d, bm, bn, false, s);
 }
 
 extern "C" int deft_pair_layer(const DeftGemmDesc* d, void* stream) {
@@ -339,13 +442,11 @@ extern "C" int deft_pair_layer(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->x2 != nullptr && d->Q > 0 && d->M % d->Q == 0, -30, "deft_pair_layer: need V' and M %% Q == 0");
     DEFT_CHECK(d->Kpad == d->Ktot && d->ldx >= d->Ktot && (((size_t)d->x2) & 15) == 0, -31, "deft_pair_layer: K must be a multiple of 32 and <= ldx");
     hipStream_t s = (hipStream_t)stream;
-    int bm = d->tile >> 16, bn = d->tile & 0xffff;
-    if (d->tile == 0) {
+    int bm = (d->tile >> 16) & 0x3fff, bn = d->tile & 0xffff;
+    const bool one_stage = (d->tile >> 30) & 1;
+    if (bm == 0) {
         bm = 128;
         bn = (d->Cout > 64 && (long long)deft_cdiv(d->M, 128) * deft_cdiv(d->Cout, 128) >= FILL_BLOCKS) ? 128 : 64;
     }
-    if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, MODE_PAIR>(*d, s);
-    if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, MODE_PAIR>(*d, s);
-    DEFT_CHECK(false, -32, "deft_pair_layer: unsupported tile %dx%d", bm, bn);
-    return -32;
+    return dispatch_igemm<MODE_PAIR>(*d, bm, bn, one_stage, s);
 }

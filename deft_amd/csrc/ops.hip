@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
     const int ox = (int)(t % OW); t /= OW;
     const int oy = (int)(t % OH);
     const int n = (int)(t / OH);
-    const int k2 = 2 * f, kk = k2 * k2;
+    const int k2 = 2 * f;
     const int py = oy + f / 2, px = ox + f / 2;
     const int iy1 = py / f, ix1 = px / f;            // tap ky1 = py - iy1*f in [0,f)
     const int ky1 = py - iy1 * f, kx1 = px - ix1 * f;
@@ -120,11 +120,11 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
             const int ix = ix1 - 1 + b, kx = kx1 + f - b * f;
             if (ix < 0 || ix >= W) continue;
             const float4 v = *(const float4*)(x + ((size_t)(n * H + iy) * W + ix) * ldx + 4 * c4);
-            const float* wp = wup + (size_t)(4 * c4) * kk + ky * k2 + kx;
-            acc[0] += v.x * wp[0];
-            acc[1] += v.y * wp[kk];
-            acc[2] += v.z * wp[2 * kk];
-            acc[3] += v.w * wp[3 * kk];
+            const float4 w = *(const float4*)(wup + (size_t)(ky * k2 + kx) * (4 * C4) + 4 * c4);   // [tap][C]
+            acc[0] += v.x * w.x;
+            acc[1] += v.y * w.y;
+            acc[2] += v.z * w.z;
+            acc[3] += v.w * w.w;
         }
     }
     const float4 s = *(const float4*)(skip + o * lds + 4 * c4);
@@ -394,11 +394,17 @@ extern "C" int deft_decode_boxes(const int* inds, const float* heads, int N, int
 // ---------------------------------------------------------------------------
 #define EM_MAXC 512
 
+// One workgroup per (detection, frame).  Threads = 4 bilinear corners x (Co/4) output quads x
+// S k-slices: each thread accumulates 4 outputs over its slice of the 9*C contraction with
+// float4 weight loads (a quad group reads Co*4 contiguous bytes per k), the slices are then
+// reduced through LDS.  The 4x4xC input neighbourhood (zero padded = the conv's padding) is
+// staged once in LDS.
 __global__ __launch_bounds__(256) void embed_map_kernel(const float* __restrict__ fmap, int H, int W, int C, int ld,
                                                         const float* __restrict__ wsel_t, const float* __restrict__ bsel, int Co,
                                                         const float* __restrict__ centers, int ndet,
                                                         float* __restrict__ out, int ldo, int col_off) {
     __shared__ __attribute__((aligned(16))) float patch[16 * EM_MAXC];
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
     __shared__ float vals[4][64];
     const int tid = threadIdx.x, i = blockIdx.x, n = blockIdx.y;
     const float gx = centers[((size_t)n * ndet + i) * 2], gy = centers[((size_t)n * ndet + i) * 2 + 1];
@@ -418,16 +424,29 @@ __global__ __launch_bounds__(256) void embed_map_kernel(const float* __restrict_
         *(float4*)&patch[pos * C + 4 * c4] = v;
     }
     __syncthreads();
-    if (tid < 4 * Co) {
-        const int q = tid / Co, o = tid - q * Co;
+    const int G = Co >> 2;                 // output quads
+    const int S = 256 / (4 * G);           // k-slices (Co=32 -> 8, 48 -> 5, 64 -> 4)
+    const int og = tid % G, q = (tid / G) & 3, sl = tid / (4 * G);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sl < S) {
         const int qy = q >> 1, qx = q & 1;
-        float acc = bsel[o];
         for (int tap = 0; tap < 9; ++tap) {
             const float* pp = &patch[((qy + tap / 3) * 4 + (qx + tap % 3)) * C];
-            const float* wp = wsel_t + (size_t)tap * C * Co + o;
-            for (int c = 0; c < C; ++c) acc += wp[(size_t)c * Co] * pp[c];
+            const float* wp = wsel_t + (size_t)tap * C * Co + 4 * og;
+            for (int c = sl; c < C; c += S) {
+                const float4 w = *(const float4*)(wp + (size_t)c * Co);
+                const float xv = pp[c];
+                acc.x += w.x * xv; acc.y += w.y * xv; acc.z += w.z * xv; acc.w += w.w * xv;
+            }
         }
-        vals[q][o] = fmaxf(acc, 0.f);
+        *(float4*)&red[tid * 4] = acc;
+    }
+    __syncthreads();
+    if (tid < 4 * Co) {                    // (corner q2, output o): sum the S slices, bias, ReLU
+        const int q2 = tid / Co, o = tid - q2 * Co;
+        float v = bsel[o];
+        for (int s2 = 0; s2 < S; ++s2) v += red[((s2 * 4 + q2) * G + (o >> 2)) * 4 + (o & 3)];
+        vals[q2][o] = fmaxf(v, 0.f);
     }
     __syncthreads();
     if (tid < Co) {
@@ -447,7 +466,8 @@ extern "C" int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, in
                               const float* wsel_t, const float* bsel, int Co,
                               const float* centers, int ndet, float* out, int ldo, int col_off, void* stream) {
     DEFT_CHECK(fmap && wsel_t && bsel && centers && out, -1, "deft_embed_map: null pointer");
-    DEFT_CHECK(C <= EM_MAXC && (C & 3) == 0 && (ld & 3) == 0 && Co <= 64 && Co > 0, -2, "deft_embed_map: C=%d (<=%d, %%4) Co=%d (<=64)", C, EM_MAXC, Co);
+    DEFT_CHECK(C <= EM_MAXC && (C & 3) == 0 && (ld & 3) == 0 && Co <= 64 && Co >= 4 && (Co & 3) == 0, -2,
+               "deft_embed_map: C=%d (<=%d, %%4) Co=%d (4..64, %%4)", C, EM_MAXC, Co);
     if (ndet <= 0) return 0;
     hipLaunchKernelGGL(embed_map_kernel, dim3(ndet, Nf), dim3(256), 0, (hipStream_t)stream,
                        fmap, H, W, C, ld, wsel_t, bsel, Co, centers, ndet, out, ldo, col_off);

@@ -274,7 +274,7 @@ class DlaSegPlan(_Plan):
             wkey = p + ".up_%d.weight" % k
             if wkey not in self._wcache:
                 w = self.sd[wkey].float()
-                self._wcache[wkey] = (self.dev(w.reshape(w.shape[0], -1)), w.shape[2] // 2)
+                self._wcache[wkey] = (self.dev(w.reshape(w.shape[0], -1).t()), w.shape[2] // 2)   # [taps][C]
             wup, f = self._wcache[wkey]
             t = self._deform(p + ".proj_%d" % k, layers[i])
             u = self.upsample_add(p + ".up_%d" % k, t, wup, layers[i - 1], f)

@@ -80,7 +80,8 @@ int deft_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, int ld
 
 /* Depthwise ConvTranspose2d(k=2f, stride f, pad f/2) + skip add:
  * y = up(x) + skip  -- IDAUp.forward dla.py:696-699 (`upsample(project(l[i])) + l[i-1]`).
- * x is [N,H,W,C]; skip and y are [N,f*H,f*W,C]; wup is the module's weight [C][2f*2f]. */
+ * x is [N,H,W,C]; skip and y are [N,f*H,f*W,C]; wup is the module's weight transposed to
+ * [2f*2f][C] (tap-major, so 4 channels of one tap are one 16-byte load). */
 int deft_upsample_add(const float* x, const float* wup, const float* skip, float* y,
                       int N, int H, int W, int C, int f, int ldx, int lds, int ldy, void* stream);
 

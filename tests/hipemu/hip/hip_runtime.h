@@ -52,6 +52,10 @@ static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+namespace hipemu { inline void* dyn_lds() { alignas(16) static char buf[160 * 1024]; return buf; } }
+#define DEFT_DYN_LDS(type, var) type* var = (type*)hipemu::dyn_lds()
 
 namespace hipemu {
 enum Yield { Y_NONE = 0, Y_WAVE = 1, Y_BLOCK = 2, Y_DONE = 3 };

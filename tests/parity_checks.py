@@ -130,7 +130,7 @@ def check_pool_upsample(lib, device):
         wup = torch.rand(Cc, 1, 2 * f, 2 * f, generator=g)
         skip = torch.randn(N, Cc, H * f, W * f, generator=g)
         sv = plan.alloc(N, H * f, W * f, Cc); fill_view(sv, skip)
-        up = plan.upsample_add("up", xv, plan.dev(wup.reshape(Cc, -1)), sv, f)
+        up = plan.upsample_add("up", xv, plan.dev(wup.reshape(Cc, -1).t()), sv, f)
         outs.append((up, F.conv_transpose2d(x, wup, None, stride=f, padding=f // 2, groups=Cc) + skip))
     plan.run()
     assert maxabs(mp.to_nchw(), F.max_pool2d(x, 2, 2)) == 0.0
@@ -220,6 +220,28 @@ def check_embed(lib, device, plan, ora_maps, sd, golden_tag=None, ndet=12):
     if golden_tag and Nf >= 1:
         assert maxabs(emb[0:1], torch.from_numpy(gold["emb"])) <= 1e-4 * max(1.0, float(np.abs(gold["emb"]).max()))
     return afe, emb
+
+
+def check_embed_map(lib, device, Cc, Co, Hm=7, Wm=9, ndet=6, Nf=2, seed=0):
+    """One (map, selector) pair of the embedding head vs conv2d + relu + grid_sample."""
+    from deft_amd.hiplib import ptr, stream_ptr
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device(device)
+    fm = torch.randn(Nf, Cc, Hm, Wm, generator=g)
+    w = torch.randn(Co, Cc, 3, 3, generator=g) * (1.0 / (9 * Cc) ** 0.5)
+    b = torch.randn(Co, generator=g) * 0.1
+    cen = torch.rand(Nf, ndet, 2, generator=g) * 2.2 - 1.1          # some centres beyond the border
+    cen[0, 0] = torch.tensor([-1.0, 1.0]); cen[0, 1] = torch.tensor([1.0, -1.0])
+    x = torch.zeros(Nf, Hm, Wm, Cc); x[:] = fm.permute(0, 2, 3, 1)
+    wt = w.permute(2, 3, 1, 0).reshape(9 * Cc, Co).contiguous()
+    out = torch.zeros(Nf, ndet, Co + 8, device=dev)
+    lib.call("deft_embed_map", ptr(x.to(dev)), Nf, Hm, Wm, Cc, Cc, ptr(wt.to(dev)), ptr(b.to(dev)), Co,
+             ptr(cen.to(dev).contiguous()), ndet, ptr(out), Co + 8, 4, stream_ptr(dev))
+    src = F.relu(F.conv2d(fm, w, b, 1, 1))
+    ref = F.grid_sample(src, cen.view(Nf, ndet, 1, 2), mode="bilinear", padding_mode="border", align_corners=False)
+    ref = ref.squeeze(3).permute(0, 2, 1)
+    assert maxabs(out[..., 4:4 + Co], ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float(out[..., :4].abs().max()) == 0.0 and float(out[..., 4 + Co:].abs().max()) == 0.0
 
 
 def check_affinity(lib, device, sd, shapes=((5, 7), (12, 12), (1, 3), (9, 2)), golden_tag=None, afe=None, scale=3.0):
