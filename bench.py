@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -90,7 +91,7 @@ def main():
     lib = hiplib.get_lib()                      # no fallback: raises if the HIP extension is missing
     sd = synth.synth_state_dict("mot")
     B = args.batch
-    comp = HipCompute(sd, B, H, W, "mot", K=KDET, device=dev, lib=lib)
+    comp = HipCompute(sd, B, H, W, "mot", K=KDET, device=dev, lib=lib, streams=args.streams)
     pipe = FramePipeline(comp, B, KDET, comp.D, history=HIST, device=dev)
     g = torch.Generator().manual_seed(1000 + rank)
     images = torch.randn(B, 3, H, W, generator=g).to(dev)      # resident in HBM before timing
@@ -121,7 +122,16 @@ def main():
     if rank == 0:
         prof = []
         lib.profile = prof
-        pipe.step(images)
+        ns, comp.nstream = comp.nstream, 1          # profile serialized on one stream: per-launch events
+        if ns > 1:                                   # (sub-batch plan 0, repeated for every sub-batch's frames)
+            for s_ in range(ns):
+                comp.plans[0].forward(images[s_ * comp.sub:(s_ + 1) * comp.sub])
+                comp.afe.extract(comp.plans[0].fmaps, comp.plans[0].centers, out=comp.emb[s_ * comp.sub:(s_ + 1) * comp.sub])
+            ring = torch.cat([pipe.tail, comp.emb], 0).contiguous()
+            comp.affinity_ring(ring, HIST, B, HIST)
+        else:
+            pipe.step(images)
+        comp.nstream = ns
         torch.cuda.synchronize()
         lib.profile = None
         GEMM = ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer")
@@ -152,7 +162,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "MOT17 1088x608 DLA-34 + DCNv2 + 100x500 affinity (BASELINE configs[1])",
-                          "frames_per_step_per_gpu": B, "detections": KDET, "history_frames": HIST,
+                          "frames_per_step_per_gpu": B, "hip_streams": args.streams, "detections": KDET, "history_frames": HIST,
                           "parallelism": "frames sharded dp%d, 1 all-gather/step" % world},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)

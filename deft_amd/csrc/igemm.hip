@@ -36,7 +36,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
     constexpr int GB = BN / 32;  // float4 groups per thread, B tile
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
-    static_assert(MODE != MODE_DCN || NSTAGE == 2, "the DCN loader is written for the 2-stage loop");
 
     DEFT_DYN_LDS(float, smem);
     float* const As = smem;
@@ -255,11 +254,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 
     if (NSTAGE == 1) {
         // one LDS stage, two barriers per chunk; next chunk's global loads fly under the MFMAs
+        const int cpt1 = (MODE == MODE_DCN) ? (p.Cin >> 5) : 1;   // chunks per tap (DCN)
+        if (MODE == MODE_DCN) {
+            dcn_params(0);
+            __syncthreads();
+        }
         load_a(0, va);
         load_b(0, vb);
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();  // all waves finished reading the previous chunk
             store_ab(0, va, vb);
+            // DCN: sampling record of the tap that chunk kt+1 opens; the other parity buffer is
+            // the one load_a(kt) read two barriers ago, this one was last read >= cpt chunks ago
+            if (MODE == MODE_DCN && kt + 1 < nk && (kt + 1) % cpt1 == 0) dcn_params((kt + 1) / cpt1);
             __syncthreads();
             if (kt + 1 < nk) {
                 load_a((kt + 1) << 5, va);
@@ -363,16 +370,17 @@ static int launch_igemm(const DeftGemmDesc& d, hipStream_t s) {
     return 0;
 }
 
-// `tile` knob: bits 0-15 BN, bits 16-29 BM, bit 30 = force the 1-stage (2-barrier) loop
+// `tile` knob: bits 0-15 BN, bits 16-28 BM, bit 30 = force the 1-stage (2-barrier) loop,
+// bit 29 = force the 2-stage (1-barrier, double LDS) loop; default: 1-stage (measured faster
+// at 3 waves/SIMD) except the 64x64 DCN tile
 template <int MODE>
 static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage, hipStream_t s) {
-    if (MODE != MODE_DCN && one_stage) {
-        constexpr int M1 = (MODE == MODE_DCN) ? MODE_CONV : MODE;
-        if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, M1, 1>(d, s);
-        if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, M1, 1>(d, s);
-        if (bm == 128 && bn == 32) return launch_igemm<128, 32, 4, 1, M1, 1>(d, s);
-        if (bm == 64 && bn == 64) return launch_igemm<64, 64, 2, 2, M1, 1>(d, s);
-        if (bm == 64 && bn == 128) return launch_igemm<64, 128, 2, 2, M1, 1>(d, s);
+    if (one_stage) {
+        if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, MODE, 1>(d, s);
+        if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, MODE, 1>(d, s);
+        if (bm == 128 && bn == 32) return launch_igemm<128, 32, 4, 1, MODE, 1>(d, s);
+        if (bm == 64 && bn == 64) return launch_igemm<64, 64, 2, 2, MODE, 1>(d, s);
+        if (bm == 64 && bn == 128) return launch_igemm<64, 128, 2, 2, MODE, 1>(d, s);
     } else {
         if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, MODE, 2>(d, s);
         if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, MODE, 2>(d, s);
@@ -407,8 +415,8 @@ extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->M == d->N * d->OH * d->OW, -13, "deft_conv2d_nhwc: M != N*OH*OW");
     DEFT_CHECK(d->ldx >= d->Cin, -14, "deft_conv2d_nhwc: ldx < Cin");
     hipStream_t s = (hipStream_t)stream;
-    int bm = (d->tile >> 16) & 0x3fff, bn = d->tile & 0xffff;
-    const bool one_stage = (d->tile >> 30) & 1;
+    int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
+    const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) {
         const long long m128 = deft_cdiv(d->M, 128);
         if (d->Cout <= 32) { bm = 128; bn = 32; }
@@ -428,13 +436,12 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->Ktot == 9 * d->Cin && d->Kpad == d->Ktot, -23, "deft_dcn_v2_nhwc: Ktot/Kpad mismatch");
     DEFT_CHECK(d->OH == d->H && d->OW == d->W && d->M == d->N * d->H * d->W, -24, "deft_dcn_v2_nhwc: geometry mismatch");
     hipStream_t s = (hipStream_t)stream;
-    int bm = (d->tile >> 16) & 0x3fff, bn = d->tile & 0xffff;
-    const bool one_stage = (d->tile >> 30) & 1;
+    int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
+    const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) {
-        bm = 64;
-        bn = (d->Cout > 64 && (long long)deft_cdiv(d->M, 64) * deft_cdiv(d->Cout, 128) >= FILL_BLOCKS) ? 128 : 64;
+        bm = 64; bn = 64;      // measured best for every DCN layer shape of DLA-34 (tools/bench_igemm.py)
     }
-    return dispatch_igemm<MODE_DCN>(*d, bm, bn, false, s);
+    return dispatch_igemm<MODE_DCN>(*d, bm, bn, ((d->tile >> 30) & 1) != 0, s);
 }
 
 extern "C" int deft_pair_layer(const DeftGemmDesc* d, void* stream) {
@@ -442,8 +449,8 @@ extern "C" int deft_pair_layer(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->x2 != nullptr && d->Q > 0 && d->M % d->Q == 0, -30, "deft_pair_layer: need V' and M %% Q == 0");
     DEFT_CHECK(d->Kpad == d->Ktot && d->ldx >= d->Ktot && (((size_t)d->x2) & 15) == 0, -31, "deft_pair_layer: K must be a multiple of 32 and <= ldx");
     hipStream_t s = (hipStream_t)stream;
-    int bm = (d->tile >> 16) & 0x3fff, bn = d->tile & 0xffff;
-    const bool one_stage = (d->tile >> 30) & 1;
+    int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
+    const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) {
         bm = 128;
         bn = (d->Cout > 64 && (long long)deft_cdiv(d->M, 128) * deft_cdiv(d->Cout, 128) >= FILL_BLOCKS) ? 128 : 64;

@@ -418,12 +418,15 @@ class AfePlan(_Plan):
         self.w5 = self.dev(sd["AFE.final_net.11.weight"].float().reshape(-1))
         self.b5 = float(sd["AFE.final_net.11.bias"].float().item())
 
-    def extract(self, fmaps, centers):
+    def extract(self, fmaps, centers, out=None):
         """fmaps: 13 Views (DlaSegPlan.fmaps); centers [Nf, ndet, 2] (x,y in [-1,1], as
-        convert_detection image.py:391-412 produces) -> embeddings [Nf, ndet, D]."""
+        convert_detection image.py:391-412 produces) -> embeddings [Nf, ndet, D] (written
+        into `out` when given: a contiguous [Nf, ndet, D] device tensor)."""
         Nf, ndet = centers.shape[0], centers.shape[1]
         centers = centers.to(self.device, torch.float32).contiguous()
-        out = torch.empty(Nf, ndet, self.D, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(Nf, ndet, self.D, dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and tuple(out.shape) == (Nf, ndet, self.D)
         s = self._stream()
         for fm, (wt, b, Co, Cc, off) in zip(fmaps, self.sel):
             assert fm.C == Cc and fm.N == Nf

@@ -18,18 +18,44 @@ from . import engine
 
 
 class HipCompute:
-    """detect+embed and affinity on the local GPU through libdeft_hip.so."""
+    """detect+embed and affinity on the local GPU through libdeft_hip.so.
 
-    def __init__(self, sd, batch, H, W, dataset="mot", K=100, max_object=100, device="cuda", lib=None):
-        self.plan = engine.DlaSegPlan(sd, batch, H, W, dataset, K=K, device=device, lib=lib)
+    `streams` > 1 splits the step's frames into that many independent sub-batches, each with
+    its own plan (own buffers) on its own HIP stream: frames share no state before the
+    embedding exchange, so the hardware overlaps one sub-batch's kernel tails (partially
+    filled last wave of workgroups) and barrier stalls with the other's workgroups."""
+
+    def __init__(self, sd, batch, H, W, dataset="mot", K=100, max_object=100, device="cuda", lib=None, streams=1):
+        assert batch % streams == 0
+        self.device = torch.device(device)
+        self.nstream, self.sub = streams, batch // streams
+        self.plans = [engine.DlaSegPlan(sd, self.sub, H, W, dataset, K=K, device=device, lib=lib) for _ in range(streams)]
+        self.plan = self.plans[0]
         self.afe = engine.AfePlan(sd, max_object, device, lib)
         self.D = self.afe.D
         self.K = K
+        self.emb = torch.zeros(batch, K, self.D, dtype=torch.float32, device=self.device)
+        if streams > 1:
+            self.side = [torch.cuda.Stream(device=self.device) for _ in range(streams)]
+            self.ev_main = torch.cuda.Event()
+            self.ev_side = [torch.cuda.Event() for _ in range(streams)]
 
     def detect_embed(self, images):
-        p = self.plan
-        p.forward(images)
-        return self.afe.extract(p.fmaps, p.centers)          # [batch, K, D]
+        if self.nstream == 1:
+            p = self.plan
+            p.forward(images)
+            return self.afe.extract(p.fmaps, p.centers, out=self.emb)          # [batch, K, D]
+        main = torch.cuda.current_stream(self.device)
+        self.ev_main.record(main)
+        for s, (p, st) in enumerate(zip(self.plans, self.side)):
+            st.wait_event(self.ev_main)                 # previous step's consumers of emb are done
+            with torch.cuda.stream(st):
+                p.forward(images[s * self.sub:(s + 1) * self.sub])
+                self.afe.extract(p.fmaps, p.centers, out=self.emb[s * self.sub:(s + 1) * self.sub])
+                self.ev_side[s].record(st)
+        for ev in self.ev_side:
+            main.wait_event(ev)
+        return self.emb
 
     def affinity(self, hist, cur):
         return self.afe.affinity(hist, cur)[0]

@@ -235,8 +235,9 @@ def check_embed_map(lib, device, Cc, Co, Hm=7, Wm=9, ndet=6, Nf=2, seed=0):
     x = torch.zeros(Nf, Hm, Wm, Cc); x[:] = fm.permute(0, 2, 3, 1)
     wt = w.permute(2, 3, 1, 0).reshape(9 * Cc, Co).contiguous()
     out = torch.zeros(Nf, ndet, Co + 8, device=dev)
-    lib.call("deft_embed_map", ptr(x.to(dev)), Nf, Hm, Wm, Cc, Cc, ptr(wt.to(dev)), ptr(b.to(dev)), Co,
-             ptr(cen.to(dev).contiguous()), ndet, ptr(out), Co + 8, 4, stream_ptr(dev))
+    xd, wd, bd, cd = x.to(dev), wt.to(dev), b.to(dev), cen.to(dev).contiguous()     # keep the device copies alive
+    lib.call("deft_embed_map", ptr(xd), Nf, Hm, Wm, Cc, Cc, ptr(wd), ptr(bd), Co,
+             ptr(cd), ndet, ptr(out), Co + 8, 4, stream_ptr(dev))
     src = F.relu(F.conv2d(fm, w, b, 1, 1))
     ref = F.grid_sample(src, cen.view(Nf, ndet, 1, 2), mode="bilinear", padding_mode="border", align_corners=False)
     ref = ref.squeeze(3).permute(0, 2, 1)

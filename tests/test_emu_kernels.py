@@ -18,7 +18,7 @@ from parity_checks import T
     (1, 6, 10, 64, 200, 1, 1, 0, T(64, 128)),       # Cout not a tile multiple
     (1, 16, 16, 16, 40, 3, 1, 1, 0),                # auto tile
     (3, 4, 4, 128, 27, 3, 1, 1, 0),                 # offset/mask conv shape, M < BM
-    (1, 10, 12, 64, 64, 3, 1, 1, T(128, 64) | (1 << 30)),    # 1-stage (2-barrier) loop variant
+    (1, 10, 12, 64, 64, 3, 1, 1, T(128, 64) | (1 << 29)),    # 2-stage (1-barrier, double LDS) loop variant
     (1, 5, 9, 32, 48, 1, 1, 0, T(64, 64)),                   # single-chunk K (nk == 1)
     (1, 5, 9, 64, 48, 1, 1, 0, T(64, 64)),                   # nk == 2
 ])
@@ -31,7 +31,8 @@ def test_concat_conv(emu_lib):
 
 
 @pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (2, 5, 6, 128, 64, 0), (1, 6, 6, 64, 160, T(64, 128)),
-                                  (1, 9, 9, 64, 64, T(128, 64)), (1, 4, 5, 256, 128, T(128, 128))])
+                                  (1, 9, 9, 64, 64, T(128, 64)), (1, 4, 5, 256, 128, T(128, 128)),
+                                  (1, 7, 9, 64, 64, T(64, 64) | (1 << 30)), (1, 5, 5, 128, 64, T(128, 64) | (1 << 30))])
 def test_dcn(emu_lib, args):
     pc.check_dcn(emu_lib, "cpu", *args[:5], tile=args[5])
 

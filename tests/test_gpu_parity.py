@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
     (2, 38, 68, 256, 256, 3, 1, 1, 0),
     (1, 152, 272, 64, 64, 3, 1, 1, 0),
     (3, 4, 4, 128, 27, 3, 1, 1, 0),
-    (1, 10, 12, 64, 64, 3, 1, 1, T(128, 64) | (1 << 30)),
+    (1, 10, 12, 64, 64, 3, 1, 1, T(128, 64) | (1 << 29)),
+    (1, 10, 12, 64, 64, 3, 1, 1, T(64, 64) | (1 << 29)),
     (1, 5, 9, 32, 48, 1, 1, 0, T(64, 64)),
     (1, 5, 9, 64, 48, 1, 1, 0, T(64, 64)),
 ])
@@ -33,7 +34,8 @@ def test_concat_conv(gpu_lib):
 
 @pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (2, 5, 6, 128, 64, 0), (1, 6, 6, 64, 160, T(64, 128)),
                                   (1, 38, 68, 256, 128, 0), (1, 76, 136, 64, 64, 0),
-                                  (1, 9, 9, 64, 64, T(128, 64)), (1, 4, 5, 256, 128, T(128, 128))])
+                                  (1, 9, 9, 64, 64, T(128, 64)), (1, 4, 5, 256, 128, T(128, 128)),
+                                  (1, 7, 9, 64, 64, T(64, 64) | (1 << 30)), (1, 5, 5, 128, 64, T(128, 64) | (1 << 30))])
 def test_dcn(gpu_lib, args):
     pc.check_dcn(gpu_lib, "cuda", *args[:5], tile=args[5])
 

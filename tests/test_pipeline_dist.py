@@ -1,0 +1,82 @@
+"""N>1 path on CPU: 2 gloo ranks run FramePipeline with a stand-in compute object and must
+reproduce, frame for frame, what a single rank computes over the same global stream order
+(frames sharded rank-major inside each step; one all-gather per step; history ring carried
+across steps).  Exercises the exchange/scheduling logic only -- kernels are covered elsewhere."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deft_amd.pipeline import FramePipeline  # noqa: E402
+
+K, D, HIST = 3, 8, 2
+
+
+class FakeCompute:
+    """Embedding = per-frame signature; 'affinity' = (history signatures, current signature)."""
+
+    def detect_embed(self, images):
+        sig = images.reshape(images.shape[0], -1).sum(1)
+        return (sig.view(-1, 1, 1) + torch.arange(K * D, dtype=torch.float32).view(1, K, D)).contiguous()
+
+    def affinity(self, hist, cur):
+        return torch.stack([h[0, 0] for h in hist] + [cur[0, 0]])
+
+
+def _frames(nsteps, world, batch):
+    g = torch.Generator().manual_seed(0)
+    return torch.randn(nsteps, world * batch, 1, 2, 2, generator=g)
+
+
+def _run(rank, world, batch, nsteps, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _frames(nsteps, world, batch)
+    pipe = FramePipeline(FakeCompute(), batch, K, D, history=HIST, device="cpu")
+    outs = []
+    for s in range(nsteps):
+        res = pipe.step(frames[s, rank * batch:(rank + 1) * batch])
+        outs.append([None if r is None else [float(v) for v in r] for r in res])   # plain lists: picklable
+    q.put((rank, outs))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _collect(world, batch, nsteps, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_run, args=(r, world, batch, nsteps, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_two_ranks_match_single_rank(batch):
+    nsteps, world = 4, 2
+    two = _collect(world, batch, nsteps, 29613 + batch)
+    one = _collect(1, world * batch, nsteps, 0)[0]           # same global frames, one rank
+    frames = _frames(nsteps, world, batch)
+    sig = frames.reshape(nsteps, world * batch, -1).sum(2)
+    for s in range(nsteps):
+        for g in range(world * batch):
+            r, b = divmod(g, batch)
+            a, ref = two[r][s][b], one[s][g]
+            gi = s * world * batch + g                        # global frame index in the stream
+            if gi == 0:
+                assert a is None and ref is None
+                continue
+            assert a == ref
+            want = [float(sig.reshape(-1)[t]) for t in range(max(0, gi - HIST), gi + 1)]
+            assert [round(float(v), 4) for v in a] == [round(v, 4) for v in want]

@@ -43,7 +43,7 @@ def conv_case(name, H, W, Ci, Co, k, stride, tiles):
         except Exception as e:  # unsupported tile
             print("%-28s tile %3dx%-3d  -- %s" % (name, tile >> 16, tile & 0xffff, str(e)[:60])); continue
         fl = plan.ops[-1][3]
-        print("%-28s tile %3dx%-3d %s %7.3f ms  %6.1f TF/s" % (name, (tile >> 16) & 0x3fff, tile & 0xffff, "1st" if tile >> 30 else "2st", ms, fl / ms / 1e9), flush=True)
+        print("%-28s tile %3dx%-3d %s %7.3f ms  %6.1f TF/s" % (name, (tile >> 16) & 0x1fff, tile & 0xffff, "2st" if (tile >> 29) & 1 else "1st", ms, fl / ms / 1e9), flush=True)
 
 
 def dcn_case(name, H, W, Ci, Co, tiles):
@@ -68,11 +68,11 @@ def dcn_case(name, H, W, Ci, Co, tiles):
             ms = timeit(plan)
         except Exception as e:
             print("%-28s tile %3dx%-3d  -- %s" % (name, tile >> 16, tile & 0xffff, str(e)[:60])); continue
-        print("%-28s tile %3dx%-3d  %7.3f ms  %6.1f TF/s   (offset conv %6.3f ms %5.1f TF/s)" % (
-            name, tile >> 16, tile & 0xffff, ms, dcn_op[3] / ms / 1e9, ms_off, off_op[3] / ms_off / 1e9), flush=True)
+        print("%-28s tile %3dx%-3d %s %7.3f ms  %6.1f TF/s   (offset conv %6.3f ms %5.1f TF/s)" % (
+            name, (tile >> 16) & 0x1fff, tile & 0xffff, "1st" if (tile >> 30) & 1 else "2st", ms, dcn_op[3] / ms / 1e9, ms_off, off_op[3] / ms_off / 1e9), flush=True)
 
 
-ONE = 1 << 30
+ONE = 1 << 29    # here: force the 2-stage loop (default is 1-stage)
 ALL = [T(128, 128), T(128, 64), T(64, 64), T(64, 128), T(128, 128) | ONE, T(128, 64) | ONE, T(64, 64) | ONE]
 conv_case("base 7x7 4->16 @608x1088", 608, 1088, 3, 16, 7, 1, [T(128, 32), T(128, 32) | ONE])
 conv_case("level0 3x3 16->16 @608", 608, 1088, 16, 16, 3, 1, [T(128, 32), T(128, 32) | ONE])
@@ -85,8 +85,8 @@ conv_case("1x1 1280->512 @19x34", 19, 34, 1280, 512, 1, 1, ALL)
 conv_case("1x1 448->128 @76x136", 76, 136, 448, 128, 1, 1, ALL)
 conv_case("head 3x3 64->256 @152x272", 152, 272, 64, 256, 3, 1, ALL)
 conv_case("head 1x1 256->1", 152, 272, 256, 1, 1, 1, [T(128, 32)])
-dcn_case("dcn 64->64 @152x272", 152, 272, 64, 64, [T(64, 64), T(128, 64)])
-dcn_case("dcn 128->64 @76x136", 76, 136, 128, 64, [T(64, 64), T(128, 64)])
-dcn_case("dcn 128->128 @76x136", 76, 136, 128, 128, [T(64, 64), T(64, 128), T(128, 64), T(128, 128)])
-dcn_case("dcn 256->256 @38x68", 38, 68, 256, 256, [T(64, 64), T(64, 128), T(128, 64), T(128, 128)])
-dcn_case("dcn 512->256 @19x34", 19, 34, 512, 256, [T(64, 64), T(64, 128)])
+dcn_case("dcn 64->64 @152x272", 152, 272, 64, 64, [T(64, 64), T(64, 64) | (1 << 30), T(128, 64) | (1 << 30)])
+dcn_case("dcn 128->64 @76x136", 76, 136, 128, 64, [T(64, 64), T(64, 64) | (1 << 30)])
+dcn_case("dcn 128->128 @76x136", 76, 136, 128, 128, [T(64, 64), T(64, 64) | (1 << 30), T(128, 64) | (1 << 30)])
+dcn_case("dcn 256->256 @38x68", 38, 68, 256, 256, [T(64, 64), T(64, 64) | (1 << 30), T(128, 64) | (1 << 30)])
+dcn_case("dcn 512->256 @19x34", 19, 34, 512, 256, [T(64, 64), T(64, 64) | (1 << 30)])
