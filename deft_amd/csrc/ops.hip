@@ -146,7 +146,7 @@ extern "C" int deft_upsample_add(const float* x, const float* wup, const float* 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-__global__ __launch_bounds__(256) void hm_peaks_kernel(const float* __restrict__ hm, int N, int H, int W, int C, int ld,
+__global__ __launch_bounds__(256) void hm_peaks_kernel(const float* __restrict__ hm, int N, int H, int W, int C, int ld, int sig,
                                                        float* __restrict__ cs, int* __restrict__ ci, int* __restrict__ cc, int cap) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)N * H * W * C) return;
@@ -156,13 +156,16 @@ __global__ __launch_bounds__(256) void hm_peaks_kernel(const float* __restrict__
     const int y = (int)(t % H);
     const int n = (int)(t / H);
     const float* base = hm + (size_t)n * H * W * ld + c;
-    const float s = sigmoidf_(base[(size_t)(y * W + x) * ld]);
+    const float raw = base[(size_t)(y * W + x) * ld];
+    const float s = sig ? sigmoidf_(raw) : raw;
     bool peak = true;
     for (int dy = -1; dy <= 1; ++dy)
         for (int dx = -1; dx <= 1; ++dx) {
             const int yy = y + dy, xx = x + dx;
-            if ((dy | dx) != 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                peak = peak && (sigmoidf_(base[(size_t)(yy * W + xx) * ld]) <= s);
+            if ((dy | dx) != 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                const float nv = base[(size_t)(yy * W + xx) * ld];
+                peak = peak && ((sig ? sigmoidf_(nv) : nv) <= s);
+            }
         }
     if (peak) {
         const int pos = atomicAdd(&cc[n], 1);
@@ -173,11 +176,11 @@ __global__ __launch_bounds__(256) void hm_peaks_kernel(const float* __restrict__
     }
 }
 
-extern "C" int deft_hm_peaks(const float* hm, int N, int H, int W, int C, int ld,
+extern "C" int deft_hm_peaks(const float* hm, int N, int H, int W, int C, int ld, int apply_sigmoid,
                              float* cand_score, int* cand_idx, int* cand_count, int cap, void* stream) {
     DEFT_CHECK(hm && cand_score && cand_idx && cand_count && cap > 0 && ld >= C, -1, "deft_hm_peaks: bad arguments");
     const long long tot = (long long)N * H * W * C;
-    hipLaunchKernelGGL(hm_peaks_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, hm, N, H, W, C, ld, cand_score, cand_idx, cand_count, cap);
+    hipLaunchKernelGGL(hm_peaks_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, hm, N, H, W, C, ld, apply_sigmoid, cand_score, cand_idx, cand_count, cap);
     DEFT_CHECK_LAUNCH("hm_peaks");
     return 0;
 }

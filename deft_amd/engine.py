@@ -315,7 +315,7 @@ class DlaSegPlan(_Plan):
         self.inds = torch.zeros(N, K, dtype=torch.int32, device=self.device)
         self.clses = torch.zeros(N, K, dtype=torch.int32, device=self.device)
         self.add("zero", "cand_count", lambda: self.cand_n.zero_())
-        a = (C.c_void_p(hm.addr), N, h, w, chm, hm.ld, ptr(self.cand_s), ptr(self.cand_i), ptr(self.cand_n), cap)
+        a = (C.c_void_p(hm.addr), N, h, w, chm, hm.ld, 1, ptr(self.cand_s), ptr(self.cand_i), ptr(self.cand_n), cap)
         self.add("deft_hm_peaks", "hm_peaks", lambda: lib.call("deft_hm_peaks", *a, self._stream()))
         b = (ptr(self.cand_s), ptr(self.cand_i), ptr(self.cand_n), N, cap, K, h * w, ptr(self.scores), ptr(self.inds), ptr(self.clses))
         self.add("deft_topk", "topk", lambda: lib.call("deft_topk", *b, self._stream()))

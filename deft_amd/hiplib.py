@@ -3,7 +3,7 @@
 The library is the product: there is NO CPU or PyTorch fallback.  `get_lib()`
 raises if deft_amd/lib/libdeft_hip.so (built by `python -m deft_amd.build` /
 __graft_entry__.build()) is missing.  The unit tests may hand an explicitly
-built emulator object (tests/hipemu) to `load(path)`; nothing in this package
+built test object to `HipLib(path)`; nothing in this package
 ever selects it.
 """
 import ctypes as C
@@ -42,7 +42,7 @@ _SIGS = {
     "deft_nhwc_to_nchw": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
     "deft_maxpool2x2": (C.c_int, [c_fp, c_fp] + [C.c_int] * 6 + [c_fp]),
     "deft_upsample_add": (C.c_int, [c_fp] * 4 + [C.c_int] * 8 + [c_fp]),
-    "deft_hm_peaks": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp] * 3 + [C.c_int, c_fp]),
+    "deft_hm_peaks": (C.c_int, [c_fp] + [C.c_int] * 6 + [c_fp] * 3 + [C.c_int, c_fp]),
     "deft_topk": (C.c_int, [c_fp] * 3 + [C.c_int] * 4 + [c_fp] * 3 + [c_fp]),
     "deft_heads_at_peaks": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, C.c_int] + [c_fp] * 5 + [C.c_int] * 2 + [c_fp, c_fp]),
     "deft_decode_boxes": (C.c_int, [c_fp, c_fp] + [C.c_int] * 8 + [c_fp] * 4),

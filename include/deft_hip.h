@@ -86,10 +86,11 @@ int deft_upsample_add(const float* x, const float* wup, const float* skip, float
                       int N, int H, int W, int C, int f, int ldx, int lds, int ldy, void* stream);
 
 /* sigmoid + 3x3 peak NMS + candidate compaction (detector.py:488, utils.py:69-74).
- * hm: logits NHWC [N,H,W,C] (ld).  For every (n) appends (score, c*H*W + y*W + x)
+ * hm: NHWC [N,H,W,C] (ld): logits when apply_sigmoid != 0, already-sigmoid'ed scores
+ * otherwise (the form model.decode.generic_decode receives).  For every (n) appends (score, c*H*W + y*W + x)
  * of every local maximum to cand_*[n*cap ...]; cand_count[n] must be zeroed by the
  * caller (hipMemsetAsync) before the call. */
-int deft_hm_peaks(const float* hm, int N, int H, int W, int C, int ld,
+int deft_hm_peaks(const float* hm, int N, int H, int W, int C, int ld, int apply_sigmoid,
                   float* cand_score, int* cand_idx, int* cand_count, int cap, void* stream);
 
 /* top-K over the candidates, descending score, ties by ascending index

@@ -306,7 +306,7 @@ def check_topk_edge_cases(lib, device):
     cn = torch.zeros(N, dtype=torch.int32, device=dev)
     sc = torch.zeros(N, K, device=dev); ind = torch.zeros(N, K, dtype=torch.int32, device=dev); cl = torch.zeros(N, K, dtype=torch.int32, device=dev)
     s = stream_ptr(dev)
-    lib.call("deft_hm_peaks", ptr(hv), N, H, W, Cc, 4, ptr(cs), ptr(ci), ptr(cn), cap, s)
+    lib.call("deft_hm_peaks", ptr(hv), N, H, W, Cc, 4, 1, ptr(cs), ptr(ci), ptr(cn), cap, s)
     lib.call("deft_topk", ptr(cs), ptr(ci), ptr(cn), N, cap, K, H * W, ptr(sc), ptr(ind), ptr(cl), s)
     ref = O.generic_decode({"hm": torch.sigmoid(hm)}, K=K)
     # frame 0: generic random map -> exact agreement with the oracle
@@ -317,3 +317,83 @@ def check_topk_edge_cases(lib, device):
     tied = [(int(cl[1, k]), int(ind[1, k])) for k in range(1, K)]
     assert tied == sorted(tied) and len(set(tied)) == K - 1
     assert abs(float(sc[1, 1]) - float(torch.sigmoid(torch.tensor(-3.0)))) <= 1e-6
+
+
+# ---------------------------------------------------------------------------
+# seams (deft_amd.integrate): same names / arguments as the reference's plugin points
+# ---------------------------------------------------------------------------
+def check_seam_dcn(lib, device):
+    from deft_amd import integrate
+    integrate.DCN.lib = lib
+    try:
+        g = torch.Generator().manual_seed(9)
+        m = integrate.DCN(64, 96, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
+        assert sorted(k for k, _ in m.state_dict().items()) == ["bias", "conv_offset_mask.bias", "conv_offset_mask.weight", "weight"]
+        with torch.no_grad():
+            m.conv_offset_mask.weight.copy_(torch.randn(27, 64, 3, 3, generator=g) * 0.02)
+            m.conv_offset_mask.bias.copy_(torch.randn(27, generator=g) * 0.5)
+            m.bias.copy_(torch.randn(96, generator=g) * 0.1)
+        x = torch.randn(2, 64, 9, 11, generator=g)
+        m = m.to(device)
+        with torch.no_grad():
+            y = m(x.to(device))
+            ref = O.dcn_v2_forward(x, m.conv_offset_mask.weight.cpu(), m.conv_offset_mask.bias.cpu(), m.weight.cpu(), m.bias.cpu())
+        assert y.shape == ref.shape and maxabs(y, ref) <= 5e-5 * max(1.0, float(ref.abs().max()))
+        with torch.no_grad():                      # parameter update must invalidate the packed copy
+            m.weight.mul_(2.0)
+            y2 = m(x.to(device))
+            ref2 = O.dcn_v2_forward(x, m.conv_offset_mask.weight.cpu(), m.conv_offset_mask.bias.cpu(), m.weight.cpu(), m.bias.cpu())
+        assert maxabs(y2, ref2) <= 1e-4 * max(1.0, float(ref2.abs().max()))
+    finally:
+        integrate.DCN.lib = None
+
+
+def check_seam_model(lib, device, dataset="mot", H=64, W=96):
+    """DeftModel + the reference's own process() sequence (detector.py:535-547) vs the oracle."""
+    from types import SimpleNamespace
+    from deft_amd import integrate
+    sd = O.synth_state_dict(dataset)
+    opt = SimpleNamespace(arch="dla_34", dataset=dataset, K=8, max_object=100)
+    model = integrate.create_model(opt, sd, device=device, lib=lib)
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0))
+    output, FeatureMaps = model(x.to(device), None, None)
+    output = output[-1]
+    with torch.no_grad():
+        ora_out, ora_maps = O.dlaseg_forward(x, sd, dataset)
+    for h in ora_out:
+        assert maxabs(output[h], ora_out[h]) <= 1e-4 * max(1.0, float(ora_out[h].abs().max())), h
+    output["hm"] = output["hm"].sigmoid_()                       # detector.py:488
+    dets = integrate.generic_decode(output, K=opt.K, opt=opt, lib=lib)
+    ref = O.generic_decode(O.sigmoid_output(ora_out), K=opt.K)
+    assert torch.equal((dets["ys"] * (W // 4) + dets["xs"]).long().cpu(), ref["inds"])
+    for k in ("scores", "bboxes", "tracking"):
+        assert maxabs(dets[k], ref[k]) <= TOL, k
+    # seams 2+3 on the model's own FeatureMaps and on NCHW tensors (the reference model's form)
+    centers = torch.rand(1, 5, 1, 1, 2, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    ref_emb = O.afe_extract(ora_maps, centers, sd)
+    e1 = model.AFE.forward_feature_extracter(FeatureMaps, centers.to(device))
+    e2 = model.AFE.forward_feature_extracter([m.to(device) for m in ora_maps], centers.to(device))
+    for e in (e1, e2):
+        assert tuple(e.shape) == tuple(ref_emb.shape) and maxabs(e, ref_emb) <= 1e-4 * max(1.0, float(ref_emb.abs().max()))
+    a = model.AFE.forward_stacker_features(e1[:, :3], e1[:, 2:], False)
+    ra = O.afe_affinity(ref_emb[:, :3], ref_emb[:, 2:], sd, 100)
+    assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.shape == ra.shape and np.abs(a - ra).max() <= 1e-4
+    af = model.AFE.forward_stacker_features(e1[:, :3], e1[:, 2:], True)       # fill_up_column (AFE.py:147-150)
+    assert af.shape == (3, 3 + 1 + 2) and np.abs(af[:, 4:] - af[:, 3:4]).max() == 0.0
+    many = model.AFE.affinity_many([e1[0, :3], e1[0, 1:5]], e1[0, 2:])
+    assert np.abs(many[0] - ra).max() <= 1e-4 and many[1].shape == (4, 4)
+
+
+def check_seam_lstm(lib, device, dataset="mot"):
+    from types import SimpleNamespace
+    from deft_amd import integrate
+    lsd = O.synth_lstm_state_dict(dataset)
+    gold = np.load(os.path.join(GOLD, "lstm_%s.npz" % dataset))
+    kf = integrate.KalmanFilterLSTM(SimpleNamespace(dataset=dataset), lsd, device=device, lib=lib)
+    xs = torch.from_numpy(gold["xs"])
+    h = torch.zeros(1, 1, 128); c = torch.zeros(1, 1, 128)
+    for s_ in range(2):
+        h, c, pred = kf.predict(h, c, xs[s_, 0].view(1, 1, -1))
+        assert sorted(pred) == list(range(1, kf.MAX_dis_fut + 1))
+        got = np.stack([pred[i + 1] for i in range(kf.MAX_dis_fut)])
+        assert np.abs(got - gold["p%d" % s_][0]).max() <= 1e-5 and maxabs(h.view(-1), torch.from_numpy(gold["h%d" % s_][0])) <= 1e-5

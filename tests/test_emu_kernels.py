@@ -76,3 +76,17 @@ def test_forward_embed_mot(emu_lib):
     sd = O.synth_state_dict("mot")
     plan, rep, (ora_out, ora_maps) = pc.check_forward(emu_lib, "cpu", "mot", 64, 96, sd=sd)
     pc.check_embed(emu_lib, "cpu", plan, ora_maps, sd)
+
+
+def test_seam_dcn_module(emu_lib):
+    pc.check_seam_dcn(emu_lib, "cpu")
+
+
+def test_seam_lstm(emu_lib):
+    pc.check_seam_lstm(emu_lib, "cpu", "mot")
+    pc.check_seam_lstm(emu_lib, "cpu", "nuscenes")
+
+
+@pytest.mark.slow
+def test_seam_model_afe_decode(emu_lib):
+    pc.check_seam_model(emu_lib, "cpu", "mot", 64, 96)

@@ -130,3 +130,17 @@ def test_full_size_properties(gpu_lib):
     assert torch.equal(p1.inds[0].cpu().long(), od["inds"][0]), "top-100 indices differ at 1088x608"
     assert pc.maxabs(p1.bboxes.cpu(), od["bboxes"]) <= pc.TOL
     assert pc.maxabs(p1.scores.cpu(), od["scores"]) <= pc.TOL
+
+
+def test_seam_dcn_module(gpu_lib):
+    pc.check_seam_dcn(gpu_lib, "cuda")
+
+
+def test_seam_lstm(gpu_lib):
+    pc.check_seam_lstm(gpu_lib, "cuda", "mot")
+    pc.check_seam_lstm(gpu_lib, "cuda", "nuscenes")
+
+
+@pytest.mark.parametrize("dataset", ["mot", "nuscenes"])
+def test_seam_model_afe_decode(gpu_lib, dataset):
+    pc.check_seam_model(gpu_lib, "cuda", dataset, 96, 128)
