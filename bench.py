@@ -135,10 +135,10 @@ def main():
         torch.cuda.synchronize()
         lib.profile = None
         GEMM = ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer")
-        gemm_ms = sum(e0.elapsed_time(e1) for (k, _, e0, e1) in prof if k in GEMM)
-        gemm_fl = sum(fl for (k, fl, _, _) in prof if k in GEMM)
+        gemm_ms = sum(e0.elapsed_time(e1) for (k, _, e0, e1, _i) in prof if k in GEMM)
+        gemm_fl = sum(fl for (k, fl, _, _, _i) in prof if k in GEMM)
         n_launch = sum(1 for p in prof if p[0] in GEMM)
-        all_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1) in prof)
+        all_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1, _i) in prof)
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
@@ -147,11 +147,11 @@ def main():
                 "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                 "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3)}
         by = {}
-        for (k, fl, e0, e1) in prof:
+        for (k, fl, e0, e1, _i) in prof:
             by.setdefault(k, [0.0, 0, 0.0]); by[k][0] += e0.elapsed_time(e1); by[k][1] += 1; by[k][2] += fl
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
-            json.dump({"by_entry_ms_launches_flops": by, "calls": [(k, fl, e0.elapsed_time(e1)) for (k, fl, e0, e1) in prof]}, f)
+            json.dump({"by_entry_ms_launches_flops": by, "calls": [(k, fl, e0.elapsed_time(e1), info) for (k, fl, e0, e1, info) in prof]}, f)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -73,7 +73,7 @@ class HipLib:
         if v != 1:
             raise DeftHipError("libdeft_hip ABI version %d, expected 1" % v)
 
-    profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1) per call
+    profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1, shape) per call
 
     def call(self, name, *args):
         prof = self.profile
@@ -85,11 +85,12 @@ class HipLib:
             raise DeftHipError("%s failed (%d): %s" % (name, rc, self.cdll.deft_last_error().decode()))
         if prof is not None:
             e1.record()
-            fl = 0.0
+            fl, info = 0.0, ""
             if name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer"):
                 d = args[0]._obj
                 fl = 2.0 * d.M * d.Cout * (d.flop_k if d.flop_k else d.Ktot)
-            prof.append((name, fl, e0, e1))
+                info = "M=%d N=%d K=%d %dx%d s%d @%dx%d" % (d.M, d.Cout, d.Ktot, d.KH, d.KW, d.stride, d.H, d.W)
+            prof.append((name, fl, e0, e1, info))
 
 
 _lib = None

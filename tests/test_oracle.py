@@ -1,0 +1,195 @@
+"""-m "not gpu": pins the oracle (oracle/deft_oracle.py).
+
+1. against the golden fixtures in tests/golden/ -- REFERENCE outputs written by
+   oracle/make_golden.py from the reference's own modules (DLASeg, AFE_module,
+   generic_decode, KalmanFilterLSTM, convert_detection) on seeded inputs;
+2. DCNv2 (third-party, un-vendored: "parity unpinned") against an independent
+   formulation of the upstream sampling rule (F.grid_sample, zeros padding,
+   align_corners=True on pixel-normalised coordinates) and against a plain conv when
+   the offsets are zero and the mask logits are large;
+3. when /root/reference is present (build container only), directly against the
+   reference modules once more, so a fixture cannot silently go stale.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import deft_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HAVE_REF = os.path.isdir("/root/reference/src/lib")
+
+
+def maxabs(a, b):
+    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+
+
+@pytest.mark.parametrize("tag,dataset", [("mot_128x160", "mot"), ("mot_224x384", "mot"), ("nuscenes_96x128", "nuscenes")])
+def test_forward_decode_embed_affinity_vs_golden(tag, dataset):
+    fx = np.load(os.path.join(GOLD, "forward_%s.npz" % tag))
+    H, W = int(fx["H"]), int(fx["W"])
+    sd = O.synth_state_dict(dataset)
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        out, maps = O.dlaseg_forward(x, sd, dataset)
+    assert len(maps) == 13
+    for k in range(13):
+        flat = maps[k].reshape(-1)
+        ref = torch.from_numpy(fx["fmap%d_val" % k])
+        scale = max(1.0, float(ref.abs().max()))
+        assert maxabs(flat[torch.from_numpy(fx["fmap%d_idx" % k])], ref) <= 2e-5 * scale, k
+        # checksum of the whole map (size-independent property): sum and abs-sum
+        assert abs(float(maps[k].double().sum()) - float(fx["fmap%d_sum" % k])) <= 1e-5 * float(fx["fmap%d_abs" % k]) + 1e-3
+    for h in O.HEADS[dataset]:
+        flat = out[h].reshape(-1)
+        assert maxabs(flat[torch.from_numpy(fx["head_%s_idx" % h])], fx["head_%s_val" % h]) <= 5e-5, h
+    K = int(fx["det_K"])
+    dets = O.generic_decode(O.sigmoid_output(out), K=K)
+    assert np.array_equal(dets["inds"].numpy(), fx["det_inds"]), "top-K indices must be bit-exact"
+    for k in ["scores", "clses", "xs", "ys", "bboxes", "tracking"]:
+        assert maxabs(dets[k], fx["det_" + k]) <= 1e-4, k
+    centers = torch.from_numpy(fx["emb_centers"])
+    emb = O.afe_extract(maps, centers, sd)
+    assert maxabs(emb, fx["emb"]) <= 2e-5 * max(1.0, float(np.abs(fx["emb"]).max()))
+    for n in range(4):
+        a = O.afe_affinity(torch.from_numpy(fx["aff%d_xp" % n]), torch.from_numpy(fx["aff%d_xn" % n]), sd, 100)
+        assert a.shape == fx["aff%d" % n].shape
+        assert maxabs(a, fx["aff%d" % n]) <= 1e-6, n
+    a = O.afe_affinity(emb[:, :7], emb[:, 5:], sd, 100)
+    assert maxabs(a, fx["aff_emb"]) <= 1e-5
+
+
+@pytest.mark.parametrize("dataset", ["mot", "nuscenes"])
+def test_lstm_vs_golden(dataset):
+    fx = np.load(os.path.join(GOLD, "lstm_%s.npz" % dataset))
+    lsd = O.synth_lstm_state_dict(dataset)
+    xs = torch.from_numpy(fx["xs"])
+    h = torch.zeros(xs.shape[1], 128); c = torch.zeros(xs.shape[1], 128)
+    for s in range(xs.shape[0]):
+        h, c, p = O.lstm_predict(h, c, xs[s], lsd)
+        assert maxabs(h, fx["h%d" % s]) <= 2e-6 and maxabs(c, fx["c%d" % s]) <= 2e-6
+        assert maxabs(p, fx["p%d" % s]) <= 2e-6
+
+
+def test_convert_detection_vs_golden():
+    fx = np.load(os.path.join(GOLD, "convert_detection.npz"))
+    got = O.convert_detection(fx["boxes"].copy(), 608.0, 1088.0)
+    assert np.array_equal(got.numpy(), fx["centers"])
+
+
+# ---------------------------------------------------------------------------------------
+# DCNv2: independent formulations (the reference holds no vector at this boundary)
+# ---------------------------------------------------------------------------------------
+def _dcn_grid_sample(x, w_off, b_off, w, b):
+    """Upstream rule restated through F.grid_sample: sample (h-1+i+dy, w-1+j+dx), zero outside
+    (-1,H)x(-1,W), bilinear with out-of-range corners contributing zero, times sigmoid(mask)."""
+    N, C, H, W = x.shape
+    om = F.conv2d(x, w_off, b_off, 1, 1)
+    o1, o2, m = torch.chunk(om, 3, 1)
+    off = torch.cat((o1, o2), 1)
+    m = torch.sigmoid(m)
+    hh = torch.arange(H, dtype=x.dtype).view(1, H, 1).expand(N, H, W)
+    ww = torch.arange(W, dtype=x.dtype).view(1, 1, W).expand(N, H, W)
+    cols = []
+    for k in range(9):
+        i, j = k // 3, k % 3
+        py = hh - 1 + i + off[:, 2 * k]
+        px = ww - 1 + j + off[:, 2 * k + 1]
+        gx = 2 * px / (W - 1) - 1 if W > 1 else torch.zeros_like(px)
+        gy = 2 * py / (H - 1) - 1 if H > 1 else torch.zeros_like(py)
+        s = F.grid_sample(x, torch.stack([gx, gy], 3), mode="bilinear", padding_mode="zeros", align_corners=True)
+        cols.append(s * m[:, k:k + 1])
+    col = torch.stack(cols, 2).reshape(N, C * 9, H * W)          # channel-major, tap-minor: k = c*9 + tap
+    y = torch.matmul(w.reshape(w.shape[0], C * 9), col) + b.view(1, -1, 1)
+    return y.view(N, -1, H, W)
+
+
+@pytest.mark.parametrize("N,C,Co,H,W,offs", [(1, 8, 6, 9, 11, 0.5), (2, 4, 5, 6, 7, 3.0), (1, 16, 8, 5, 5, 8.0)])
+def test_dcn_oracle_vs_grid_sample_formulation(N, C, Co, H, W, offs):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g)
+    w_off = torch.randn(27, C, 3, 3, generator=g) * 0.05
+    b_off = torch.randn(27, generator=g) * offs            # several pixels: all zero-padding branches hit
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    a = O.dcn_v2_forward(x, w_off, b_off, w, b)
+    r = _dcn_grid_sample(x, w_off, b_off, w, b)
+    assert maxabs(a, r) <= 2e-5 * max(1.0, float(r.abs().max()))
+
+
+def test_dcn_zero_offsets_is_masked_conv():
+    """Upstream initialises conv_offset_mask to zero: offsets 0, mask sigmoid(0)=0.5 -> y = 0.5*conv(x)+b."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 8, 7, 9, generator=g)
+    w = torch.randn(5, 8, 3, 3, generator=g) * 0.2
+    b = torch.randn(5, generator=g)
+    y = O.dcn_v2_forward(x, torch.zeros(27, 8, 3, 3), torch.zeros(27), w, b)
+    ref = 0.5 * F.conv2d(x, w, None, 1, 1) + b.view(1, -1, 1, 1)
+    assert maxabs(y, ref) <= 1e-5
+
+
+def test_dcn_linearity_in_weights():
+    """Size-independent property: the output is linear in (weight, bias) for fixed offsets."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(1, 4, 6, 6, generator=g)
+    w_off = torch.randn(27, 4, 3, 3, generator=g) * 0.05
+    b_off = torch.randn(27, generator=g)
+    w1 = torch.randn(3, 4, 3, 3, generator=g); w2 = torch.randn(3, 4, 3, 3, generator=g)
+    z = torch.zeros(3)
+    y = O.dcn_v2_forward(x, w_off, b_off, w1 + 2 * w2, z)
+    assert maxabs(y, O.dcn_v2_forward(x, w_off, b_off, w1, z) + 2 * O.dcn_v2_forward(x, w_off, b_off, w2, z)) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------
+# decode / affinity edge cases of the oracle itself
+# ---------------------------------------------------------------------------------------
+def test_decode_tie_order_and_few_peaks():
+    """torch.topk on equal scores: the oracle (and the reference) keep whatever ATen returns;
+    the HIP path documents ascending-index tie order -- here only check the K>peaks padding
+    and that distinct scores come out sorted."""
+    hm = torch.zeros(1, 1, 8, 8)
+    hm[0, 0, 2, 3] = 0.9; hm[0, 0, 5, 5] = 0.7; hm[0, 0, 7, 0] = 0.8
+    out = {"hm": hm, "reg": torch.zeros(1, 2, 8, 8), "wh": torch.ones(1, 2, 8, 8)}
+    d = O.generic_decode(out, K=5)
+    assert d["inds"][0, :3].tolist() == [2 * 8 + 3, 7 * 8 + 0, 5 * 8 + 5]
+    assert d["scores"][0, :3].tolist() == pytest.approx([0.9, 0.8, 0.7])
+    assert float(d["scores"][0, 3]) == 0.0
+
+
+def test_affinity_rows_are_softmax_bounded():
+    sd = O.synth_state_dict("mot")
+    g = torch.Generator().manual_seed(3)
+    a = O.afe_affinity(torch.rand(1, 1, 416, generator=g), torch.rand(1, 100, 416, generator=g), sd, 100)   # P=1, Q=max
+    assert a.shape == (1, 101) and a.min() >= 0 and a.max() <= 1
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.skipif(not HAVE_REF, reason="/root/reference only exists in the build container")
+def test_oracle_vs_reference_modules_live():
+    """Re-runs the pinning of oracle/make_golden.py for one small config against the live
+    reference modules (DLASeg + AFE + generic_decode)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "oracle"))
+    import make_golden as MG
+    import ref_import
+    torch.set_grad_enabled(False)
+    try:
+        model, opt = ref_import.build_reference_model("mot", MG.OracleDCN)
+        sd = O.synth_state_dict("mot")
+        model.load_state_dict(sd, strict=True)
+        x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(4))
+        ref_out, ref_maps = model(x)
+        ora_out, ora_maps = O.dlaseg_forward(x, sd, "mot")
+        for k in range(13):
+            assert maxabs(ref_maps[k], ora_maps[k]) <= 2e-5 * max(1.0, float(ref_maps[k].abs().max()))
+        for h in ref_out[-1]:
+            assert maxabs(ref_out[-1][h], ora_out[h]) <= 5e-5
+        c = torch.rand(1, 5, 1, 1, 2, generator=torch.Generator().manual_seed(5)) * 2 - 1
+        assert maxabs(model.AFE.forward_feature_extracter(ref_maps, c), O.afe_extract(ora_maps, c, sd)) <= 2e-5
+    finally:
+        torch.set_grad_enabled(True)
+        for m in ("dcn_v2",):                       # do not leave the stub module behind for other tests
+            sys.modules.pop(m, None)
