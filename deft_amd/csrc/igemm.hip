@@ -6,8 +6,10 @@
 //
 // Tile: BM x BN outputs per 256-thread workgroup (4 wavefronts of 64), K consumed
 // in chunks of 32.  The A/B chunks are staged global -> VGPR -> LDS ([rows][32+4]
-// floats, 144-B row stride: conflict-free for ds_read_b128), with the next
-// chunk's global loads in flight while the current chunk's MFMAs issue.
+// floats, 144-B row stride: conflict-free for ds_read_b128 / ds_write_b128), with the
+// next chunk's global loads in flight while the current chunk's MFMAs issue (the
+// staging registers are plain locals: nothing may live in scratch, a scratch round
+// trip puts an s_waitcnt vmcnt in front of the MFMAs and serialises load and math).
 // v_mfma_f32_32x32x2_f32 contracts two k per instruction; the k index a lane
 // half h feeds at step kk is k = 16*h + kk, so every lane reads its 16 k-values
 // as four ds_read_b128 (the k permutation is the same for A and B, so the
@@ -16,6 +18,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native 4-vector for all staging traffic: HIP's f32x4 is a struct whose plain copies lower to
+// memcpy through a private (scratch) alloca that SROA does not split
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 
@@ -28,12 +33,98 @@ constexpr int igemm_lds_floats() {
     return NSTAGE * (BM + BN) * LDS_STRIDE + (MODE == MODE_DCN ? 2 * BM * 12 : 0);
 }
 
+// Position of the 32-wide K chunk being loaded: tap (r,s) and first channel c0.  When a chunk
+// lies inside one tap (1x1, or Cin >= 32) these are workgroup-uniform and live in SGPRs.
+struct KCursor {
+    int r, s, c0;
+};
+
+template <int GA>
+struct ARows {          // per-thread state of the GA tile rows this thread stages, fixed over K
+    int r0[GA], r1[GA], r2[GA];
+};
+
+template <int GA>
+__device__ __forceinline__ void load_a_conv(const DeftGemmDesc& p, const ARows<GA>& rw, const KCursor& kc, int kbase,
+                                            int g, bool uniform_tap, unsigned inv_kw, f32x4 (&va)[GA]) {
+    if (uniform_tap) {
+        const int c = kc.c0 + g * 4;
+        const bool kok = c < p.Cin;          // 1x1: c is the flat k -> masks the K padding; k>1: always true
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            const int iy = rw.r0[i] + kc.r, ix = rw.r1[i] + kc.s;
+            const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            // unconditional load from a clamped (always valid) address + select: no branch per load
+            const unsigned off = ok ? (unsigned)((rw.r2[i] + iy * p.W + ix) * p.ldx + c) : 0u;
+            f32x4 v = *(const f32x4*)(p.x + off);
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            va[i] = v;
+        }
+    } else {                               // Cin in {4, 8, 16}: a chunk spans several taps -> per-lane tap
+        const int kflat = kbase + g * 4;
+        const int c = kflat & (p.Cin - 1);
+        const int tap = kflat >> p.cin_log2;
+        const int r = (int)(((unsigned)tap * inv_kw) >> 16);      // tap / KW for tap < 64 (exact, see host check)
+        const int s = tap - r * p.KW;
+        const bool kok = kflat < p.Ktot;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            const int iy = rw.r0[i] + r, ix = rw.r1[i] + s;
+            const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? (unsigned)((rw.r2[i] + iy * p.W + ix) * p.ldx + c) : 0u;
+            f32x4 v = *(const f32x4*)(p.x + off);
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            va[i] = v;
+        }
+    }
+}
+
+template <int GA, int BM>
+__device__ __forceinline__ void load_a_dcn(const DeftGemmDesc& p, const ARows<GA>& rw, const float* prm, int tap, int c,
+                                           int rbase, f32x4 (&va)[GA]) {
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const float* pr = prm + ((tap & 1) * BM + rbase + 32 * i) * 12;
+        const f32x4 po = *(const f32x4*)pr;          // invalid corners: offset 0, weight 0
+        const f32x4 pw = *(const f32x4*)(pr + 4);
+        const float mask = pr[8];
+        const float* base = p.x + (unsigned)(rw.r2[i] * p.ldx + c);
+        const f32x4 v1 = *(const f32x4*)(base + (unsigned)(__float_as_int(po.x) * p.ldx));
+        const f32x4 v2 = *(const f32x4*)(base + (unsigned)(__float_as_int(po.y) * p.ldx));
+        const f32x4 v3 = *(const f32x4*)(base + (unsigned)(__float_as_int(po.z) * p.ldx));
+        const f32x4 v4 = *(const f32x4*)(base + (unsigned)(__float_as_int(po.w) * p.ldx));
+        f32x4 v;
+        v.x = (pw.x * v1.x + pw.y * v2.x + pw.z * v3.x + pw.w * v4.x) * mask;
+        v.y = (pw.x * v1.y + pw.y * v2.y + pw.z * v3.y + pw.w * v4.y) * mask;
+        v.z = (pw.x * v1.z + pw.y * v2.z + pw.z * v3.z + pw.w * v4.z) * mask;
+        v.w = (pw.x * v1.w + pw.y * v2.w + pw.z * v3.w + pw.w * v4.w) * mask;
+        va[i] = v;
+    }
+}
+
+template <int GA>
+__device__ __forceinline__ void load_a_pair(const DeftGemmDesc& p, const ARows<GA>& rw, int kflat, f32x4 (&va)[GA]) {
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const bool ok = rw.r0[i] != ROW_INVALID;
+        const f32x4 u = *(const f32x4*)(p.x + (unsigned)((ok ? rw.r0[i] : 0) + kflat));
+        const f32x4 t = *(const f32x4*)(p.x2 + (unsigned)((ok ? rw.r1[i] : 0) + kflat));
+        f32x4 v;
+        v.x = fmaxf(u.x + t.x, 0.f);
+        v.y = fmaxf(u.y + t.y, 0.f);
+        v.z = fmaxf(u.z + t.z, 0.f);
+        v.w = fmaxf(u.w + t.w, 0.f);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        va[i] = v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
 __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, int ntiles) {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    constexpr int GA = BM / 32;  // float4 groups per thread, A tile
-    constexpr int GB = BN / 32;  // float4 groups per thread, B tile
+    constexpr int GA = BM / 32;  // f32x4 groups per thread, A tile
+    constexpr int GB = BN / 32;  // f32x4 groups per thread, B tile
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
 
@@ -60,15 +151,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
     const int mt = bid / ntiles, nt = bid - mt * ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int g = tid & 7;       // which float4 of the 32-wide k chunk this thread stages
+    const int g = tid & 7;       // which f32x4 of the 32-wide k chunk this thread stages
     const int rbase = tid >> 3;  // 0..31: staged rows are rbase + 32*i
 
     // per-row loader state, fixed for the whole K loop
-    int r0[GA], r1[GA], r2[GA];
+    ARows<GA> rw;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
         const int m = m0 + rbase + 32 * i;
-        r0[i] = ROW_INVALID; r1[i] = 0; r2[i] = 0;
+        rw.r0[i] = ROW_INVALID; rw.r1[i] = 0; rw.r2[i] = 0;
         if (m < p.M) {
             if (MODE == MODE_PAIR) {
                 int u = m / p.Q;
@@ -78,8 +169,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                     u = p.u0 + c * p.du + (u - c * p.Tper);
                     j = p.v0 + c * p.dv + j;
                 }
-                r0[i] = u * p.ldx;
-                r1[i] = j * p.ldx;
+                rw.r0[i] = u * p.ldx;
+                rw.r1[i] = j * p.ldx;
             } else {
                 const int ohw = p.OH * p.OW;
                 const int n = m / ohw;
@@ -87,12 +178,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                 const int oy = rem / p.OW;
                 const int ox = rem - oy * p.OW;
                 if (MODE == MODE_CONV) {
-                    r0[i] = oy * p.stride - p.pad;
-                    r1[i] = ox * p.stride - p.pad;
+                    rw.r0[i] = oy * p.stride - p.pad;
+                    rw.r1[i] = ox * p.stride - p.pad;
                 } else {
-                    r0[i] = 0;
+                    rw.r0[i] = 0;
                 }
-                r2[i] = n * p.H * p.W;
+                rw.r2[i] = n * p.H * p.W;
             }
         }
     }
@@ -128,82 +219,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                 }
             }
             float* pr = prm + ((tap & 1) * BM + tid) * 12;
-            *(float4*)(pr) = make_float4(__int_as_float(o1), __int_as_float(o2), __int_as_float(o3), __int_as_float(o4));
-            *(float4*)(pr + 4) = make_float4(w1, w2, w3, w4);
-            *(float4*)(pr + 8) = make_float4(mask, 0.f, 0.f, 0.f);
+            *(f32x4*)(pr) = f32x4{__int_as_float(o1), __int_as_float(o2), __int_as_float(o3), __int_as_float(o4)};
+            *(f32x4*)(pr + 4) = f32x4{w1, w2, w3, w4};
+            *(f32x4*)(pr + 8) = f32x4{mask, 0.f, 0.f, 0.f};
         }
     };
 
-    auto load_a = [&](int kc, float4* va) {
-        const int kflat = kc + g * 4;
+    // ---- chunk loaders: `cur` walks the chunks in issue order (0, 1, 2, ...) ----
+    const bool uniform_tap = MODE != MODE_CONV || p.KH * p.KW == 1 || p.Cin >= 32;
+    const unsigned inv_kw = (65536u + (unsigned)p.KW - 1u) / (unsigned)p.KW;
+    KCursor cur = {0, 0, 0};
+    int kload = 0;                                   // k offset of the next chunk to load
+    f32x4 va[GA], vb[GB];
+
+    auto load_next = [&]() {                         // issue the global loads of chunk `kload` into va/vb
         if (MODE == MODE_CONV) {
-            int c = kflat, r = 0, s = 0;
-            if (p.KH * p.KW > 1) {
-                c = kflat & (p.Cin - 1);
-                const int tap = kflat >> p.cin_log2;
-                r = tap / p.KW;
-                s = tap - r * p.KW;
-            }
-            const bool kok = kflat < p.Ktot;
-#pragma unroll
-            for (int i = 0; i < GA; ++i) {
-                const int iy = r0[i] + r, ix = r1[i] + s;
-                const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                // unconditional load from a clamped (always valid) address + select: no branch per load
-                const int pix = ok ? r2[i] + iy * p.W + ix : 0;
-                float4 v = *(const float4*)(p.x + (size_t)pix * p.ldx + (ok ? c : 0));
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                va[i] = v;
-            }
+            load_a_conv<GA>(p, rw, cur, kload, g, uniform_tap, inv_kw, va);
         } else if (MODE == MODE_DCN) {
-            const int c = kflat & (p.Cin - 1);
-            const int tap = kflat >> p.cin_log2;  // 0..8 (Kpad == Ktot since Cin % 32 == 0)
-#pragma unroll
-            for (int i = 0; i < GA; ++i) {
-                const float* pr = prm + ((tap & 1) * BM + rbase + 32 * i) * 12;
-                const float4 po = *(const float4*)pr;          // invalid corners: offset 0, weight 0
-                const float4 pw = *(const float4*)(pr + 4);
-                const float mask = pr[8];
-                const float* base = p.x + (size_t)r2[i] * p.ldx + c;
-                const float4 v1 = *(const float4*)(base + (size_t)__float_as_int(po.x) * p.ldx);
-                const float4 v2 = *(const float4*)(base + (size_t)__float_as_int(po.y) * p.ldx);
-                const float4 v3 = *(const float4*)(base + (size_t)__float_as_int(po.z) * p.ldx);
-                const float4 v4 = *(const float4*)(base + (size_t)__float_as_int(po.w) * p.ldx);
-                float4 v;
-                v.x = (pw.x * v1.x + pw.y * v2.x + pw.z * v3.x + pw.w * v4.x) * mask;
-                v.y = (pw.x * v1.y + pw.y * v2.y + pw.z * v3.y + pw.w * v4.y) * mask;
-                v.z = (pw.x * v1.z + pw.y * v2.z + pw.z * v3.z + pw.w * v4.z) * mask;
-                v.w = (pw.x * v1.w + pw.y * v2.w + pw.z * v3.w + pw.w * v4.w) * mask;
-                va[i] = v;
-            }
+            load_a_dcn<GA, BM>(p, rw, prm, kload >> p.cin_log2, (kload & (p.Cin - 1)) + g * 4, rbase, va);
         } else {
+            load_a_pair<GA>(p, rw, kload + g * 4, va);
+        }
+        const float* wp = p.w + (unsigned)((n0 + rbase) * p.Kpad + kload + g * 4);
 #pragma unroll
-            for (int i = 0; i < GA; ++i) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r0[i] != ROW_INVALID) {
-                    const float4 u = *(const float4*)(p.x + r0[i] + kflat);
-                    const float4 t = *(const float4*)(p.x2 + r1[i] + kflat);
-                    v.x = fmaxf(u.x + t.x, 0.f);
-                    v.y = fmaxf(u.y + t.y, 0.f);
-                    v.z = fmaxf(u.z + t.z, 0.f);
-                    v.w = fmaxf(u.w + t.w, 0.f);
-                }
-                va[i] = v;
+        for (int i = 0; i < GB; ++i) vb[i] = *(const f32x4*)(wp + (unsigned)(32 * i * p.Kpad));
+        kload += 32;
+        if (MODE == MODE_CONV) {                     // advance the (tap, channel) cursor: scalar unit only
+            cur.c0 += 32;
+            if (p.KH * p.KW > 1 && cur.c0 >= p.Cin) {
+                cur.c0 = 0;
+                if (++cur.s == p.KW) { cur.s = 0; ++cur.r; }
             }
         }
     };
-    auto load_b = [&](int kc, float4* vb) {
+    auto store_ab = [&](int stage) {
+        float* as = As + stage * BM * LDS_STRIDE + rbase * LDS_STRIDE + g * 4;
+        float* bs = Bs + stage * BN * LDS_STRIDE + rbase * LDS_STRIDE + g * 4;
 #pragma unroll
-        for (int i = 0; i < GB; ++i)
-            vb[i] = *(const float4*)(p.w + (size_t)(n0 + rbase + 32 * i) * p.Kpad + kc + g * 4);
-    };
-    auto store_ab = [&](int stage, const float4* va, const float4* vb) {
-        float* as = As + stage * BM * LDS_STRIDE;
-        float* bs = Bs + stage * BN * LDS_STRIDE;
+        for (int i = 0; i < GA; ++i) *(f32x4*)&as[32 * i * LDS_STRIDE] = va[i];
 #pragma unroll
-        for (int i = 0; i < GA; ++i) *(float4*)&as[(rbase + 32 * i) * LDS_STRIDE + g * 4] = va[i];
-#pragma unroll
-        for (int i = 0; i < GB; ++i) *(float4*)&bs[(rbase + 32 * i) * LDS_STRIDE + g * 4] = vb[i];
+        for (int i = 0; i < GB; ++i) *(f32x4*)&bs[32 * i * LDS_STRIDE] = vb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -214,30 +269,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 va[GA], vb[GB];
     const int nk = p.Kpad >> 5;
     const int frow = lane & 31;        // row of the 32-row MFMA tile this lane feeds
     const int fk = (lane >> 5) * 16;   // first of this lane's 16 k-values in the chunk
     float a[TM][16], b[TN][16];
 
     auto read_frags = [&](int stage) {
-        const float* as = As + stage * BM * LDS_STRIDE;
-        const float* bs = Bs + stage * BN * LDS_STRIDE;
+        const float* as = As + stage * BM * LDS_STRIDE + (wm * TM * 32 + frow) * LDS_STRIDE + fk;
+        const float* bs = Bs + stage * BN * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE + fk;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const float4* ap = (const float4*)&as[((wm * TM + i) * 32 + frow) * LDS_STRIDE + fk];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 t = ap[q];
+                const f32x4 t = *(const f32x4*)&as[i * 32 * LDS_STRIDE + 4 * q];
                 a[i][4 * q + 0] = t.x; a[i][4 * q + 1] = t.y; a[i][4 * q + 2] = t.z; a[i][4 * q + 3] = t.w;
             }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float4* bp = (const float4*)&bs[((wn * TN + j) * 32 + frow) * LDS_STRIDE + fk];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 t = bp[q];
+                const f32x4 t = *(const f32x4*)&bs[j * 32 * LDS_STRIDE + 4 * q];
                 b[j][4 * q + 0] = t.x; b[j][4 * q + 1] = t.y; b[j][4 * q + 2] = t.z; b[j][4 * q + 3] = t.w;
             }
         }
@@ -259,19 +311,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
             dcn_params(0);
             __syncthreads();
         }
-        load_a(0, va);
-        load_b(0, vb);
+        load_next();
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();  // all waves finished reading the previous chunk
-            store_ab(0, va, vb);
+            store_ab(0);
             // DCN: sampling record of the tap that chunk kt+1 opens; the other parity buffer is
             // the one load_a(kt) read two barriers ago, this one was last read >= cpt chunks ago
             if (MODE == MODE_DCN && kt + 1 < nk && (kt + 1) % cpt1 == 0) dcn_params((kt + 1) / cpt1);
             __syncthreads();
-            if (kt + 1 < nk) {
-                load_a((kt + 1) << 5, va);
-                load_b((kt + 1) << 5, vb);
-            }
+            if (kt + 1 < nk) load_next();
             read_frags(0);
             mfma_chunk();
         }
@@ -287,18 +335,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                 if (c0 % cpt == 0) dcn_params(c0 / cpt);
             __syncthreads();
         }
-        load_a(0, va);
-        load_b(0, vb);
-        store_ab(0, va, vb);
-        if (nk > 1) {
-            load_a(32, va);
-            load_b(32, vb);
-        }
+        load_next();
+        store_ab(0);
+        if (nk > 1) load_next();
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            read_frags(cur);
-            if (kt + 1 < nk) store_ab(cur ^ 1, va, vb);
+            const int cs = kt & 1;
+            read_frags(cs);
+            if (kt + 1 < nk) store_ab(cs ^ 1);
             if (MODE == MODE_DCN) {
                 // record of the tap whose first chunk is kt+3: visible after this iteration's
                 // barrier, first used by load_a(kt+3) in iteration kt+1; the other parity buffer
@@ -306,10 +350,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                 const int c3 = kt + 3;
                 if (c3 < nk && c3 % cpt == 0) dcn_params(c3 / cpt);
             }
-            if (kt + 2 < nk) {
-                load_a((kt + 2) << 5, va);
-                load_b((kt + 2) << 5, vb);
-            }
+            if (kt + 2 < nk) load_next();
             mfma_chunk();
             __syncthreads();
         }
@@ -332,22 +373,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
             const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {       // 4 rows at a time keeps the epilogue's VGPR footprint small
-                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                float rv0 = 0.f, rv1 = 0.f, rv2 = 0.f, rv3 = 0.f;
+                const int mq = mb + 8 * q;
                 if (has_res) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        int m = mb + t + 8 * q;
-                        m = m < p.M ? m : p.M - 1;
-                        rv[t] = p.res[(size_t)m * p.ldr + coc];
-                    }
+                    const int mc = p.M - 1;
+                    rv0 = p.res[(size_t)(mq + 0 < p.M ? mq + 0 : mc) * p.ldr + coc];
+                    rv1 = p.res[(size_t)(mq + 1 < p.M ? mq + 1 : mc) * p.ldr + coc];
+                    rv2 = p.res[(size_t)(mq + 2 < p.M ? mq + 2 : mc) * p.ldr + coc];
+                    rv3 = p.res[(size_t)(mq + 3 < p.M ? mq + 3 : mc) * p.ldr + coc];
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int m = mb + t + 8 * q;
-                    float v = acc[i][j][4 * q + t] * sc + sh + rv[t];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (cok && m < p.M) p.y[(size_t)m * p.ldy + co] = v;
-                }
+                float v0 = acc[i][j][4 * q + 0] * sc + sh + rv0;
+                float v1 = acc[i][j][4 * q + 1] * sc + sh + rv1;
+                float v2 = acc[i][j][4 * q + 2] * sc + sh + rv2;
+                float v3 = acc[i][j][4 * q + 3] * sc + sh + rv3;
+                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                float* yp = p.y + (size_t)mq * p.ldy + co;
+                if (cok && mq + 0 < p.M) yp[0] = v0;
+                if (cok && mq + 1 < p.M) yp[(size_t)p.ldy] = v1;
+                if (cok && mq + 2 < p.M) yp[(size_t)2 * p.ldy] = v2;
+                if (cok && mq + 3 < p.M) yp[(size_t)3 * p.ldy] = v3;
             }
         }
     }
@@ -400,6 +444,8 @@ static int check_common(const DeftGemmDesc* d, const char* who) {
     DEFT_CHECK((d->ldx & 3) == 0 && (((size_t)d->x) & 15) == 0 && (((size_t)d->w) & 15) == 0, -5, "%s: x/w must be 16-byte aligned, ldx %% 4 == 0", who);
     DEFT_CHECK(d->ldy >= d->Cout, -6, "%s: ldy=%d < Cout=%d", who, d->ldy, d->Cout);
     DEFT_CHECK(!d->res || d->ldr >= d->Cout, -7, "%s: ldr=%d < Cout=%d", who, d->ldr, d->Cout);
+    // loaders address with 32-bit element offsets
+    DEFT_CHECK((long long)deft_cdiv(d->Cout, 128) * 128 * d->Kpad < (1ll << 31), -8, "%s: weight matrix exceeds 2^31 elements", who);
     return 0;
 }
 
@@ -414,6 +460,10 @@ extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
                "deft_conv2d_nhwc: Cin=%d must be a power of two for KHxKW>1", d->Cin);
     DEFT_CHECK(d->M == d->N * d->OH * d->OW, -13, "deft_conv2d_nhwc: M != N*OH*OW");
     DEFT_CHECK(d->ldx >= d->Cin, -14, "deft_conv2d_nhwc: ldx < Cin");
+    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 31), -16, "deft_conv2d_nhwc: input exceeds 2^31 elements (split the batch)");
+    DEFT_CHECK(d->KW >= 1 && d->KW <= 16 && d->Kpad / (d->Cin < 32 ? d->Cin : 32) <= 4096, -17, "deft_conv2d_nhwc: KW=%d out of range", d->KW);
+    DEFT_CHECK(d->Cin >= 32 || d->KH * d->KW == 1 || d->Kpad / d->Cin <= 64, -18,
+               "deft_conv2d_nhwc: Cin=%d < 32 supports at most 64 taps (incl. K padding)", d->Cin);
     hipStream_t s = (hipStream_t)stream;
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);
@@ -435,9 +485,9 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
                "deft_dcn_v2_nhwc: Cin=%d must be a power of two >= 32", d->Cin);
     DEFT_CHECK(d->Ktot == 9 * d->Cin && d->Kpad == d->Ktot, -23, "deft_dcn_v2_nhwc: Ktot/Kpad mismatch");
     DEFT_CHECK(d->OH == d->H && d->OW == d->W && d->M == d->N * d->H * d->W, -24, "deft_dcn_v2_nhwc: geometry mismatch");
+    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 31), -25, "deft_dcn_v2_nhwc: input exceeds 2^31 elements (split the batch)");
     hipStream_t s = (hipStream_t)stream;
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
-    const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) {
         bm = 64; bn = 64;      // measured best for every DCN layer shape of DLA-34 (tools/bench_igemm.py)
     }
