@@ -31,4 +31,23 @@ void deft_set_error(const char* fmt, ...);
 #define DEFT_DYN_LDS(type, var) extern __shared__ __attribute__((aligned(16))) type var[]
 #endif
 
+// native 4-vector for all staging traffic: HIP's float4 is a struct whose plain copies lower to
+// memcpy through a private (scratch) alloca that SROA does not split
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer loads (SRD in SGPRs + 32-bit byte offset in a VGPR).  An offset >= num_records
+// returns 0 from the hardware: im2col zero padding / invalid tile rows cost one v_cndmask on
+// the OFFSET instead of a select on the loaded data (which would pull the s_waitcnt vmcnt in
+// front of the MFMAs).  DEFT_OOB + any in-tile offset stays >= 2^31 without wrapping.
+#define DEFT_OOB 0x80000000u
+#ifndef DEFT_BUFFER_HOOKS      /* the unit-test SIMT emulator pre-defines these hooks */
+typedef __amdgpu_buffer_rsrc_t deft_rsrc_t;
+__device__ __forceinline__ deft_rsrc_t deft_make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+#endif
+
 static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -39,86 +39,6 @@ struct KCursor {
     int r, s, c0;
 };
 
-template <int GA>
-struct ARows {          // per-thread state of the GA tile rows this thread stages, fixed over K
-    int r0[GA], r1[GA], r2[GA];
-};
-
-template <int GA>
-__device__ __forceinline__ void load_a_conv(const DeftGemmDesc& p, const ARows<GA>& rw, const KCursor& kc, int kbase,
-                                            int g, bool uniform_tap, unsigned inv_kw, f32x4 (&va)[GA]) {
-    if (uniform_tap) {
-        const int c = kc.c0 + g * 4;
-        const bool kok = c < p.Cin;          // 1x1: c is the flat k -> masks the K padding; k>1: always true
-#pragma unroll
-        for (int i = 0; i < GA; ++i) {
-            const int iy = rw.r0[i] + kc.r, ix = rw.r1[i] + kc.s;
-            const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            // unconditional load from a clamped (always valid) address + select: no branch per load
-            const unsigned off = ok ? (unsigned)((rw.r2[i] + iy * p.W + ix) * p.ldx + c) : 0u;
-            f32x4 v = *(const f32x4*)(p.x + off);
-            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            va[i] = v;
-        }
-    } else {                               // Cin in {4, 8, 16}: a chunk spans several taps -> per-lane tap
-        const int kflat = kbase + g * 4;
-        const int c = kflat & (p.Cin - 1);
-        const int tap = kflat >> p.cin_log2;
-        const int r = (int)(((unsigned)tap * inv_kw) >> 16);      // tap / KW for tap < 64 (exact, see host check)
-        const int s = tap - r * p.KW;
-        const bool kok = kflat < p.Ktot;
-#pragma unroll
-        for (int i = 0; i < GA; ++i) {
-            const int iy = rw.r0[i] + r, ix = rw.r1[i] + s;
-            const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)((rw.r2[i] + iy * p.W + ix) * p.ldx + c) : 0u;
-            f32x4 v = *(const f32x4*)(p.x + off);
-            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            va[i] = v;
-        }
-    }
-}
-
-template <int GA, int BM>
-__device__ __forceinline__ void load_a_dcn(const DeftGemmDesc& p, const ARows<GA>& rw, const float* prm, int tap, int c,
-                                           int rbase, f32x4 (&va)[GA]) {
-#pragma unroll
-    for (int i = 0; i < GA; ++i) {
-        const float* pr = prm + ((tap & 1) * BM + rbase + 32 * i) * 12;
-        const f32x4 po = *(const f32x4*)pr;          // invalid corners: offset 0, weight 0
-        const f32x4 pw = *(const f32x4*)(pr + 4);
-        const float mask = pr[8];
-        const float* base = p.x + (unsigned)(rw.r2[i] * p.ldx + c);
-        const f32x4 v1 = *(const f32x4*)(base + (unsigned)(__float_as_int(po.x) * p.ldx));
-        const f32x4 v2 = *(const f32x4*)(base + (unsigned)(__float_as_int(po.y) * p.ldx));
-        const f32x4 v3 = *(const f32x4*)(base + (unsigned)(__float_as_int(po.z) * p.ldx));
-        const f32x4 v4 = *(const f32x4*)(base + (unsigned)(__float_as_int(po.w) * p.ldx));
-        f32x4 v;
-        v.x = (pw.x * v1.x + pw.y * v2.x + pw.z * v3.x + pw.w * v4.x) * mask;
-        v.y = (pw.x * v1.y + pw.y * v2.y + pw.z * v3.y + pw.w * v4.y) * mask;
-        v.z = (pw.x * v1.z + pw.y * v2.z + pw.z * v3.z + pw.w * v4.z) * mask;
-        v.w = (pw.x * v1.w + pw.y * v2.w + pw.z * v3.w + pw.w * v4.w) * mask;
-        va[i] = v;
-    }
-}
-
-template <int GA>
-__device__ __forceinline__ void load_a_pair(const DeftGemmDesc& p, const ARows<GA>& rw, int kflat, f32x4 (&va)[GA]) {
-#pragma unroll
-    for (int i = 0; i < GA; ++i) {
-        const bool ok = rw.r0[i] != ROW_INVALID;
-        const f32x4 u = *(const f32x4*)(p.x + (unsigned)((ok ? rw.r0[i] : 0) + kflat));
-        const f32x4 t = *(const f32x4*)(p.x2 + (unsigned)((ok ? rw.r1[i] : 0) + kflat));
-        f32x4 v;
-        v.x = fmaxf(u.x + t.x, 0.f);
-        v.y = fmaxf(u.y + t.y, 0.f);
-        v.z = fmaxf(u.z + t.z, 0.f);
-        v.w = fmaxf(u.w + t.w, 0.f);
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        va[i] = v;
-    }
-}
-
 template <int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
 __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, int ntiles) {
     constexpr int TM = BM / (WM * 32);
@@ -154,12 +74,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
     const int g = tid & 7;       // which f32x4 of the 32-wide k chunk this thread stages
     const int rbase = tid >> 3;  // 0..31: staged rows are rbase + 32*i
 
-    // per-row loader state, fixed for the whole K loop
-    ARows<GA> rw;
+    const deft_rsrc_t rx = deft_make_rsrc(p.x);
+    const deft_rsrc_t rx2 = deft_make_rsrc(MODE == MODE_PAIR ? p.x2 : p.x);
+
+    // per-row loader state, fixed for the whole K loop.
+    //   CONV: r0/r1 = top-left input coordinate of the window (ROW_INVALID fails every bounds
+    //         test), r2 = n*H*W.   DCN: r2 = n*H*W.   PAIR: r0/r1 = BYTE offsets of the U'/V' rows
+    //         (DEFT_OOB for rows beyond M: the buffer loads return 0 and relu(0+0) = 0).
+    int r0[GA], r1[GA], r2[GA];
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
         const int m = m0 + rbase + 32 * i;
-        rw.r0[i] = ROW_INVALID; rw.r1[i] = 0; rw.r2[i] = 0;
+        r0[i] = MODE == MODE_PAIR ? (int)DEFT_OOB : ROW_INVALID;
+        r1[i] = MODE == MODE_PAIR ? (int)DEFT_OOB : 0;
+        r2[i] = 0;
         if (m < p.M) {
             if (MODE == MODE_PAIR) {
                 int u = m / p.Q;
@@ -169,8 +97,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                     u = p.u0 + c * p.du + (u - c * p.Tper);
                     j = p.v0 + c * p.dv + j;
                 }
-                rw.r0[i] = u * p.ldx;
-                rw.r1[i] = j * p.ldx;
+                r0[i] = u * p.ldx * 4;
+                r1[i] = j * p.ldx * 4;
             } else {
                 const int ohw = p.OH * p.OW;
                 const int n = m / ohw;
@@ -178,12 +106,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                 const int oy = rem / p.OW;
                 const int ox = rem - oy * p.OW;
                 if (MODE == MODE_CONV) {
-                    rw.r0[i] = oy * p.stride - p.pad;
-                    rw.r1[i] = ox * p.stride - p.pad;
+                    r0[i] = oy * p.stride - p.pad;
+                    r1[i] = ox * p.stride - p.pad;
                 } else {
-                    rw.r0[i] = 0;
+                    r0[i] = 0;
                 }
-                rw.r2[i] = n * p.H * p.W;
+                r2[i] = n * p.H * p.W;
             }
         }
     }
@@ -225,20 +153,60 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
         }
     };
 
-    // ---- chunk loaders: `cur` walks the chunks in issue order (0, 1, 2, ...) ----
+    // ---- staging registers.  issue_loads() only ISSUES memory operations (no arithmetic on the
+    // returned data), finish_store() does the per-mode arithmetic and the LDS stores: the MFMAs of
+    // the current chunk sit between the two, so the loads fly under them. ----
     const bool uniform_tap = MODE != MODE_CONV || p.KH * p.KW == 1 || p.Cin >= 32;
     const unsigned inv_kw = (65536u + (unsigned)p.KW - 1u) / (unsigned)p.KW;
     KCursor cur = {0, 0, 0};
     int kload = 0;                                   // k offset of the next chunk to load
-    f32x4 va[GA], vb[GB];
+    f32x4 s0[GA], s1[GA], s2[GA], s3[GA], sw[GA], vb[GB];
+    float sm[GA];
 
-    auto load_next = [&]() {                         // issue the global loads of chunk `kload` into va/vb
+    auto issue_loads = [&]() {
         if (MODE == MODE_CONV) {
-            load_a_conv<GA>(p, rw, cur, kload, g, uniform_tap, inv_kw, va);
+            int c, r, s;
+            bool kok;
+            if (uniform_tap) {
+                c = cur.c0 + g * 4; r = cur.r; s = cur.s;
+                kok = c < p.Cin;             // 1x1: c is the flat k -> masks the K padding; k>1: always true
+            } else {                         // Cin in {4, 8, 16}: a chunk spans several taps -> per-lane tap
+                const int kflat = kload + g * 4;
+                c = kflat & (p.Cin - 1);
+                const int tap = kflat >> p.cin_log2;
+                r = (int)(((unsigned)tap * inv_kw) >> 16);      // tap / KW for tap < 64 (host checks the range)
+                s = tap - r * p.KW;
+                kok = kflat < p.Ktot;
+            }
+#pragma unroll
+            for (int i = 0; i < GA; ++i) {
+                const int iy = r0[i] + r, ix = r1[i] + s;
+                const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = (unsigned)(((r2[i] + iy * p.W + ix) * p.ldx + c) * 4);
+                s0[i] = deft_buffer_load_x4(rx, ok ? off : DEFT_OOB);
+            }
         } else if (MODE == MODE_DCN) {
-            load_a_dcn<GA, BM>(p, rw, prm, kload >> p.cin_log2, (kload & (p.Cin - 1)) + g * 4, rbase, va);
+            const int tap = kload >> p.cin_log2;
+            const int c = (kload & (p.Cin - 1)) + g * 4;
+#pragma unroll
+            for (int i = 0; i < GA; ++i) {
+                const float* pr = prm + ((tap & 1) * BM + rbase + 32 * i) * 12;
+                const f32x4 po = *(const f32x4*)pr;          // invalid corners: offset 0, weight 0
+                sw[i] = *(const f32x4*)(pr + 4);
+                sm[i] = pr[8];
+                const int pb = r2[i];
+                s0[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.x)) * p.ldx + c) * 4));
+                s1[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.y)) * p.ldx + c) * 4));
+                s2[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.z)) * p.ldx + c) * 4));
+                s3[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.w)) * p.ldx + c) * 4));
+            }
         } else {
-            load_a_pair<GA>(p, rw, kload + g * 4, va);
+            const unsigned kb = (unsigned)((kload + g * 4) * 4);
+#pragma unroll
+            for (int i = 0; i < GA; ++i) {
+                s0[i] = deft_buffer_load_x4(rx, (unsigned)r0[i] + kb);
+                s1[i] = deft_buffer_load_x4(rx2, (unsigned)r1[i] + kb);
+            }
         }
         const float* wp = p.w + (unsigned)((n0 + rbase) * p.Kpad + kload + g * 4);
 #pragma unroll
@@ -252,11 +220,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
             }
         }
     };
-    auto store_ab = [&](int stage) {
+    auto finish_store = [&](int stage) {
         float* as = As + stage * BM * LDS_STRIDE + rbase * LDS_STRIDE + g * 4;
         float* bs = Bs + stage * BN * LDS_STRIDE + rbase * LDS_STRIDE + g * 4;
 #pragma unroll
-        for (int i = 0; i < GA; ++i) *(f32x4*)&as[32 * i * LDS_STRIDE] = va[i];
+        for (int i = 0; i < GA; ++i) {
+            f32x4 v;
+            if (MODE == MODE_CONV) {
+                v = s0[i];
+            } else if (MODE == MODE_DCN) {
+                v = (sw[i].x * s0[i] + sw[i].y * s1[i] + sw[i].z * s2[i] + sw[i].w * s3[i]) * sm[i];
+            } else {
+                const f32x4 t = s0[i] + s1[i];
+                v = f32x4{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)};
+            }
+            *(f32x4*)&as[32 * i * LDS_STRIDE] = v;
+        }
 #pragma unroll
         for (int i = 0; i < GB; ++i) *(f32x4*)&bs[32 * i * LDS_STRIDE] = vb[i];
     };
@@ -302,56 +281,51 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);       // nothing of finish_store() may be scheduled above the MFMAs
     };
 
+    const int cpt = (MODE == MODE_DCN) ? (p.Cin >> 5) : 1;   // chunks per tap (DCN)
     if (NSTAGE == 1) {
-        // one LDS stage, two barriers per chunk; next chunk's global loads fly under the MFMAs
-        const int cpt1 = (MODE == MODE_DCN) ? (p.Cin >> 5) : 1;   // chunks per tap (DCN)
+        // one LDS stage, two barriers per chunk:  store chunk kt | barrier | issue loads kt+1,
+        // fragments + MFMAs of chunk kt | barrier
         if (MODE == MODE_DCN) {
             dcn_params(0);
             __syncthreads();
         }
-        load_next();
+        issue_loads();
         for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();  // all waves finished reading the previous chunk
-            store_ab(0);
-            // DCN: sampling record of the tap that chunk kt+1 opens; the other parity buffer is
-            // the one load_a(kt) read two barriers ago, this one was last read >= cpt chunks ago
-            if (MODE == MODE_DCN && kt + 1 < nk && (kt + 1) % cpt1 == 0) dcn_params((kt + 1) / cpt1);
+            finish_store(0);
+            // DCN: sampling record of the tap that chunk kt+1 opens; the other parity buffer is the
+            // one issue_loads(kt) read before the previous barrier, this one was last read >= cpt chunks ago
+            if (MODE == MODE_DCN && kt + 1 < nk && (kt + 1) % cpt == 0) dcn_params((kt + 1) / cpt);
             __syncthreads();
-            if (kt + 1 < nk) load_next();
+            if (kt + 1 < nk) issue_loads();
             read_frags(0);
             mfma_chunk();
+            __syncthreads();  // all waves finished reading this chunk
         }
     } else {
-        // two LDS stages, ONE barrier per chunk.  Iteration kt: read fragments of chunk kt,
-        // park chunk kt+1 (registers, loaded one iteration ago) in the other stage, issue the
-        // global loads of chunk kt+2, then the MFMAs of chunk kt.  The stage written at kt was
-        // last read at kt-1 (barrier in between); it is read at kt+1 (barrier in between).
-        const int cpt = (MODE == MODE_DCN) ? (p.Cin >> 5) : 1;   // chunks per tap (DCN)
+        // two LDS stages, ONE barrier per chunk.  Iteration kt: issue the loads of chunk kt+1,
+        // fragments + MFMAs of chunk kt (stage kt&1), then finish chunk kt+1 into the other stage.
+        // That stage was last read in iteration kt-1 and is next read in iteration kt+1, each
+        // separated from the store by a barrier.
         if (MODE == MODE_DCN) {
-            // sampling records whose first chunk is 0,1,2 must exist before the first loads
-            for (int c0 = 0; c0 <= 2 && c0 < nk; ++c0)
-                if (c0 % cpt == 0) dcn_params(c0 / cpt);
+            dcn_params(0);
+            if (cpt == 1 && nk > 1) dcn_params(1);
             __syncthreads();
         }
-        load_next();
-        store_ab(0);
-        if (nk > 1) load_next();
+        issue_loads();
+        finish_store(0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cs = kt & 1;
+            if (kt + 1 < nk) issue_loads();
+            // DCN: record of the tap that chunk kt+2 opens (tap T): its parity buffer held tap T-2,
+            // last read by issue_loads in an earlier iteration; this iteration reads tap T-1.
+            if (MODE == MODE_DCN && kt + 2 < nk && (kt + 2) % cpt == 0) dcn_params((kt + 2) / cpt);
             read_frags(cs);
-            if (kt + 1 < nk) store_ab(cs ^ 1);
-            if (MODE == MODE_DCN) {
-                // record of the tap whose first chunk is kt+3: visible after this iteration's
-                // barrier, first used by load_a(kt+3) in iteration kt+1; the other parity buffer
-                // (tap-1) is still being read by this iteration's load_a(kt+2).
-                const int c3 = kt + 3;
-                if (c3 < nk && c3 % cpt == 0) dcn_params(c3 / cpt);
-            }
-            if (kt + 2 < nk) load_next();
             mfma_chunk();
+            if (kt + 1 < nk) finish_store(cs ^ 1);
             __syncthreads();
         }
     }

@@ -243,4 +243,13 @@ static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4);
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+// buffer-load hooks of deft_amd/csrc/common.h: num_records = 2^31-1, offsets >= 2^31 read as zero
+#define DEFT_BUFFER_HOOKS 1
+struct deft_rsrc_t { const char* base; };
+static inline deft_rsrc_t deft_make_rsrc(const void* base) { return deft_rsrc_t{(const char*)base}; }
+static inline hipemu_f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off) {
+    hipemu_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (byte_off < 0x7FFFFFFFu - 15u) memcpy(&v, r.base + byte_off, 16);
+    return v;
+}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
