@@ -134,7 +134,7 @@ def main():
         comp.nstream = ns
         torch.cuda.synchronize()
         lib.profile = None
-        GEMM = ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer")
+        GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer")
         gemm_ms = sum(e0.elapsed_time(e1) for (k, _, e0, e1, _i) in prof if k in GEMM)
         gemm_fl = sum(fl for (k, fl, _, _, _i) in prof if k in GEMM)
         n_launch = sum(1 for p in prof if p[0] in GEMM)

@@ -27,10 +27,14 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 #define LDS_STRIDE 36
 #define ROW_INVALID (-(1 << 28))
 
-// dynamic-LDS layout (floats): As[NSTAGE][BM*36] | Bs[NSTAGE][BN*36] | DCN sampling params [2][BM*12]
-template <int BM, int BN, int NSTAGE, int MODE>
+// dynamic-LDS layout (floats): As[NSTAGE][BM*36] | Bs[NSTAGE][BN*36] | DCN sampling params [2][BM*12];
+// with intra-workgroup split-K (WK > 1) the same region is reused after the K loop for the
+// partial accumulators of the wk > 0 waves: [(WK-1)][32x32 tiles of the block][16][64].
+template <int BM, int BN, int WK, int NSTAGE, int MODE>
 constexpr int igemm_lds_floats() {
-    return NSTAGE * (BM + BN) * LDS_STRIDE + (MODE == MODE_DCN ? 2 * BM * 12 : 0);
+    constexpr int stage = NSTAGE * (BM + BN) * LDS_STRIDE + (MODE == MODE_DCN ? 2 * BM * 12 : 0);
+    constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
+    return stage > red ? stage : red;
 }
 
 // Position of the 32-wide K chunk being loaded: tap (r,s) and first channel c0.  When a chunk
@@ -39,13 +43,18 @@ struct KCursor {
     int r, s, c0;
 };
 
-template <int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
-__global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, int ntiles) {
+// WM x WN x WK = 4 wavefronts: (wm, wn) pick the wave's TM x TN grid of 32x32 output tiles, wk
+// its share of every chunk's 16 MFMA k-steps (intra-workgroup split-K for problems too small to
+// fill 256 CUs with bigger tiles: all four waves still stage the chunk, partial sums are
+// combined through LDS in wave order, so the result is deterministic).
+template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
+__device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, int ntiles, int bid) {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int GA = BM / 32;  // f32x4 groups per thread, A tile
     constexpr int GB = BN / 32;  // f32x4 groups per thread, B tile
-    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int KK = 16 / WK;  // MFMA k-steps per chunk per wave
+    static_assert(WM * WN * WK == 4, "4 wavefronts per workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
 
     DEFT_DYN_LDS(float, smem);
@@ -56,12 +65,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = wave / (WM * WN);
+    const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
 
     // XCD-aware, bijective workgroup remap: block b runs on XCD b%8 (observed), so give
     // every XCD one contiguous run of tiles -- neighbouring n-tiles of an m-tile then
     // share their A rows in that XCD's private L2.
-    int bid = blockIdx.x;
     {
         const int nwg = mtiles * ntiles;
         const int q = nwg >> 3, r = nwg & 7;
@@ -99,6 +108,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
                 }
                 r0[i] = u * p.ldx * 4;
                 r1[i] = j * p.ldx * 4;
+            } else if (MODE == MODE_CONV && p.rowmap != nullptr) {
+                // sparse output rows: rowmap[m] = {n*H*W, (y << 16) | x} of the row's output pixel, or {_, -1}
+                const int e0 = p.rowmap[2 * m], e1 = p.rowmap[2 * m + 1];
+                if (e1 >= 0) {
+                    r0[i] = (e1 >> 16) * p.stride - p.pad;
+                    r1[i] = (e1 & 0xffff) * p.stride - p.pad;
+                    r2[i] = e0;
+                }
             } else {
                 const int ohw = p.OH * p.OW;
                 const int n = m / ohw;
@@ -250,8 +267,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 
     const int nk = p.Kpad >> 5;
     const int frow = lane & 31;        // row of the 32-row MFMA tile this lane feeds
-    const int fk = (lane >> 5) * 16;   // first of this lane's 16 k-values in the chunk
-    float a[TM][16], b[TN][16];
+    const int fk = (lane >> 5) * 16 + wk * KK;   // first of this lane's k-values in the chunk (this wave's share)
+    float a[TM][KK], b[TN][KK];
 
     auto read_frags = [&](int stage) {
         const float* as = As + stage * BM * LDS_STRIDE + (wm * TM * 32 + frow) * LDS_STRIDE + fk;
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < KK / 4; ++q) {
                 const f32x4 t = *(const f32x4*)&as[i * 32 * LDS_STRIDE + 4 * q];
                 a[i][4 * q + 0] = t.x; a[i][4 * q + 1] = t.y; a[i][4 * q + 2] = t.z; a[i][4 * q + 3] = t.w;
             }
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < KK / 4; ++q) {
                 const f32x4 t = *(const f32x4*)&bs[j * 32 * LDS_STRIDE + 4 * q];
                 b[j][4 * q + 0] = t.x; b[j][4 * q + 1] = t.y; b[j][4 * q + 2] = t.z; b[j][4 * q + 3] = t.w;
             }
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
     };
     auto mfma_chunk = [&]() {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -330,6 +347,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
         }
     }
 
+    if (WK > 1) {
+        // both loop forms end on a barrier: the staging region is free.  Waves wk > 0 park their
+        // partial tiles (lane-contiguous: conflict-free), wave wk == 0 adds them in wk order.
+        float* red = smem;
+        const int tbase = ((wave % (WM * WN)) * TM * TN) * 1024 + lane;
+        constexpr int per_wk = WM * WN * TM * TN * 1024;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(wk - 1) * per_wk + tbase + (i * TN + j) * 1024 + r * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w = 1; w < WK; ++w)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(w - 1) * per_wk + tbase + (i * TN + j) * 1024 + r * 64];
+    }
+
     // epilogue: D reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31);
     // the 32 lanes of a half-wave write 32 consecutive channels of one pixel (128 B).
     // Residual loads are hoisted out of the per-element path (one uniform branch, 16
@@ -371,41 +414,64 @@ __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int NSTAGE>
-static int launch_igemm(const DeftGemmDesc& d, hipStream_t s) {
-    const int mtiles = deft_cdiv(d.M, BM), ntiles = deft_cdiv(d.Cout, BN);
-    constexpr int lds_bytes = igemm_lds_floats<BM, BN, NSTAGE, MODE>() * 4;
+template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
+__global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, int ntiles) {
+    igemm_body<BM, BN, WM, WN, WK, MODE, NSTAGE>(p, mtiles, ntiles, blockIdx.x);
+}
+
+// grouped form: blockIdx.y picks one of several independent problems (descriptors in device
+// memory, same tile configuration); blocks beyond a problem's tile count exit at once.
+template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
+__global__ __launch_bounds__(256) void igemm_group_kernel(const DeftGemmDesc* __restrict__ descs) {
+    const DeftGemmDesc p = descs[blockIdx.y];
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
+    if ((int)blockIdx.x >= mtiles * ntiles) return;
+    igemm_body<BM, BN, WM, WN, WK, MODE, NSTAGE>(p, mtiles, ntiles, blockIdx.x);
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
+static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, int ngroups, int max_tiles, hipStream_t s) {
+    constexpr int lds_bytes = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE>() * 4;
     static bool attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
     if (lds_bytes > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, MODE, NSTAGE>,
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        DEFT_CHECK(e == hipSuccess, -101, "igemm: hipFuncSetAttribute(%d B LDS) failed: %s", lds_bytes, hipGetErrorString(e));
+        e = hipFuncSetAttribute((const void*)igemm_group_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         DEFT_CHECK(e == hipSuccess, -101, "igemm: hipFuncSetAttribute(%d B LDS) failed: %s", lds_bytes, hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, NSTAGE>), dim3(mtiles * ntiles), dim3(256), lds_bytes, s, d,
-                       mtiles, ntiles);
+    if (group_dev != nullptr) {
+        hipLaunchKernelGGL((igemm_group_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>), dim3(max_tiles, ngroups), dim3(256), lds_bytes, s, group_dev);
+    } else {
+        const int mtiles = deft_cdiv(d.M, BM), ntiles = deft_cdiv(d.Cout, BN);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>), dim3(mtiles * ntiles), dim3(256), lds_bytes, s, d,
+                           mtiles, ntiles);
+    }
     DEFT_CHECK_LAUNCH("igemm");
     return 0;
 }
 
 // `tile` knob: bits 0-15 BN, bits 16-28 BM, bit 30 = force the 1-stage (2-barrier) loop,
-// bit 29 = force the 2-stage (1-barrier, double LDS) loop; default: 1-stage (measured faster
-// at 3 waves/SIMD) except the 64x64 DCN tile
+// bit 29 = force the 2-stage (1-barrier, double LDS) loop.  64x32 and 32x32 are the split-K
+// tiles (WK = 2 / 4).
 template <int MODE>
-static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage, hipStream_t s) {
-    if (one_stage) {
-        if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, MODE, 1>(d, s);
-        if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, MODE, 1>(d, s);
-        if (bm == 128 && bn == 32) return launch_igemm<128, 32, 4, 1, MODE, 1>(d, s);
-        if (bm == 64 && bn == 64) return launch_igemm<64, 64, 2, 2, MODE, 1>(d, s);
-        if (bm == 64 && bn == 128) return launch_igemm<64, 128, 2, 2, MODE, 1>(d, s);
-    } else {
-        if (bm == 128 && bn == 128) return launch_igemm<128, 128, 2, 2, MODE, 2>(d, s);
-        if (bm == 128 && bn == 64) return launch_igemm<128, 64, 2, 2, MODE, 2>(d, s);
-        if (bm == 128 && bn == 32) return launch_igemm<128, 32, 4, 1, MODE, 2>(d, s);
-        if (bm == 64 && bn == 64) return launch_igemm<64, 64, 2, 2, MODE, 2>(d, s);
-        if (bm == 64 && bn == 128) return launch_igemm<64, 128, 2, 2, MODE, 2>(d, s);
-    }
+static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage, hipStream_t s,
+                          const DeftGemmDesc* group_dev = nullptr, int ngroups = 0, int max_m = 0, int max_n = 0) {
+    const int mt = group_dev ? deft_cdiv(max_m, bm) * deft_cdiv(max_n, bn) : 0;
+#define DEFT_TILE(BM_, BN_, WM_, WN_, WK_)                                                                   \
+    if (bm == BM_ && bn == BN_)                                                                              \
+        return one_stage ? launch_igemm<BM_, BN_, WM_, WN_, WK_, MODE, 1>(d, group_dev, ngroups, mt, s)      \
+                         : launch_igemm<BM_, BN_, WM_, WN_, WK_, MODE, 2>(d, group_dev, ngroups, mt, s);
+    DEFT_TILE(128, 128, 2, 2, 1)
+    DEFT_TILE(128, 64, 2, 2, 1)
+    DEFT_TILE(128, 32, 4, 1, 1)
+    DEFT_TILE(64, 64, 2, 2, 1)
+    DEFT_TILE(64, 128, 2, 2, 1)
+    DEFT_TILE(64, 32, 2, 1, 2)
+    DEFT_TILE(32, 32, 1, 1, 4)
+#undef DEFT_TILE
     DEFT_CHECK(false, -15, "igemm: unsupported tile %dx%d", bm, bn);
     return -15;
 }
@@ -426,29 +492,60 @@ static int check_common(const DeftGemmDesc* d, const char* who) {
 // blocks needed before a bigger tile is worth it: 2 workgroups on each of 256 CUs
 #define FILL_BLOCKS 512
 
-extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
-    if (int e = check_common(d, "deft_conv2d_nhwc")) return e;
-    DEFT_CHECK((d->Cin & 3) == 0, -10, "deft_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad channels)", d->Cin);
-    DEFT_CHECK(d->Ktot == d->KH * d->KW * d->Cin, -11, "deft_conv2d_nhwc: Ktot mismatch");
+static int check_conv(const DeftGemmDesc* d, const char* who) {
+    if (int e = check_common(d, who)) return e;
+    DEFT_CHECK((d->Cin & 3) == 0, -10, "%s: Cin=%d must be a multiple of 4 (pad channels)", who, d->Cin);
+    DEFT_CHECK(d->Ktot == d->KH * d->KW * d->Cin, -11, "%s: Ktot mismatch", who);
     DEFT_CHECK(d->KH * d->KW == 1 || ((d->Cin & (d->Cin - 1)) == 0 && (1 << d->cin_log2) == d->Cin), -12,
-               "deft_conv2d_nhwc: Cin=%d must be a power of two for KHxKW>1", d->Cin);
-    DEFT_CHECK(d->M == d->N * d->OH * d->OW, -13, "deft_conv2d_nhwc: M != N*OH*OW");
-    DEFT_CHECK(d->ldx >= d->Cin, -14, "deft_conv2d_nhwc: ldx < Cin");
-    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 31), -16, "deft_conv2d_nhwc: input exceeds 2^31 elements (split the batch)");
-    DEFT_CHECK(d->KW >= 1 && d->KW <= 16 && d->Kpad / (d->Cin < 32 ? d->Cin : 32) <= 4096, -17, "deft_conv2d_nhwc: KW=%d out of range", d->KW);
+               "%s: Cin=%d must be a power of two for KHxKW>1", who, d->Cin);
+    DEFT_CHECK(d->rowmap != nullptr || d->M == d->N * d->OH * d->OW, -13, "%s: M != N*OH*OW", who);
+    DEFT_CHECK(d->rowmap == nullptr || (d->H < 65536 && d->W < 65536), -19, "%s: rowmap packs y/x in 16 bits", who);
+    DEFT_CHECK(d->ldx >= d->Cin, -14, "%s: ldx < Cin", who);
+    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -16, "%s: input exceeds 2 GiB (split the batch)", who);
+    DEFT_CHECK(d->KW >= 1 && d->KW <= 16, -17, "%s: KW=%d out of range", who, d->KW);
     DEFT_CHECK(d->Cin >= 32 || d->KH * d->KW == 1 || d->Kpad / d->Cin <= 64, -18,
-               "deft_conv2d_nhwc: Cin=%d < 32 supports at most 64 taps (incl. K padding)", d->Cin);
+               "%s: Cin=%d < 32 supports at most 64 taps (incl. K padding)", who, d->Cin);
+    return 0;
+}
+
+// automatic tile choice for a conv problem of M rows x Cout columns
+static void pick_conv_tile(int M, int Cout, int& bm, int& bn) {
+    const long long m128 = deft_cdiv(M, 128);
+    if (Cout <= 32) {
+        bn = 32;
+        bm = m128 >= 384 ? 128 : 32;     // few rows: 32x32 split-K tile, 4 waves per output tile (measured:
+                                         // 38x68x8 rows 68 -> 48 us, 19x34x8 rows 124 -> 54 us vs 128x32)
+    } else if (Cout > 64 && m128 * deft_cdiv(Cout, 128) >= FILL_BLOCKS) { bm = 128; bn = 128; }
+    else if (m128 * deft_cdiv(Cout, 64) >= FILL_BLOCKS) { bm = 128; bn = 64; }
+    else { bm = 64; bn = 64; }
+}
+
+extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
+    if (int e = check_conv(d, "deft_conv2d_nhwc")) return e;
     hipStream_t s = (hipStream_t)stream;
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);
-    if (bm == 0) {
-        const long long m128 = deft_cdiv(d->M, 128);
-        if (d->Cout <= 32) { bm = 128; bn = 32; }
-        else if (d->Cout > 64 && m128 * deft_cdiv(d->Cout, 128) >= FILL_BLOCKS) { bm = 128; bn = 128; }
-        else if (m128 * deft_cdiv(d->Cout, 64) >= FILL_BLOCKS) { bm = 128; bn = 64; }
-        else { bm = 64; bn = 64; }
-    }
+    if (bm == 0) pick_conv_tile(d->M, d->Cout, bm, bn);
     return dispatch_igemm<MODE_CONV>(*d, bm, bn, one_stage, s);
+}
+
+extern "C" int deft_conv2d_group(const DeftGemmDesc* descs, const DeftGemmDesc* descs_dev, int ngroups, void* stream) {
+    DEFT_CHECK(descs && descs_dev && ngroups > 0 && ngroups <= 65535, -40, "deft_conv2d_group: bad arguments");
+    int max_m = 0, max_n = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        if (int e = check_conv(descs + i, "deft_conv2d_group")) return e;
+        max_m = descs[i].M > max_m ? descs[i].M : max_m;
+        max_n = descs[i].Cout > max_n ? descs[i].Cout : max_n;
+    }
+    int bm = (descs[0].tile >> 16) & 0x1fff, bn = descs[0].tile & 0xffff;
+    const bool one_stage = !((descs[0].tile >> 29) & 1);
+    if (bm == 0) {          // one tile for all groups: judge the fill by the total tile count
+        long long t32 = 0;
+        for (int i = 0; i < ngroups; ++i) t32 += (long long)deft_cdiv(descs[i].M, 128) * deft_cdiv(descs[i].Cout, 32);
+        bn = 32;
+        bm = t32 >= 1024 ? 128 : (t32 >= 256 ? 64 : 32);
+    }
+    return dispatch_igemm<MODE_CONV>(descs[0], bm, bn, one_stage, (hipStream_t)stream, descs_dev, ngroups, max_m, max_n);
 }
 
 extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
@@ -459,7 +556,7 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
                "deft_dcn_v2_nhwc: Cin=%d must be a power of two >= 32", d->Cin);
     DEFT_CHECK(d->Ktot == 9 * d->Cin && d->Kpad == d->Ktot, -23, "deft_dcn_v2_nhwc: Ktot/Kpad mismatch");
     DEFT_CHECK(d->OH == d->H && d->OW == d->W && d->M == d->N * d->H * d->W, -24, "deft_dcn_v2_nhwc: geometry mismatch");
-    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 31), -25, "deft_dcn_v2_nhwc: input exceeds 2^31 elements (split the batch)");
+    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -25, "deft_dcn_v2_nhwc: input exceeds 2 GiB (split the batch)");
     hipStream_t s = (hipStream_t)stream;
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     if (bm == 0) {

@@ -479,6 +479,76 @@ extern "C" int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, in
 }
 
 // ---------------------------------------------------------------------------
+// fused embedding head, steps 1 and 3 (step 2 = grouped sparse-row conv GEMM, igemm.hip)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ centers, int Nf, int ndet,
+                                                         const int* __restrict__ map_hw, int nmaps,
+                                                         int* __restrict__ rowmap, float* __restrict__ bw) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int per = Nf * ndet;
+    if (t >= nmaps * per) return;
+    const int k = t / per, d = t - k * per;          // map, (frame, detection)
+    const int n = d / ndet;
+    const int H = map_hw[2 * k], W = map_hw[2 * k + 1];
+    const float gx = centers[2 * d], gy = centers[2 * d + 1];
+    // grid_sample: unnormalise (align_corners=False), clip to the border, bilinear corners
+    float fx = ((gx + 1.f) * W - 1.f) / 2.f, fy = ((gy + 1.f) * H - 1.f) / 2.f;
+    fx = fminf((float)(W - 1), fmaxf(fx, 0.f));
+    fy = fminf((float)(H - 1), fmaxf(fy, 0.f));
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const bool xin = x0 + 1 <= W - 1, yin = y0 + 1 <= H - 1;
+    const float w4[4] = {(x1f - fx) * (y1f - fy), xin ? (fx - x0f) * (y1f - fy) : 0.f,
+                         yin ? (x1f - fx) * (fy - y0f) : 0.f, (xin && yin) ? (fx - x0f) * (fy - y0f) : 0.f};
+    const bool ok4[4] = {true, xin, yin, xin && yin};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t r = ((size_t)k * per + d) * 4 + q;
+        rowmap[2 * r] = n * H * W;
+        rowmap[2 * r + 1] = ok4[q] ? (((y0 + (q >> 1)) << 16) | (x0 + (q & 1))) : -1;
+        bw[r] = w4[q];
+    }
+}
+
+extern "C" int deft_embed_rows(const float* centers, int Nf, int ndet, const int* map_hw, int nmaps,
+                               int* rowmap, float* bw, void* stream) {
+    DEFT_CHECK(centers && map_hw && rowmap && bw && nmaps > 0, -1, "deft_embed_rows: bad arguments");
+    if (Nf * ndet <= 0) return 0;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(deft_cdiv((long long)nmaps * Nf * ndet, 256)), dim3(256), 0, (hipStream_t)stream,
+                       centers, Nf, ndet, map_hw, nmaps, rowmap, bw);
+    DEFT_CHECK_LAUNCH("embed_rows");
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void embed_blend_kernel(const float* __restrict__ tmp, const float* __restrict__ bw,
+                                                          const int* __restrict__ map_out, int per,
+                                                          float* __restrict__ out, int ldo) {
+    const int k = blockIdx.y;
+    const int toff = map_out[4 * k], ldt = map_out[4 * k + 1], Co = map_out[4 * k + 2], col = map_out[4 * k + 3];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= per * Co) return;
+    const int d = t / Co, o = t - d * Co;
+    const float* tp = tmp + (size_t)toff + (size_t)d * 4 * ldt + o;
+    const float* w = bw + ((size_t)k * per + d) * 4;
+    float r = tp[0] * w[0];
+    r += tp[ldt] * w[1];
+    r += tp[2 * ldt] * w[2];
+    r += tp[3 * ldt] * w[3];
+    out[(size_t)d * ldo + col + o] = r;
+}
+
+extern "C" int deft_embed_blend(const float* tmp, const float* bw, const int* map_out, int nmaps, int Nf, int ndet,
+                                float* out, int ldo, void* stream) {
+    DEFT_CHECK(tmp && bw && map_out && out && nmaps > 0, -1, "deft_embed_blend: bad arguments");
+    if (Nf * ndet <= 0) return 0;
+    hipLaunchKernelGGL(embed_blend_kernel, dim3(deft_cdiv((long long)Nf * ndet * 64, 256), nmaps), dim3(256), 0, (hipStream_t)stream,
+                       tmp, bw, map_out, Nf * ndet, out, ldo);
+    DEFT_CHECK_LAUNCH("embed_blend");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // affinity tail: final 64->1 + ReLU, dual softmax with analytic padding   (AFE.py:119-150)
 // ---------------------------------------------------------------------------
 #define AF_MAXOBJ 112   // 112*112*4 B = 49 KB of LDS (opts.py:339 max_object = 100)

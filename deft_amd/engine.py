@@ -379,13 +379,14 @@ class AfePlan(_Plan):
         super().__init__(device, lib)
         self.max_object = max_object
         nsel = 13
-        self.sel = []
+        self.sel, self.sel_t = [], []
         off = 0
         for k in range(nsel):
             w = sd["AFE.selector.%d.weight" % k].float()          # [Co,C,3,3]
             Co, Cc = w.shape[0], w.shape[1]
-            wt = w.permute(2, 3, 1, 0).reshape(9 * Cc, Co)        # [(r,s,c)][Co]
-            self.sel.append((self.dev(wt), self.dev(sd["AFE.selector.%d.bias" % k].float()), Co, Cc, off))
+            wp, K = pack_conv_weight(w)                            # implicit-GEMM layout [CoPad][Kpad]
+            self.sel.append((self.dev(wp), K, self.dev(sd["AFE.selector.%d.bias" % k].float()), Co, Cc, off))
+            self.sel_t.append(self.dev(w.permute(2, 3, 1, 0).reshape(9 * Cc, Co)))   # [(r,s,c)][Co] for deft_embed_map
             off += Co
         self.D = D = off
         # ---- pair MLP, separable first layer with both BatchNorms folded in fp64 ----
@@ -418,17 +419,72 @@ class AfePlan(_Plan):
         self.w5 = self.dev(sd["AFE.final_net.11.weight"].float().reshape(-1))
         self.b5 = float(sd["AFE.final_net.11.bias"].float().item())
 
+    def _embed_group(self, fmaps, Nf, ndet):
+        """Per (feature-map buffers, Nf, ndet): the 13 sparse-row conv descriptors (host + device
+        copies) and the scratch of the fused embedding head."""
+        key = (tuple(fm.addr for fm in fmaps), Nf, ndet)
+        if not hasattr(self, "_egroups"):
+            self._egroups = {}
+        if key in self._egroups:
+            return self._egroups[key]
+        dev = self.device
+        nm = len(self.sel)
+        M = Nf * ndet * 4
+        ldts = [_rup(Co, 4) for (_, _, _, Co, _, _) in self.sel]
+        toffs = [0]
+        for ld in ldts:
+            toffs.append(toffs[-1] + M * ld)
+        g = {"rowmap": torch.zeros(nm * M * 2, dtype=torch.int32, device=dev),
+             "bw": torch.zeros(nm * Nf * ndet * 4, dtype=torch.float32, device=dev),
+             "tmp": torch.zeros(toffs[-1], dtype=torch.float32, device=dev),
+             "map_hw": torch.tensor([[fm.H, fm.W] for fm in fmaps], dtype=torch.int32).to(dev),
+             "map_out": torch.tensor([[toffs[k], ldts[k], self.sel[k][3], self.sel[k][5]] for k in range(nm)], dtype=torch.int32).to(dev)}
+        descs = (GemmDesc * nm)()
+        for k, (fm, (wp, K, bias, Co, Cc, off)) in enumerate(zip(fmaps, self.sel)):
+            assert fm.C == Cc and fm.N == Nf
+            d = descs[k]
+            d.x = fm.addr; d.x2 = None; d.w = wp.data_ptr(); d.scale = None; d.shift = bias.data_ptr(); d.res = None
+            d.y = g["tmp"].data_ptr() + 4 * toffs[k]
+            d.N, d.H, d.W, d.Cin, d.ldx = fm.N, fm.H, fm.W, fm.C, fm.ld
+            d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, Co, ldts[k], 0
+            d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
+            d.Ktot, d.Kpad, d.cin_log2, d.M = K, wp.shape[1], int(math.log2(fm.C)), M
+            d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = 0
+            d.rowmap = g["rowmap"].data_ptr() + 4 * (k * M * 2)
+        g["descs"] = descs
+        g["descs_dev"] = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        self._egroups[key] = g
+        return g
+
     def extract(self, fmaps, centers, out=None):
         """fmaps: 13 Views (DlaSegPlan.fmaps); centers [Nf, ndet, 2] (x,y in [-1,1], as
         convert_detection image.py:391-412 produces) -> embeddings [Nf, ndet, D] (written
-        into `out` when given: a contiguous [Nf, ndet, D] device tensor)."""
+        into `out` when given: a contiguous [Nf, ndet, D] device tensor).
+        Three launches: corner rows + blend weights, ONE grouped sparse-row conv GEMM over the 13
+        selector convs (ReLU epilogue), bilinear blend into the embedding columns."""
         Nf, ndet = centers.shape[0], centers.shape[1]
         centers = centers.to(self.device, torch.float32).contiguous()
         if out is None:
             out = torch.empty(Nf, ndet, self.D, dtype=torch.float32, device=self.device)
         assert out.is_contiguous() and tuple(out.shape) == (Nf, ndet, self.D)
+        if Nf * ndet == 0:
+            return out
+        g = self._embed_group(fmaps, Nf, ndet)
         s = self._stream()
-        for fm, (wt, b, Co, Cc, off) in zip(fmaps, self.sel):
+        nm = len(self.sel)
+        self.lib.call("deft_embed_rows", ptr(centers), Nf, ndet, ptr(g["map_hw"]), nm, ptr(g["rowmap"]), ptr(g["bw"]), s)
+        self.lib.call("deft_conv2d_group", g["descs"], C.c_void_p(g["descs_dev"].data_ptr()), nm, s)
+        self.lib.call("deft_embed_blend", ptr(g["tmp"]), ptr(g["bw"]), ptr(g["map_out"]), nm, Nf, ndet, ptr(out), self.D, s)
+        return out
+
+    def extract_per_map(self, fmaps, centers, out=None):
+        """Same result through deft_embed_map (one launch per map); kept for the single-map ABI entry."""
+        Nf, ndet = centers.shape[0], centers.shape[1]
+        centers = centers.to(self.device, torch.float32).contiguous()
+        if out is None:
+            out = torch.empty(Nf, ndet, self.D, dtype=torch.float32, device=self.device)
+        s = self._stream()
+        for fm, (wp, K, b, Co, Cc, off), wt in zip(fmaps, self.sel, self.sel_t):
             assert fm.C == Cc and fm.N == Nf
             self.lib.call("deft_embed_map", C.c_void_p(fm.addr), Nf, fm.H, fm.W, fm.C, fm.ld, ptr(wt), ptr(b), Co,
                           ptr(centers), ndet, ptr(out), self.D, off, s)

@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("Ktot", C.c_int), ("Kpad", C.c_int), ("cin_log2", C.c_int), ("M", C.c_int),
         ("relu", C.c_int), ("Q", C.c_int), ("ldom", C.c_int), ("tile", C.c_int),
         ("Tper", C.c_int), ("u0", C.c_int), ("du", C.c_int), ("v0", C.c_int), ("dv", C.c_int),
+        ("rowmap", c_fp),
     ]
 
 
@@ -36,6 +37,7 @@ _SIGS = {
     "deft_version": (C.c_int, []),
     "deft_last_error": (C.c_char_p, []),
     "deft_conv2d_nhwc": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "deft_conv2d_group": (C.c_int, [C.POINTER(GemmDesc), c_fp, C.c_int, c_fp]),
     "deft_dcn_v2_nhwc": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "deft_pair_layer": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "deft_nchw_to_nhwc": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
@@ -47,6 +49,8 @@ _SIGS = {
     "deft_heads_at_peaks": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, C.c_int] + [c_fp] * 5 + [C.c_int] * 2 + [c_fp, c_fp]),
     "deft_decode_boxes": (C.c_int, [c_fp, c_fp] + [C.c_int] * 8 + [c_fp] * 4),
     "deft_embed_map": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp]),
+    "deft_embed_rows": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),
+    "deft_embed_blend": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp]),
     "deft_affinity_finish": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_float, c_fp] + [C.c_int] * 3 + [c_fp, c_fp]),
     "deft_lstm_step": (C.c_int, [c_fp] * 3 + [C.c_int] * 3 + [c_fp] * 8 + [c_fp]),
 }
@@ -70,8 +74,8 @@ class HipLib:
             fn.restype = res
             fn.argtypes = args
         v = self.cdll.deft_version()
-        if v != 1:
-            raise DeftHipError("libdeft_hip ABI version %d, expected 1" % v)
+        if v != 2:
+            raise DeftHipError("libdeft_hip ABI version %d, expected 2" % v)
 
     profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1, shape) per call
 
@@ -86,7 +90,11 @@ class HipLib:
         if prof is not None:
             e1.record()
             fl, info = 0.0, ""
-            if name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer"):
+            if name == "deft_conv2d_group":
+                ds = args[0]
+                fl = sum(2.0 * ds[i].M * ds[i].Cout * ds[i].Ktot for i in range(args[2]))
+                info = "group of %d" % args[2]
+            elif name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer"):
                 d = args[0]._obj
                 fl = 2.0 * d.M * d.Cout * (d.flop_k if d.flop_k else d.Ktot)
                 info = "M=%d N=%d K=%d %dx%d s%d @%dx%d" % (d.M, d.Cout, d.Ktot, d.KH, d.KW, d.stride, d.H, d.W)

@@ -128,7 +128,9 @@ class AfeSeam:
         emb = self.plan.extract(views, centers)
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
-        del self.plan._keep[keep:]                    # temporaries of the NCHW adapter
+        if len(self.plan._keep) > keep:               # NCHW adapter made temporaries: drop them and the
+            del self.plan._keep[keep:]                # descriptors built on their addresses
+            self.plan._egroups.clear()
         return emb[0:1]
 
     def forward_stacker_features(self, xp, xn, fill_up_column=True):

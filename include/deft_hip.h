@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 1
+#define DEFT_ABI_VERSION 2
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -45,6 +45,11 @@ typedef struct DeftGemmDesc {
      * frame, t its history row, j its object; U' row = u0 + c*du + t, V' row = v0 + c*dv + j.
      * Tper == 0: rows are (t, j), U' row = t, V' row = j.                                   */
     int Tper, u0, du, v0, dv;
+    /* conv, sparse output rows (NULL = dense grid): rowmap[2m] = n*H*W, rowmap[2m+1] = (y << 16) | x
+     * of the output pixel GEMM row m stands for, or -1 for an unused row (written as shift/ReLU
+     * of a zero accumulator).  Output row m is y + m*ldy.  Used by the embedding head, which
+     * needs the selector convs only at the bilinear neighbours of the detection centres.     */
+    const int* rowmap;
 } DeftGemmDesc;
 
 int deft_version(void);
@@ -55,6 +60,12 @@ const char* deft_last_error(void);
  * dla.py:47-87 (BasicBlock), :184-207 (Root), :301-345 (base/levels),
  * base_model.py:37-66 (heads), AFE.py:331-347 (final_net 1x1 stack). */
 int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream);
+
+/* `ngroups` independent conv problems in ONE launch (blockIdx.y = group): `descs` is the host
+ * copy (validation, tile choice), `descs_dev` the same array in device memory (read by the
+ * kernel).  One tile configuration for all groups (descs[0].tile, 0 = auto).  Used for the 13
+ * selector convs of AFE_module.forward_selector_stacker1 (AFE.py:162-188). */
+int deft_conv2d_group(const DeftGemmDesc* descs, const DeftGemmDesc* descs_dev, int ngroups, void* stream);
 
 /* DCNv2 main contraction: bilinear offset gather * sigmoid(mask) fused into the
  * A-operand loader (no global im2col buffer), then +bias/BN/ReLU epilogue.
@@ -128,6 +139,19 @@ int deft_decode_boxes(const int* inds, const float* heads, int N, int K, int Wm,
 int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, int ld,
                    const float* wsel_t, const float* bsel, int Co,
                    const float* centers, int ndet, float* out, int ldo, int col_off, void* stream);
+
+/* Embedding head, fused over all maps (AFE.py:162-188), step 1: for every (map k, frame n, detection
+ * i) turn the centre (x,y in [-1,1], grid_sample align_corners=False, border padding) into the four
+ * bilinear corner pixels -> rowmap[k][(n*ndet+i)*4+q] (DeftGemmDesc.rowmap format, q = 2*dy+dx;
+ * corners outside the map are unused rows) and the four blend weights bw[k][n*ndet+i][4] (0 for
+ * unused corners).  map_hw [nmaps][2] = (H, W) per map, device memory.
+ * Step 2 is deft_conv2d_group over the selector convs (ReLU epilogue) into tmp; step 3:
+ * out[(n*ndet+i)*ldo + col_off_k + o] = sum_q bw[k][..][q] * tmp_k[((n*ndet+i)*4+q)*ldt_k + o].
+ * map_out [nmaps][4] = (float offset of tmp_k inside tmp, ldt_k, Co_k, col_off_k), device memory. */
+int deft_embed_rows(const float* centers, int Nf, int ndet, const int* map_hw, int nmaps,
+                    int* rowmap, float* bw, void* stream);
+int deft_embed_blend(const float* tmp, const float* bw, const int* map_out, int nmaps, int Nf, int ndet,
+                     float* out, int ldo, void* stream);
 
 /* Tail of the affinity estimator for F history frames against one current frame:
  * x = relu(h4 . w5 + b5) per pair, then the dual softmax with the analytic padding

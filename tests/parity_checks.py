@@ -245,6 +245,82 @@ def check_embed_map(lib, device, Cc, Co, Hm=7, Wm=9, ndet=6, Nf=2, seed=0):
     assert float(out[..., :4].abs().max()) == 0.0 and float(out[..., 4 + Co:].abs().max()) == 0.0
 
 
+def check_embed_fused(lib, device, Nf=2, ndet=7, seed=0):
+    """Fused embedding head (deft_embed_rows -> deft_conv2d_group on sparse rows -> deft_embed_blend)
+    over maps of different C / size / Co, against conv2d + relu + grid_sample and against the
+    per-map entry point deft_embed_map."""
+    g = torch.Generator().manual_seed(seed)
+    cfg = [(16, 12, 14, 32), (64, 7, 9, 48), (128, 5, 4, 64), (32, 3, 3, 32), (256, 2, 5, 32)]   # (C, H, W, Co)
+    plan = engine._Plan(device, lib)
+    afe = engine.AfePlan.__new__(engine.AfePlan)
+    engine._Plan.__init__(afe, device, lib)
+    afe.sel, afe.sel_t, fmaps, refs_in = [], [], [], []
+    off = 0
+    for (Cc, Hm, Wm, Co) in cfg:
+        fm = torch.randn(Nf, Cc, Hm, Wm, generator=g)
+        w = torch.randn(Co, Cc, 3, 3, generator=g) * (1.0 / (9 * Cc) ** 0.5)
+        b = torch.randn(Co, generator=g) * 0.1
+        v = plan.alloc(Nf, Hm, Wm, Cc); fill_view(v, fm)
+        wp, K = engine.pack_conv_weight(w)
+        afe.sel.append((afe.dev(wp), K, afe.dev(b), Co, Cc, off))
+        afe.sel_t.append(afe.dev(w.permute(2, 3, 1, 0).reshape(9 * Cc, Co)))
+        fmaps.append(v); refs_in.append((fm, w, b))
+        off += Co
+    afe.D = off
+    cen = torch.rand(Nf, ndet, 2, generator=g) * 2.2 - 1.1          # some centres beyond the border
+    cen[0, 0] = torch.tensor([-1.0, 1.0]); cen[0, 1] = torch.tensor([1.0, -1.0]); cen[0, 2] = torch.tensor([0.9999, 0.9999])
+    out = afe.extract(fmaps, cen).cpu()
+    out2 = afe.extract(fmaps, cen).cpu()                             # cached descriptors, same answer
+    assert torch.equal(out, out2)
+    per = afe.extract_per_map(fmaps, cen).cpu()
+    col = 0
+    for (fm, w, b), (Cc, Hm, Wm, Co) in zip(refs_in, cfg):
+        src = F.relu(F.conv2d(fm, w, b, 1, 1))
+        ref = F.grid_sample(src, cen.view(Nf, ndet, 1, 2), mode="bilinear", padding_mode="border", align_corners=False)
+        ref = ref.squeeze(3).permute(0, 2, 1)
+        tol = 2e-5 * max(1.0, float(ref.abs().max()))
+        assert maxabs(out[..., col:col + Co], ref) <= tol, ("embed_fused", Cc, Hm, Wm, Co)
+        assert maxabs(per[..., col:col + Co], ref) <= tol
+        col += Co
+
+
+def check_sparse_conv(lib, device, tile=0, seed=0):
+    """deft_conv2d_nhwc with a rowmap: GEMM rows are arbitrary output pixels (or unused)."""
+    g = torch.Generator().manual_seed(seed)
+    N, H, W, Ci, Co = 2, 9, 11, 32, 40
+    plan = engine._Plan(device, lib)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.1
+    shift = torch.randn(Co, generator=g)
+    xv = plan.alloc(N, H, W, Ci); fill_view(xv, x)
+    wp, K = engine.pack_conv_weight(w)
+    M = 77
+    n_i = torch.randint(0, N, (M,), generator=g); y_i = torch.randint(0, H, (M,), generator=g); x_i = torch.randint(0, W, (M,), generator=g)
+    unused = torch.rand(M, generator=g) < 0.2
+    rm = torch.stack([n_i * H * W, torch.where(unused, torch.full((M,), -1), (y_i << 16) | x_i)], 1).to(torch.int32).contiguous()
+    rmd = plan.dev(rm)
+    out = torch.full((M, 44), 7.0)
+    outd = plan.dev(out)
+    from deft_amd.hiplib import GemmDesc
+    import ctypes as C, math
+    d = GemmDesc()
+    shd, wd = plan.dev(shift), plan.dev(wp)
+    d.x = xv.addr; d.x2 = None; d.w = wd.data_ptr(); d.scale = None; d.shift = shd.data_ptr(); d.res = None; d.y = outd.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Ci, xv.ld
+    d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, Co, 44, 0
+    d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
+    d.Ktot, d.Kpad, d.cin_log2, d.M = K, wp.shape[1], int(math.log2(Ci)), M
+    d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = tile
+    d.rowmap = rmd.data_ptr()
+    lib.call("deft_conv2d_nhwc", C.byref(d), plan._stream())
+    dense = F.relu(F.conv2d(x, w, shift, 1, 1))
+    got = outd.cpu()
+    for m in range(M):
+        ref = F.relu(shift) if bool(unused[m]) else dense[n_i[m], :, y_i[m], x_i[m]]
+        assert maxabs(got[m, :Co], ref) <= 2e-5 * max(1.0, float(ref.abs().max())), ("sparse", m)
+    assert float((got[:, Co:] - 7.0).abs().max()) == 0.0
+
+
 def check_affinity(lib, device, sd, shapes=((5, 7), (12, 12), (1, 3), (9, 2)), golden_tag=None, afe=None, scale=3.0):
     afe = afe or engine.AfePlan(sd, 100, device, lib)
     D = afe.D

@@ -23,6 +23,10 @@ pytestmark = pytest.mark.gpu
     (1, 10, 12, 64, 64, 3, 1, 1, T(64, 64) | (1 << 29)),
     (1, 5, 9, 32, 48, 1, 1, 0, T(64, 64)),
     (1, 5, 9, 64, 48, 1, 1, 0, T(64, 64)),
+    (2, 7, 9, 64, 27, 3, 1, 1, T(64, 32)),                   # intra-workgroup split-K, 2 waves per output tile
+    (2, 7, 9, 64, 27, 3, 1, 1, T(32, 32)),                   # 4 waves per output tile
+    (1, 6, 5, 16, 20, 3, 1, 1, T(32, 32) | (1 << 29)),       # split-K + 2-stage loop + Cin < 32
+    (1, 11, 13, 128, 27, 3, 1, 1, 0),                        # auto tile -> split-K (few rows, Cout <= 32)
 ])
 def test_conv(gpu_lib, args):
     pc.check_conv(gpu_lib, "cuda", *args, res=(args[4] % 3 == 1), relu=(args[3] != 448))
@@ -56,6 +60,15 @@ def test_layout(gpu_lib):
 @pytest.mark.parametrize("C,Co", [(16, 32), (64, 48), (128, 64), (512, 32)])
 def test_embed_map(gpu_lib, C, Co):
     pc.check_embed_map(gpu_lib, "cuda", C, Co)
+
+
+def test_embed_fused(gpu_lib):
+    pc.check_embed_fused(gpu_lib, "cuda")
+
+
+@pytest.mark.parametrize("tile", [0, T(128, 32), T(64, 32), T(32, 32), T(64, 64)])
+def test_sparse_row_conv(gpu_lib, tile):
+    pc.check_sparse_conv(gpu_lib, "cuda", tile)
 
 
 def test_topk_edge_cases(gpu_lib):

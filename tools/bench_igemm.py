@@ -74,6 +74,18 @@ def dcn_case(name, H, W, Ci, Co, tiles):
 
 ONE = 1 << 29    # here: force the 2-stage loop (default is 1-stage)
 ALL = [T(128, 128), T(128, 64), T(64, 64), T(64, 128), T(128, 128) | ONE, T(128, 64) | ONE, T(64, 64) | ONE]
+if len(sys.argv) > 2 and sys.argv[2] == "asym":     # asymptotic loop efficiency: long K, many tiles, no im2col
+    conv_case("gemm 1x1 2304->256 @152x272", 152, 272, 2304, 256, 1, 1, ALL)
+    conv_case("gemm 3x3 256->256 @152x272", 152, 272, 256, 256, 3, 1, ALL)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "small":    # few-row problems: split-K tiles vs 128x32
+    N32 = [T(128, 32), T(64, 32), T(32, 32), T(64, 32) | ONE, T(32, 32) | ONE]
+    conv_case("offset 3x3 64->27 @152x272", 152, 272, 64, 27, 3, 1, N32)
+    conv_case("offset 3x3 128->27 @76x136", 76, 136, 128, 27, 3, 1, N32)
+    conv_case("offset 3x3 256->27 @38x68", 38, 68, 256, 27, 3, 1, N32)
+    conv_case("offset 3x3 512->27 @19x34", 19, 34, 512, 27, 3, 1, N32)
+    conv_case("3x3 512->512 @19x34", 19, 34, 512, 512, 3, 1, [T(64, 64), T(64, 64) | ONE])
+    sys.exit(0)
 conv_case("base 7x7 4->16 @608x1088", 608, 1088, 3, 16, 7, 1, [T(128, 32), T(128, 32) | ONE])
 conv_case("level0 3x3 16->16 @608", 608, 1088, 16, 16, 3, 1, [T(128, 32), T(128, 32) | ONE])
 conv_case("level1 3x3s2 16->32", 608, 1088, 16, 32, 3, 2, [T(128, 32)])
