@@ -113,7 +113,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 const int e0 = p.rowmap[2 * m], e1 = p.rowmap[2 * m + 1];
                 if (e1 >= 0) {
                     r0[i] = (e1 >> 16) * p.stride - p.pad;
-                    r1[i] = (e1 & 0xffff) * p.stride - p.pad;
+                    r1[i] = (e1 & 0xffff) * (p.stride_w > 0 ? p.stride_w : p.stride) - p.pad;
                     r2[i] = e0;
                 }
             } else {
@@ -124,7 +124,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 const int ox = rem - oy * p.OW;
                 if (MODE == MODE_CONV) {
                     r0[i] = oy * p.stride - p.pad;
-                    r1[i] = ox * p.stride - p.pad;
+                    r1[i] = ox * (p.stride_w > 0 ? p.stride_w : p.stride) - p.pad;
                 } else {
                     r0[i] = 0;
                 }
@@ -508,13 +508,15 @@ static int check_conv(const DeftGemmDesc* d, const char* who) {
     return 0;
 }
 
-// automatic tile choice for a conv problem of M rows x Cout columns
-static void pick_conv_tile(int M, int Cout, int& bm, int& bn) {
+// automatic tile choice for a conv problem of M rows x Cout columns.  The split-K tile changes
+// the fp32 summation order, so whether it is used depends on the rows PER IMAGE only: results
+// are then bit-identical whatever the batch size (the WK = 1 tiles all sum in the same order).
+static void pick_conv_tile(int M, int rows_per_image, int Cout, int& bm, int& bn) {
     const long long m128 = deft_cdiv(M, 128);
     if (Cout <= 32) {
         bn = 32;
-        bm = m128 >= 384 ? 128 : 32;     // few rows: 32x32 split-K tile, 4 waves per output tile (measured:
-                                         // 38x68x8 rows 68 -> 48 us, 19x34x8 rows 124 -> 54 us vs 128x32)
+        bm = deft_cdiv(rows_per_image, 128) >= 256 ? 128 : 32;   // small maps: 32x32 split-K tile, 4 waves per
+                                         // output tile (38x68x8 rows 68 -> 48 us, 19x34x8 rows 124 -> 54 us vs 128x32)
     } else if (Cout > 64 && m128 * deft_cdiv(Cout, 128) >= FILL_BLOCKS) { bm = 128; bn = 128; }
     else if (m128 * deft_cdiv(Cout, 64) >= FILL_BLOCKS) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
@@ -525,7 +527,7 @@ extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);
-    if (bm == 0) pick_conv_tile(d->M, d->Cout, bm, bn);
+    if (bm == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);
     return dispatch_igemm<MODE_CONV>(*d, bm, bn, one_stage, s);
 }
 
@@ -539,12 +541,7 @@ extern "C" int deft_conv2d_group(const DeftGemmDesc* descs, const DeftGemmDesc* 
     }
     int bm = (descs[0].tile >> 16) & 0x1fff, bn = descs[0].tile & 0xffff;
     const bool one_stage = !((descs[0].tile >> 29) & 1);
-    if (bm == 0) {          // one tile for all groups: judge the fill by the total tile count
-        long long t32 = 0;
-        for (int i = 0; i < ngroups; ++i) t32 += (long long)deft_cdiv(descs[i].M, 128) * deft_cdiv(descs[i].Cout, 32);
-        bn = 32;
-        bm = t32 >= 1024 ? 128 : (t32 >= 256 ? 64 : 32);
-    }
+    if (bm == 0) { bm = 32; bn = 32; }   // one fixed (split-K) tile: few rows per group, result independent of the row count
     return dispatch_igemm<MODE_CONV>(descs[0], bm, bn, one_stage, (hipStream_t)stream, descs_dev, ngroups, max_m, max_n);
 }
 

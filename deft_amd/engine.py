@@ -70,6 +70,19 @@ def pack_conv_weight(w, cin_pad=None):
     return out, K
 
 
+def pack_pair_conv_weight(w, cin_pad=None):
+    """Pixel-pair form of a stride-1 conv with few output channels: output columns
+    [p*Co + co] (p = 0,1: left/right pixel of the pair), window KH x (KW+1) with horizontal
+    stride 2:  W'[p*Co+co][r][s'][c] = W[co][c][r][s'-p] (0 outside).  The added zeros are exact
+    no-ops in the fp32 accumulation chain; only the summation order inside a K chunk differs from
+    the plain form (fp32 round-off level).  -> ([CoPad][Kpad], K')."""
+    Co, Ci, KH, KW = w.shape
+    w2 = torch.zeros(2 * Co, Ci, KH, KW + 1, dtype=torch.float32)
+    w2[:Co, :, :, :KW] = w.float()
+    w2[Co:, :, :, 1:] = w.float()
+    return pack_conv_weight(w2, cin_pad)
+
+
 class _Plan:
     """Common machinery: device buffers + an ordered list of bound C-ABI calls."""
 
@@ -143,6 +156,29 @@ class _Plan:
         self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * Cout * KH * KW * cin)
         return out
 
+    def conv_pair(self, name, x, w_packed, K, KH, KW, pad, Cout, scale2, shift2, relu, true_k):
+        """Stride-1 conv with Cout <= 16 computed on pixel pairs (see pack_pair_conv_weight):
+        GEMM rows = (n, oy, ox/2), 2*Cout columns, window KH x (KW+1), stride_w 2."""
+        OH, OW = x.H + 2 * pad - KH + 1, x.W + 2 * pad - KW + 1
+        assert OW % 2 == 0 and Cout % 4 == 0
+        out = self.alloc(x.N, OH, OW, Cout)
+        assert out.ld == Cout
+        d = GemmDesc()
+        d.x = x.addr; d.x2 = None; d.w = w_packed.data_ptr()
+        d.scale = scale2.data_ptr() if scale2 is not None else None
+        d.shift = shift2.data_ptr() if shift2 is not None else None
+        d.res = None; d.y = out.addr
+        d.N, d.H, d.W, d.Cin, d.ldx = x.N, x.H, x.W, x.C, x.ld
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = OH, OW // 2, 2 * Cout, 2 * Cout, 0
+        d.KH, d.KW, d.stride, d.pad, d.stride_w = KH, KW + 1, 1, pad, 2
+        d.Ktot, d.Kpad = K, w_packed.shape[1]
+        d.cin_log2 = int(math.log2(x.C))
+        d.M = x.N * OH * (OW // 2)
+        d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0
+        d.flop_k = true_k
+        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * x.N * OH * OW * Cout * true_k)
+        return out
+
     def maxpool(self, name, x, out=None):
         if out is None:
             out = self.alloc(x.N, x.H // 2, x.W // 2, x.C)
@@ -182,6 +218,15 @@ class DlaSegPlan(_Plan):
 
     # ---- weights -----------------------------------------------------------
     def _conv_bn(self, name, x, wkey, bnkey, KH, stride, pad, relu, out=None, res=None, cin_pad=None):
+        w = self.sd[wkey + ".weight"]
+        if w.shape[0] <= 16 and stride == 1 and out is None and res is None and x.W % 2 == 0 and KH > 1:
+            # 16-channel full-resolution layers (base_layer, level0): pixel-pair GEMM, 32 useful columns
+            if wkey not in self._wcache:
+                wp, K = pack_pair_conv_weight(w, cin_pad)
+                alpha, beta = _bn_fold(self.sd, bnkey)
+                self._wcache[wkey] = (self.dev(wp), K, self.dev(torch.cat([alpha, alpha])), self.dev(torch.cat([beta, beta])))
+            wp, K, alpha2, beta2 = self._wcache[wkey]
+            return self.conv_pair(name, x, wp, K, KH, KH, pad, w.shape[0], alpha2, beta2, relu, KH * KH * w.shape[1])
         if wkey not in self._wcache:
             wp, K = pack_conv_weight(self.sd[wkey + ".weight"], cin_pad)
             alpha, beta = _bn_fold(self.sd, bnkey)

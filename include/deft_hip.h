@@ -45,6 +45,11 @@ typedef struct DeftGemmDesc {
      * frame, t its history row, j its object; U' row = u0 + c*du + t, V' row = v0 + c*dv + j.
      * Tper == 0: rows are (t, j), U' row = t, V' row = j.                                   */
     int Tper, u0, du, v0, dv;
+    /* conv: horizontal stride when > 0 (vertical stays `stride`); 0 = same as `stride`.  Lets the
+     * 16-channel full-resolution layers run as "pixel-pair" convs: one GEMM row = two adjacent
+     * output pixels (2 x 16 = 32 output columns, KW+1 wide window, stride_w = 2) -- full 32-wide
+     * MFMA tiles instead of 16 useful + 16 padding columns.  Zero weights add exact zeros.      */
+    int stride_w, reserved0;
     /* conv, sparse output rows (NULL = dense grid): rowmap[2m] = n*H*W, rowmap[2m+1] = (y << 16) | x
      * of the output pixel GEMM row m stands for, or -1 for an unused row (written as shift/ReLU
      * of a zero accumulator).  Output row m is y + m*ldy.  Used by the embedding head, which

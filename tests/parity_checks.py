@@ -61,6 +61,29 @@ def check_conv(lib, device, N, H, W, Ci, Co, k, stride, pad, tile, res=False, re
     return err
 
 
+def check_conv_pair(lib, device, Ci, k, N=2, H=6, W=10, Co=16, seed=0):
+    """Pixel-pair form of the 16-channel stride-1 convs (engine.conv_pair): equals conv2d and the
+    plain implicit GEMM to fp32 round-off (the extra zero weights are exact no-ops, but the k
+    positions inside a 32-wide chunk -- and with them the summation order -- differ)."""
+    g = torch.Generator().manual_seed(seed)
+    plan = engine._Plan(device, lib)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (Ci * k * k) ** 0.5)
+    scale = torch.rand(Co, generator=g) + 0.5
+    shift = torch.randn(Co, generator=g)
+    cp = (Ci + 3) // 4 * 4
+    xv = plan.alloc(N, H, W, cp); fill_view(xv, x)
+    wp2, K2 = engine.pack_pair_conv_weight(w, cp)
+    out = plan.conv_pair("p", xv, plan.dev(wp2), K2, k, k, k // 2, Co, plan.dev(torch.cat([scale, scale])),
+                         plan.dev(torch.cat([shift, shift])), True, k * k * Ci)
+    wp, K = engine.pack_conv_weight(w, cp)
+    plain = plan.conv("c", xv, plan.dev(wp), K, k, k, 1, k // 2, Co, plan.dev(scale), plan.dev(shift), True)
+    plan.run()
+    ref = F.relu(F.conv2d(x, w, None, 1, k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    assert maxabs(out.to_nchw(), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert maxabs(out.to_nchw(), plain.to_nchw()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def check_concat_conv(lib, device):
     """Root-style 1x1 conv reading a channel-concat buffer in place, output written
     into a channel slice of another buffer (dla.py:199-207)."""

@@ -30,6 +30,11 @@ def test_conv(emu_lib, args):
     pc.check_conv(emu_lib, "cpu", *args, res=(args[4] % 3 == 1), relu=(args[3] != 448))
 
 
+@pytest.mark.parametrize("Ci,k", [(3, 7), (16, 3), (8, 5)])
+def test_conv_pixel_pair(emu_lib, Ci, k):
+    pc.check_conv_pair(emu_lib, "cpu", Ci, k)
+
+
 def test_concat_conv(emu_lib):
     pc.check_concat_conv(emu_lib, "cpu")
 

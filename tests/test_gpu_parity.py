@@ -32,6 +32,11 @@ def test_conv(gpu_lib, args):
     pc.check_conv(gpu_lib, "cuda", *args, res=(args[4] % 3 == 1), relu=(args[3] != 448))
 
 
+@pytest.mark.parametrize("Ci,k", [(3, 7), (16, 3), (8, 5)])
+def test_conv_pixel_pair(gpu_lib, Ci, k):
+    pc.check_conv_pair(gpu_lib, "cuda", Ci, k)
+
+
 def test_concat_conv(gpu_lib):
     pc.check_concat_conv(gpu_lib, "cuda")
 
