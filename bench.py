@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
     ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--autotune", action="store_true", help="per-layer tile search at plan-build time (engine._Plan.autotune)")
+    ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,6 +97,9 @@ def main():
     pipe = FramePipeline(comp, B, KDET, comp.D, history=HIST, device=dev)
     g = torch.Generator().manual_seed(1000 + rank)
     images = torch.randn(B, 3, H, W, generator=g).to(dev)      # resident in HBM before timing
+
+    if args.autotune:                                    # plan-build time, outside the timed region
+        comp.autotune(images, verbose=args.verbose and rank == 0)
 
     def sync():
         if world > 1:

@@ -1,6 +1,7 @@
 // FP32-MFMA implicit GEMM for gfx950 with three A-operand loaders:
 //   MODE_CONV : NHWC im2col (any KHxKW / stride / pad; concat inputs via ld)
-//   MODE_DCN  : DCNv2 modulated deformable gather (bilinear, zero pad, * sigmoid(mask))
+//   MODE_DCN  : DCNv2 modulated deformable gather (bilinear, zero pad, * sigmoid(mask)); K order
+//               (32-channel block, tap, channel) -- weights packed to match (engine.pack_dcn_weight)
 //   MODE_PAIR : affinity pair grid, A[(i,j)][k] = relu(U'[i][k] + V'[j][k])
 // and one epilogue: y = acc*scale[co] + shift[co] (+ residual) (ReLU).
 //
@@ -27,12 +28,12 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 #define LDS_STRIDE 36
 #define ROW_INVALID (-(1 << 28))
 
-// dynamic-LDS layout (floats): As[NSTAGE][BM*36] | Bs[NSTAGE][BN*36] | DCN sampling params [2][BM*12];
+// dynamic-LDS layout (floats): As[NSTAGE][BM*36] | Bs[NSTAGE][BN*36] | DCN sampling records [9][BM][8] + masks [9][BM];
 // with intra-workgroup split-K (WK > 1) the same region is reused after the K loop for the
 // partial accumulators of the wk > 0 waves: [(WK-1)][32x32 tiles of the block][16][64].
 template <int BM, int BN, int WK, int NSTAGE, int MODE>
 constexpr int igemm_lds_floats() {
-    constexpr int stage = NSTAGE * (BM + BN) * LDS_STRIDE + (MODE == MODE_DCN ? 2 * BM * 12 : 0);
+    constexpr int stage = NSTAGE * (BM + BN) * LDS_STRIDE + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
     constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
     return stage > red ? stage : red;
 }
@@ -133,12 +134,17 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         }
     }
 
-    // DCN: one thread per tile row computes the bilinear sampling record of (row, tap) once
-    // per tap -- upstream DCNv2 modulated_deformable_im2col + dmcn_im2col_bilinear semantics --
-    // into prm[tap&1][row][12] = {4 pixel offsets, 4 corner weights, sigmoid(mask)}.
-    auto dcn_params = [&](int tap) {
-        if (tid < BM) {
-            const int m = m0 + tid;
+    // DCN: the bilinear sampling records of all (tile row, tap) pairs are computed ONCE, before the
+    // K loop -- upstream DCNv2 modulated_deformable_im2col + dmcn_im2col_bilinear semantics -- into
+    // prm[tap][row][8] = {4 pixel offsets, 4 corner weights} and msk[tap][row] = sigmoid(mask).
+    // The K order of the DCN contraction is (32-channel block, tap, channel): all nine taps of one
+    // channel block are consumed back to back, so the 4x4-pixel neighbourhood lines of that block
+    // stay in the CU's 32 KB L1 across the 36 corner reads that touch them.
+    float* const msk = prm + 9 * BM * 8;
+    if (MODE == MODE_DCN) {
+        for (int idx = tid; idx < 9 * BM; idx += 256) {
+            const int tap = idx / BM, row = idx - tap * BM;
+            const int m = m0 + row;
             int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
             float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mask = 0.f;
             if (m < p.M) {
@@ -163,12 +169,13 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                     if (h_high <= p.H - 1 && w_high <= p.W - 1) { o4 = h_high * p.W + w_high; w4 = lh * lw; }
                 }
             }
-            float* pr = prm + ((tap & 1) * BM + tid) * 12;
+            float* pr = prm + idx * 8;
             *(f32x4*)(pr) = f32x4{__int_as_float(o1), __int_as_float(o2), __int_as_float(o3), __int_as_float(o4)};
             *(f32x4*)(pr + 4) = f32x4{w1, w2, w3, w4};
-            *(f32x4*)(pr + 8) = f32x4{mask, 0.f, 0.f, 0.f};
+            msk[idx] = mask;
         }
-    };
+        __syncthreads();
+    }
 
     // ---- staging registers.  issue_loads() only ISSUES memory operations (no arithmetic on the
     // returned data), finish_store() does the per-mode arithmetic and the LDS stores: the MFMAs of
@@ -203,14 +210,14 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 s0[i] = deft_buffer_load_x4(rx, ok ? off : DEFT_OOB);
             }
         } else if (MODE == MODE_DCN) {
-            const int tap = kload >> p.cin_log2;
-            const int c = (kload & (p.Cin - 1)) + g * 4;
+            const int tap = cur.s;                       // chunk j = (channel block cur.c0/32, tap cur.s)
+            const int c = cur.c0 + g * 4;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
-                const float* pr = prm + ((tap & 1) * BM + rbase + 32 * i) * 12;
+                const float* pr = prm + (tap * BM + rbase + 32 * i) * 8;
                 const f32x4 po = *(const f32x4*)pr;          // invalid corners: offset 0, weight 0
                 sw[i] = *(const f32x4*)(pr + 4);
-                sm[i] = pr[8];
+                sm[i] = msk[tap * BM + rbase + 32 * i];
                 const int pb = r2[i];
                 s0[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.x)) * p.ldx + c) * 4));
                 s1[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.y)) * p.ldx + c) * 4));
@@ -235,6 +242,8 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 cur.c0 = 0;
                 if (++cur.s == p.KW) { cur.s = 0; ++cur.r; }
             }
+        } else if (MODE == MODE_DCN) {               // (channel block, tap) order: tap fastest
+            if (++cur.s == 9) { cur.s = 0; cur.c0 += 32; }
         }
     };
     auto finish_store = [&](int stage) {
@@ -301,20 +310,12 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         __builtin_amdgcn_sched_barrier(0);       // nothing of finish_store() may be scheduled above the MFMAs
     };
 
-    const int cpt = (MODE == MODE_DCN) ? (p.Cin >> 5) : 1;   // chunks per tap (DCN)
     if (NSTAGE == 1) {
         // one LDS stage, two barriers per chunk:  store chunk kt | barrier | issue loads kt+1,
         // fragments + MFMAs of chunk kt | barrier
-        if (MODE == MODE_DCN) {
-            dcn_params(0);
-            __syncthreads();
-        }
         issue_loads();
         for (int kt = 0; kt < nk; ++kt) {
             finish_store(0);
-            // DCN: sampling record of the tap that chunk kt+1 opens; the other parity buffer is the
-            // one issue_loads(kt) read before the previous barrier, this one was last read >= cpt chunks ago
-            if (MODE == MODE_DCN && kt + 1 < nk && (kt + 1) % cpt == 0) dcn_params((kt + 1) / cpt);
             __syncthreads();
             if (kt + 1 < nk) issue_loads();
             read_frags(0);
@@ -326,20 +327,12 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         // fragments + MFMAs of chunk kt (stage kt&1), then finish chunk kt+1 into the other stage.
         // That stage was last read in iteration kt-1 and is next read in iteration kt+1, each
         // separated from the store by a barrier.
-        if (MODE == MODE_DCN) {
-            dcn_params(0);
-            if (cpt == 1 && nk > 1) dcn_params(1);
-            __syncthreads();
-        }
         issue_loads();
         finish_store(0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cs = kt & 1;
             if (kt + 1 < nk) issue_loads();
-            // DCN: record of the tap that chunk kt+2 opens (tap T): its parity buffer held tap T-2,
-            // last read by issue_loads in an earlier iteration; this iteration reads tap T-1.
-            if (MODE == MODE_DCN && kt + 2 < nk && (kt + 2) % cpt == 0) dcn_params((kt + 2) / cpt);
             read_frags(cs);
             mfma_chunk();
             if (kt + 1 < nk) finish_store(cs ^ 1);
@@ -453,9 +446,9 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
     return 0;
 }
 
-// `tile` knob: bits 0-15 BN, bits 16-28 BM, bit 30 = force the 1-stage (2-barrier) loop,
-// bit 29 = force the 2-stage (1-barrier, double LDS) loop.  64x32 and 32x32 are the split-K
-// tiles (WK = 2 / 4).
+// `tile` knob: bits 0-15 BN, bits 16-28 BM (0 = automatic), bit 29 = use the 2-stage (1-barrier,
+// double LDS) loop instead of the default 1-stage (2-barrier) loop.  64x32 and 32x32 are the
+// split-K tiles (WK = 2 / 4).
 template <int MODE>
 static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage, hipStream_t s,
                           const DeftGemmDesc* group_dev = nullptr, int ngroups = 0, int max_m = 0, int max_n = 0) {
@@ -556,10 +549,11 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -25, "deft_dcn_v2_nhwc: input exceeds 2 GiB (split the batch)");
     hipStream_t s = (hipStream_t)stream;
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
-    if (bm == 0) {
-        bm = 64; bn = 64;      // measured best for every DCN layer shape of DLA-34 (tools/bench_igemm.py)
+    const bool one_stage = !((d->tile >> 29) & 1);
+    if (bm == 0) {             // BM = 64 keeps the 9-tap sampling records at 20 KB of LDS (4 workgroups per CU)
+        bm = 64; bn = d->Cout >= 256 ? 128 : 64;      // tools/bench_igemm.py dcn
     }
-    return dispatch_igemm<MODE_DCN>(*d, bm, bn, ((d->tile >> 30) & 1) != 0, s);
+    return dispatch_igemm<MODE_DCN>(*d, bm, bn, one_stage, s);
 }
 
 extern "C" int deft_pair_layer(const DeftGemmDesc* d, void* stream) {

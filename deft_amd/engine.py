@@ -70,6 +70,17 @@ def pack_conv_weight(w, cin_pad=None):
     return out, K
 
 
+def pack_dcn_weight(w):
+    """DCN main weight [Co,Ci,3,3] -> [CoPad(128)][9*Ci] in the DCN kernel's K order
+    k = ((c // 32) * 9 + tap) * 32 + c % 32  (include/deft_hip.h, deft_dcn_v2_nhwc)."""
+    Co, Ci, KH, KW = w.shape
+    assert KH == 3 and KW == 3 and Ci % 32 == 0
+    t = w.float().permute(0, 2, 3, 1).reshape(Co, 9, Ci // 32, 32).permute(0, 2, 1, 3).reshape(Co, 9 * Ci)
+    out = torch.zeros(_rup(Co, 128), 9 * Ci, dtype=torch.float32)
+    out[:Co] = t
+    return out, 9 * Ci
+
+
 def pack_pair_conv_weight(w, cin_pad=None):
     """Pixel-pair form of a stride-1 conv with few output channels: output columns
     [p*Co + co] (p = 0,1: left/right pixel of the pair), window KH x (KW+1) with horizontal
@@ -90,6 +101,7 @@ class _Plan:
         self.device = torch.device(device)
         self.lib = lib if lib is not None else hiplib.get_lib()
         self.ops = []          # (kind, name, callable, flops)
+        self._gemms = []       # (entry, name, descriptor) of every implicit-GEMM launch, for autotune()
         self._keep = []        # tensors / descriptors kept alive
         self.profile = None    # when set to a list, run() appends (name, kind, flops, ms)
 
@@ -128,6 +140,52 @@ class _Plan:
         self._keep.append(desc)
         lib, ref = self.lib, C.byref(desc)
         self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
+        self._gemms.append((entry, name, desc))
+
+    def autotune(self, reps=4, verbose=False):
+        """Per-layer tile search on the GPU this plan will run on (the cuDNN-benchmark / MIOpen-find
+        step of the reference stack, done once per plan): every implicit-GEMM launch is timed alone
+        with each candidate (tile, loop form) and the fastest is written into its descriptor.
+        Only result-identical candidates are tried: the WK = 1 tiles all accumulate in the same
+        order, so tuning never changes an output bit; split-K layers keep their tile."""
+        if self.device.type != "cuda":
+            return
+        T = lambda bm, bn: (bm << 16) | bn
+        two = 1 << 29
+        cands = {"deft_conv2d_nhwc": [T(128, 128), T(128, 64), T(64, 64), T(64, 128)],
+                 "deft_dcn_v2_nhwc": [T(64, 64), T(64, 128), T(128, 64)],
+                 "deft_pair_layer": [T(128, 128), T(128, 64), T(64, 64)]}
+        lib, s = self.lib, self._stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        memo = {}
+        for entry, name, d in self._gemms:
+            key = (entry, d.M, d.Cout, d.Ktot, d.Cin, d.KH, d.KW, d.stride, d.H, d.W, d.ldx, d.ldy, bool(d.res), bool(d.rowmap))
+            if key not in memo:
+                if d.Cout <= 32 or d.rowmap:
+                    opts = [0, two] if not d.rowmap else [d.tile]          # keep the (split-K) tile, try both loop forms
+                    if d.Cout <= 32 and -(-(d.OH * d.OW) // 128) >= 256:
+                        opts = [T(128, 32), T(128, 32) | two]
+                else:
+                    opts = [t | st for t in cands[entry] for st in (0, two)]
+                best, best_t = d.tile, None
+                for t in opts:
+                    d.tile = t
+                    try:
+                        lib.call(entry, C.byref(d), s)                      # warm-up + validity
+                    except hiplib.DeftHipError:
+                        continue
+                    e0.record()
+                    for _ in range(reps):
+                        lib.call(entry, C.byref(d), s)
+                    e1.record(); e1.synchronize()
+                    ms = e0.elapsed_time(e1) / reps
+                    if best_t is None or ms < best_t:
+                        best, best_t = t, ms
+                memo[key] = best
+                if verbose:
+                    print("autotune %-28s M=%d N=%d K=%d -> %dx%d %s (%.3f ms)" % (name, d.M, d.Cout, d.Ktot, (best >> 16) & 0x1fff, best & 0xffff,
+                                                                            "2st" if best & two else "1st", best_t or 0.0))
+            d.tile = memo[key]
 
     def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0,
              true_cin=None):
@@ -290,7 +348,7 @@ class DlaSegPlan(_Plan):
         key = p + ".conv"
         if key not in self._wcache:
             wo, Ko = pack_conv_weight(sd[p + ".conv.conv_offset_mask.weight"])
-            wm, Km = pack_conv_weight(sd[p + ".conv.weight"])
+            wm, Km = pack_dcn_weight(sd[p + ".conv.weight"])
             alpha, beta = _bn_fold(sd, p + ".actf.0")
             shift = sd[p + ".conv.bias"].float() * alpha + beta
             self._wcache[key] = (self.dev(wo), Ko, self.dev(sd[p + ".conv.conv_offset_mask.bias"].float()),

@@ -115,7 +115,7 @@ def load(path):
 def get_lib():
     global _lib
     if _lib is None:
-        _lib = HipLib(LIB_PATH)
+        _lib = HipLib(os.environ.get("DEFT_HIP_LIB", LIB_PATH))     # override: A/B builds of the same HIP sources
     return _lib
 
 

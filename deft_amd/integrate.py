@@ -60,7 +60,7 @@ class DCN(nn.Module):
                self.conv_offset_mask.bias._version, str(dev))
         if self._packed is None or self._packed[0] != ver:
             wo, Ko = engine.pack_conv_weight(self.conv_offset_mask.weight.detach().cpu())
-            wm, Km = engine.pack_conv_weight(self.weight.detach().cpu())
+            wm, Km = engine.pack_dcn_weight(self.weight.detach().cpu())
             self._packed = (ver, wo.to(dev), Ko, self.conv_offset_mask.bias.detach().float().to(dev).contiguous(),
                             wm.to(dev), Km, self.bias.detach().float().to(dev).contiguous())
         return self._packed[1:]

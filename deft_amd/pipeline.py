@@ -40,6 +40,14 @@ class HipCompute:
             self.ev_main = torch.cuda.Event()
             self.ev_side = [torch.cuda.Event() for _ in range(streams)]
 
+    def autotune(self, images, verbose=False):
+        """One-off per-layer tile search (engine._Plan.autotune) on real activations: run the
+        sub-batch plans once on `images` [batch,3,H,W], then time the candidates."""
+        for s_, p in enumerate(self.plans):
+            p.forward(images[s_ * self.sub:(s_ + 1) * self.sub])
+            torch.cuda.synchronize(self.device)
+            p.autotune(verbose=verbose and s_ == 0)
+
     def detect_embed(self, images):
         if self.nstream == 1:
             p = self.plan

@@ -77,7 +77,9 @@ int deft_conv2d_group(const DeftGemmDesc* descs, const DeftGemmDesc* descs_dev, 
  * Replaces dcn_v2.DCN.forward (third-party CharlesShang/DCNv2, imported at
  * dla.py:25-29, constructed dla.py:652-660, called dla.py:663) together with
  * DeformConv.actf (dla.py:649-651).  x2 is produced by deft_conv2d_nhwc with the
- * conv_offset_mask weights (Cout 27 -> ld 32). */
+ * conv_offset_mask weights (Cout 27 -> ld 32).  The weight matrix uses the DCN K order
+ * k = ((c / 32) * 9 + tap) * 32 + c % 32 (all nine taps of a 32-channel block back to back: the
+ * gathered neighbourhood stays in L1 across taps), not the conv order (tap * Cin + c). */
 int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream);
 
 /* Pair-MLP layer 2 of the affinity estimator: A[(i,j)][k] = relu(U'[i][k]+V'[j][k])

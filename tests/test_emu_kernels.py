@@ -41,7 +41,7 @@ def test_concat_conv(emu_lib):
 
 @pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (2, 5, 6, 128, 64, 0), (1, 6, 6, 64, 160, T(64, 128)),
                                   (1, 9, 9, 64, 64, T(128, 64)), (1, 4, 5, 256, 128, T(128, 128)),
-                                  (1, 7, 9, 64, 64, T(64, 64) | (1 << 30)), (1, 5, 5, 128, 64, T(128, 64) | (1 << 30))])
+                                  (1, 7, 9, 64, 64, T(64, 64) | (1 << 29)), (1, 5, 5, 128, 64, T(128, 64) | (1 << 29))])
 def test_dcn(emu_lib, args):
     pc.check_dcn(emu_lib, "cpu", *args[:5], tile=args[5])
 

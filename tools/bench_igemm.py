@@ -69,7 +69,7 @@ def dcn_case(name, H, W, Ci, Co, tiles):
         except Exception as e:
             print("%-28s tile %3dx%-3d  -- %s" % (name, tile >> 16, tile & 0xffff, str(e)[:60])); continue
         print("%-28s tile %3dx%-3d %s %7.3f ms  %6.1f TF/s   (offset conv %6.3f ms %5.1f TF/s)" % (
-            name, (tile >> 16) & 0x1fff, tile & 0xffff, "1st" if (tile >> 30) & 1 else "2st", ms, dcn_op[3] / ms / 1e9, ms_off, off_op[3] / ms_off / 1e9), flush=True)
+            name, (tile >> 16) & 0x1fff, tile & 0xffff, "2st" if (tile >> 29) & 1 else "1st", ms, dcn_op[3] / ms / 1e9, ms_off, off_op[3] / ms_off / 1e9), flush=True)
 
 
 ONE = 1 << 29    # here: force the 2-stage loop (default is 1-stage)
@@ -77,6 +77,15 @@ ALL = [T(128, 128), T(128, 64), T(64, 64), T(64, 128), T(128, 128) | ONE, T(128,
 if len(sys.argv) > 2 and sys.argv[2] == "asym":     # asymptotic loop efficiency: long K, many tiles, no im2col
     conv_case("gemm 1x1 2304->256 @152x272", 152, 272, 2304, 256, 1, 1, ALL)
     conv_case("gemm 3x3 256->256 @152x272", 152, 272, 256, 256, 3, 1, ALL)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "dcn":
+    DT = [T(64, 64), T(64, 64) | ONE, T(64, 128), T(64, 128) | ONE, T(128, 64)]
+    dcn_case("dcn 64->64 @152x272", 152, 272, 64, 64, DT)
+    dcn_case("dcn 128->64 @76x136", 76, 136, 128, 64, DT)
+    dcn_case("dcn 128->128 @76x136", 76, 136, 128, 128, DT)
+    dcn_case("dcn 256->128 @38x68", 38, 68, 256, 128, DT)
+    dcn_case("dcn 256->256 @38x68", 38, 68, 256, 256, DT)
+    dcn_case("dcn 512->256 @19x34", 19, 34, 512, 256, DT)
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "small":    # few-row problems: split-K tiles vs 128x32
     N32 = [T(128, 32), T(64, 32), T(32, 32), T(64, 32) | ONE, T(32, 32) | ONE]
@@ -97,8 +106,8 @@ conv_case("1x1 1280->512 @19x34", 19, 34, 1280, 512, 1, 1, ALL)
 conv_case("1x1 448->128 @76x136", 76, 136, 448, 128, 1, 1, ALL)
 conv_case("head 3x3 64->256 @152x272", 152, 272, 64, 256, 3, 1, ALL)
 conv_case("head 1x1 256->1", 152, 272, 256, 1, 1, 1, [T(128, 32)])
-dcn_case("dcn 64->64 @152x272", 152, 272, 64, 64, [T(64, 64), T(64, 64) | (1 << 30), T(128, 64) | (1 << 30)])
-dcn_case("dcn 128->64 @76x136", 76, 136, 128, 64, [T(64, 64), T(64, 64) | (1 << 30)])
-dcn_case("dcn 128->128 @76x136", 76, 136, 128, 128, [T(64, 64), T(64, 64) | (1 << 30), T(128, 64) | (1 << 30)])
-dcn_case("dcn 256->256 @38x68", 38, 68, 256, 256, [T(64, 64), T(64, 64) | (1 << 30), T(128, 64) | (1 << 30)])
-dcn_case("dcn 512->256 @19x34", 19, 34, 512, 256, [T(64, 64), T(64, 64) | (1 << 30)])
+dcn_case("dcn 64->64 @152x272", 152, 272, 64, 64, [T(64, 64), T(64, 64) | ONE, T(128, 64)])
+dcn_case("dcn 128->64 @76x136", 76, 136, 128, 64, [T(64, 64), T(64, 64) | ONE])
+dcn_case("dcn 128->128 @76x136", 76, 136, 128, 128, [T(64, 64), T(64, 64) | ONE, T(128, 64)])
+dcn_case("dcn 256->256 @38x68", 38, 68, 256, 256, [T(64, 64), T(64, 64) | ONE, T(128, 64)])
+dcn_case("dcn 512->256 @19x34", 19, 34, 512, 256, [T(64, 64), T(64, 64) | ONE])
