@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autotune", action="store_true", help="per-layer tile search at plan-build time (engine._Plan.autotune)")

@@ -48,6 +48,12 @@ __device__ __forceinline__ deft_rsrc_t deft_make_rsrc(const void* base) {
 __device__ __forceinline__ f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+// LDS-DMA (`buffer_load_dwordx4 ... lds`): lane l of the wave deposits its 16 bytes at
+// lds_wave_base + 16*l (wave-uniform base in M0, lane-linear image); out-of-range lanes deposit
+// zeros (verified on gfx950: tools/probe/lds_dma_oob.hip).  Completion is counted by vmcnt.
+__device__ __forceinline__ void deft_buffer_load_lds_x4(deft_rsrc_t r, float* lds_wave_base, unsigned byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)byte_off, 0, 0, 0);
+}
 #endif
 
 static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

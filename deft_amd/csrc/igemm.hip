@@ -33,7 +33,8 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 // partial accumulators of the wk > 0 waves: [(WK-1)][32x32 tiles of the block][16][64].
 template <int BM, int BN, int WK, int NSTAGE, int MODE>
 constexpr int igemm_lds_floats() {
-    constexpr int stage = NSTAGE * (BM + BN) * LDS_STRIDE + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
+    constexpr int ld = (MODE == MODE_CONV && NSTAGE == 2) ? 32 : LDS_STRIDE;      // LDS-DMA image is unpadded
+    constexpr int stage = NSTAGE * (BM + BN) * ld + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
     constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
     return stage > red ? stage : red;
 }
@@ -58,10 +59,17 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     static_assert(WM * WN * WK == 4, "4 wavefronts per workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
 
+    // CONV with NSTAGE == 2 is the LDS-DMA form: A and B chunks go global -> LDS directly
+    // (buffer_load ... lds, zero fill for the im2col padding by out-of-range offsets), no staging
+    // VGPRs and no ds_write pass.  The DMA image is lane-linear, so rows are 128 B unpadded and
+    // the 16-byte k-slot c of row R sits at physical slot c ^ ((R >> 1) & 7): conflict-free for
+    // the ds_read_b128 fragment reads, applied on the SOURCE address of the DMA.
+    constexpr bool DMA = (MODE == MODE_CONV && NSTAGE == 2);
+    constexpr int LD = DMA ? 32 : LDS_STRIDE;
     DEFT_DYN_LDS(float, smem);
     float* const As = smem;
-    float* const Bs = smem + NSTAGE * BM * LDS_STRIDE;
-    float* const prm = Bs + NSTAGE * BN * LDS_STRIDE;   // DCN only
+    float* const Bs = smem + NSTAGE * BM * LD;
+    float* const prm = Bs + NSTAGE * BN * LD;   // DCN only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,7 +93,8 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     const int rbase = tid >> 3;  // 0..31: staged rows are rbase + 32*i
 
     const deft_rsrc_t rx = deft_make_rsrc(p.x);
-    const deft_rsrc_t rx2 = deft_make_rsrc(MODE == MODE_PAIR ? p.x2 : p.x);
+    const deft_rsrc_t rx2 = deft_make_rsrc(MODE == MODE_PAIR ? p.x2 : (DMA ? p.w : p.x));   // DMA: the weight matrix
+    const int gs = DMA ? (g ^ ((rbase >> 1) & 7)) : g;    // k-slot this thread fetches (DMA: swizzled)
 
     // per-row loader state, fixed for the whole K loop.
     //   CONV: r0/r1 = top-left input coordinate of the window (ROW_INVALID fails every bounds
@@ -187,15 +196,16 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     f32x4 s0[GA], s1[GA], s2[GA], s3[GA], sw[GA], vb[GB];
     float sm[GA];
 
+    int dma_stage = 0;                               // DMA form: LDS stage the next issue_loads() fills
     auto issue_loads = [&]() {
         if (MODE == MODE_CONV) {
             int c, r, s;
             bool kok;
             if (uniform_tap) {
-                c = cur.c0 + g * 4; r = cur.r; s = cur.s;
+                c = cur.c0 + gs * 4; r = cur.r; s = cur.s;
                 kok = c < p.Cin;             // 1x1: c is the flat k -> masks the K padding; k>1: always true
             } else {                         // Cin in {4, 8, 16}: a chunk spans several taps -> per-lane tap
-                const int kflat = kload + g * 4;
+                const int kflat = kload + gs * 4;
                 c = kflat & (p.Cin - 1);
                 const int tap = kflat >> p.cin_log2;
                 r = (int)(((unsigned)tap * inv_kw) >> 16);      // tap / KW for tap < 64 (host checks the range)
@@ -207,7 +217,8 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 const int iy = r0[i] + r, ix = r1[i] + s;
                 const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const unsigned off = (unsigned)(((r2[i] + iy * p.W + ix) * p.ldx + c) * 4);
-                s0[i] = deft_buffer_load_x4(rx, ok ? off : DEFT_OOB);
+                if (DMA) deft_buffer_load_lds_x4(rx, As + dma_stage * BM * 32 + (wave * 8 + 32 * i) * 32, ok ? off : DEFT_OOB);
+                else s0[i] = deft_buffer_load_x4(rx, ok ? off : DEFT_OOB);
             }
         } else if (MODE == MODE_DCN) {
             const int tap = cur.s;                       // chunk j = (channel block cur.c0/32, tap cur.s)
@@ -232,9 +243,16 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 s1[i] = deft_buffer_load_x4(rx2, (unsigned)r1[i] + kb);
             }
         }
-        const float* wp = p.w + (unsigned)((n0 + rbase) * p.Kpad + kload + g * 4);
+        if (DMA) {
+            const unsigned wo = (unsigned)(((n0 + rbase) * p.Kpad + kload + gs * 4) * 4);
 #pragma unroll
-        for (int i = 0; i < GB; ++i) vb[i] = *(const f32x4*)(wp + (unsigned)(32 * i * p.Kpad));
+            for (int i = 0; i < GB; ++i)
+                deft_buffer_load_lds_x4(rx2, Bs + dma_stage * BN * 32 + (wave * 8 + 32 * i) * 32, wo + (unsigned)(32 * i * p.Kpad * 4));
+        } else {
+            const float* wp = p.w + (unsigned)((n0 + rbase) * p.Kpad + kload + g * 4);
+#pragma unroll
+            for (int i = 0; i < GB; ++i) vb[i] = *(const f32x4*)(wp + (unsigned)(32 * i * p.Kpad));
+        }
         kload += 32;
         if (MODE == MODE_CONV) {                     // advance the (tap, channel) cursor: scalar unit only
             cur.c0 += 32;
@@ -279,14 +297,15 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     const int fk = (lane >> 5) * 16 + wk * KK;   // first of this lane's k-values in the chunk (this wave's share)
     float a[TM][KK], b[TN][KK];
 
+    const int fsw = (frow >> 1) & 7;   // DMA image: swizzle term of this lane's fragment rows
     auto read_frags = [&](int stage) {
-        const float* as = As + stage * BM * LDS_STRIDE + (wm * TM * 32 + frow) * LDS_STRIDE + fk;
-        const float* bs = Bs + stage * BN * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE + fk;
+        const float* as = As + stage * BM * LD + (wm * TM * 32 + frow) * LD + (DMA ? 0 : fk);
+        const float* bs = Bs + stage * BN * LD + (wn * TN * 32 + frow) * LD + (DMA ? 0 : fk);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int q = 0; q < KK / 4; ++q) {
-                const f32x4 t = *(const f32x4*)&as[i * 32 * LDS_STRIDE + 4 * q];
+                const f32x4 t = *(const f32x4*)&as[i * 32 * LD + (DMA ? (((fk >> 2) + q) ^ fsw) * 4 : 4 * q)];
                 a[i][4 * q + 0] = t.x; a[i][4 * q + 1] = t.y; a[i][4 * q + 2] = t.z; a[i][4 * q + 3] = t.w;
             }
         }
@@ -294,7 +313,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int q = 0; q < KK / 4; ++q) {
-                const f32x4 t = *(const f32x4*)&bs[j * 32 * LDS_STRIDE + 4 * q];
+                const f32x4 t = *(const f32x4*)&bs[j * 32 * LD + (DMA ? (((fk >> 2) + q) ^ fsw) * 4 : 4 * q)];
                 b[j][4 * q + 0] = t.x; b[j][4 * q + 1] = t.y; b[j][4 * q + 2] = t.z; b[j][4 * q + 3] = t.w;
             }
         }
@@ -327,15 +346,18 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         // fragments + MFMAs of chunk kt (stage kt&1), then finish chunk kt+1 into the other stage.
         // That stage was last read in iteration kt-1 and is next read in iteration kt+1, each
         // separated from the store by a barrier.
+        // (CONV: issue_loads() is the LDS-DMA itself, finish_store() is empty, and the barrier's
+        // s_waitcnt vmcnt(0) is what makes chunk kt+1 visible.)
         issue_loads();
-        finish_store(0);
+        if (!DMA) finish_store(0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cs = kt & 1;
+            dma_stage = cs ^ 1;
             if (kt + 1 < nk) issue_loads();
             read_frags(cs);
             mfma_chunk();
-            if (kt + 1 < nk) finish_store(cs ^ 1);
+            if (!DMA && kt + 1 < nk) finish_store(cs ^ 1);
             __syncthreads();
         }
     }

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ cs,
                                                    const int* __restrict__ cc, int cap, int K, int HW,
                                                    float* __restrict__ out_s, int* __restrict__ out_i, int* __restrict__ out_c) {
     __shared__ int hist[2048];
+    __shared__ int ssum[256];
     __shared__ unsigned long long sel[TOPK_MAXK];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_kth, s_nsel;
@@ -225,14 +226,33 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ cs,
                 if (pass == 0 || (key >> hi) == prefix) atomicAdd(&hist[(int)((key >> lo) & ((1u << bits) - 1))], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int kth = s_kth, b = (1 << bits) - 1;
-                for (; b > 0; --b) {
-                    if (hist[b] >= kth) break;
-                    kth -= hist[b];
+            // locate the bin (from the top) where the running count reaches kth: every thread owns
+            // 8 consecutive bins; inclusive suffix sums over the 256 owners (Hillis-Steele in LDS), then
+            // the one owner whose range contains the crossing walks its 8 bins.
+            {
+                const int kth = s_kth;     // read before the barriers below: the owner rewrites it at the end
+                int own = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) own += hist[tid * 8 + q];     // bins >= (1 << bits) are zero
+                ssum[tid] = own;
+                __syncthreads();
+                for (int d = 1; d < 256; d <<= 1) {
+                    const int add = tid + d < 256 ? ssum[tid + d] : 0;
+                    __syncthreads();
+                    ssum[tid] += add;
+                    __syncthreads();
                 }
-                s_kth = kth;
-                s_prefix = (prefix << bits) | (unsigned long long)b;
+                const int above = tid + 1 < 256 ? ssum[tid + 1] : 0;      // count in the bins above my range
+                const bool mine = (ssum[tid] >= kth && above < kth) || (tid == 0 && ssum[0] < kth);
+                if (mine) {
+                    int rem = kth - above, b = tid * 8 + 7;
+                    for (; b > tid * 8; --b) {
+                        if (hist[b] >= rem) break;
+                        rem -= hist[b];
+                    }
+                    s_kth = rem;
+                    s_prefix = (prefix << bits) | (unsigned long long)b;
+                }
             }
             __syncthreads();
             hi = lo;
@@ -349,6 +369,53 @@ extern "C" int deft_heads_at_peaks(const float* feat, int N, int H, int W, int C
     hipLaunchKernelGGL(heads_at_peaks_kernel, dim3(deft_cdiv(K, HP_PPB), N), dim3(256), 0, (hipStream_t)stream,
                        feat, H, W, Cf, ld, inds, K, w0t, b0, w2, b2, head_of, nheads, Ctot, out);
     DEFT_CHECK_LAUNCH("heads_at_peaks");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// regression heads at the K peaks as a sparse-row conv GEMM: rows of the peaks (step 1), the
+// 3x3 (Cf -> nheads*256) + bias + ReLU layer runs in deft_conv2d_nhwc with DeftGemmDesc.rowmap
+// (step 2, MFMA), then the per-head 1x1 (256 -> c) here (step 3).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void peak_rows_kernel(const int* __restrict__ inds, int NK, int K, int H, int W, int* __restrict__ rowmap) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NK) return;
+    const int n = i / K, ind = inds[i];
+    rowmap[2 * i] = n * H * W;
+    rowmap[2 * i + 1] = ((ind / W) << 16) | (ind % W);
+}
+
+extern "C" int deft_peak_rows(const int* inds, int N, int K, int H, int W, int* rowmap, void* stream) {
+    DEFT_CHECK(inds && rowmap && H > 0 && W > 0 && H < 65536 && W < 65536, -1, "deft_peak_rows: bad arguments");
+    if (N * K <= 0) return 0;
+    hipLaunchKernelGGL(peak_rows_kernel, dim3(deft_cdiv(N * K, 256)), dim3(256), 0, (hipStream_t)stream, inds, N * K, K, H, W, rowmap);
+    DEFT_CHECK_LAUNCH("peak_rows");
+    return 0;
+}
+
+// one wavefront per peak: out[i][c] = b2[c] + sum_o w2[c][o] * hid[i][head_of[c]*256 + o]
+__global__ __launch_bounds__(256) void heads_finish_kernel(const float* __restrict__ hid, int ldh, int NK,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           const int* __restrict__ head_of, int Ctot, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= NK) return;
+    const float* hp = hid + (size_t)i * ldh;
+    for (int c = 0; c < Ctot; ++c) {
+        const float* hv = hp + head_of[c] * 256;
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part += w2[(size_t)c * 256 + lane + 64 * q] * hv[lane + 64 * q];
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) out[(size_t)i * Ctot + c] = part + b2[c];
+    }
+}
+
+extern "C" int deft_heads_finish(const float* hid, int ldh, int NK, const float* w2, const float* b2, const int* head_of,
+                                 int Ctot, float* out, void* stream) {
+    DEFT_CHECK(hid && w2 && b2 && head_of && out && Ctot > 0 && ldh >= 256, -1, "deft_heads_finish: bad arguments");
+    if (NK <= 0) return 0;
+    hipLaunchKernelGGL(heads_finish_kernel, dim3(deft_cdiv(NK, 4)), dim3(256), 0, (hipStream_t)stream, hid, ldh, NK, w2, b2, head_of, Ctot, out);
+    DEFT_CHECK_LAUNCH("heads_finish");
     return 0;
 }
 

@@ -433,20 +433,37 @@ class DlaSegPlan(_Plan):
         Ctot = off
         self.Ctot = Ctot
         Cf = self.feat.C
-        w0t = torch.stack([sd[k + ".0.weight"].float().permute(2, 3, 1, 0).reshape(9 * Cf, 256) for k in reg])   # [nh][(r,s,c)][256]
-        b0 = torch.stack([sd[k + ".0.bias"].float() for k in reg])
+        nh = len(reg)
+        w0 = torch.cat([sd[k + ".0.weight"].float() for k in reg])                       # [nh*256, Cf, 3, 3]
+        w0p, K0 = pack_conv_weight(w0)
+        b0 = torch.cat([sd[k + ".0.bias"].float() for k in reg])
         w2 = torch.cat([sd[k + ".2.weight"].float().reshape(self.heads[k], 256) for k in reg])
         b2 = torch.cat([sd[k + ".2.bias"].float() for k in reg])
         head_of = torch.tensor([i for i, k in enumerate(reg) for _ in range(self.heads[k])], dtype=torch.int32)
-        w0t, b0, w2, b2, head_of = map(self.dev, (w0t, b0, w2, b2, head_of))
+        w0p, b0, w2, b2, head_of = map(self.dev, (w0p, b0, w2, b2, head_of))
         self.head_vals = torch.zeros(N, K, Ctot, dtype=torch.float32, device=self.device)
         self.cts = torch.zeros(N, K, 2, dtype=torch.float32, device=self.device)
         self.bboxes = torch.zeros(N, K, 4, dtype=torch.float32, device=self.device)
         self.centers = torch.zeros(N, K, 2, dtype=torch.float32, device=self.device)
-        c_ = (C.c_void_p(self.feat.addr), N, h, w, Cf, self.feat.ld, ptr(self.inds), K, ptr(w0t), ptr(b0), ptr(w2), ptr(b2),
-              ptr(head_of), len(reg), Ctot, ptr(self.head_vals))
-        self.add("deft_heads_at_peaks", "heads_at_peaks", lambda: lib.call("deft_heads_at_peaks", *c_, self._stream()),
-                 2.0 * N * K * len(reg) * (9 * Cf * 256) + 2.0 * N * K * Ctot * 256)
+        # regression heads at the K peaks: peak rows -> sparse-row conv GEMM (all heads' 3x3 layers as one
+        # [N*K] x [nh*256] x [9*Cf] problem on the matrix cores) -> per-head 1x1
+        self.peak_rows = torch.zeros(N * K * 2, dtype=torch.int32, device=self.device)
+        self.peak_hid = torch.zeros(N * K, nh * 256, dtype=torch.float32, device=self.device)
+        r_ = (ptr(self.inds), N, K, h, w, ptr(self.peak_rows))
+        self.add("deft_peak_rows", "peak_rows", lambda: lib.call("deft_peak_rows", *r_, self._stream()))
+        d = GemmDesc()
+        d.x = self.feat.addr; d.x2 = None; d.w = w0p.data_ptr(); d.scale = None; d.shift = b0.data_ptr(); d.res = None
+        d.y = self.peak_hid.data_ptr()
+        d.N, d.H, d.W, d.Cin, d.ldx = N, h, w, Cf, self.feat.ld
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, nh * 256, nh * 256, 0
+        d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
+        d.Ktot, d.Kpad, d.cin_log2, d.M = K0, w0p.shape[1], int(math.log2(Cf)), N * K
+        d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = (64 << 16) | 64
+        d.rowmap = self.peak_rows.data_ptr()
+        self.gemm("deft_conv2d_nhwc", "heads_at_peaks.0", d, 2.0 * N * K * nh * 256 * 9 * Cf)
+        f_ = (ptr(self.peak_hid), nh * 256, N * K, ptr(w2), ptr(b2), ptr(head_of), Ctot, ptr(self.head_vals))
+        self.add("deft_heads_finish", "heads_at_peaks.2", lambda: lib.call("deft_heads_finish", *f_, self._stream()),
+                 2.0 * N * K * Ctot * 256)
         d_ = (ptr(self.inds), ptr(self.head_vals), N, K, w, h, Ctot, self.reg_off.get("reg", -1), self.reg_off.get("wh", -1),
               self.reg_off.get("ltrb_amodal", -1), ptr(self.cts), ptr(self.bboxes), ptr(self.centers))
         self.add("deft_decode_boxes", "decode_boxes", lambda: lib.call("deft_decode_boxes", *d_, self._stream()))

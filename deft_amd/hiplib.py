@@ -48,6 +48,8 @@ _SIGS = {
     "deft_hm_peaks": (C.c_int, [c_fp] + [C.c_int] * 6 + [c_fp] * 3 + [C.c_int, c_fp]),
     "deft_topk": (C.c_int, [c_fp] * 3 + [C.c_int] * 4 + [c_fp] * 3 + [c_fp]),
     "deft_heads_at_peaks": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, C.c_int] + [c_fp] * 5 + [C.c_int] * 2 + [c_fp, c_fp]),
+    "deft_peak_rows": (C.c_int, [c_fp] + [C.c_int] * 4 + [c_fp, c_fp]),
+    "deft_heads_finish": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_int, c_fp, c_fp]),
     "deft_decode_boxes": (C.c_int, [c_fp, c_fp] + [C.c_int] * 8 + [c_fp] * 4),
     "deft_embed_map": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp]),
     "deft_embed_rows": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),

@@ -128,6 +128,15 @@ int deft_heads_at_peaks(const float* feat, int N, int H, int W, int Cf, int ld,
                         const float* w2, const float* b2, const int* head_of,
                         int nheads, int Ctot, float* out, void* stream);
 
+/* The same heads as three launches with the 3x3 layer on the matrix cores: deft_peak_rows turns the
+ * peak indices (ind = y*W+x per frame) into DeftGemmDesc.rowmap rows; deft_conv2d_nhwc with that
+ * rowmap computes hid [N*K][nheads*256] = relu(conv3x3(feat) + b0) for all heads at once (weights
+ * concatenated along Cout); deft_heads_finish applies each head's 1x1 (256 -> c_h) + bias:
+ * out[i][c] = b2[c] + sum_o w2[c][o] * hid[i][head_of[c]*256 + o]. */
+int deft_peak_rows(const int* inds, int N, int K, int H, int W, int* rowmap, void* stream);
+int deft_heads_finish(const float* hid, int ldh, int NK, const float* w2, const float* b2, const int* head_of,
+                      int Ctot, float* out, void* stream);
+
 /* Box assembly of generic_decode (decode.py:118-196): from (ind, head values) to
  * xs, ys, bboxes.  off_* are channel offsets into `heads` rows (-1 = head absent).
  * cts [N][K][2], bboxes [N][K][4].  centers (nullable) [N][K][2]: box centres mapped

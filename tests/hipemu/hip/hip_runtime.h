@@ -252,4 +252,8 @@ static inline hipemu_f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off)
     if (byte_off < 0x7FFFFFFFu - 15u) memcpy(&v, r.base + byte_off, 16);
     return v;
 }
+static inline void deft_buffer_load_lds_x4(deft_rsrc_t r, float* lds_wave_base, unsigned byte_off) {
+    const hipemu_f32x4 v = deft_buffer_load_x4(r, byte_off);
+    memcpy(lds_wave_base + 4 * hipemu::S().lane, &v, 16);
+}
 static inline void __builtin_amdgcn_sched_barrier(int) {}

@@ -344,6 +344,58 @@ def check_sparse_conv(lib, device, tile=0, seed=0):
     assert float((got[:, Co:] - 7.0).abs().max()) == 0.0
 
 
+def check_heads_at_peaks(lib, device, seed=0):
+    """Regression heads at K peak pixels: the single-kernel entry (deft_heads_at_peaks) and the
+    three-launch MFMA form (deft_peak_rows + sparse-row deft_conv2d_nhwc + deft_heads_finish)
+    against conv2d -> relu -> conv2d gathered at the peaks."""
+    import ctypes as C, math
+    from deft_amd.hiplib import GemmDesc, ptr
+    g = torch.Generator().manual_seed(seed)
+    N, H, W, Cf, K = 2, 9, 11, 64, 7
+    heads = [2, 2, 4, 1]
+    nh, Ctot = len(heads), sum(heads)
+    plan = engine._Plan(device, lib)
+    feat = torch.randn(N, Cf, H, W, generator=g)
+    fv = plan.alloc(N, H, W, Cf); fill_view(fv, feat)
+    w0 = [torch.randn(256, Cf, 3, 3, generator=g) * 0.05 for _ in heads]
+    b0 = [torch.randn(256, generator=g) * 0.1 for _ in heads]
+    w2 = [torch.randn(c, 256, 1, 1, generator=g) * 0.1 for c in heads]
+    b2 = [torch.randn(c, generator=g) for c in heads]
+    inds = torch.randint(0, H * W, (N, K), generator=g).to(torch.int32)
+    inds[0, 0] = 0; inds[0, 1] = H * W - 1                      # corners: the 3x3 window leaves the map
+    ref = torch.cat([F.conv2d(F.relu(F.conv2d(feat, w0[h], b0[h], 1, 1)), w2[h], b2[h]) for h in range(nh)], 1)
+    ref = ref.permute(0, 2, 3, 1).reshape(N, H * W, Ctot).gather(1, inds.long().unsqueeze(2).expand(N, K, Ctot))
+    indd = plan.dev(inds)
+    w2c, b2c = plan.dev(torch.cat([w.reshape(-1, 256) for w in w2])), plan.dev(torch.cat(b2))
+    head_of = plan.dev(torch.tensor([h for h, c in enumerate(heads) for _ in range(c)], dtype=torch.int32))
+    s = plan._stream()
+    # (a) single-kernel entry
+    w0t = plan.dev(torch.stack([w.permute(2, 3, 1, 0).reshape(9 * Cf, 256) for w in w0]))
+    b0s = plan.dev(torch.stack(b0))
+    out_a = plan.dev(torch.zeros(N, K, Ctot))
+    lib.call("deft_heads_at_peaks", C.c_void_p(fv.addr), N, H, W, Cf, fv.ld, ptr(indd), K, ptr(w0t), ptr(b0s), ptr(w2c), ptr(b2c),
+             ptr(head_of), nh, Ctot, ptr(out_a), s)
+    # (b) MFMA form
+    rows = plan.dev(torch.zeros(N * K * 2, dtype=torch.int32))
+    hid = plan.dev(torch.zeros(N * K, nh * 256))
+    out_b = plan.dev(torch.zeros(N, K, Ctot))
+    w0p, K0 = engine.pack_conv_weight(torch.cat(w0))
+    w0d, b0d = plan.dev(w0p), plan.dev(torch.cat(b0))
+    lib.call("deft_peak_rows", ptr(indd), N, K, H, W, ptr(rows), s)
+    d = GemmDesc()
+    d.x = fv.addr; d.x2 = None; d.w = w0d.data_ptr(); d.scale = None; d.shift = b0d.data_ptr(); d.res = None; d.y = hid.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.ldx = N, H, W, Cf, fv.ld
+    d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, nh * 256, nh * 256, 0
+    d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
+    d.Ktot, d.Kpad, d.cin_log2, d.M = K0, w0p.shape[1], int(math.log2(Cf)), N * K
+    d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = 0
+    d.rowmap = rows.data_ptr()
+    lib.call("deft_conv2d_nhwc", C.byref(d), s)
+    lib.call("deft_heads_finish", ptr(hid), nh * 256, N * K, ptr(w2c), ptr(b2c), ptr(head_of), Ctot, ptr(out_b), s)
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert maxabs(out_a, ref) <= tol and maxabs(out_b, ref) <= tol
+
+
 def check_affinity(lib, device, sd, shapes=((5, 7), (12, 12), (1, 3), (9, 2)), golden_tag=None, afe=None, scale=3.0):
     afe = afe or engine.AfePlan(sd, 100, device, lib)
     D = afe.D

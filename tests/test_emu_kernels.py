@@ -73,6 +73,10 @@ def test_sparse_row_conv(emu_lib, tile):
     pc.check_sparse_conv(emu_lib, "cpu", tile)
 
 
+def test_heads_at_peaks(emu_lib):
+    pc.check_heads_at_peaks(emu_lib, "cpu")
+
+
 def test_topk_edge_cases(emu_lib):
     pc.check_topk_edge_cases(emu_lib, "cpu")
 

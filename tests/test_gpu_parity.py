@@ -76,6 +76,10 @@ def test_sparse_row_conv(gpu_lib, tile):
     pc.check_sparse_conv(gpu_lib, "cuda", tile)
 
 
+def test_heads_at_peaks(gpu_lib):
+    pc.check_heads_at_peaks(gpu_lib, "cuda")
+
+
 def test_topk_edge_cases(gpu_lib):
     pc.check_topk_edge_cases(gpu_lib, "cuda")
 
