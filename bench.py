@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autotune", action="store_true", help="per-layer tile search at plan-build time (engine._Plan.autotune)")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--serialize", action="store_true",
+                    help="profiling aid: same sub-batch plans, launched back to back on one stream (per-kernel durations "
+                         "comparable with the roofline's per-launch HIP events)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,6 +97,7 @@ def main():
     sd = synth.synth_state_dict("mot")
     B = args.batch
     comp = HipCompute(sd, B, H, W, "mot", K=KDET, device=dev, lib=lib, streams=args.streams)
+    comp.serialize = args.serialize
     pipe = FramePipeline(comp, B, KDET, comp.D, history=HIST, device=dev)
     g = torch.Generator().manual_seed(1000 + rank)
     images = torch.randn(B, 3, H, W, generator=g).to(dev)      # resident in HBM before timing
@@ -127,16 +131,9 @@ def main():
     if rank == 0:
         prof = []
         lib.profile = prof
-        ns, comp.nstream = comp.nstream, 1          # profile serialized on one stream: per-launch events
-        if ns > 1:                                   # (sub-batch plan 0, repeated for every sub-batch's frames)
-            for s_ in range(ns):
-                comp.plans[0].forward(images[s_ * comp.sub:(s_ + 1) * comp.sub])
-                comp.afe.extract(comp.plans[0].fmaps, comp.plans[0].centers, out=comp.emb[s_ * comp.sub:(s_ + 1) * comp.sub])
-            ring = torch.cat([pipe.tail, comp.emb], 0).contiguous()
-            comp.affinity_ring(ring, HIST, B, HIST)
-        else:
-            pipe.step(images)
-        comp.nstream = ns
+        ser, comp.serialize = comp.serialize, True   # same sub-batch plans, back to back on one stream: per-launch events
+        pipe.step(images)
+        comp.serialize = ser
         torch.cuda.synchronize()
         lib.profile = None
         GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer")

@@ -48,7 +48,14 @@ class HipCompute:
             torch.cuda.synchronize(self.device)
             p.autotune(verbose=verbose and s_ == 0)
 
+    serialize = False      # profiling aid: run the sub-batch plans one after the other on the current stream
+
     def detect_embed(self, images):
+        if self.serialize and self.nstream > 1:
+            for s, p in enumerate(self.plans):
+                p.forward(images[s * self.sub:(s + 1) * self.sub])
+                self.afe.extract(p.fmaps, p.centers, out=self.emb[s * self.sub:(s + 1) * self.sub])
+            return self.emb
         if self.nstream == 1:
             p = self.plan
             p.forward(images)

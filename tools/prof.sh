@@ -7,7 +7,7 @@
 set -u
 TAG=$1; shift
 ONE=""
-if [ $# -eq 0 ]; then set -- python bench.py --no-cpu-baseline --steps 6 --warmup 2; ONE="--streams 1"; fi
+if [ $# -eq 0 ]; then set -- python bench.py --no-cpu-baseline --steps 6 --warmup 2; ONE="--serialize"; fi
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -15,12 +15,17 @@ export TMPDIR=/tmp
 "$@" > "$OUT/bench.log" 2>&1
 cp gpurun_out/bench_ops.json "$OUT/" 2>/dev/null
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o "$TAG" --output-format csv -- bash -c "cd $ROOT && $*" > "$OUT/stats.log" 2>&1
+# kernel durations are taken with the launches serialised on ONE stream (the same condition as bench.py's
+# per-launch HIP-event roofline measurement); with 2 streams concurrent kernels share the chip and every
+# duration inflates
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o "$TAG" --output-format csv -- bash -c "cd $ROOT && $* $ONE" > "$OUT/stats.log" 2>&1
+if [ "${PROF_ONLY_STATS:-0}" != "1" ]; then
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_sq" -o p --output-format csv -- bash -c "cd $ROOT && $* $ONE" > "$OUT/pmc_sq.log" 2>&1
 if [ "${PROF_HBM:-1}" = "1" ]; then
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p --output-format csv -- bash -c "cd $ROOT && $* $ONE" > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p --output-format csv -- bash -c "cd $ROOT && $* $ONE" > "$OUT/pmc_write.log" 2>&1
+fi
 fi
 cd "$ROOT"
 # rocprofv3 may nest its output under <dir>/<host>/<pid>: flatten

@@ -43,6 +43,12 @@ if os.path.exists(st):
             break
         out.append("| `%s` | %s | %.2f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                     float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    ig = [(int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(st)) if "igemm" in r["Name"]]
+    if ig:
+        out.append("")
+        out.append("All `igemm*` kernels together: %d launches, average %.1f us (compare `roofline.avg_launch_us` of the bench line; "
+                   "this pass runs the launches serialised on one stream, like bench.py's per-launch HIP-event measurement)."
+                   % (sum(c for c, _ in ig), sum(t for _, t in ig) / sum(c for c, _ in ig) / 1e3))
     out.append("")
 sq = os.path.join(src, "pmc_sq", "p_counter_collection.csv")
 if os.path.exists(sq):
