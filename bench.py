@@ -128,14 +128,15 @@ def main():
     # ---- roofline of the dominant kernel family: one profiled step, HIP events per launch
     #      (torch events on the stream every kernel is launched on) ----
     roof = None
+    prof = []
     if rank == 0:
-        prof = []
         lib.profile = prof
-        ser, comp.serialize = comp.serialize, True   # same sub-batch plans, back to back on one stream: per-launch events
-        pipe.step(images)
-        comp.serialize = ser
-        torch.cuda.synchronize()
-        lib.profile = None
+    ser, comp.serialize = comp.serialize, True   # same sub-batch plans, back to back on one stream: per-launch events
+    pipe.step(images)                            # EVERY rank runs the step (it contains the all-gather); rank 0 records
+    comp.serialize = ser
+    torch.cuda.synchronize()
+    lib.profile = None
+    if rank == 0:
         GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer")
         gemm_ms = sum(e0.elapsed_time(e1) for (k, _, e0, e1, _i) in prof if k in GEMM)
         gemm_fl = sum(fl for (k, fl, _, _, _i) in prof if k in GEMM)

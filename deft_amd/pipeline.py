@@ -106,7 +106,10 @@ class FramePipeline:
         outs = []
         if base >= self.history and hasattr(self.c, "affinity_ring"):
             # steady state: every local frame has `history` predecessors -> one batched chain
-            blk = self.c.affinity_ring(ring.contiguous(), base, self.batch, self.history)
+            # only the frames this rank scores and their history: the layer-1 products U'/V' are not
+            # computed for the other ranks' frames of the step
+            own = ring[base - self.history: base + self.batch].contiguous()
+            blk = self.c.affinity_ring(own, self.history, self.batch, self.history)
             outs = [blk[b] for b in range(self.batch)]
         for b in range(self.batch if not outs else 0):
             g = base + b
