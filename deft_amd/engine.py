@@ -42,6 +42,21 @@ class View:
     def addr(self):
         return self.buf.data_ptr() + 4 * self.c0
 
+    @property
+    def shape(self):
+        """NCHW shape, as the reference reads it off FeatureMaps (tracker.py:821 `FeatureMaps[0].shape[0]`)."""
+        return (self.N, self.C, self.H, self.W)
+
+    def __getitem__(self, n):
+        """Frame slice `fm[0]` (tracker.py:821-825 keeps the un-flipped frame of a flip-test pair)."""
+        assert isinstance(n, int) and 0 <= n < self.N
+        v = View(self.buf, 1, self.H, self.W, self.C, self.ld, self.c0 + n * self.H * self.W * self.ld)
+        return v
+
+    def unsqueeze(self, dim):
+        assert dim == 0 and self.N == 1
+        return self
+
     def sub(self, c0, C):
         return View(self.buf, self.N, self.H, self.W, C, self.ld, self.c0 + c0)
 

@@ -93,10 +93,10 @@ def test_affinity(emu_lib):
 
 @pytest.mark.slow
 def test_forward_embed_mot(emu_lib):
-    """Whole path on a 64x96 frame (emulated): backbone+DCN neck+heads+decode+embedding."""
+    """Whole path on a 32x64 frame (emulated): backbone+DCN neck+heads+decode+embedding."""
     import deft_oracle as O
     sd = O.synth_state_dict("mot")
-    plan, rep, (ora_out, ora_maps) = pc.check_forward(emu_lib, "cpu", "mot", 64, 96, sd=sd)
+    plan, rep, (ora_out, ora_maps) = pc.check_forward(emu_lib, "cpu", "mot", 32, 64, sd=sd)
     pc.check_embed(emu_lib, "cpu", plan, ora_maps, sd)
 
 
@@ -111,4 +111,4 @@ def test_seam_lstm(emu_lib):
 
 @pytest.mark.slow
 def test_seam_model_afe_decode(emu_lib):
-    pc.check_seam_model(emu_lib, "cpu", "mot", 64, 96)
+    pc.check_seam_model(emu_lib, "cpu", "mot", 32, 64)

@@ -28,17 +28,25 @@ class FakeCompute:
         return torch.stack([h[0, 0] for h in hist] + [cur[0, 0]])
 
 
+class FakeRingCompute(FakeCompute):
+    """Also offers the batched steady-state entry the product compute has (HipCompute.affinity_ring)."""
+
+    def affinity_ring(self, ring, g0, Bc, hist):
+        assert ring.is_contiguous() and g0 - hist >= 0 and g0 + Bc <= ring.shape[0]
+        return torch.stack([torch.stack([ring[t, 0, 0] for t in range(g0 + c - hist, g0 + c + 1)]) for c in range(Bc)])
+
+
 def _frames(nsteps, world, batch):
     g = torch.Generator().manual_seed(0)
     return torch.randn(nsteps, world * batch, 1, 2, 2, generator=g)
 
 
-def _run(rank, world, batch, nsteps, port, q):
+def _run(rank, world, batch, nsteps, port, q, ring=False):
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     frames = _frames(nsteps, world, batch)
-    pipe = FramePipeline(FakeCompute(), batch, K, D, history=HIST, device="cpu")
+    pipe = FramePipeline(FakeRingCompute() if ring else FakeCompute(), batch, K, D, history=HIST, device="cpu")
     outs = []
     for s in range(nsteps):
         res = pipe.step(frames[s, rank * batch:(rank + 1) * batch])
@@ -49,10 +57,10 @@ def _run(rank, world, batch, nsteps, port, q):
         dist.destroy_process_group()
 
 
-def _collect(world, batch, nsteps, port):
+def _collect(world, batch, nsteps, port, ring=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_run, args=(r, world, batch, nsteps, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_run, args=(r, world, batch, nsteps, port, q, ring)) for r in range(world)]
     for p in ps:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
@@ -80,3 +88,15 @@ def test_two_ranks_match_single_rank(batch):
             assert a == ref
             want = [float(sig.reshape(-1)[t]) for t in range(max(0, gi - HIST), gi + 1)]
             assert [round(float(v), 4) for v in a] == [round(v, 4) for v in want]
+
+
+def test_two_ranks_ring_path_matches_per_frame_path():
+    """The batched ring entry (taken once every local frame has `history` predecessors) must give
+    every rank exactly what the per-frame path gives a single rank."""
+    nsteps, world, batch = 4, 2, 3
+    two = _collect(world, batch, nsteps, 29655, ring=True)
+    one = _collect(1, world * batch, nsteps, 0, ring=False)[0]
+    for s in range(nsteps):
+        for g in range(world * batch):
+            r, b = divmod(g, batch)
+            assert two[r][s][b] == one[s][g], (s, g)

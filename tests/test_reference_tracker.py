@@ -1,0 +1,87 @@
+"""-m "not gpu" (build container only: needs /root/reference).  DROP-IN check at the level
+`src/test.py` consumes: the reference's OWN `Tracker` (utils/tracker.py, FeatureRecorder, STrack,
+matching) is run twice over the same short synthetic stream --
+  side A: with the reference model (DLASeg + AFE_module on PyTorch-CPU, oracle DCN),
+  side B: with deft_amd.integrate.DeftModel (HIP kernels; here through the SIMT emulator) --
+and must produce the same tracks: ids, boxes, and the recorder's similarity matrices.  This
+exercises seams 2, 3 and 6 of SURVEY.md §8(b) under the reference's real call pattern
+(tracker.py:826 forward_feature_extracter, :87 forward_stacker_features per stored frame)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HAVE_REF = os.path.isdir("/root/reference/src/lib")
+pytestmark = [pytest.mark.skipif(not HAVE_REF, reason="/root/reference only exists in the build container"), pytest.mark.slow]
+
+
+def _results(dets, thr):
+    """generic_post_process for an identity affine (post_process.py:29-60): map coords -> input px."""
+    out = []
+    for i in range(dets["scores"].shape[1]):
+        sc = float(dets["scores"][0, i])
+        if sc < thr:
+            break
+        out.append({"score": sc, "class": int(dets["clses"][0, i]) + 1, "bbox": dets["bboxes"][0, i].numpy().astype(np.float32) * 4.0})
+    return out
+
+
+def test_reference_tracker_runs_on_deft_model(emu_lib):
+    import deft_oracle as O
+    import make_golden as MG
+    import ref_import
+    import ref_shims
+    from deft_amd import integrate
+    ref_shims.install()
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]           # utils/tracker.py:139 parses argv at import
+    try:
+        model_ref, _ = ref_import.build_reference_model("mot", MG.OracleDCN)
+        from model.decode import generic_decode
+        from opts import opts
+        from utils import tracker as RT
+        from utils.basetrack import BaseTrack
+    finally:
+        sys.argv = argv
+    opt = opts().parse(["tracking", "--dataset", "mot", "--gpus", "-1"])
+    torch.set_grad_enabled(False)
+    try:
+        sd = O.synth_state_dict("mot")
+        model_ref.load_state_dict(sd, strict=True)
+        model_ref.eval()
+        model_b = integrate.DeftModel(sd, "mot", K=20, max_object=opt.max_object, device="cpu", lib=emu_lib)
+        H, W, T = 32, 64, 3
+        frames = [torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(40 + t)) for t in range(T)]
+
+        def run(model):
+            BaseTrack._count = 0
+            trk = RT.Tracker(opt, model, h=H, w=W)
+            per_frame = []
+            for x in frames:
+                out, fmaps = model(x, None, None)
+                out = dict(out[-1])
+                out["hm"] = out["hm"].sigmoid()
+                dets = generic_decode(out, K=20, opt=opt)
+                dets = {k: v.detach().cpu() for k, v in dets.items()}
+                res = _results(dets, thr=float(np.sort(dets["scores"][0].numpy())[::-1][5]))      # top-6 detections
+                targets = trk.update(res, fmaps)
+                per_frame.append(sorted((t.track_id, [float(v) for v in t.tlwh]) for t in targets))
+            return per_frame, trk.recorder.all_similarity
+
+        ref_tracks, ref_sim = run(model_ref)
+        got_tracks, got_sim = run(model_b)
+        assert [[tid for tid, _ in f] for f in got_tracks] == [[tid for tid, _ in f] for f in ref_tracks]
+        assert sum(len(f) for f in ref_tracks) > 0, "the synthetic stream must produce tracks"
+        for fa, fb in zip(ref_tracks, got_tracks):
+            for (_, a), (_, b) in zip(fa, fb):
+                assert np.abs(np.array(a) - np.array(b)).max() <= 1e-3
+        assert sorted(ref_sim) == sorted(got_sim)
+        for f in ref_sim:
+            assert sorted(ref_sim[f]) == sorted(got_sim[f])
+            for p in ref_sim[f]:
+                assert np.abs(np.asarray(ref_sim[f][p]) - np.asarray(got_sim[f][p])).max() <= 1e-4
+    finally:
+        torch.set_grad_enabled(True)
+        for m in ("dcn_v2",):
+            sys.modules.pop(m, None)
