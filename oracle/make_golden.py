@@ -191,6 +191,7 @@ if __name__ == "__main__":
     run("mot", 128, 160, "mot_128x160")
     run("mot", 224, 384, "mot_224x384")
     run("nuscenes", 96, 128, "nuscenes_96x128")
+    run("kitti_tracking", 96, 320, "kitti_96x320")          # BASELINE config D aspect (1280x384), 3 classes
     run_lstm("mot")
     run_lstm("nuscenes")
     run_convert_detection()

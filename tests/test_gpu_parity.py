@@ -90,7 +90,8 @@ def test_lstm(gpu_lib, dataset):
 
 
 @pytest.mark.parametrize("tag,dataset,H,W", [("mot_128x160", "mot", 128, 160), ("mot_224x384", "mot", 224, 384),
-                                              ("nuscenes_96x128", "nuscenes", 96, 128)])
+                                              ("nuscenes_96x128", "nuscenes", 96, 128),
+                                              ("kitti_96x320", "kitti_tracking", 96, 320)])
 def test_forward_embed_affinity_golden(gpu_lib, tag, dataset, H, W):
     """Whole path vs the oracle AND the golden fixture written from the reference modules."""
     sd = O.synth_state_dict(dataset)

@@ -27,7 +27,8 @@ def maxabs(a, b):
     return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
 
 
-@pytest.mark.parametrize("tag,dataset", [("mot_128x160", "mot"), ("mot_224x384", "mot"), ("nuscenes_96x128", "nuscenes")])
+@pytest.mark.parametrize("tag,dataset", [("mot_128x160", "mot"), ("mot_224x384", "mot"), ("nuscenes_96x128", "nuscenes"),
+                                          ("kitti_96x320", "kitti_tracking")])
 def test_forward_decode_embed_affinity_vs_golden(tag, dataset):
     fx = np.load(os.path.join(GOLD, "forward_%s.npz" % tag))
     H, W = int(fx["H"]), int(fx["W"])
