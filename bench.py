@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autotune", action="store_true", help="per-layer tile search at plan-build time (engine._Plan.autotune)")
+    ap.add_argument("--graphs", action="store_true", help="replay each sub-batch's launch list as a captured hipGraph")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--serialize", action="store_true",
                     help="profiling aid: same sub-batch plans, launched back to back on one stream (per-kernel durations "
@@ -105,6 +106,9 @@ def main():
     if args.autotune:                                    # plan-build time, outside the timed region
         comp.autotune(images, verbose=args.verbose and rank == 0)
 
+    if args.graphs:
+        comp.capture(images)
+
     def sync():
         if world > 1:
             dist.barrier()
@@ -131,9 +135,11 @@ def main():
     prof = []
     if rank == 0:
         lib.profile = prof
+    gr, comp.graphs = comp.graphs, None          # per-launch events need eager launches
     ser, comp.serialize = comp.serialize, True   # same sub-batch plans, back to back on one stream: per-launch events
     pipe.step(images)                            # EVERY rank runs the step (it contains the all-gather); rank 0 records
     comp.serialize = ser
+    comp.graphs = gr
     torch.cuda.synchronize()
     lib.profile = None
     if rank == 0:
@@ -165,7 +171,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "MOT17 1088x608 DLA-34 + DCNv2 + 100x500 affinity (BASELINE configs[1])",
-                          "frames_per_step_per_gpu": B, "hip_streams": args.streams, "detections": KDET, "history_frames": HIST,
+                          "frames_per_step_per_gpu": B, "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": KDET, "history_frames": HIST,
                           "parallelism": "frames sharded dp%d, 1 all-gather/step" % world},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)

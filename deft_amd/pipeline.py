@@ -48,29 +48,66 @@ class HipCompute:
             torch.cuda.synchronize(self.device)
             p.autotune(verbose=verbose and s_ == 0)
 
+    graphs = None          # per sub-batch hipGraph of (plan launches + embedding extraction), see capture()
+
+    def capture(self, images):
+        """Capture each sub-batch's launch list (backbone, neck, heads, decode, embedding: ~170
+        launches) into a hipGraph and replay it per step: the per-launch host cost (Python +
+        hipLaunchKernel, ~10-20 us each) disappears from the critical path, which matters when the
+        sub-batch is small (latency mode).  Buffers are static (plan-owned), so replays are valid."""
+        assert self.device.type == "cuda"
+        side = self.side if self.nstream > 1 else [torch.cuda.Stream(device=self.device)]
+        self.graphs = []
+        for s_, p in enumerate(self.plans):
+            sl = slice(s_ * self.sub, (s_ + 1) * self.sub)
+            p.forward(images[sl]); self.afe.extract(p.fmaps, p.centers, out=self.emb[sl])      # warm-up: attributes, caches
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side[s_ % len(side)]):
+                p.run()
+                self.afe.extract(p.fmaps, p.centers, out=self.emb[sl])
+            self.graphs.append(g)
+        torch.cuda.synchronize(self.device)
+
+    def _run_plan(self, s_, images):
+        p = self.plans[s_]
+        sl = slice(s_ * self.sub, (s_ + 1) * self.sub)
+        if self.graphs is not None:
+            p.image.copy_(images[sl], non_blocking=True)
+            self.graphs[s_].replay()
+        else:
+            p.forward(images[sl])
+            self.afe.extract(p.fmaps, p.centers, out=self.emb[sl])
+
     serialize = False      # profiling aid: run the sub-batch plans one after the other on the current stream
 
     def detect_embed(self, images):
-        if self.serialize and self.nstream > 1:
-            for s, p in enumerate(self.plans):
-                p.forward(images[s * self.sub:(s + 1) * self.sub])
-                self.afe.extract(p.fmaps, p.centers, out=self.emb[s * self.sub:(s + 1) * self.sub])
-            return self.emb
-        if self.nstream == 1:
-            p = self.plan
-            p.forward(images)
-            return self.afe.extract(p.fmaps, p.centers, out=self.emb)          # [batch, K, D]
+        if (self.serialize and self.nstream > 1) or self.nstream == 1:
+            for s in range(len(self.plans)):
+                self._run_plan(s, images)
+            return self.emb                                                     # [batch, K, D]
         main = torch.cuda.current_stream(self.device)
-        self.ev_main.record(main)
+        if not self.emb_released:                       # nobody told us when emb was consumed: wait for everything
+            self.ev_main.record(main)                   # queued on the main stream so far
+        self.emb_released = False
         for s, (p, st) in enumerate(zip(self.plans, self.side)):
-            st.wait_event(self.ev_main)                 # previous step's consumers of emb are done
+            st.wait_event(self.ev_main)                 # the previous step's readers of emb are done
             with torch.cuda.stream(st):
-                p.forward(images[s * self.sub:(s + 1) * self.sub])
-                self.afe.extract(p.fmaps, p.centers, out=self.emb[s * self.sub:(s + 1) * self.sub])
+                self._run_plan(s, images)
                 self.ev_side[s].record(st)
         for ev in self.ev_side:
             main.wait_event(ev)
         return self.emb
+
+    emb_released = False
+
+    def release_emb(self):
+        """Called by the pipeline once the step's embeddings have been copied out of `emb` (into the
+        history ring): the NEXT step's detection may start on the side streams while this step's
+        affinity chain is still running on the main stream (cross-step overlap)."""
+        if self.nstream > 1:
+            self.ev_main.record(torch.cuda.current_stream(self.device))
+            self.emb_released = True
 
     def affinity(self, hist, cur):
         return self.afe.affinity(hist, cur)[0]
@@ -101,7 +138,12 @@ class FramePipeline:
             allf = self.gathered
         else:
             allf = emb
-        ring = torch.cat([self.tail[self.history - self.tail_valid:], allf], 0) if self.tail_valid else allf
+        if self.tail_valid:
+            ring = torch.cat([self.tail[self.history - self.tail_valid:], allf], 0)      # copies the embeddings out
+            if hasattr(self.c, "release_emb"):
+                self.c.release_emb()
+        else:
+            ring = allf
         base = self.tail_valid + self.rank * self.batch
         outs = []
         if base >= self.history and hasattr(self.c, "affinity_ring"):
