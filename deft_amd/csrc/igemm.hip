@@ -255,10 +255,17 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         }
         kload += 32;
         if (MODE == MODE_CONV) {                     // advance the (tap, channel) cursor: scalar unit only
-            cur.c0 += 32;
-            if (p.KH * p.KW > 1 && cur.c0 >= p.Cin) {
-                cur.c0 = 0;
-                if (++cur.s == p.KW) { cur.s = 0; ++cur.r; }
+            if (p.korder == 1) {                     // (32-channel block, r, s, c): taps fastest, see deft_hip.h
+                if (++cur.s == p.KW) {
+                    cur.s = 0;
+                    if (++cur.r == p.KH) { cur.r = 0; cur.c0 += 32; }
+                }
+            } else {
+                cur.c0 += 32;
+                if (p.KH * p.KW > 1 && cur.c0 >= p.Cin) {
+                    cur.c0 = 0;
+                    if (++cur.s == p.KW) { cur.s = 0; ++cur.r; }
+                }
             }
         } else if (MODE == MODE_DCN) {               // (channel block, tap) order: tap fastest
             if (++cur.s == 9) { cur.s = 0; cur.c0 += 32; }
@@ -518,6 +525,8 @@ static int check_conv(const DeftGemmDesc* d, const char* who) {
     DEFT_CHECK(d->ldx >= d->Cin, -14, "%s: ldx < Cin", who);
     DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -16, "%s: input exceeds 2 GiB (split the batch)", who);
     DEFT_CHECK(d->KW >= 1 && d->KW <= 16, -17, "%s: KW=%d out of range", who, d->KW);
+    DEFT_CHECK(d->korder == 0 || (d->korder == 1 && (d->Cin & 31) == 0 && d->Kpad == d->Ktot), -20,
+               "%s: korder=%d needs Cin %% 32 == 0 (Cin=%d)", who, d->korder, d->Cin);
     DEFT_CHECK(d->Cin >= 32 || d->KH * d->KW == 1 || d->Kpad / d->Cin <= 64, -18,
                "%s: Cin=%d < 32 supports at most 64 taps (incl. K padding)", who, d->Cin);
     return 0;

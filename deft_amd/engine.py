@@ -73,13 +73,30 @@ def _bn_fold(sd, p):
     return alpha, beta
 
 
-def pack_conv_weight(w, cin_pad=None):
-    """[Co,Ci,KH,KW] -> [CoPad(128)][Kpad(32)] with k = (r*KW+s)*CiPad + c."""
+import os as _os
+KORDER_BLOCK = _os.environ.get("DEFT_KORDER", "0") == "1"     # pack k>1 convs with Cin % 32 == 0 in (channel block, tap, channel)
+# order (DeftGemmDesc.korder = 1).  Measured neutral on MI355X for the dense convs (A/B in one process, tools/bench_igemm.py), so off.
+
+
+def conv_korder(w_shape, cin_pad=None):
+    Co, Ci, KH, KW = w_shape
+    cp = Ci if cin_pad is None else cin_pad
+    return 1 if (KORDER_BLOCK and KH * KW > 1 and cp % 32 == 0) else 0
+
+
+def pack_conv_weight(w, cin_pad=None, korder=None):
+    """[Co,Ci,KH,KW] -> [CoPad(128)][Kpad(32)]; korder 0: k = (r*KW+s)*CiPad + c;
+    korder 1: k = ((c//32)*KH*KW + r*KW+s)*32 + c%32 (include/deft_hip.h, DeftGemmDesc.korder).
+    Default: conv_korder(w.shape) -- callers pass the same value in the descriptor."""
     Co, Ci, KH, KW = w.shape
     cp = Ci if cin_pad is None else cin_pad
+    if korder is None:
+        korder = conv_korder(w.shape, cin_pad)
     t = torch.zeros(Co, KH, KW, cp, dtype=torch.float32)
     t[..., :Ci] = w.float().permute(0, 2, 3, 1)
     K = KH * KW * cp
+    if korder == 1:
+        t = t.reshape(Co, KH * KW, cp // 32, 32).permute(0, 2, 1, 3)
     out = torch.zeros(_rup(Co, 128), _rup(K, 32), dtype=torch.float32)
     out[:Co, :K] = t.reshape(Co, K)
     return out, K
@@ -203,7 +220,7 @@ class _Plan:
             d.tile = memo[key]
 
     def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0,
-             true_cin=None):
+             true_cin=None, korder=None):
         OH = (x.H + 2 * pad - KH) // stride + 1
         OW = (x.W + 2 * pad - KW) // stride + 1
         if out is None:
@@ -224,6 +241,7 @@ class _Plan:
         d.cin_log2 = int(math.log2(x.C)) if KH * KW > 1 else 0
         d.M = x.N * OH * OW
         d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = tile
+        d.korder = conv_korder((Cout, x.C, KH, KW)) if korder is None else korder
         cin = x.C if true_cin is None else true_cin
         d.flop_k = KH * KW * cin
         self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * Cout * KH * KW * cin)
@@ -474,6 +492,7 @@ class DlaSegPlan(_Plan):
         d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
         d.Ktot, d.Kpad, d.cin_log2, d.M = K0, w0p.shape[1], int(math.log2(Cf)), N * K
         d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = (64 << 16) | 64
+        d.korder = conv_korder(w0.shape)
         d.rowmap = self.peak_rows.data_ptr()
         self.gemm("deft_conv2d_nhwc", "heads_at_peaks.0", d, 2.0 * N * K * nh * 256 * 9 * Cf)
         f_ = (ptr(self.peak_hid), nh * 256, N * K, ptr(w2), ptr(b2), ptr(head_of), Ctot, ptr(self.head_vals))
@@ -585,6 +604,7 @@ class AfePlan(_Plan):
             d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
             d.Ktot, d.Kpad, d.cin_log2, d.M = K, wp.shape[1], int(math.log2(fm.C)), M
             d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = 0
+            d.korder = conv_korder((Co, fm.C, 3, 3))
             d.rowmap = g["rowmap"].data_ptr() + 4 * (k * M * 2)
         g["descs"] = descs
         g["descs_dev"] = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)

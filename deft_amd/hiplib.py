@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
         ("Ktot", C.c_int), ("Kpad", C.c_int), ("cin_log2", C.c_int), ("M", C.c_int),
         ("relu", C.c_int), ("Q", C.c_int), ("ldom", C.c_int), ("tile", C.c_int),
         ("Tper", C.c_int), ("u0", C.c_int), ("du", C.c_int), ("v0", C.c_int), ("dv", C.c_int),
-        ("stride_w", C.c_int), ("reserved0", C.c_int),
+        ("stride_w", C.c_int), ("korder", C.c_int),
         ("rowmap", c_fp),
     ]
 

@@ -49,7 +49,11 @@ typedef struct DeftGemmDesc {
      * 16-channel full-resolution layers run as "pixel-pair" convs: one GEMM row = two adjacent
      * output pixels (2 x 16 = 32 output columns, KW+1 wide window, stride_w = 2) -- full 32-wide
      * MFMA tiles instead of 16 useful + 16 padding columns.  Zero weights add exact zeros.      */
-    int stride_w, reserved0;
+    int stride_w;
+    /* conv K order of the packed weights: 0 = (r, s, c) tap-major; 1 = (c/32, r, s, c%32): all taps of a
+     * 32-channel block back to back, so the im2col rows of neighbouring taps (the same input lines shifted
+     * by one pixel) are re-read from the CU's L1 instead of L2.  Needs Cin % 32 == 0.                   */
+    int korder;
     /* conv, sparse output rows (NULL = dense grid): rowmap[2m] = n*H*W, rowmap[2m+1] = (y << 16) | x
      * of the output pixel GEMM row m stands for, or -1 for an unused row (written as shift/ReLU
      * of a zero accumulator).  Output row m is y + m*ldy.  Used by the embedding head, which

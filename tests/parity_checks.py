@@ -334,6 +334,7 @@ def check_sparse_conv(lib, device, tile=0, seed=0):
     d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
     d.Ktot, d.Kpad, d.cin_log2, d.M = K, wp.shape[1], int(math.log2(Ci)), M
     d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = tile
+    d.korder = engine.conv_korder(w.shape)
     d.rowmap = rmd.data_ptr()
     lib.call("deft_conv2d_nhwc", C.byref(d), plan._stream())
     dense = F.relu(F.conv2d(x, w, shift, 1, 1))
@@ -389,6 +390,7 @@ def check_heads_at_peaks(lib, device, seed=0):
     d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
     d.Ktot, d.Kpad, d.cin_log2, d.M = K0, w0p.shape[1], int(math.log2(Cf)), N * K
     d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = 0
+    d.korder = engine.conv_korder((nh * 256, Cf, 3, 3))
     d.rowmap = rows.data_ptr()
     lib.call("deft_conv2d_nhwc", C.byref(d), s)
     lib.call("deft_heads_finish", ptr(hid), nh * 256, N * K, ptr(w2c), ptr(b2c), ptr(head_of), Ctot, ptr(out_b), s)
