@@ -60,5 +60,5 @@ class Detector(object):
         return output, dets, plan.fmaps
 
     def reset_tracking(self, opt):
-        """detector.py:677-686 (tracker state is owned by deft_amd.tracker)."""
+        """detector.py:677-686 (the recorder mirror lives in deft_amd.tracker)."""
         self.pre_images = None

@@ -85,3 +85,48 @@ def test_reference_tracker_runs_on_deft_model(emu_lib):
         torch.set_grad_enabled(True)
         for m in ("dcn_v2",):
             sys.modules.pop(m, None)
+
+
+def test_feature_recorder_mirror_matches_reference(emu_lib):
+    """deft_amd.tracker.FeatureRecorder (one launch chain per frame) against the reference's
+    FeatureRecorder driven by the reference AFE_module on CPU: same keys, same matrices, incl.
+    the decay2 branch (gap >= m_frame) and the eviction of the oldest stored frame."""
+    import deft_oracle as O
+    import make_golden as MG
+    import ref_import
+    import ref_shims
+    from deft_amd import integrate, tracker as DT
+    ref_shims.install()
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        model_ref, _ = ref_import.build_reference_model("mot", MG.OracleDCN)
+        from utils import tracker as RT
+    finally:
+        sys.argv = argv
+    torch.set_grad_enabled(False)
+    try:
+        sd = O.synth_state_dict("mot")
+        model_ref.load_state_dict(sd, strict=True)
+        model_ref.eval()
+
+        class M:        # only .AFE is used by the recorder
+            AFE = integrate.AfeSeam(sd, 100, "cpu", emu_lib)
+        g = torch.Generator().manual_seed(21)
+        ref = RT.FeatureRecorder("mot"); ref.max_record_frame = 4
+        got = DT.FeatureRecorder("mot", max_record_frame=4)
+        for frame, n in [(1, 3), (2, 5), (3, 1), (4, 4), (16, 2), (17, 6)]:      # jump 4 -> 16: decay2 branch; 6 frames > 4 kept
+            feats = torch.rand(1, n, 416, generator=g) * 3
+            boxes = np.asarray(torch.rand(n, 4, generator=g) * 100)
+            ref.update(model_ref, frame, feats, boxes)
+            got.update(M, frame, feats, boxes)
+            assert list(ref.all_frame_index) == list(got.all_frame_index)
+            assert sorted(ref.all_similarity) == sorted(got.all_similarity)
+            for f in ref.all_similarity:
+                assert sorted(ref.all_similarity[f]) == sorted(got.all_similarity[f])
+                for p in ref.all_similarity[f]:
+                    a, b = np.asarray(ref.all_similarity[f][p]), np.asarray(got.all_similarity[f][p])
+                    assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5, (f, p)
+        assert got.get_box(17, 2) is not None and got.get_box(1, 0) is None and got.get_features(99) is None
+    finally:
+        torch.set_grad_enabled(True)
+        sys.modules.pop("dcn_v2", None)
