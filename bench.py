@@ -133,10 +133,11 @@ def main():
     #      (torch events on the stream every kernel is launched on) ----
     roof = None
     prof = []
-    if rank == 0:
-        lib.profile = prof
     gr, comp.graphs = comp.graphs, None          # per-launch events need eager launches
     ser, comp.serialize = comp.serialize, True   # same sub-batch plans, back to back on one stream: per-launch events
+    pipe.step(images)                            # un-profiled step queued first: the host then runs AHEAD of the GPU, so the
+    if rank == 0:                                # event intervals below hold kernel time, not Python launch latency
+        lib.profile = prof
     pipe.step(images)                            # EVERY rank runs the step (it contains the all-gather); rank 0 records
     comp.serialize = ser
     comp.graphs = gr
@@ -148,12 +149,18 @@ def main():
         gemm_fl = sum(fl for (k, fl, _, _, _i) in prof if k in GEMM)
         n_launch = sum(1 for p in prof if p[0] in GEMM)
         all_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1, _i) in prof)
+        # fixed cost of one (event, launch, event) bracket: the smallest kernels of the step (a few us of real work)
+        tiny = sorted(e0.elapsed_time(e1) for (k, _, e0, e1, _i) in prof if k in ("deft_peak_rows", "deft_embed_rows", "deft_decode_boxes"))
+        ev_over_ms = tiny[len(tiny) // 2] if tiny else 0.0
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        ach_corr = gemm_fl / (max(gemm_ms - n_launch * ev_over_ms, 1e-6) * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
                 "kernel": "igemm_kernel<*> (fp32 MFMA implicit GEMM: conv / DCNv2 / pair loaders)",
                 "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
                 "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
+                "event_bracket_overhead_us": round(ev_over_ms * 1e3, 2),     # median bracket of the step's ~2 us kernels
+                "achieved_minus_bracket_overhead": round(ach_corr, 3),
                 "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3)}
         by = {}
         for (k, fl, e0, e1, _i) in prof:
