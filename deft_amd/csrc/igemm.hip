@@ -143,9 +143,20 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         }
     }
 
+    // byte offset of (window top-left pixel | image origin for DCN, this thread's k-slot): the per-chunk
+    // address is then ONE add of a workgroup-uniform tap/channel term -- no integer multiplies in the K loop
+    int rb[GA];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        if (MODE == MODE_CONV)         // unsigned wrap-around arithmetic: padding rows give 'negative' bases, invalid rows garbage (never used)
+            rb[i] = (int)((((unsigned)r2[i] + (unsigned)r0[i] * (unsigned)p.W + (unsigned)r1[i]) * (unsigned)p.ldx + (unsigned)(gs * 4)) * 4u);
+        else if (MODE == MODE_DCN) rb[i] = (r2[i] * p.ldx + g * 4) * 4;
+        else rb[i] = 0;
+    }
+
     // DCN: the bilinear sampling records of all (tile row, tap) pairs are computed ONCE, before the
     // K loop -- upstream DCNv2 modulated_deformable_im2col + dmcn_im2col_bilinear semantics -- into
-    // prm[tap][row][8] = {4 pixel offsets, 4 corner weights} and msk[tap][row] = sigmoid(mask).
+    // prm[tap][row][8] = {4 corner byte offsets, 4 corner weights} and msk[tap][row] = sigmoid(mask).
     // The K order of the DCN contraction is (32-channel block, tap, channel): all nine taps of one
     // channel block are consumed back to back, so the 4x4-pixel neighbourhood lines of that block
     // stay in the CU's 32 KB L1 across the 36 corner reads that touch them.
@@ -172,10 +183,11 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                     const int h_low = (int)hl, w_low = (int)wl;
                     const int h_high = h_low + 1, w_high = w_low + 1;
                     mask = 1.f / (1.f + expf(-ml));
-                    if (h_low >= 0 && w_low >= 0) { o1 = h_low * p.W + w_low; w1 = hh * hw_; }
-                    if (h_low >= 0 && w_high <= p.W - 1) { o2 = h_low * p.W + w_high; w2 = hh * lw; }
-                    if (h_high <= p.H - 1 && w_low >= 0) { o3 = h_high * p.W + w_low; w3 = lh * hw_; }
-                    if (h_high <= p.H - 1 && w_high <= p.W - 1) { o4 = h_high * p.W + w_high; w4 = lh * lw; }
+                    const int pb = p.ldx * 4;       // records hold BYTE offsets of the corner pixels inside the image
+                    if (h_low >= 0 && w_low >= 0) { o1 = (h_low * p.W + w_low) * pb; w1 = hh * hw_; }
+                    if (h_low >= 0 && w_high <= p.W - 1) { o2 = (h_low * p.W + w_high) * pb; w2 = hh * lw; }
+                    if (h_high <= p.H - 1 && w_low >= 0) { o3 = (h_high * p.W + w_low) * pb; w3 = lh * hw_; }
+                    if (h_high <= p.H - 1 && w_high <= p.W - 1) { o4 = (h_high * p.W + w_high) * pb; w4 = lh * lw; }
                 }
             }
             float* pr = prm + idx * 8;
@@ -199,41 +211,42 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     int dma_stage = 0;                               // DMA form: LDS stage the next issue_loads() fills
     auto issue_loads = [&]() {
         if (MODE == MODE_CONV) {
-            int c, r, s;
+            int r, s, toff;                                  // tap of this lane's k-slot, byte offset of (tap, channel)
             bool kok;
             if (uniform_tap) {
-                c = cur.c0 + gs * 4; r = cur.r; s = cur.s;
-                kok = c < p.Cin;             // 1x1: c is the flat k -> masks the K padding; k>1: always true
+                r = cur.r; s = cur.s;
+                toff = ((r * p.W + s) * p.ldx + cur.c0) * 4;                     // scalar unit
+                kok = cur.c0 + gs * 4 < p.Cin;   // 1x1: c is the flat k -> masks the K padding; k>1: always true
             } else {                         // Cin in {4, 8, 16}: a chunk spans several taps -> per-lane tap
                 const int kflat = kload + gs * 4;
-                c = kflat & (p.Cin - 1);
                 const int tap = kflat >> p.cin_log2;
                 r = (int)(((unsigned)tap * inv_kw) >> 16);      // tap / KW for tap < 64 (host checks the range)
                 s = tap - r * p.KW;
+                toff = ((r * p.W + s) * p.ldx + (kflat & (p.Cin - 1)) - gs * 4) * 4;   // rb already holds the gs*16 term
                 kok = kflat < p.Ktot;
             }
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
                 const int iy = r0[i] + r, ix = r1[i] + s;
                 const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const unsigned off = (unsigned)(((r2[i] + iy * p.W + ix) * p.ldx + c) * 4);
+                const unsigned off = (unsigned)(rb[i] + toff);
                 if (DMA) deft_buffer_load_lds_x4(rx, As + dma_stage * BM * 32 + (wave * 8 + 32 * i) * 32, ok ? off : DEFT_OOB);
                 else s0[i] = deft_buffer_load_x4(rx, ok ? off : DEFT_OOB);
             }
         } else if (MODE == MODE_DCN) {
             const int tap = cur.s;                       // chunk j = (channel block cur.c0/32, tap cur.s)
-            const int c = cur.c0 + g * 4;
+            const int cb4 = cur.c0 * 4;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
                 const float* pr = prm + (tap * BM + rbase + 32 * i) * 8;
                 const f32x4 po = *(const f32x4*)pr;          // invalid corners: offset 0, weight 0
                 sw[i] = *(const f32x4*)(pr + 4);
                 sm[i] = msk[tap * BM + rbase + 32 * i];
-                const int pb = r2[i];
-                s0[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.x)) * p.ldx + c) * 4));
-                s1[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.y)) * p.ldx + c) * 4));
-                s2[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.z)) * p.ldx + c) * 4));
-                s3[i] = deft_buffer_load_x4(rx, (unsigned)(((pb + __float_as_int(po.w)) * p.ldx + c) * 4));
+                const int pb = rb[i] + cb4;
+                s0[i] = deft_buffer_load_x4(rx, (unsigned)(pb + __float_as_int(po.x)));
+                s1[i] = deft_buffer_load_x4(rx, (unsigned)(pb + __float_as_int(po.y)));
+                s2[i] = deft_buffer_load_x4(rx, (unsigned)(pb + __float_as_int(po.z)));
+                s3[i] = deft_buffer_load_x4(rx, (unsigned)(pb + __float_as_int(po.w)));
             }
         } else {
             const unsigned kb = (unsigned)((kload + g * 4) * 4);
