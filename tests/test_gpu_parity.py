@@ -155,6 +155,36 @@ def test_full_size_properties(gpu_lib):
     assert pc.maxabs(p1.scores.cpu(), od["scores"]) <= pc.TOL
 
 
+@pytest.mark.parametrize("dataset,H,W", [("kitti_tracking", 384, 1280), ("nuscenes", 448, 800)])
+def test_full_size_other_configs(gpu_lib, dataset, H, W):
+    """BASELINE configs D (KITTI 1280x384) and E (nuScenes 800x448, one camera) at full size against
+    the oracle: top-K indices ordered-equal, floats within 1e-3, embeddings within 1e-4 relative,
+    plus the batched LSTM step the configs name."""
+    from deft_amd import engine
+    sd = O.synth_state_dict(dataset)
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(3))
+    plan = engine.DlaSegPlan(sd, 1, H, W, dataset, K=100, device="cuda", lib=gpu_lib)
+    plan.forward(x.cuda())
+    with torch.no_grad():
+        out, maps = O.dlaseg_forward(x, sd, dataset)
+    od = O.generic_decode(O.sigmoid_output(out), K=100)
+    assert float(od["scores"][0, -1]) > 0, "need >= 100 real peaks for an ordered comparison"
+    assert torch.equal(plan.inds[0].cpu().long(), od["inds"][0]) and torch.equal(plan.clses[0].cpu().float(), od["clses"][0])
+    d = plan.dets()
+    for k in ["scores", "bboxes", "tracking"] + [k for k in ("rot", "dim", "amodel_offset") if k in od]:
+        assert pc.maxabs(d[k].cpu(), od[k]) <= pc.TOL, k
+    afe = engine.AfePlan(sd, 100, "cuda", gpu_lib)
+    cen = torch.rand(1, 30, 2, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    emb = afe.extract(plan.fmaps, cen).cpu()
+    ref = O.afe_extract(maps, cen.view(1, 30, 1, 1, 2), sd)
+    assert pc.maxabs(emb, ref) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    hist = [emb[0, :30] for _ in range(2)]
+    aff, starts = afe.affinity(hist, emb[0, 10:])
+    ref_a = torch.from_numpy(O.afe_affinity(emb[:, :30], emb[:, 10:], sd, 100))
+    assert pc.maxabs(aff[starts[0]:starts[1]], ref_a) <= 1e-4
+    pc.check_lstm(gpu_lib, "cuda", "mot" if dataset == "kitti_tracking" else "nuscenes")
+
+
 def test_seam_dcn_module(gpu_lib):
     pc.check_seam_dcn(gpu_lib, "cuda")
 
