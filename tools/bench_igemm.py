@@ -33,8 +33,9 @@ def conv_case(name, H, W, Ci, Co, k, stride, tiles):
         plan = engine._Plan("cuda", lib)
         cp = (Ci + 3) // 4 * 4
         xv = plan.alloc(B, H, W, cp)
-        xv.buf.normal_()
-        w = torch.randn(Co, Ci, k, k) * 0.05
+        if os.environ.get("DEFT_ZERO") != "1":          # DEFT_ZERO=1: zero operands (DVFS probe: same work, less switching power)
+            xv.buf.normal_()
+        w = torch.randn(Co, Ci, k, k) * (0.0 if os.environ.get("DEFT_ZERO") == "1" else 0.05)
         wp, K = engine.pack_conv_weight(w, cp)
         sc = plan.dev(torch.rand(Co) + 0.5); sh = plan.dev(torch.randn(Co))
         try:
