@@ -54,3 +54,37 @@ def test_gemm_desc_layout_matches_header():
     for decl in re.findall(r"(?:const float\*|float\*|const int\*|int)\s+([^;]+);", body):
         names += [n.strip() for n in decl.split(",")]
     assert names == [n for n, _ in GemmDesc._fields_]
+
+
+def test_error_conventions(emu_lib):
+    """Every entry point returns a negative code and a message naming the violated precondition
+    (include/deft_hip.h); the binding raises DeftHipError with that text -- nothing is silently
+    'fixed up' or routed elsewhere.  (Host-side checks only: no kernel runs.)"""
+    import ctypes as C
+    import torch
+    from deft_amd import hiplib
+    from deft_amd.hiplib import GemmDesc, ptr
+    x = torch.zeros(64, dtype=torch.float32)
+    d = GemmDesc()
+    with pytest.raises(hiplib.DeftHipError, match="null x/w/y"):
+        emu_lib.call("deft_conv2d_nhwc", C.byref(d), None)
+    d.x = x.data_ptr(); d.w = x.data_ptr(); d.y = x.data_ptr()
+    d.M, d.Cout, d.Kpad, d.Ktot, d.ldx, d.ldy = 4, 4, 48, 48, 4, 4          # Kpad not a multiple of 32
+    with pytest.raises(hiplib.DeftHipError, match="multiple of 32"):
+        emu_lib.call("deft_conv2d_nhwc", C.byref(d), None)
+    d.Kpad, d.Ktot, d.KH, d.KW, d.Cin, d.N, d.H, d.W, d.OH, d.OW = 64, 54, 3, 3, 6, 1, 2, 2, 2, 2
+    with pytest.raises(hiplib.DeftHipError, match="multiple of 4"):
+        emu_lib.call("deft_conv2d_nhwc", C.byref(d), None)
+    d.Cin, d.Ktot, d.Kpad, d.ldx = 12, 108, 128, 12                             # 3x3 with Cin not a power of two
+    with pytest.raises(hiplib.DeftHipError, match="power of two"):
+        emu_lib.call("deft_conv2d_nhwc", C.byref(d), None)
+    d.Cin, d.Ktot, d.Kpad, d.ldx, d.cin_log2, d.tile = 16, 144, 160, 16, 4, (96 << 16) | 96
+    with pytest.raises(hiplib.DeftHipError, match="unsupported tile"):
+        emu_lib.call("deft_conv2d_nhwc", C.byref(d), None)
+    d.tile = 0; d.x2 = None
+    with pytest.raises(hiplib.DeftHipError, match="offset/mask map missing"):
+        emu_lib.call("deft_dcn_v2_nhwc", C.byref(d), None)
+    with pytest.raises(hiplib.DeftHipError, match="K=0 must be in"):
+        emu_lib.call("deft_topk", ptr(x), ptr(x.int()), ptr(x.int()), 1, 4, 0, 4, ptr(x), ptr(x.int()), ptr(x.int()), None)
+    with pytest.raises(hiplib.DeftHipError, match="nin="):
+        emu_lib.call("deft_lstm_step", *([ptr(x)] * 3), 1, 40, 20, *([ptr(x)] * 8), None)

@@ -197,3 +197,37 @@ def test_seam_lstm(gpu_lib):
 @pytest.mark.parametrize("dataset", ["mot", "nuscenes"])
 def test_seam_model_afe_decode(gpu_lib, dataset):
     pc.check_seam_model(gpu_lib, "cuda", dataset, 96, 128)
+
+
+def test_frame_pipeline_matches_per_frame_affinity(gpu_lib):
+    """The product pipeline (HipCompute on 2 HIP streams + FramePipeline: batched detect/embed, ring
+    affinity, cross-step overlap) against the plain per-frame calls on the same embeddings, and the
+    embeddings against the oracle."""
+    from deft_amd import engine
+    from deft_amd.pipeline import FramePipeline, HipCompute
+    sd = O.synth_state_dict("mot")
+    H, W, B, K, HIST = 96, 160, 4, 12, 2
+    comp = HipCompute(sd, B, H, W, "mot", K=K, device="cuda", lib=gpu_lib, streams=2)
+    pipe = FramePipeline(comp, B, K, comp.D, history=HIST, device="cuda")
+    afe = engine.AfePlan(sd, 100, "cuda", gpu_lib)
+    g = torch.Generator().manual_seed(77)
+    embs = []
+    for step in range(3):
+        x = torch.randn(B, 3, H, W, generator=g)
+        outs = pipe.step(x.cuda())
+        torch.cuda.synchronize()
+        emb = comp.emb.clone()                      # this step's embeddings [B,K,D]
+        if step == 0:                               # embeddings vs the oracle at the plan's own detection centres
+            with torch.no_grad():
+                _, maps = O.dlaseg_forward(x[:1], sd, "mot")
+            ref = O.afe_extract(maps, comp.plans[0].centers[0:1].cpu().view(1, K, 1, 1, 2), sd)
+            assert pc.maxabs(emb[0:1].cpu(), ref) <= 1e-4 * max(1.0, float(ref.abs().max()))
+        for b in range(B):
+            embs.append(emb[b])
+            gidx = len(embs) - 1
+            hist = embs[max(0, gidx - HIST):gidx]
+            if not hist:
+                assert outs[b] is None
+                continue
+            want, _ = afe.affinity(hist, embs[gidx])
+            assert tuple(outs[b].shape) == tuple(want.shape) and pc.maxabs(outs[b], want) <= 1e-5, (step, b)
