@@ -145,17 +145,23 @@ def main():
     lib.profile = None
     if rank == 0:
         GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer")
-        gemm_ms = sum(e0.elapsed_time(e1) for (k, _, e0, e1, _i) in prof if k in GEMM)
-        gemm_fl = sum(fl for (k, fl, _, _, _i) in prof if k in GEMM)
+        gemm_ms = sum(e0.elapsed_time(e1) for (k, _, e0, e1, _i, _b) in prof if k in GEMM)
+        gemm_fl = sum(fl for (k, fl, _, _, _i, _b) in prof if k in GEMM)
         n_launch = sum(1 for p in prof if p[0] in GEMM)
-        all_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1, _i) in prof)
+        all_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1, _i, _b) in prof)
         # fixed cost of one (event, launch, event) bracket: the smallest kernels of the step (a few us of real work)
-        tiny = sorted(e0.elapsed_time(e1) for (k, _, e0, e1, _i) in prof if k in ("deft_peak_rows", "deft_embed_rows", "deft_decode_boxes"))
+        tiny = sorted(e0.elapsed_time(e1) for (k, _, e0, e1, _i, _b) in prof if k in ("deft_peak_rows", "deft_embed_rows", "deft_decode_boxes"))
         ev_over_ms = tiny[len(tiny) // 2] if tiny else 0.0
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
         ach_corr = gemm_fl / (max(gemm_ms - n_launch * ev_over_ms, 1e-6) * 1e-3) / 1e12
+        traffic, tsrc = None, None                    # HBM bytes per launch from the committed PMC passes of this build, if any
+        tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": round(sum(b for (k, _, _, _, _i, b) in prof if k in GEMM) / max(1, n_launch)),
                 "kernel": "igemm_kernel<*> (fp32 MFMA implicit GEMM: conv / DCNv2 / pair loaders)",
                 "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
                 "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
@@ -163,11 +169,11 @@ def main():
                 "achieved_minus_bracket_overhead": round(ach_corr, 3),
                 "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3)}
         by = {}
-        for (k, fl, e0, e1, _i) in prof:
+        for (k, fl, e0, e1, _i, _b) in prof:
             by.setdefault(k, [0.0, 0, 0.0]); by[k][0] += e0.elapsed_time(e1); by[k][1] += 1; by[k][2] += fl
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
-            json.dump({"by_entry_ms_launches_flops": by, "calls": [(k, fl, e0.elapsed_time(e1), info) for (k, fl, e0, e1, info) in prof]}, f)
+            json.dump({"by_entry_ms_launches_flops": by, "calls": [(k, fl, e0.elapsed_time(e1), info) for (k, fl, e0, e1, info, _b) in prof]}, f)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:

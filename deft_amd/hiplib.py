@@ -80,7 +80,7 @@ class HipLib:
         if v != 2:
             raise DeftHipError("libdeft_hip ABI version %d, expected 2" % v)
 
-    profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1, shape) per call
+    profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1, shape, algorithmic_bytes) per call
 
     def call(self, name, *args):
         prof = self.profile
@@ -92,16 +92,25 @@ class HipLib:
             raise DeftHipError("%s failed (%d): %s" % (name, rc, self.cdll.deft_last_error().decode()))
         if prof is not None:
             e1.record()
-            fl, info = 0.0, ""
+            fl, info, nbytes = 0.0, "", 0.0
+
+            def alg_bytes(d):      # operands read once + output written once (fp32)
+                if name == "deft_pair_layer":
+                    return 4.0 * (d.M * d.Cout + d.Cout * d.Ktot + 2.0 * (d.M // max(d.Q, 1) + d.Q) * d.Ktot)
+                rows_in = d.M * d.KH * d.KW if d.rowmap else d.N * d.H * d.W
+                return 4.0 * (min(rows_in, d.N * d.H * d.W) * d.Cin + d.M * d.Cout * (2 if d.res else 1) + d.Cout * d.Ktot
+                              + (d.M * 27 if name == "deft_dcn_v2_nhwc" else 0))
             if name == "deft_conv2d_group":
                 ds = args[0]
                 fl = sum(2.0 * ds[i].M * ds[i].Cout * ds[i].Ktot for i in range(args[2]))
+                nbytes = sum(alg_bytes(ds[i]) for i in range(args[2]))
                 info = "group of %d" % args[2]
             elif name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer"):
                 d = args[0]._obj
                 fl = 2.0 * d.M * d.Cout * (d.flop_k if d.flop_k else d.Ktot)
+                nbytes = alg_bytes(d)
                 info = "M=%d N=%d K=%d %dx%d s%d @%dx%d" % (d.M, d.Cout, d.Ktot, d.KH, d.KW, d.stride, d.H, d.W)
-            prof.append((name, fl, e0, e1, info))
+            prof.append((name, fl, e0, e1, info, nbytes))
 
 
 _lib = None

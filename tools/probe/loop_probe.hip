@@ -131,6 +131,73 @@ void run2(const float* src, float* out, int wgs) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("F=4 prefetch-2 wg/CU=%d %-40s %.1f TFLOP/s\n", wgs, "(two staging register sets)", (double)grid * 4 * chunks * 64.0 * 4096.0 / ms / 1e9);
 }
+// wave specialisation: waves 0-3 only read fragments + MFMA, wave 4 issues every LDS-DMA of the chunk
+// (2 LDS stages, unpadded swizzled image, one barrier per chunk)
+template <bool SPECIAL>
+__global__ __launch_bounds__(320) void k3(const float* __restrict__ src, float* out, int chunks, int W, int ldx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 256 * 32; i += blockDim.x) smem[i] = 0.001f * (float)((i * 7 + blockIdx.x) % 97 - 48);
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)(blockIdx.x % 512) * 32768), 0, 0x7FFFFFFF, 0x00020000);
+    const int nload = SPECIAL ? 1 : 4;              // waves that issue DMA
+    const bool loader = SPECIAL ? wave == 4 : wave < 4;
+    const bool consumer = wave < 4;
+    const int lw = SPECIAL ? 0 : wave;              // loader index
+    auto dma = [&](int kt, int stage) {             // 32 KB = 32 wave-instructions per chunk, split over the loader waves
+        for (int j = lw; j < 32; j += nload) {
+            const int row = j * 8 + (lane >> 3), g = lane & 7;
+            const int iy = row + (kt % 3), ix = g + (kt % 5);
+            const bool ok = (unsigned)iy < 4096u && (unsigned)ix < (unsigned)W;
+            const unsigned off = ok ? (unsigned)((((iy * W + ix) * ldx + (g ^ ((row >> 1) & 7)) * 4) & 32767) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * 8192 + j * 256), 16, off, 0, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float a[2][16], b[2][16];
+    const int wm = (wave >> 1) & 1, wn = wave & 1, frow = lane & 31, fk = (lane >> 5) * 16, fsw = (frow >> 1) & 7;
+    if (loader) dma(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < chunks; ++kt) {
+        const int cs = kt & 1;
+        if (loader) dma(kt + 1, cs ^ 1);
+        if (consumer) {
+            const float* As = smem + cs * 8192; const float* Bs = As + 4096;
+            for (int i = 0; i < 2; ++i) for (int q = 0; q < 4; ++q) {
+                const f32x4 t = *(const f32x4*)&As[((wm * 2 + i) * 32 + frow) * 32 + (((fk >> 2) + q) ^ fsw) * 4];
+                a[i][4 * q] = t.x; a[i][4 * q + 1] = t.y; a[i][4 * q + 2] = t.z; a[i][4 * q + 3] = t.w;
+            }
+            for (int j = 0; j < 2; ++j) for (int q = 0; q < 4; ++q) {
+                const f32x4 t = *(const f32x4*)&Bs[((wn * 2 + j) * 32 + frow) * 32 + (((fk >> 2) + q) ^ fsw) * 4];
+                b[j][4 * q] = t.x; b[j][4 * q + 1] = t.y; b[j][4 * q + 2] = t.z; b[j][4 * q + 3] = t.w;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (consumer) out[blockIdx.x * 256 + tid] = s;
+}
+template <bool SPECIAL> void run3(const float* src, float* out, int wgs) {
+    const int grid = 256 * wgs, chunks = 600, nthr = SPECIAL ? 320 : 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k3<SPECIAL>, dim3(grid), dim3(nthr), 65536, 0, src, out, 20, 272, 64);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k3<SPECIAL>, dim3(grid), dim3(nthr), 65536, 0, src, out, chunks, 272, 64);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("LDS-DMA 2-stage, %s, wg/CU=%d: %.1f TFLOP/s\n", SPECIAL ? "1 loader wave + 4 MFMA waves" : "every wave loads (as shipped)", wgs,
+           (double)grid * 4 * chunks * 64.0 * 4096.0 / ms / 1e9);
+}
 template <int F> void run(const float* src, float* out, const char* what, int wgs = 3) {
     const int grid = 256 * wgs, chunks = 600;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -147,8 +214,9 @@ int main() {
     hipMemset(src, 0, 512 * 32768 * 4);
     run<2>(src, out, "warm-up", 3); run<2>(src, out, "warm-up", 3);
     for (int rep = 0; rep < 2; ++rep) {
-        for (int w = 2; w <= 3; ++w) run<4>(src, out, "+ loads + address VALU", w);
-        for (int w = 2; w <= 3; ++w) run2(src, out, w);
+        run<4>(src, out, "+ loads + address VALU", 2);
+        run3<false>(src, out, 2);
+        run3<true>(src, out, 2);
     }
     run<0>(src, out, "MFMA only");
     run<1>(src, out, "+ 16 ds_read_b128 fragment reads / chunk");

@@ -84,6 +84,17 @@ if os.path.exists(fe) and os.path.exists(wr):
         out.append("| `%s` | %d | %.1f | %.1f | %.1f |" % (k, nf[k], pf[k]["FETCH_SIZE"] / nf[k] / 1024, 2 * pf[k]["FETCH_SIZE"] / nf[k] / 1024,
                                                      pw.get(k, {}).get("WRITE_SIZE", 0) / max(1, nw.get(k, 1)) / 1024))
     out.append("")
+if os.path.exists(fe) and os.path.exists(wr):
+    # dominant kernel family for bench.py's roofline.traffic: HBM bytes per launch, averaged over all igemm launches
+    fk = [k for k in pf if "igemm" in k]
+    nl = sum(nf[k] for k in fk)
+    fetch = sum(pf[k]["FETCH_SIZE"] for k in fk) * 1024.0 * 2.0          # KiB -> B, gfx950 wide-stream correction x2
+    write = sum(pw.get(k, {}).get("WRITE_SIZE", 0.0) for k in fk) * 1024.0
+    json.dump({"kernel": "igemm*", "launches": nl, "fetch_bytes_per_launch": fetch / max(nl, 1), "write_bytes_per_launch": write / max(nl, 1),
+               "traffic_bytes_per_launch": (fetch + write) / max(nl, 1),
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof.sh), KiB units, FETCH_SIZE x2 per "
+                         "MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated"},
+              open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 ops = os.path.join(src, "bench_ops.json")
 if os.path.exists(ops):
     d = json.load(open(ops))
