@@ -231,3 +231,26 @@ def test_frame_pipeline_matches_per_frame_affinity(gpu_lib):
                 continue
             want, _ = afe.affinity(hist, embs[gidx])
             assert tuple(outs[b].shape) == tuple(want.shape) and pc.maxabs(outs[b], want) <= 1e-5, (step, b)
+
+
+def test_detector_mirror_loads_reference_checkpoint(gpu_lib, tmp_path):
+    """deft_amd.detector.Detector(opt): reads a checkpoint in the reference's format (model.py:40-53:
+    {"epoch", "state_dict"} with DataParallel's "module." prefix), keeps the reference's process()
+    signature, returns generic_decode's dict as numpy with ONE device->host copy."""
+    from types import SimpleNamespace
+    from deft_amd.detector import Detector
+    sd = O.synth_state_dict("mot")
+    ck = tmp_path / "model_last.pth"
+    torch.save({"epoch": 7, "state_dict": {"module." + k: v for k, v in sd.items()}}, ck)
+    opt = SimpleNamespace(dataset="mot", K=20, max_object=100, gpus=[0], load_model=str(ck))
+    det = Detector(opt)
+    x = torch.randn(1, 3, 128, 160, generator=torch.Generator().manual_seed(0))
+    output, dets, fmaps = det.process(x)
+    with torch.no_grad():
+        out, maps = O.dlaseg_forward(x, sd, "mot")
+    od = O.generic_decode(O.sigmoid_output(out), K=20)
+    assert isinstance(dets["scores"], __import__("numpy").ndarray) and len(fmaps) == 13
+    assert (dets["inds"][0] == od["inds"][0].numpy()).all()
+    for k in ("scores", "bboxes", "tracking"):
+        assert pc.maxabs(torch.from_numpy(dets[k]), od[k]) <= pc.TOL, k
+    det.reset_tracking(opt)
