@@ -704,45 +704,48 @@ class AfePlan(_Plan):
         """Batched steady-state form used by the frame pipeline.  ring [R, K, D]: embeddings of
         consecutive frames of one stream (every frame K objects); current frames are ring[g0+c],
         c < Bc, each scored against ring[g0+c-hist : g0+c] (tracker.py:76-90 for `hist` stored
-        frames).  U'/V' are computed once per ring frame; one pair-GEMM chain covers all
-        Bc*hist frame pairs.  Returns [Bc, hist*K, K+1]."""
+        frames).  U'/V' are computed once per ring frame; one pair-GEMM chain covers up to
+        `CH` current frames (the kernels address activations with 32-bit byte offsets: <= 2 GiB
+        per tensor), so large batches run as a few chains.  Returns [Bc, hist*K, K+1]."""
         R, K, D = ring.shape
         assert ring.is_contiguous() and D == self.D and D == self.Kd and g0 - hist >= 0 and g0 + Bc <= R
         assert K <= self.max_object
+        (w2, K2, c2, s2, t2), (w3, K3, c3, s3, t3), (w4, K4, c4, s4, t4) = self.layers
+        CH = max(1, min(Bc, ((1 << 29) - 1) // (hist * K * K * max(c2, 512))))
         key = (R, K, Bc, hist)
         if not hasattr(self, "_ring"):
             self._ring = {}
         if key not in self._ring:
             dev = self.device
-            (w2, K2, c2, s2, t2), (w3, K3, c3, s3, t3), (w4, K4, c4, s4, t4) = self.layers
-            M = Bc * hist * K * K
+            Mc = CH * hist * K * K
             buf = {"U": torch.empty(R * K, 512, dtype=torch.float32, device=dev),
                    "V": torch.empty(R * K, 512, dtype=torch.float32, device=dev),
-                   "h2": torch.empty(M, c2, dtype=torch.float32, device=dev),
-                   "h3": torch.empty(M, c3, dtype=torch.float32, device=dev),
-                   "h4": torch.empty(M, c4, dtype=torch.float32, device=dev),
+                   "h2": torch.empty(Mc, c2, dtype=torch.float32, device=dev),
+                   "h3": torch.empty(Mc, c3, dtype=torch.float32, device=dev),
+                   "h4": torch.empty(Mc, c4, dtype=torch.float32, device=dev),
                    "out": torch.empty(Bc, hist * K, K + 1, dtype=torch.float32, device=dev),
-                   "rs": torch.arange(0, Bc * hist + 1, dtype=torch.int32, device=dev) * K}
+                   "rs": torch.arange(0, CH * hist + 1, dtype=torch.int32, device=dev) * K}
             self._ring[key] = buf
         b = self._ring[key]
-        (w2, K2, c2, s2, t2), (w3, K3, c3, s3, t3), (w4, K4, c4, s4, t4) = self.layers
         self._lin(ring, R * K, D, D, self.Ua, self.Kd, 512, None, None, False, b["U"], 512)
         self._lin(ring, R * K, D, D, self.Vb, self.Kd, 512, None, self.cb, False, b["V"], 512)
-        M = Bc * hist * K * K
-        d = GemmDesc()
-        d.x = b["U"].data_ptr(); d.x2 = b["V"].data_ptr(); d.w = w2.data_ptr()
-        d.scale = s2.data_ptr(); d.shift = t2.data_ptr(); d.res = None; d.y = b["h2"].data_ptr()
-        d.N, d.H, d.W, d.Cin, d.ldx = M, 1, 1, 512, 512
-        d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, c2, c2, 0
-        d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
-        d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
-        d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0
-        d.Tper, d.u0, d.du, d.v0, d.dv = hist * K, (g0 - hist) * K, K, g0 * K, K
-        self.lib.call("deft_pair_layer", C.byref(d), self._stream())
-        self._lin(b["h2"], M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, b["h3"], c3)
-        self._lin(b["h3"], M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, b["h4"], c4)
-        self.lib.call("deft_affinity_finish", ptr(b["h4"]), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(b["rs"]),
-                      Bc * hist, K, self.max_object, ptr(b["out"]), self._stream())
+        for c0 in range(0, Bc, CH):
+            nc = min(CH, Bc - c0)
+            M = nc * hist * K * K
+            d = GemmDesc()
+            d.x = b["U"].data_ptr(); d.x2 = b["V"].data_ptr(); d.w = w2.data_ptr()
+            d.scale = s2.data_ptr(); d.shift = t2.data_ptr(); d.res = None; d.y = b["h2"].data_ptr()
+            d.N, d.H, d.W, d.Cin, d.ldx = M, 1, 1, 512, 512
+            d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, c2, c2, 0
+            d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+            d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
+            d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0
+            d.Tper, d.u0, d.du, d.v0, d.dv = hist * K, (g0 + c0 - hist) * K, K, (g0 + c0) * K, K
+            self.lib.call("deft_pair_layer", C.byref(d), self._stream())
+            self._lin(b["h2"], M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, b["h3"], c3)
+            self._lin(b["h3"], M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, b["h4"], c4)
+            self.lib.call("deft_affinity_finish", ptr(b["h4"]), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(b["rs"]),
+                          nc * hist, K, self.max_object, C.c_void_p(b["out"].data_ptr() + 4 * c0 * hist * K * (K + 1)), self._stream())
         return b["out"]
 
     @staticmethod
