@@ -40,7 +40,8 @@ typedef struct DeftGemmDesc {
     int relu;                     /* apply max(.,0) last                                     */
     int Q;                        /* pair: number of current-frame objects                   */
     int ldom;                     /* dcn: pixel stride of x2                                 */
-    int tile;                     /* 0 = auto; else (BM<<16)|BN to force a tile config       */
+    int tile;                     /* 0 = auto; else (BM<<16)|BN forces a tile; bit 29 selects the
+                                     2-stage loop (conv: LDS-DMA form) instead of the 1-stage one */
     /* pair, batched form (Tper > 0): rows are (c, t, j) with c = m / (Tper*Q) the current
      * frame, t its history row, j its object; U' row = u0 + c*du + t, V' row = v0 + c*dv + j.
      * Tper == 0: rows are (t, j), U' row = t, V' row = j.                                   */
