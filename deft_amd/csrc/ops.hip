@@ -146,29 +146,43 @@ extern "C" int deft_upsample_add(const float* x, const float* wup, const float* 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// One 16x16 pixel tile of one (frame, class) per workgroup: the 18x18 neighbourhood is read and
+// sigmoid'ed ONCE into LDS (the first version did 9 strided global reads + 9 expf per pixel).
 __global__ __launch_bounds__(256) void hm_peaks_kernel(const float* __restrict__ hm, int N, int H, int W, int C, int ld, int sig,
                                                        float* __restrict__ cs, int* __restrict__ ci, int* __restrict__ cc, int cap) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)N * H * W * C) return;
-    const int c = (int)(i % C);
-    long long t = i / C;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int n = (int)(t / H);
+    __shared__ float t[18][19];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z / C, c = blockIdx.z - n * C;
+    const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
     const float* base = hm + (size_t)n * H * W * ld + c;
-    const float raw = base[(size_t)(y * W + x) * ld];
-    const float s = sig ? sigmoidf_(raw) : raw;
-    bool peak = true;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = y + dy, xx = x + dx;
-            if ((dy | dx) != 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                const float nv = base[(size_t)(yy * W + xx) * ld];
-                peak = peak && ((sig ? sigmoidf_(nv) : nv) <= s);
-            }
+    for (int i = tid; i < 18 * 18; i += 256) {
+        const int ty = i / 18, tx = i - ty * 18;
+        const int yy = y0 + ty - 1, xx = x0 + tx - 1;
+        float v = -3.0e38f;                                      // outside the map: never blocks a peak
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+            const float raw = base[(size_t)(yy * W + xx) * ld];
+            v = sig ? sigmoidf_(raw) : raw;
         }
+        t[ty][tx] = v;
+    }
+    __syncthreads();
+    __shared__ int s_cnt, s_base;
+    if (tid == 0) s_cnt = 0;
+    const int ty = tid >> 4, tx = tid & 15;
+    const int y = y0 + ty, x = x0 + tx;
+    const float s = t[ty + 1][tx + 1];
+    bool peak = y < H && x < W;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) peak = peak && (t[ty + dy][tx + dx] <= s);
+    __syncthreads();
+    const int slot = peak ? atomicAdd(&s_cnt, 1) : 0;           // rank inside the tile (LDS atomic)
+    __syncthreads();
+    if (tid == 0 && s_cnt > 0) s_base = atomicAdd(&cc[n], s_cnt);   // ONE global atomic per tile reserves the range
+    __syncthreads();
     if (peak) {
-        const int pos = atomicAdd(&cc[n], 1);
+        const int pos = s_base + slot;
         if (pos < cap) {
             cs[(size_t)n * cap + pos] = s;
             ci[(size_t)n * cap + pos] = c * H * W + y * W + x;
@@ -179,8 +193,9 @@ __global__ __launch_bounds__(256) void hm_peaks_kernel(const float* __restrict__
 extern "C" int deft_hm_peaks(const float* hm, int N, int H, int W, int C, int ld, int apply_sigmoid,
                              float* cand_score, int* cand_idx, int* cand_count, int cap, void* stream) {
     DEFT_CHECK(hm && cand_score && cand_idx && cand_count && cap > 0 && ld >= C, -1, "deft_hm_peaks: bad arguments");
-    const long long tot = (long long)N * H * W * C;
-    hipLaunchKernelGGL(hm_peaks_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, hm, N, H, W, C, ld, apply_sigmoid, cand_score, cand_idx, cand_count, cap);
+    DEFT_CHECK((long long)N * C <= 65535, -2, "deft_hm_peaks: N*C=%lld exceeds the grid limit", (long long)N * C);
+    hipLaunchKernelGGL(hm_peaks_kernel, dim3(deft_cdiv(W, 16), deft_cdiv(H, 16), N * C), dim3(256), 0, (hipStream_t)stream,
+                       hm, N, H, W, C, ld, apply_sigmoid, cand_score, cand_idx, cand_count, cap);
     DEFT_CHECK_LAUNCH("hm_peaks");
     return 0;
 }
