@@ -88,8 +88,10 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("DEFT_FORCE_DIST") == "1":      # DEFT_FORCE_DIST: 1-rank RCCL group (path check on a 1-GPU box)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from deft_amd import hiplib, synth
@@ -110,7 +112,7 @@ def main():
         comp.capture(images)
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -187,8 +189,19 @@ def main():
                           "frames_per_step_per_gpu": B, "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": KDET, "history_frames": HIST,
                           "parallelism": "frames sharded dp%d, 1 all-gather/step" % world},
                "roofline": roof, "cpu_baseline": cpu}
+    # RCCL prints its version banner through C stdio on every rank; it would otherwise be flushed at process exit,
+    # AFTER the JSON line.  Flush it everywhere first, then rank 0 prints the JSON as the last stdout line.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

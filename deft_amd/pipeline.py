@@ -127,13 +127,15 @@ class FramePipeline:
         self.tail = torch.zeros(history, K, D, dtype=torch.float32, device=self.device)
         self.tail_valid = 0
         self.gathered = torch.zeros(self.world * batch, K, D, dtype=torch.float32, device=self.device)
+        # test hook: run the collective even in a 1-rank group (exercises the RCCL path on a 1-GPU box)
+        self.force_gather = bool(dist.is_available() and dist.is_initialized() and self.world == 1)
 
     def step(self, images):
         """images [batch,3,H,W]: this rank's frames  (global frame index within the step =
         rank*batch + b).  Returns the list (one per local frame) of affinity blocks
         [sum_f P_f, Q+1] against the up-to-`history` preceding frames of the stream."""
         emb = self.c.detect_embed(images)                                   # [batch,K,D]
-        if self.world > 1:
+        if self.world > 1 or self.force_gather:
             dist.all_gather_into_tensor(self.gathered, emb.contiguous(), group=self.group)
             allf = self.gathered
         else:
