@@ -100,3 +100,80 @@ def test_two_ranks_ring_path_matches_per_frame_path():
         for g in range(world * batch):
             r, b = divmod(g, batch)
             assert two[r][s][b] == one[s][g], (s, g)
+
+
+# ---------------------------------------------------------------------------------------
+# the same sharding with the REAL affinity kernels (SIMT-emulator build of the HIP sources):
+# embeddings are synthetic, the affinity blocks go through AfePlan.affinity / affinity_ring
+# ---------------------------------------------------------------------------------------
+class EmuAffinityCompute:
+    def __init__(self):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import subprocess
+        import deft_oracle as O
+        from deft_amd import engine, hiplib
+        so = os.path.join(ROOT, "tests", "hipemu", "_build", "libdeft_emu.so")
+        if not os.path.exists(so):
+            subprocess.check_call([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh")])
+        self.sd = O.synth_state_dict("mot")
+        self.afe = engine.AfePlan(self.sd, 100, "cpu", hiplib.HipLib(so))
+        self.D = self.afe.D
+
+    def detect_embed(self, images):                     # [batch, ...] -> [batch, K2, D]: deterministic stand-in embeddings
+        out = []
+        for f in images:                                  # per-frame seed: the embedding depends on the frame alone
+            g = torch.Generator().manual_seed(int(f.reshape(-1).sum().abs() * 1000) % 100000)
+            out.append(torch.rand(K2, self.D, generator=g) * 3)
+        return torch.stack(out).contiguous()
+
+    def affinity(self, hist, cur):
+        return self.afe.affinity(hist, cur)[0]
+
+    def affinity_ring(self, ring, g0, Bc, hist):
+        return self.afe.affinity_ring(ring, g0, Bc, hist).clone()
+
+
+K2 = 5
+
+
+def _run_emu(rank, world, batch, nsteps, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _frames(nsteps, world, batch)
+    comp = EmuAffinityCompute()
+    pipe = FramePipeline(comp, batch, K2, comp.D, history=HIST, device="cpu")
+    outs = []
+    for s in range(nsteps):
+        res = pipe.step(frames[s, rank * batch:(rank + 1) * batch])
+        outs.append([None if r is None else r.reshape(-1).tolist() for r in res])
+    q.put((rank, outs))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_real_affinity_kernels():
+    nsteps, world, batch = 3, 2, 2
+    ctx = mp.get_context("spawn")
+
+    def collect(w, b, port):
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_run_emu, args=(r, w, b, nsteps, port, q)) for r in range(w)]
+        for p in ps:
+            p.start()
+        got = dict(q.get(timeout=300) for _ in range(w))
+        for p in ps:
+            p.join(60)
+            assert p.exitcode == 0
+        return got
+    two = collect(world, batch, 29677)
+    one = collect(1, world * batch, 0)[0]
+    for s in range(nsteps):
+        for g in range(world * batch):
+            r, b = divmod(g, batch)
+            a, ref = two[r][s][b], one[s][g]
+            if ref is None:
+                assert a is None
+                continue
+            assert len(a) == len(ref) and max(abs(x - y) for x, y in zip(a, ref)) <= 1e-6, (s, g)
