@@ -53,39 +53,26 @@ class FeatureRecorder:
             delta = pow(decay, gap / 3.0) if gap < m_frame else pow(decay2, gap / 3.0)
             self.all_similarity[frame_index][p] = sim * delta
 
-    # ---- accessors, tracker.py:92-136 ----
-    def get_feature(self, frame_index, detection_index):
-        if frame_index in self.all_frame_index:
-            features = self.all_features[frame_index]
-            if len(features) == 0:
-                return None
-            if detection_index < len(features):
-                return features[detection_index]
-        return None
+    # ---- accessors with the reference's contract (tracker.py:92-136): None for an unknown frame, an empty
+    #      frame or an index past the end ----
+    def _stored(self, table, frame_index):
+        if frame_index not in self.all_frame_index:
+            return None
+        entry = table[frame_index]
+        return entry if len(entry) else None
 
-    def get_box(self, frame_index, detection_index):
-        if frame_index in self.all_frame_index:
-            boxes = self.all_boxes[frame_index]
-            if len(boxes) == 0:
-                return None
-            if detection_index < len(boxes):
-                return boxes[detection_index]
-        return None
+    def _item(self, table, frame_index, k):
+        entry = self._stored(table, frame_index)
+        return entry[k] if entry is not None and k < len(entry) else None
 
     def get_features(self, frame_index):
-        if frame_index in self.all_frame_index:
-            features = self.all_features[frame_index]
-        else:
-            return None
-        if len(features) == 0:
-            return None
-        return features
+        return self._stored(self.all_features, frame_index)
 
     def get_boxes(self, frame_index):
-        if frame_index in self.all_frame_index:
-            boxes = self.all_boxes[frame_index]
-        else:
-            return None
-        if len(boxes) == 0:
-            return None
-        return boxes
+        return self._stored(self.all_boxes, frame_index)
+
+    def get_feature(self, frame_index, detection_index):
+        return self._item(self.all_features, frame_index, detection_index)
+
+    def get_box(self, frame_index, detection_index):
+        return self._item(self.all_boxes, frame_index, detection_index)
