@@ -692,44 +692,52 @@ extern "C" int deft_affinity_finish(const float* h4, int ldh, int C4, const floa
 // ---------------------------------------------------------------------------
 // batched single-step LSTM + 2 Linears   (kalman_filter_lstm.py:9-29, 65-78)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict__ x, float* __restrict__ h, float* __restrict__ c,
-                                                        int nin, int nout,
-                                                        const float* __restrict__ wih_t, const float* __restrict__ whh_t,
-                                                        const float* __restrict__ bias,
-                                                        const float* __restrict__ w1_t, const float* __restrict__ b1,
-                                                        const float* __restrict__ w2_t, const float* __restrict__ b2,
-                                                        float* __restrict__ pred) {
-    __shared__ float xin[32], hin[128], gates[512], hnew[128], o1[64];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    if (tid < nin) xin[tid] = x[(size_t)t * nin + tid];
-    if (tid < 128) hin[tid] = h[(size_t)t * 128 + tid];
-    __syncthreads();
-    float acc = bias[tid];
-    for (int k = 0; k < nin; ++k) acc += wih_t[k * 512 + tid] * xin[k];
-    for (int k = 0; k < 128; ++k) acc += whh_t[k * 512 + tid] * hin[k];
+// One block of 512 threads = one track.  xin [nin] / hin [128] are already in LDS; on return o2 (LDS, nout
+// values) holds the second Linear's output; h, c rows are updated in place.
+struct LstmW {
+    const float *wih_t, *whh_t, *bias, *w1_t, *b1, *w2_t, *b2;
+};
+__device__ __forceinline__ void lstm_block(const float* xin, const float* hin, float* gates, float* hnew, float* o1, float* o2,
+                                           float* __restrict__ hrow, float* __restrict__ crow, int nin, int nout, const LstmW& w) {
+    const int tid = threadIdx.x;
+    float acc = w.bias[tid];
+    for (int k = 0; k < nin; ++k) acc += w.wih_t[k * 512 + tid] * xin[k];
+    for (int k = 0; k < 128; ++k) acc += w.whh_t[k * 512 + tid] * hin[k];
     gates[tid] = acc;
     __syncthreads();
     if (tid < 128) {
         const float ig = sigmoidf_(gates[tid]), fg = sigmoidf_(gates[128 + tid]);
         const float gg = tanhf(gates[256 + tid]), og = sigmoidf_(gates[384 + tid]);
-        const float cn = fg * c[(size_t)t * 128 + tid] + ig * gg;
+        const float cn = fg * crow[tid] + ig * gg;
         const float hn = og * tanhf(cn);
-        c[(size_t)t * 128 + tid] = cn;
-        h[(size_t)t * 128 + tid] = hn;
+        crow[tid] = cn;
+        hrow[tid] = hn;
         hnew[tid] = hn;
     }
     __syncthreads();
     if (tid < 64) {
-        float a = b1[tid];
-        for (int k = 0; k < 128; ++k) a += w1_t[k * 64 + tid] * hnew[k];
+        float a = w.b1[tid];
+        for (int k = 0; k < 128; ++k) a += w.w1_t[k * 64 + tid] * hnew[k];
         o1[tid] = a;
     }
     __syncthreads();
     if (tid < nout) {
-        float a = b2[tid];
-        for (int k = 0; k < 64; ++k) a += w2_t[k * nout + tid] * o1[k];
-        pred[(size_t)t * nout + tid] = a;
+        float a = w.b2[tid];
+        for (int k = 0; k < 64; ++k) a += w.w2_t[k * nout + tid] * o1[k];
+        o2[tid] = a;
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict__ x, float* __restrict__ h, float* __restrict__ c,
+                                                        int nin, int nout, LstmW w, float* __restrict__ pred) {
+    __shared__ float xin[32], hin[128], gates[512], hnew[128], o1[64], o2[64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (tid < nin) xin[tid] = x[(size_t)t * nin + tid];
+    if (tid < 128) hin[tid] = h[(size_t)t * 128 + tid];
+    __syncthreads();
+    lstm_block(xin, hin, gates, hnew, o1, o2, h + (size_t)t * 128, c + (size_t)t * 128, nin, nout, w);
+    if (tid < nout) pred[(size_t)t * nout + tid] = o2[tid];
 }
 
 extern "C" int deft_lstm_step(const float* x, float* h, float* c, int T, int nin, int nout,
@@ -739,7 +747,137 @@ extern "C" int deft_lstm_step(const float* x, float* h, float* c, int T, int nin
     DEFT_CHECK(x && h && c && wih_t && whh_t && bias && w1_t && b1 && w2_t && b2 && pred, -1, "deft_lstm_step: null pointer");
     DEFT_CHECK(nin > 0 && nin <= 32 && nout > 0 && nout <= 64, -2, "deft_lstm_step: nin=%d (<=32) nout=%d (<=64)", nin, nout);
     if (T <= 0) return 0;
-    hipLaunchKernelGGL(lstm_step_kernel, dim3(T), dim3(512), 0, (hipStream_t)stream, x, h, c, nin, nout, wih_t, whh_t, bias, w1_t, b1, w2_t, b2, pred);
+    const LstmW w = {wih_t, whh_t, bias, w1_t, b1, w2_t, b2};
+    hipLaunchKernelGGL(lstm_step_kernel, dim3(T), dim3(512), 0, (hipStream_t)stream, x, h, c, nin, nout, w, pred);
     DEFT_CHECK_LAUNCH("lstm_step");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// fused motion-model update: feature builder + LSTM step + future boxes
+// (tracker.py:408-480 / 482-580, kalman_filter_lstm.py:65-78)
+// ---------------------------------------------------------------------------
+// last [S][DEFT_MOTION_LAST] doubles per track slot: [0] 0 = no previous observation (STrack.first_time), 1 = has one;
+// [1] last_frame_id; 2-D: [2] last_cx [3] last_cy [4] last_w(=tlwh[2]) [5] last_h(=tlwh[3]);
+// 3-D: [2] last_h [3] last_w [4] last_l [5] last_cx [6] last_cy [7] last_cz [8] last_rot_y.
+__global__ __launch_bounds__(512) void motion_step_kernel(const int* __restrict__ slot, const double* __restrict__ box, int dim, int frame_id,
+                                                          float* __restrict__ h, float* __restrict__ c, double* __restrict__ last,
+                                                          int nin, int nout, LstmW w, float* __restrict__ feat, double* __restrict__ pred) {
+    __shared__ float xin[32], hin[128], gates[512], hnew[128], o1[64], o2[64];
+    __shared__ double bx[8];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int s = slot[t];
+    double* L = last + (size_t)s * DEFT_MOTION_LAST;
+    if (tid < dim) bx[tid] = box[(size_t)t * dim + tid];
+    if (tid < 128) hin[tid] = h[(size_t)s * 128 + tid];
+    __syncthreads();
+    if (tid == 0) {
+        // every operation below is the reference's float64 Python arithmetic in the same order; the
+        // features are rounded to float32 once at the end (`.float()`, tracker.py:465 / 569)
+        const bool first = L[0] == 0.0;
+        const double dt = (double)frame_id - L[1];
+        double f[18];
+        if (dim == 4) {
+            const double cx = bx[0] + bx[2] / 2, cy = bx[1] + bx[3] / 2, bw = bx[2], bh = bx[3];
+            f[0] = cx; f[1] = cy;
+            f[2] = first ? 0.0 : (cx - L[2]) / dt; f[3] = first ? 0.0 : (cy - L[3]) / dt;
+            f[4] = bh; f[5] = bw; f[6] = bw / bh;
+            f[7] = first ? 0.0 : bh - L[5]; f[8] = first ? 0.0 : bw - L[4];
+            f[9] = f[2]; f[10] = f[3];
+            L[2] = cx; L[3] = cy; L[4] = bw; L[5] = bh;
+        } else {
+            const double bh = bx[0], bw = bx[1], bl = bx[2], cx = bx[3], cy = bx[4], cz = bx[5], rot = bx[6];
+            f[0] = cx; f[1] = cy; f[2] = cz;
+            f[3] = first ? 0.0 : cx - L[5]; f[4] = first ? 0.0 : cy - L[6]; f[5] = first ? 0.0 : cz - L[7];
+            f[6] = bh; f[7] = bw; f[8] = bl;
+            f[9] = first ? 0.0 : bh - L[2]; f[10] = first ? 0.0 : bw - L[3]; f[11] = first ? 0.0 : bl - L[4];
+            f[12] = first ? 0.0 : (cx - L[5]) / dt; f[13] = first ? 0.0 : (cy - L[6]) / dt; f[14] = first ? 0.0 : (cz - L[7]) / dt;
+            f[15] = rot; f[16] = first ? 0.0 : rot - L[8]; f[17] = first ? 0.0 : (rot - L[8]) / dt;
+            L[2] = bh; L[3] = bw; L[4] = bl; L[5] = cx; L[6] = cy; L[7] = cz; L[8] = rot;
+        }
+        L[0] = 1.0; L[1] = (double)frame_id;
+        for (int k = 0; k < nin; ++k) {
+            xin[k] = (float)f[k];
+            feat[(size_t)t * nin + k] = xin[k];
+        }
+    }
+    __syncthreads();
+    lstm_block(xin, hin, gates, hnew, o1, o2, h + (size_t)s * 128, c + (size_t)s * 128, nin, nout, w);
+    const int nfut = nout / 4;
+    if (tid < nfut) {
+        // numpy in-place `float32 += float64`: the sum is formed in float64 and stored as float32
+        const float* a = o2 + tid * 4;
+        if (dim == 4) {
+            const double cx = bx[0] + bx[2] / 2, cy = bx[1] + bx[3] / 2;
+            const float p0 = (float)((double)a[0] + cx), p1 = (float)((double)a[1] + cy);
+            const float ph = (float)((double)a[2] + bx[3]), pw = (float)((double)a[3] + bx[2]);
+            double* o = pred + ((size_t)t * nfut + tid) * 4;           // xyah: (cx, cy, w/h, h)
+            o[0] = p0; o[1] = p1; o[2] = pw / ph; o[3] = ph;
+        } else {
+            double* o = pred + ((size_t)t * nfut + tid) * 7;           // (h, w, l, x, y, z, rot_y)
+            o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2];
+            o[3] = (float)((double)a[0] + bx[3]); o[4] = (float)((double)a[1] + bx[4]);
+            o[5] = (float)((double)a[2] + bx[5]); o[6] = (float)((double)a[3] + bx[6]);
+        }
+    }
+}
+
+extern "C" int deft_motion_step(const int* slot, const double* box, int T, int dim, int frame_id,
+                                float* h, float* c, double* last, int nin, int nout,
+                                const float* wih_t, const float* whh_t, const float* bias,
+                                const float* w1_t, const float* b1, const float* w2_t, const float* b2,
+                                float* feat, double* pred, void* stream) {
+    DEFT_CHECK(slot && box && h && c && last && wih_t && whh_t && bias && w1_t && b1 && w2_t && b2 && feat && pred, -1,
+               "deft_motion_step: null pointer");
+    DEFT_CHECK((dim == 4 && nin == 11) || (dim == 7 && nin == 18), -2,
+               "deft_motion_step: dim=%d nin=%d (tlwh: 4/11, 3-D box: 7/18)", dim, nin);
+    DEFT_CHECK(nout > 0 && nout <= 64 && nout % 4 == 0, -2, "deft_motion_step: nout=%d (multiple of 4, <= 64)", nout);
+    if (T <= 0) return 0;
+    const LstmW w = {wih_t, whh_t, bias, w1_t, b1, w2_t, b2};
+    hipLaunchKernelGGL(motion_step_kernel, dim3(T), dim3(512), 0, (hipStream_t)stream, slot, box, dim, frame_id, h, c, last, nin, nout, w, feat, pred);
+    DEFT_CHECK_LAUNCH("motion_step");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// track x detection similarity of one frame (tracker.py:219-252, 663-688)
+// ---------------------------------------------------------------------------
+#define TS_MAXNODES 8
+__global__ __launch_bounds__(128) void track_similarity_kernel(const float* __restrict__ sim, int ld, const int* __restrict__ node_row,
+                                                               const float* __restrict__ node_scale, const int* __restrict__ node_cnt,
+                                                               int L, float* __restrict__ out) {
+    const int t = blockIdx.x;
+    const int n = node_cnt[t];
+    for (int j = threadIdx.x; j < ld; j += 128) {
+        float v[TS_MAXNODES];
+#pragma unroll
+        for (int i = 0; i < TS_MAXNODES; ++i)
+            v[i] = i < n ? sim[(size_t)node_row[t * L + i] * ld + j] * node_scale[t * L + i] : INFINITY;
+#pragma unroll
+        for (int a = 0; a < TS_MAXNODES - 1; ++a)
+#pragma unroll
+            for (int b = 0; b < TS_MAXNODES - 1 - a; ++b) {
+                const float lo = fminf(v[b], v[b + 1]), hi = fmaxf(v[b], v[b + 1]);
+                v[b] = lo; v[b + 1] = hi;
+            }
+        // numpy.median: the middle value, or the float32 mean of the two middle values
+        const int k1 = n >> 1, k0 = (n & 1) ? k1 : k1 - 1;
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TS_MAXNODES; ++i) {
+            if (i == k0) m0 = v[i];
+            if (i == k1) m1 = v[i];
+        }
+        out[(size_t)t * ld + j] = n == 0 ? 0.f : (n & 1) ? m1 : (m0 + m1) / 2.f;
+    }
+}
+
+extern "C" int deft_track_similarity(const float* sim, int rows, int Q, const int* node_row, const float* node_scale,
+                                     const int* node_cnt, int T, int L, float* out, void* stream) {
+    DEFT_CHECK(sim && node_row && node_scale && node_cnt && out, -1, "deft_track_similarity: null pointer");
+    DEFT_CHECK(rows > 0 && Q > 0 && L > 0 && L <= TS_MAXNODES, -2, "deft_track_similarity: rows=%d Q=%d L=%d (L <= %d)", rows, Q, L, TS_MAXNODES);
+    if (T <= 0) return 0;
+    hipLaunchKernelGGL(track_similarity_kernel, dim3(T), dim3(128), 0, (hipStream_t)stream, sim, Q + 1, node_row, node_scale, node_cnt, L, out);
+    DEFT_CHECK_LAUNCH("track_similarity");
     return 0;
 }

@@ -777,3 +777,18 @@ class LstmPlan(_Plan):
         self.lib.call("deft_lstm_step", ptr(x), ptr(h), ptr(c), T, self.nin, self.nout, ptr(self.wih_t), ptr(self.whh_t),
                       ptr(self.bias), ptr(self.w1_t), ptr(self.b1), ptr(self.w2_t), ptr(self.b2), ptr(pred), self._stream())
         return pred.view(T, -1, 4)
+
+    def motion_step(self, slot, box, frame_id, h, c, last):
+        """Feature builder + LSTM step + future boxes for the tracks updated in one frame, ONE launch
+        (tracker.py:408-480 / 482-580).  slot int32 [T]; box float64 [T, 4|7]; h, c [S,128] float32 and
+        last [S,9] float64 are the persistent per-track rows (updated in place).  Returns
+        (feat float32 [T,nin], pred float64 [T, nout//4, 4|7])."""
+        T, dim = box.shape
+        assert slot.dtype == torch.int32 and box.dtype == torch.float64 and last.dtype == torch.float64
+        assert slot.is_contiguous() and box.is_contiguous() and h.is_contiguous() and c.is_contiguous() and last.is_contiguous()
+        feat = torch.empty(T, self.nin, dtype=torch.float32, device=self.device)
+        pred = torch.empty(T, self.nout // 4, dim, dtype=torch.float64, device=self.device)
+        self.lib.call("deft_motion_step", ptr(slot), ptr(box), T, dim, int(frame_id), ptr(h), ptr(c), ptr(last), self.nin, self.nout,
+                      ptr(self.wih_t), ptr(self.whh_t), ptr(self.bias), ptr(self.w1_t), ptr(self.b1), ptr(self.w2_t), ptr(self.b2),
+                      ptr(feat), ptr(pred), self._stream())
+        return feat, pred

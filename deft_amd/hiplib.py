@@ -56,8 +56,11 @@ _SIGS = {
     "deft_embed_blend": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp]),
     "deft_affinity_finish": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_float, c_fp] + [C.c_int] * 3 + [c_fp, c_fp]),
     "deft_lstm_step": (C.c_int, [c_fp] * 3 + [C.c_int] * 3 + [c_fp] * 8 + [c_fp]),
+    "deft_motion_step": (C.c_int, [c_fp, c_fp] + [C.c_int] * 3 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp] * 7 + [c_fp, c_fp, c_fp]),
+    "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
+ABI_VERSION = 3
 
 
 class DeftHipError(RuntimeError):
@@ -77,8 +80,8 @@ class HipLib:
             fn.restype = res
             fn.argtypes = args
         v = self.cdll.deft_version()
-        if v != 2:
-            raise DeftHipError("libdeft_hip ABI version %d, expected 2" % v)
+        if v != ABI_VERSION:
+            raise DeftHipError("libdeft_hip ABI version %d, expected %d -- rebuild: python -m deft_amd.build" % (v, ABI_VERSION))
 
     profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1, shape, algorithmic_bytes) per call
 
@@ -134,7 +137,7 @@ def ptr(t):
     """Device (or, under the test emulator, host) address of a tensor; None -> NULL."""
     if t is None:
         return None
-    assert t.dtype in (torch.float32, torch.int32), t.dtype
+    assert t.dtype in (torch.float32, torch.int32, torch.float64), t.dtype
     return C.c_void_p(t.data_ptr())
 
 

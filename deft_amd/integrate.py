@@ -102,6 +102,8 @@ class AfeSeam:
         self.plan = engine.AfePlan(state_dict, max_object, device, _lib(lib))
         self.device = self.plan.device
         self.max_object = max_object
+        self.host_copy = True       # affinity_many also returns the blocks as numpy (the reference's recorder layout)
+        self.last_device = None
 
     def _views(self, FeatureMaps):
         """Accept the 13 maps either as NHWC Views (DeftModel) or as NCHW tensors (reference model)."""
@@ -147,6 +149,9 @@ class AfeSeam:
         """All stored frames against the current one in ONE launch chain -- what
         FeatureRecorder.update's loop (tracker.py:76-90) asks for, without the per-pair D2H."""
         out, starts = self.plan.affinity(hist, cur)
+        self.last_device = (out, starts)          # kept for deft_amd.tracker.get_similarity (no host round trip)
+        if not self.host_copy:
+            return [None] * len(hist)
         y = out.detach().cpu().numpy()
         return [y[starts[f]:starts[f + 1]] for f in range(len(hist))]
 
@@ -155,12 +160,39 @@ class AfeSeam:
 # seam 4: LSTM motion model
 # ---------------------------------------------------------------------------------------------
 class KalmanFilterLSTM(object):
-    """kalman_filter_lstm.py:32-78 `KalmanFilterLSTM`: predict(h0, c0, new_features)."""
+    """kalman_filter_lstm.py:32-102 `KalmanFilterLSTM`: same constructor (`KalmanFilterLSTM(opt)` loads
+    `opt.load_model_traj`; tracker.py:144, 301, 661 build one per Tracker AND one per activated track), same
+    `predict` and `gating_distance`.  Packed weights are cached per (checkpoint, device): the per-track
+    constructions of tracker.py:301 cost nothing."""
 
-    def __init__(self, opt, lstm_state_dict, device="cuda", lib=None):
+    _plans = {}
+
+    def __init__(self, opt, lstm_state_dict=None, device=None, lib=None):
         self.opt = opt
-        self.plan = engine.LstmPlan(lstm_state_dict, device, _lib(lib))
         self.MAX_dis_fut = 4 if opt.dataset == "nuscenes" else 5
+        if device is None:
+            gpus = getattr(opt, "gpus", [0])
+            device = "cuda" if gpus and gpus[0] >= 0 else "cpu"          # kalman_filter_lstm.py:55
+        if lstm_state_dict is not None:
+            self.plan = engine.LstmPlan(lstm_state_dict, device, _lib(lib))
+            return
+        path = getattr(opt, "load_model_traj", "")
+        key = (path, opt.dataset, str(device), id(lib))
+        if key not in KalmanFilterLSTM._plans:
+            KalmanFilterLSTM._plans[key] = engine.LstmPlan(self._load(path, opt.dataset), device, _lib(lib))
+        self.plan = KalmanFilterLSTM._plans[key]
+
+    @staticmethod
+    def _load(path, dataset):
+        """model.py:40-53 for the trajectory checkpoint; with no path the reference keeps a freshly
+        initialised DecoderRNN (kalman_filter_lstm.py:51-52) -- same module construction here."""
+        if path:
+            ck = torch.load(path, map_location="cpu")
+            sd = ck["state_dict"] if "state_dict" in ck else ck
+            return {(k[7:] if k.startswith("module.") and not k.startswith("module_list") else k): v for k, v in sd.items()}
+        nin, nout = (18, 16) if dataset == "nuscenes" else (11, 20)
+        m = nn.ModuleDict({"lstm": nn.LSTM(nin, 128), "out1": nn.Linear(128, 64), "out2": nn.Linear(64, nout)})
+        return {k: v.detach() for k, v in m.state_dict().items()}
 
     def predict(self, h0, c0, new_features):
         """h0, c0 [1,1,128]; new_features [1,1,nin] -> (hn, cn, {1..MAX_dis_fut: float32[4]})."""
@@ -174,6 +206,26 @@ class KalmanFilterLSTM(object):
     def predict_batch(self, h, c, feats):
         """All tracks updated this frame at once: h, c [T,128] in place, feats [T,nin] -> [T,fut,4]."""
         return self.plan.step(feats, h, c)
+
+    def gating_distance(self, mean, covariance, measurements, only_position=False, metric="maha"):
+        """kalman_filter_lstm.py:80-102 (host numpy, float64; called by matching.fuse_motion / fuse_motion_ddd).
+        Kept as written: the "gaussian" metric compares components 3:-1 of the vectors AFTER the
+        only_position slice, so on the 2-D path (matching.py:353-366) the slice is empty and the
+        distance is 0 for every detection; on the 3-D path it is the centre distance."""
+        mean = np.asarray(mean); measurements = np.asarray(measurements)
+        if only_position:
+            mean, covariance = mean[:2], covariance[:2, :2]
+            measurements = measurements[:, :2]
+        if metric == "gaussian":
+            d = measurements[:, 3:-1] - mean[3:-1]
+            return np.sqrt(np.sum(d * d, axis=1))
+        if metric == "maha":
+            import scipy.linalg
+            d = measurements - mean
+            chol = np.linalg.cholesky(covariance)
+            z = scipy.linalg.solve_triangular(chol, d.T, lower=True, check_finite=False, overwrite_b=True)
+            return np.sum(z * z, axis=0)
+        raise ValueError("invalid distance metric")
 
 
 # ---------------------------------------------------------------------------------------------

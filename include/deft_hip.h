@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 2
+#define DEFT_ABI_VERSION 3
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -191,6 +191,33 @@ int deft_lstm_step(const float* x, float* h, float* c, int T, int nin, int nout,
                    const float* wih_t, const float* whh_t, const float* bias,
                    const float* w1_t, const float* b1, const float* w2_t, const float* b2,
                    float* pred, void* stream);
+
+/* The whole per-track motion update of one frame in ONE launch, for the T tracks matched/activated in it:
+ * feature builder + LSTM step + future boxes.  Replaces, per track, STrack.update_lstm_features (tracker.py:408-480;
+ * dim = 4, box = tlwh, nin = 11) or update_lstm_features_ddd (tracker.py:482-580; dim = 7, box = (h,w,l,x,y,z,rot_y),
+ * nin = 18) including its KalmanFilterLSTM.predict call and device->host copy (tracker.py:467, 571).
+ * slot [T]: row of each track in the persistent state arrays h, c [S][128] (float, zero for a new track) and
+ * last [S][DEFT_MOTION_LAST] (double, zero for a new track: [0] = "has a previous observation", [1] = its frame id,
+ * [2..] = the previous box quantities the deltas/velocities are taken against).  box [T][dim] double.
+ * The features are formed in float64 in the reference's order of operations and rounded to float32 once
+ * (bit-identical to the reference's `.float()`); feat [T][nin] returns them.  pred [T][nout/4][dim] double:
+ * 2-D (cx, cy, w/h, h) per future step (float32 values widened, tracker.py:471-480), 3-D (h, w, l, x, y, z, rot_y)
+ * (tracker.py:573-580). */
+#define DEFT_MOTION_LAST 9
+int deft_motion_step(const int* slot, const double* box, int T, int dim, int frame_id,
+                     float* h, float* c, double* last, int nin, int nout,
+                     const float* wih_t, const float* whh_t, const float* bias,
+                     const float* w1_t, const float* b1, const float* w2_t, const float* b2,
+                     float* feat, double* pred, void* stream);
+
+/* Track x detection similarity of one frame without a host round trip of the affinity blocks
+ * (STrack.get_similarity tracker.py:219-252 + Tracker.get_similarity :663-688).  sim [rows][Q+1]: the output of
+ * deft_affinity_finish (all stored frames stacked).  For track t, node_row [T][L] lists its selected nodes (oldest
+ * first) as absolute rows of `sim`, node_scale [T][L] the decay factor of each node's frame (tracker.py:84-90),
+ * node_cnt [T] how many (0..L, L <= 8).  out [T][Q+1] = column-wise numpy.median of the scaled rows (float32; the
+ * mean of the two middle values for an even count), a zero row for a track without nodes. */
+int deft_track_similarity(const float* sim, int rows, int Q, const int* node_row, const float* node_scale,
+                          const int* node_cnt, int T, int L, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -306,3 +306,75 @@ def lstm_predict(h0, c0, x, lsd):
     h = torch.sigmoid(o) * torch.tanh(c)
     y = (h @ lsd["out1.weight"].t() + lsd["out1.bias"]) @ lsd["out2.weight"].t() + lsd["out2.bias"]
     return h, c, y.view(x.shape[0], -1, 4)
+
+
+class MotionTrack:
+    """One track's motion-model state: STrack.update_lstm_features (tracker.py:408-480, 2-D, box = tlwh) and
+    STrack.update_lstm_features_ddd (tracker.py:482-580, 3-D, box = (h, w, l, x, y, z, rot_y)).  Python-float
+    (float64) feature arithmetic, `.float()` once, lstm_predict, then the in-place numpy post-processing of the
+    predictions (float32 arrays `+=` float64 scalars: summed in float64, stored as float32)."""
+
+    def __init__(self, lsd, ddd=False):
+        self.lsd, self.ddd = lsd, ddd
+        self.h = torch.zeros(1, 128); self.c = torch.zeros(1, 128)
+        self.prev = None                 # (frame_id, quantities of the previous observation)
+        self.features = None
+
+    def update(self, box, frame_id):
+        b = [float(v) for v in np.asarray(box, dtype=np.float64)]
+        if not self.ddd:
+            cx, cy, w, h = b[0] + b[2] / 2, b[1] + b[3] / 2, b[2], b[3]
+            if self.prev is None:
+                dcx = dcy = dh = dw = 0.0
+            else:
+                f0, pcx, pcy, pw, ph = self.prev
+                dcx, dcy = (cx - pcx) / (frame_id - f0), (cy - pcy) / (frame_id - f0)
+                dh, dw = h - ph, w - pw
+            self.prev = (frame_id, cx, cy, w, h)
+            feats = [cx, cy, dcx, dcy, h, w, w / h, dh, dw, dcx, dcy]                    # tracker.py:448-462
+        else:
+            h, w, l, cx, cy, cz, rot = b
+            if self.prev is None:
+                d = [0.0] * 7; v = [0.0] * 4
+            else:
+                f0, ph, pw, pl, px, py, pz, prot = self.prev
+                d = [cx - px, cy - py, cz - pz, h - ph, w - pw, l - pl, rot - prot]
+                v = [(cx - px) / (frame_id - f0), (cy - py) / (frame_id - f0), (cz - pz) / (frame_id - f0),
+                     (rot - prot) / (frame_id - f0)]
+            self.prev = (frame_id, h, w, l, cx, cy, cz, rot)
+            feats = [cx, cy, cz, d[0], d[1], d[2], h, w, l, d[3], d[4], d[5], v[0], v[1], v[2], rot, d[6], v[3]]   # :544-566
+        x = torch.from_numpy(np.array([feats])).float()
+        self.features = x[0].numpy().copy()
+        self.h, self.c, pred = lstm_predict(self.h, self.c, x, self.lsd)
+        pred = pred[0].numpy().copy()                   # float32 [nfut, 4]
+        out = {}
+        for i in range(pred.shape[0]):
+            p = pred[i]
+            if not self.ddd:                            # tracker.py:471-480 -> (cx, cy, w/h, h)
+                p[:2] += np.array([cx, cy]); p[2] += np.float64(h); p[3] += np.float64(w)      # float64 sums, float32 stores
+                ph_, pw_ = p[2], p[3]
+                p[3] = ph_; p[2] = pw_
+                p[2] /= p[3]
+                out[1 + i] = p
+            else:                                       # tracker.py:573-580 -> (h, w, l, x, y, z, rot_y) float64
+                p[:3] += np.array([cx, cy, cz]); p[3] += np.float64(rot)
+                out[1 + i] = np.array([h, w, l] + p.tolist())
+        return out
+
+
+def track_similarity(sim_frame, tracks_nodes, frame_index, num_detections, dataset, max_track_node=50):
+    """Tracker.get_similarity (tracker.py:663-688) with STrack.get_similarity (:219-252) for every track.
+    sim_frame: {previous frame -> float32 [P, Q+1]} (= recorder.all_similarity[frame_index], decay applied);
+    tracks_nodes: per track its nodes [(frame_index, id), ...] oldest first.  -> float64 [T, Q+1]."""
+    mm = 2 if dataset == "nuscenes" else 4
+    rows_out = []
+    for nodes in tracks_nodes:
+        rows = [sim_frame[f][i, :] for f, i in nodes if frame_index - f < max_track_node]
+        if not rows:
+            rows_out.append([0.0] * (num_detections + 1))
+            continue
+        a = np.array(rows)
+        if a.shape[0] > mm + 1:
+            a = a[a.shape[0] - mm:]
+        rows_out.append(np.median(a, axis=0).tolist())
+    return np.array(rows_out)

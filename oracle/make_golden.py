@@ -185,14 +185,134 @@ def run_convert_detection():
     np.savez_compressed(os.path.join(GOLD, "convert_detection.npz"), boxes=boxes, centers=ref.numpy())
 
 
+def _tracker_module():
+    """utils/tracker.py parses sys.argv at import (tracker.py:139) and needs lap/cython_bbox/numba stand-ins."""
+    sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+    import ref_shims
+    ref_shims.install()
+    ref_import.install_stubs(OracleDCN)
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        from opts import opts
+        from utils import tracker as RT
+    finally:
+        sys.argv = argv
+    return RT, opts
+
+
+def run_motion(dataset):
+    """STrack.update_lstm_features / _ddd (tracker.py:408-580) of the reference, driven directly on one track:
+    features (captured at the predict call), LSTM state and future_predictions per step."""
+    RT, opts = _tracker_module()
+    opt = opts().parse(["tracking" if dataset != "nuscenes" else "tracking,ddd", "--dataset", dataset, "--gpus", "-1"])
+    opt.lstm = True
+    lsd = O.synth_lstm_state_dict(dataset)
+    kf = RT.KalmanFilterLSTM(opt)
+    kf.model.load_state_dict(lsd, strict=True)
+    kf.model.eval()
+    seen = []
+    real_predict = kf.predict
+
+    def spy(h0, c0, new_features):
+        seen.append(new_features.reshape(-1).numpy().copy())
+        return real_predict(h0, c0, new_features)
+    kf.predict = spy
+    RT.STrack.shared_kalman_lstm = kf
+    ddd = dataset == "nuscenes"
+    g = np.random.RandomState(11 + ddd)
+    frames = [1, 2, 3, 5, 6, 9, 10]                      # gaps: the velocities divide by the frame distance
+    if ddd:
+        boxes = np.cumsum(g.randn(len(frames), 7) * 0.3, 0) + np.array([1.6, 1.9, 4.5, 3.0, 1.2, 25.0, 0.4])
+    else:
+        boxes = np.cumsum(g.randn(len(frames), 4) * 3.0, 0) + np.array([300.0, 180.0, 42.0, 110.0])
+    trk = RT.STrack(np.array([0.0, 0.0, 1.0, 1.0]), 0.9, RT.Node(1, 0), 30, use_lstm=True, opt=opt,
+                    ddd_bbox=boxes[0] if ddd else None, depth=1.0)
+    mo = O.MotionTrack(lsd, ddd)
+    fix = {"frames": np.array(frames), "boxes": boxes}
+    with torch.no_grad():
+        for s, (f, b) in enumerate(zip(frames, boxes)):
+            trk.frame_id = f
+            if ddd:
+                trk.update_lstm_features_ddd(b.copy())
+            else:
+                trk.update_lstm_features(b.copy())
+            ora = mo.update(b, f)
+            ref_fut = np.stack([np.asarray(trk.future_predictions[k]) for k in sorted(trk.future_predictions)])
+            ora_fut = np.stack([np.asarray(ora[k]) for k in sorted(ora)])
+            assert np.array_equal(seen[-1], mo.features), "motion features must be bit-identical"
+            d = max(maxabs(trk.hn.reshape(-1), mo.h.reshape(-1)), float(np.abs(ref_fut - ora_fut).max() / max(1.0, np.abs(ref_fut).max())))
+            print("  motion[%s] step %d frame %d maxabs %.3e" % (dataset, s, f, d))
+            assert d <= 2e-6 and ref_fut.dtype == ora_fut.dtype
+            fix["feat%d" % s] = seen[-1]; fix["fut%d" % s] = ref_fut
+            fix["h%d" % s] = trk.hn.reshape(-1).numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "motion_%s.npz" % dataset), **fix)
+
+
+def run_track_similarity():
+    """Tracker.get_similarity (tracker.py:663-688) of the reference on hand-built recorder contents: tracks with
+    0, 1, 2, 4, 5, 6 and 9 nodes (all three branches of STrack.get_similarity), a node older than
+    max_track_node, both decay branches."""
+    RT, _ = _tracker_module()
+    g = np.random.RandomState(5)
+    frame, ndet = 60, 7
+    prev = [8, 52, 54, 55, 56, 57, 58, 59]
+    counts = {8: 3, 52: 4, 54: 6, 55: 5, 56: 6, 57: 4, 58: 6, 59: 5}
+    sim = {}
+    for p in prev:
+        gap = frame - p
+        delta = pow(RT.decay, gap / 3.0) if gap < 10 else pow(RT.decay2, gap / 3.0)
+        sim[p] = g.rand(counts[p], ndet + 1).astype(np.float32) * delta
+    tracks_nodes = [
+        [],
+        [(59, 1)],
+        [(8, 2)],                                           # only node is >= max_track_node frames old -> zero row
+        [(57, 0), (59, 4)],
+        [(8, 0), (55, 1), (56, 2), (58, 3), (59, 0)],       # old node dropped -> 4 rows
+        [(54, 5), (55, 4), (56, 5), (57, 3), (58, 5)],      # mm+1 rows: all used
+        [(52, 1), (54, 0), (55, 0), (56, 0), (58, 0), (59, 2)],             # > mm+1: last 4
+        [(52, 3), (54, 1), (54, 2), (55, 2), (56, 1), (57, 1), (57, 2), (58, 1), (59, 3)],
+    ]
+
+    class Rec:
+        all_similarity = {frame: sim}
+
+    class Self:
+        recorder = Rec()
+    pool = []
+    for nodes in tracks_nodes:
+        t = RT.STrack.__new__(RT.STrack)
+        t.nodes = [RT.Node(f, i) for f, i in nodes]
+        t.dataset = "mot"
+        pool.append(t)
+    fix = {"frame": frame, "ndet": ndet, "prev": np.array(prev)}
+    for p in prev:
+        fix["sim_%d" % p] = sim[p]
+    fix["nodes"] = np.array([(t, f, i) for t, nodes in enumerate(tracks_nodes) for f, i in nodes])
+    for ds in ("mot", "nuscenes"):
+        for t in pool:
+            t.dataset = ds
+        ref = RT.Tracker.get_similarity(Self(), frame, pool, ndet)
+        ora = O.track_similarity(sim, tracks_nodes, frame, ndet, ds)
+        assert ref.dtype == ora.dtype and np.array_equal(ref, ora), "track similarity must be bit-identical"
+        fix["out_" + ds] = ref
+    for t in pool:
+        t.nodes = []                                         # STrack.__del__ walks .nodes
+    np.savez_compressed(os.path.join(GOLD, "track_similarity.npz"), **fix)
+    print("  track similarity: %d tracks, oracle == reference" % len(pool))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    run("mot", 128, 160, "mot_128x160")
-    run("mot", 224, 384, "mot_224x384")
-    run("nuscenes", 96, 128, "nuscenes_96x128")
-    run("kitti_tracking", 96, 320, "kitti_96x320")          # BASELINE config D aspect (1280x384), 3 classes
-    run_lstm("mot")
-    run_lstm("nuscenes")
-    run_convert_detection()
+    if "--only-tracker" not in sys.argv:                         # the forward fixtures take a few minutes
+        run("mot", 128, 160, "mot_128x160")
+        run("mot", 224, 384, "mot_224x384")
+        run("nuscenes", 96, 128, "nuscenes_96x128")
+        run("kitti_tracking", 96, 320, "kitti_96x320")          # BASELINE config D aspect (1280x384), 3 classes
+        run_lstm("mot")
+        run_lstm("nuscenes")
+        run_convert_detection()
+    run_motion("mot")
+    run_motion("nuscenes")
+    run_track_similarity()
     print("golden fixtures written to", os.path.abspath(GOLD))

@@ -552,3 +552,103 @@ def check_seam_lstm(lib, device, dataset="mot"):
         assert sorted(pred) == list(range(1, kf.MAX_dis_fut + 1))
         got = np.stack([pred[i + 1] for i in range(kf.MAX_dis_fut)])
         assert np.abs(got - gold["p%d" % s_][0]).max() <= 1e-5 and maxabs(h.view(-1), torch.from_numpy(gold["h%d" % s_][0])) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# a8 / a9 host mirrors in deft_amd/tracker.py
+# ---------------------------------------------------------------------------------------
+class _Node:
+    def __init__(self, frame_index, id):
+        self.frame_index, self.id = frame_index, id
+
+
+def _similarity_harness(lib, device, sim_blocks, deltas, dataset):
+    """A `self` for deft_amd.tracker.get_similarity: recorder._dev as FeatureRecorder.update leaves it."""
+    from types import SimpleNamespace
+    from deft_amd import engine
+    prev = sorted(sim_blocks)
+    starts = [0]
+    for p in prev:
+        starts.append(starts[-1] + sim_blocks[p].shape[0])
+    dev = torch.device(device)
+    out = torch.from_numpy(np.concatenate([sim_blocks[p] for p in prev], 0)).to(dev)
+    index = {p: (k, np.float32(deltas[p])) for k, p in enumerate(prev)}
+    plan = engine._Plan(device, lib)
+    return SimpleNamespace(recorder=SimpleNamespace(_dev=None, _pack=(out, starts, index)), dataset=dataset,
+                           model=SimpleNamespace(AFE=SimpleNamespace(plan=plan)))
+
+
+def check_track_similarity(lib, device):
+    from deft_amd import tracker as DT
+    gold = np.load(os.path.join(GOLD, "track_similarity.npz"))
+    frame, ndet = int(gold["frame"]), int(gold["ndet"])
+    prev = [int(p) for p in gold["prev"]]
+    ntr = gold["out_mot"].shape[0]                                # track 0 has no nodes
+    tracks_nodes = [[(int(f), int(i)) for t, f, i in gold["nodes"] if t == k] for k in range(ntr)]
+    pool = [SimpleNamespaceNodes(nodes) for nodes in tracks_nodes]
+    # 1. golden: the reference's Tracker.get_similarity outputs on the (already decayed) blocks, delta = 1
+    blocks = {p: gold["sim_%d" % p] for p in prev}
+    for ds in ("mot", "nuscenes"):
+        me = _similarity_harness(lib, device, blocks, {p: 1.0 for p in prev}, ds)
+        me.recorder._dev = (frame,) + me.recorder._pack
+        got = DT.get_similarity(me, frame, pool, ndet)
+        assert got.dtype == np.float64 and np.array_equal(got, gold["out_" + ds]), ds
+    # 2. decay applied on the device: raw blocks + float32(delta) must equal numpy's `block * delta`
+    g = np.random.RandomState(9)
+    raw = {p: g.rand(*blocks[p].shape).astype(np.float32) for p in prev}
+    deltas = {p: (1.0 if frame - p < 10 else pow(0.01, (frame - p) / 3.0)) for p in prev}
+    deltas[59] = 0.3                                              # a factor that is not exactly representable
+    me = _similarity_harness(lib, device, raw, deltas, "mot")
+    me.recorder._dev = (frame,) + me.recorder._pack
+    got = DT.get_similarity(me, frame, pool, ndet)
+    want = O.track_similarity({p: raw[p] * deltas[p] for p in prev}, tracks_nodes, frame, ndet, "mot")
+    assert np.array_equal(got, want)
+    assert DT.get_similarity(me, frame, [], ndet).shape == (0,)   # tracker.py:684-686
+
+
+class SimpleNamespaceNodes:
+    def __init__(self, nodes):
+        self.nodes = [_Node(f, i) for f, i in nodes]
+
+
+def check_motion(lib, device, dataset="mot"):
+    """deft_motion_step through MotionBank: (1) the reference STrack's own features / future boxes (golden),
+    (2) several tracks with different histories in one launch against the per-track oracle."""
+    from deft_amd import engine, tracker as DT
+    lsd = O.synth_lstm_state_dict(dataset)
+    ddd = dataset == "nuscenes"
+    gold = np.load(os.path.join(GOLD, "motion_%s.npz" % dataset))
+    bank = DT.MotionBank(engine.LstmPlan(lsd, device, lib), capacity=2)
+    s0 = bank.alloc()
+    for k, (f, b) in enumerate(zip(gold["frames"], gold["boxes"])):
+        feat, fut = bank.step([s0], b[None], int(f))
+        assert np.array_equal(feat[0], gold["feat%d" % k]), ("features must be bit-identical", k)
+        ref = gold["fut%d" % k]
+        assert np.abs(fut[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+        if not ddd:
+            assert np.array_equal(fut[0].astype(np.float32).astype(np.float64), fut[0])      # float32 values, widened
+        assert maxabs(bank.h[s0].cpu(), torch.from_numpy(gold["h%d" % k])) <= 1e-5
+    # several tracks, staggered births, gaps, a freed and re-used slot, capacity growth
+    g = np.random.RandomState(3)
+    dim = 7 if ddd else 4
+    base = np.array([1.6, 1.9, 4.5, 3.0, 1.2, 25.0, 0.4]) if ddd else np.array([300.0, 180.0, 42.0, 110.0])
+    tracks = {}
+    for frame in range(1, 9):
+        if frame in (1, 2, 4):
+            for _ in range(2):
+                tracks[len(tracks)] = {"slot": bank.alloc(), "ora": O.MotionTrack(lsd, ddd), "box": base + g.randn(dim) * (0.2 if ddd else 20)}
+        live = [k for k in tracks if (k + frame) % 4 != 0 and "dead" not in tracks[k]]          # each track skips some frames
+        for k in live:
+            tracks[k]["box"] = tracks[k]["box"] + g.randn(dim) * (0.1 if ddd else 2.0)
+        feat, fut = bank.step([tracks[k]["slot"] for k in live], np.stack([tracks[k]["box"] for k in live]), frame)
+        for j, k in enumerate(live):
+            want = tracks[k]["ora"].update(tracks[k]["box"], frame)
+            assert np.array_equal(feat[j], tracks[k]["ora"].features), (frame, k)
+            w = np.stack([np.asarray(want[i], dtype=np.float64) for i in sorted(want)])
+            assert np.abs(fut[j] - w).max() <= 1e-5 * max(1.0, np.abs(w).max()), (frame, k)
+        if frame == 5:                                            # track 0 dies; its slot goes to the next new track
+            tracks[0]["dead"] = True
+            bank.free(tracks[0]["slot"])
+            tracks[len(tracks)] = {"slot": bank.alloc(), "ora": O.MotionTrack(lsd, ddd), "box": base.copy()}
+            assert tracks[len(tracks) - 1]["slot"] == tracks[0]["slot"]
+    assert bank.h.shape[0] >= 6

@@ -112,3 +112,12 @@ def test_seam_lstm(emu_lib):
 @pytest.mark.slow
 def test_seam_model_afe_decode(emu_lib):
     pc.check_seam_model(emu_lib, "cpu", "mot", 32, 64)
+
+
+def test_track_similarity(emu_lib):
+    pc.check_track_similarity(emu_lib, "cpu")
+
+
+@pytest.mark.parametrize("dataset", ["mot", "nuscenes"])
+def test_motion_step(emu_lib, dataset):
+    pc.check_motion(emu_lib, "cpu", dataset)

@@ -89,6 +89,15 @@ def test_lstm(gpu_lib, dataset):
     pc.check_lstm(gpu_lib, "cuda", dataset)
 
 
+@pytest.mark.parametrize("dataset", ["mot", "nuscenes"])
+def test_motion_step(gpu_lib, dataset):
+    pc.check_motion(gpu_lib, "cuda", dataset)
+
+
+def test_track_similarity(gpu_lib):
+    pc.check_track_similarity(gpu_lib, "cuda")
+
+
 @pytest.mark.parametrize("tag,dataset,H,W", [("mot_128x160", "mot", 128, 160), ("mot_224x384", "mot", 224, 384),
                                               ("nuscenes_96x128", "nuscenes", 96, 128),
                                               ("kitti_96x320", "kitti_tracking", 96, 320)])

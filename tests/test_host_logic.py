@@ -1,0 +1,82 @@
+"""-m "not gpu": host-side logic of the seam objects that needs no reference checkout: the motion-model
+seam's constructor/caching and `gating_distance` (kalman_filter_lstm.py:80-102), node selection of the track
+similarity (tracker.py:219-252), slot management of the motion bank."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from deft_amd import integrate, tracker as DT
+
+
+def _opt(dataset="mot"):
+    return SimpleNamespace(dataset=dataset, load_model_traj="", gpus=[-1])
+
+
+def test_kalman_lstm_seam_constructs_like_the_reference(emu_lib, tmp_path):
+    """`KalmanFilterLSTM(opt)` (tracker.py:144, 301, 661): no state dict argument; weights from
+    opt.load_model_traj ("module." prefixes stripped, model.py:49-53) or a fresh DecoderRNN; the packed
+    plan is shared between instances."""
+    a = integrate.KalmanFilterLSTM(_opt(), lib=emu_lib)
+    b = integrate.KalmanFilterLSTM(_opt(), lib=emu_lib)
+    assert a.plan is b.plan and a.MAX_dis_fut == 5 and a.plan.nin == 11 and a.plan.nout == 20
+    n = integrate.KalmanFilterLSTM(_opt("nuscenes"), lib=emu_lib)
+    assert n.MAX_dis_fut == 4 and n.plan.nin == 18 and n.plan.nout == 16 and n.plan is not a.plan
+    import deft_oracle as O
+    lsd = O.synth_lstm_state_dict("mot")
+    path = str(tmp_path / "traj.pth")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in lsd.items()}}, path)
+    o = _opt(); o.load_model_traj = path
+    k = integrate.KalmanFilterLSTM(o, lib=emu_lib)
+    x = torch.randn(1, 1, 11, generator=torch.Generator().manual_seed(0))
+    h, c, pred = k.predict(torch.zeros(1, 1, 128), torch.zeros(1, 1, 128), x)
+    ho, co, po = O.lstm_predict(torch.zeros(1, 128), torch.zeros(1, 128), x[0], lsd)
+    assert (h.view(-1) - ho.view(-1)).abs().max() <= 1e-5 and sorted(pred) == [1, 2, 3, 4, 5]
+    assert np.abs(np.stack([pred[i] for i in range(1, 6)]) - po[0].numpy()).max() <= 1e-5
+
+
+def test_gating_distance():
+    k = integrate.KalmanFilterLSTM.__new__(integrate.KalmanFilterLSTM)      # host-only method
+    mean = np.array([10.0, 20.0, 0.5, 40.0])
+    cov = np.diag([4.0, 9.0, 1.0, 1.0])
+    meas = np.array([[12.0, 23.0, 0.5, 41.0], [10.0, 20.0, 0.7, 40.0]])
+    d = k.gating_distance(mean, cov, meas, only_position=True, metric="maha")
+    assert np.allclose(d, [(2 / 2) ** 2 + (3 / 3) ** 2, 0.0])
+    d4 = k.gating_distance(mean, cov, meas, only_position=False, metric="maha")
+    assert np.allclose(d4, [1 + 1 + 0 + 1, 0.04])
+    # the reference's "gaussian" metric on the 2-D path looks at an empty slice: distance 0 for everything
+    assert np.array_equal(k.gating_distance(mean, cov, meas, only_position=True, metric="gaussian"), [0.0, 0.0])
+    # 3-D (7 components): centre distance over components 3..5
+    m7 = np.array([1.5, 1.8, 4.0, 2.0, 1.0, 30.0, 0.1])
+    z7 = np.array([[1.4, 1.7, 4.2, 5.0, 1.0, 34.0, 0.3]])
+    assert np.allclose(k.gating_distance(m7, np.eye(7), z7, only_position=False, metric="gaussian"), [5.0])
+    with pytest.raises(ValueError):
+        k.gating_distance(mean, cov, meas, metric="euclid")
+
+
+def test_select_nodes():
+    N = lambda f: SimpleNamespace(frame_index=f, id=0)
+    nodes = [N(f) for f in (1, 40, 50, 55, 56, 57, 58)]
+    pick = lambda fr, ds: [n.frame_index for n in DT.select_nodes(nodes, fr, ds)]
+    assert pick(59, "mot") == [55, 56, 57, 58]                 # 7 usable > mm+1 -> last mm = 4
+    assert pick(59, "nuscenes") == [57, 58]
+    assert pick(59, "mot") == pick(59, "kitti_tracking")
+    assert [n.frame_index for n in DT.select_nodes(nodes[:5], 59, "mot")] == [40, 50, 55, 56]    # frame 1 is 58 frames old -> dropped
+    assert [n.frame_index for n in DT.select_nodes(nodes[1:6], 59, "mot")] == [40, 50, 55, 56, 57]   # mm+1 rows: all
+    assert DT.select_nodes(nodes[:1], 59, "mot") == []
+
+
+def test_motion_bank_slots(emu_lib):
+    import deft_oracle as O
+    from deft_amd import engine
+    bank = DT.MotionBank(engine.LstmPlan(O.synth_lstm_state_dict("mot"), "cpu", emu_lib), capacity=2)
+    s = [bank.alloc() for _ in range(5)]
+    assert sorted(s) == [0, 1, 2, 3, 4] and bank.h.shape[0] == 8
+    bank.step(s[:2], np.array([[10.0, 10, 5, 9], [50.0, 20, 6, 12]]), 1)
+    assert float(bank.last[s[0], 0]) == 1.0 and float(bank.last[s[0], 1]) == 1.0
+    bank.free(s[0])
+    again = bank.alloc()
+    assert again == s[0] and float(bank.last[again].abs().sum()) == 0.0 and float(bank.h[again].abs().sum()) == 0.0
+    with pytest.raises(AssertionError):
+        bank.step([s[1], s[1]], np.zeros((2, 4)) + 5.0, 2)       # one row per track and launch

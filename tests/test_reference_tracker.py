@@ -130,3 +130,106 @@ def test_feature_recorder_mirror_matches_reference(emu_lib):
     finally:
         torch.set_grad_enabled(True)
         sys.modules.pop("dcn_v2", None)
+
+
+def _moving_boxes(t, n=5):
+    """n well separated boxes drifting a few px per frame (tlbr + score), input-pixel units."""
+    out = []
+    for i in range(n):
+        x0 = 6.0 + 11.0 * i + 0.8 * t * (1 if i % 2 else -0.5)
+        y0 = 4.0 + 2.0 * i + 0.5 * t
+        w, h = 7.0 + 0.3 * i + 0.1 * t, 12.0 + 0.5 * i
+        out.append({"score": 0.9 - 0.05 * i, "class": 1, "bbox": np.array([x0, y0, x0 + w, y0 + h], np.float32)})
+    return out
+
+
+def test_reference_tracker_with_lstm_seam(emu_lib):
+    """Seam 4 under the reference's real call pattern: the reference Tracker with `opt.lstm` on (the 2-D
+    builder, tracker.py:408-480) runs once with its own KalmanFilterLSTM and once with
+    deft_amd.integrate.KalmanFilterLSTM bound to the same name (tracker.py:144, 301, 661 construct it as
+    `KalmanFilterLSTM(opt)`; matching.fuse_motion calls `.gating_distance`).  Same detections and
+    FeatureMaps on both sides; tracks, LSTM states and future predictions must agree."""
+    import deft_oracle as O
+    import make_golden as MG
+    import ref_import
+    import ref_shims
+    from deft_amd import integrate
+    ref_shims.install()
+    ref_import.install_stubs(MG.OracleDCN)
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        from opts import opts
+        from utils import tracker as RT
+        from utils.basetrack import BaseTrack
+    finally:
+        sys.argv = argv
+    opt = opts().parse(["tracking", "--dataset", "mot", "--gpus", "-1"])
+    opt.lstm = True                                            # opts.py:478 turns it off for 2-D datasets; the code path exists
+    torch.set_grad_enabled(False)
+    ref_cls = RT.KalmanFilterLSTM
+    try:
+        sd = O.synth_state_dict("mot")
+        lsd = O.synth_lstm_state_dict("mot")
+
+        class M:
+            AFE = integrate.AfeSeam(sd, opt.max_object, "cpu", emu_lib)
+        H, W, T = 32, 64, 6
+        chans = [16, 32, 64, 128, 256, 512, 64, 128, 256, 512, 64, 64, 64]
+        strides = [1, 2, 4, 8, 16, 32, 4, 8, 16, 32, 4, 4, 4]
+        g = torch.Generator().manual_seed(77)
+        fmaps = [torch.randn(1, c, H // s, W // s, generator=g) for c, s in zip(chans, strides)]
+
+        def make_ref(o):
+            k = ref_cls(o)
+            k.model.load_state_dict(lsd, strict=True)
+            k.model.eval()
+            return k
+
+        def run(factory):
+            RT.KalmanFilterLSTM = factory
+            RT.STrack.shared_kalman_lstm = factory(opt)
+            BaseTrack._count = 0
+            trk = RT.Tracker(opt, M, h=H, w=W)
+            assert trk.use_lstm
+            log = []
+            for t in range(T):
+                dets = _moving_boxes(t)
+                if t == 3:
+                    dets = dets[:3]                            # two tracks go unmatched for a frame, then come back
+                targets = trk.update(dets, fmaps)
+                log.append(sorted((s.track_id, s.tracklet_len, s.tlwh.tolist(), s.hn.reshape(-1).tolist(),
+                                   {k: v.tolist() for k, v in s.future_predictions.items()}) for s in targets))
+            return log
+
+        ref = run(make_ref)
+        got = run(lambda o: integrate.KalmanFilterLSTM(o, lsd, device="cpu", lib=emu_lib))
+        assert max(s[1] for s in ref[-1]) >= 2, "tracks must have been updated (non-first-time feature path)"
+
+        # the per-frame forms: recorder mirror + device-side Tracker.get_similarity + ONE motion launch per frame
+        from deft_amd import tracker as DT
+        bank = DT.MotionBank(integrate.KalmanFilterLSTM(opt, lsd, device="cpu", lib=emu_lib))
+        undo = DT.install_batched_motion(RT.STrack, bank)
+        ref_get, ref_rec = RT.Tracker.get_similarity, RT.FeatureRecorder
+        RT.Tracker.get_similarity = DT.get_similarity
+        RT.FeatureRecorder = DT.FeatureRecorder                   # Tracker.__init__ (tracker.py:651) builds it by this name
+        try:
+            batched = run(lambda o: integrate.KalmanFilterLSTM(o, lsd, device="cpu", lib=emu_lib))
+        finally:
+            undo()
+            RT.Tracker.get_similarity, RT.FeatureRecorder = ref_get, ref_rec
+        assert bank.launches <= T, "one motion launch per frame, not one per track"
+        assert "future_predictions" not in RT.STrack.__dict__
+
+        for fa, fb in list(zip(ref, got)) + list(zip(ref, batched)):
+            assert [(a[0], a[1]) for a in fa] == [(b[0], b[1]) for b in fb]
+            for a, b in zip(fa, fb):
+                assert np.abs(np.array(a[2]) - np.array(b[2])).max() <= 1e-4
+                if len(b[3]) == len(a[3]) and any(b[3]):          # the batched form keeps (h, c) in the bank, not on the track
+                    assert np.abs(np.array(a[3]) - np.array(b[3])).max() <= 1e-5
+                assert sorted(a[4]) == sorted(b[4])
+                for k in a[4]:
+                    assert np.abs(np.array(a[4][k]) - np.array(b[4][k])).max() <= 1e-3 * max(1.0, np.abs(a[4][k]).max())
+    finally:
+        RT.KalmanFilterLSTM = ref_cls
+        torch.set_grad_enabled(True)
+        sys.modules.pop("dcn_v2", None)
