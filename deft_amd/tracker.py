@@ -251,3 +251,25 @@ def install_batched_motion(STrack, bank):
             else:
                 setattr(STrack, k, v)
     return undo
+
+
+def accelerate(tracker_module, kf=None):
+    """One call that binds every per-frame form in this package to the reference's `utils.tracker` module
+    (pass the imported module): FeatureRecorder mirror, device-side `Tracker.get_similarity`, vectorised
+    `matching.fuse_motion(_ddd)` / `linear_assignment` / IoU, and -- when a motion model `kf`
+    (deft_amd.integrate.KalmanFilterLSTM) is given, i.e. `opt.lstm` -- the batched motion update.  The track
+    state machine (`Tracker.update`, `STrack`) stays the reference's.  Returns undo()."""
+    from . import association
+    RT = tracker_module
+    saved = (RT.Tracker.get_similarity, RT.FeatureRecorder)
+    RT.Tracker.get_similarity = get_similarity
+    RT.FeatureRecorder = FeatureRecorder
+    undos = [association.bind(RT.matching)]
+    if kf is not None:
+        undos.append(install_batched_motion(RT.STrack, MotionBank(kf)))
+
+    def undo():
+        for u in undos:
+            u()
+        RT.Tracker.get_similarity, RT.FeatureRecorder = saved
+    return undo

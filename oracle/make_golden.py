@@ -301,6 +301,57 @@ def run_track_similarity():
     print("  track similarity: %d tracks, oracle == reference" % len(pool))
 
 
+def run_association():
+    """matching.fuse_motion / fuse_motion_ddd (matching.py:311-415) of the reference with the reference's own
+    KalmanFilter / KalmanFilterLSTM.gating_distance, on mock tracks: inputs and outputs as fixtures for
+    deft_amd.association (vectorised).  linear_assignment/ious go through third-party packages that are absent
+    here (lap, cython_bbox): unpinned, checked against brute force in tests/test_association.py."""
+    RT, opts = _tracker_module()
+    from types import SimpleNamespace
+    from utils import matching
+    from utils.tracking_utils.kalman_filter import KalmanFilter
+    opt = opts().parse(["tracking", "--dataset", "mot", "--gpus", "-1"])
+    g = np.random.RandomState(17)
+    T, N = 7, 9
+    det_tlwh = np.abs(g.randn(N, 4)) * np.array([300, 150, 20, 40]) + np.array([50, 30, 15, 30])
+    dets = [SimpleNamespace(to_xyah=(lambda b=b: RT.STrack.tlwh_to_xyah(b))) for b in det_tlwh]
+    fix = {"det_tlwh": det_tlwh}
+
+    def spd(n):
+        a = g.randn(n, n)
+        return a @ a.T + n * np.eye(n)
+    # Kalman branch (use_lstm=False): mean [8], covariance [8,8]; means placed near some detections
+    means = np.stack([np.r_[RT.STrack.tlwh_to_xyah(det_tlwh[t % N]) + g.randn(4) * np.array([6, 6, 0.01, 2]) * (1 + 4 * (t % 3 == 0)), g.randn(4)] for t in range(T)])
+    covs = np.stack([spd(8) * (4.0 if t % 2 else 40.0) for t in range(T)])
+    tracks = [SimpleNamespace(mean=means[t], covariance=covs[t]) for t in range(T)]
+    cost = g.rand(T, N)
+    fix.update(kal_mean=means, kal_cov=covs, kal_cost=cost,
+               kal_out=matching.fuse_motion(KalmanFilter(), cost.copy(), tracks, dets, frame_id=5, use_lstm=False))
+    # LSTM branch: tracks with >= 300 observations (maha on the prediction + np.cov covariance) and younger ones
+    kfl = RT.KalmanFilterLSTM(opt)
+    preds = np.stack([RT.STrack.tlwh_to_xyah(det_tlwh[(t + 2) % N]) + g.randn(4) * np.array([5, 5, 0.01, 2]) for t in range(T)]).astype(np.float32)
+    nobs = np.array([300, 5, 450, 299, 1, 300, 20])
+    cov4 = np.stack([spd(4) * 3.0 for _ in range(T)])
+    tracks = [SimpleNamespace(observations=[0] * int(nobs[t]), covariance=cov4[t], prediction_at_frame=(lambda f, t=t: preds[t])) for t in range(T)]
+    cost = g.rand(T, N)
+    fix.update(lstm_pred=preds, lstm_nobs=nobs, lstm_cov=cov4, lstm_cost=cost,
+               lstm_out=matching.fuse_motion(kfl, cost.copy(), tracks, dets, frame_id=5, use_lstm=True))
+    assert np.isinf(fix["kal_out"]).any() and np.isinf(fix["lstm_out"]).any() and np.isfinite(fix["lstm_out"]).any()
+    # 3-D branch
+    det_ddd = np.abs(g.randn(N, 7)) + np.array([1.5, 1.8, 4.2, 0, 1, 20, 0]) + g.randn(N, 7) * np.array([0, 0, 0, 8, 0.3, 10, 1])
+    trk_ddd = det_ddd[g.permutation(N)[:T]] + g.randn(T, 7) * np.array([0.1, 0.1, 0.1, 3, 0.2, 3, 0.1])
+    depth = trk_ddd[:, 5].copy(); depth[0] = 80.0
+    dets3 = [SimpleNamespace(ddd_bbox=b) for b in det_ddd]
+    tracks3 = [SimpleNamespace(ddd_bbox=trk_ddd[t], depth=depth[t], covariance=np.eye(7)) for t in range(T)]
+    cost = g.rand(T, N)
+    fix.update(ddd_det=det_ddd, ddd_trk=trk_ddd, ddd_depth=depth, ddd_cost=cost)
+    for cls in ("pedestrian", "car"):
+        fix["ddd_out_" + cls] = matching.fuse_motion_ddd(kfl, cost.copy(), tracks3, dets3, frame_id=5, classe_name=cls)
+        assert np.isinf(fix["ddd_out_" + cls]).any()
+    np.savez_compressed(os.path.join(GOLD, "association.npz"), **fix)
+    print("  association fixtures written (reference fuse_motion / fuse_motion_ddd)")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -315,4 +366,5 @@ if __name__ == "__main__":
     run_motion("mot")
     run_motion("nuscenes")
     run_track_similarity()
+    run_association()
     print("golden fixtures written to", os.path.abspath(GOLD))

@@ -1,0 +1,127 @@
+"""-m "not gpu": deft_amd.association (vectorised host side of the association step).
+  * fuse_motion / fuse_motion_ddd against REFERENCE outputs (tests/golden/association.npz, written by
+    oracle/make_golden.py from matching.py:311-415 with the reference's KalmanFilter / KalmanFilterLSTM);
+  * lapjv / linear_assignment / bbox_overlaps: the reference takes these from `lap` and `cython_bbox`, which are
+    not installed here (parity unpinned) -- checked against brute force and a scalar restatement."""
+import itertools
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from deft_amd import association as A
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _xyah(b):
+    r = np.asarray(b, dtype=np.float64).copy()
+    r[:2] += r[2:] / 2
+    r[2] /= r[3]
+    return r
+
+
+def _same(a, b):
+    assert np.array_equal(np.isinf(a), np.isinf(b))
+    f = np.isfinite(a)
+    assert np.allclose(a[f], b[f], rtol=1e-12, atol=1e-12)
+
+
+def test_fuse_motion_vs_reference_fixture():
+    fx = np.load(os.path.join(GOLD, "association.npz"))
+    dets = [SimpleNamespace(to_xyah=(lambda b=b: _xyah(b))) for b in fx["det_tlwh"]]
+    T = fx["kal_mean"].shape[0]
+    tracks = [SimpleNamespace(mean=fx["kal_mean"][t], covariance=fx["kal_cov"][t]) for t in range(T)]
+    cost = fx["kal_cost"].copy()
+    out = A.fuse_motion(None, cost, tracks, dets, frame_id=5, use_lstm=False)
+    assert out is cost                                        # in place, like the reference
+    _same(out, fx["kal_out"])
+    tracks = [SimpleNamespace(observations=[0] * int(fx["lstm_nobs"][t]), covariance=fx["lstm_cov"][t],
+                              prediction_at_frame=(lambda f, t=t: fx["lstm_pred"][t])) for t in range(T)]
+    _same(A.fuse_motion(None, fx["lstm_cost"].copy(), tracks, dets, frame_id=5, use_lstm=True), fx["lstm_out"])
+    young = fx["lstm_nobs"] < 300
+    assert np.array_equal(fx["lstm_out"][young], 0.9 * fx["lstm_cost"][young])       # the 2-D "gaussian" distance is 0
+    assert A.fuse_motion(None, np.zeros((0, 3)), [], dets[:3], 5).shape == (0, 3)
+
+
+def test_fuse_motion_ddd_vs_reference_fixture():
+    fx = np.load(os.path.join(GOLD, "association.npz"))
+    dets = [SimpleNamespace(ddd_bbox=b) for b in fx["ddd_det"]]
+    tracks = [SimpleNamespace(ddd_bbox=fx["ddd_trk"][t], depth=fx["ddd_depth"][t]) for t in range(fx["ddd_trk"].shape[0])]
+    for cls in ("pedestrian", "car"):
+        _same(A.fuse_motion_ddd(None, fx["ddd_cost"].copy(), tracks, dets, frame_id=5, classe_name=cls), fx["ddd_out_" + cls])
+
+
+def test_not_positive_definite_raises_like_cholesky():
+    dets = [SimpleNamespace(to_xyah=lambda: np.array([1.0, 2.0, 0.5, 10.0]))]
+    bad = SimpleNamespace(mean=np.zeros(8), covariance=-np.eye(8))
+    with pytest.raises(np.linalg.LinAlgError):
+        A.fuse_motion(None, np.zeros((1, 1)), [bad], dets, 1, use_lstm=False)
+
+
+def _brute(cost, limit):
+    """Optimal partial assignment: minimise sum(matched costs) + limit/2 per unmatched row and column."""
+    n, m = cost.shape
+    best, arg = np.inf, None
+    for k in range(min(n, m) + 1):
+        for rows in itertools.combinations(range(n), k):
+            for cols in itertools.permutations(range(m), k):
+                c = sum(cost[r, cc] for r, cc in zip(rows, cols)) + (n + m - 2 * k) * limit / 2.0
+                if c < best:
+                    best, arg = c, sorted(zip(rows, cols))
+    return arg
+
+
+@pytest.mark.parametrize("n,m,seed", [(3, 4, 0), (4, 3, 1), (4, 4, 2), (1, 5, 3), (5, 2, 4)])
+def test_linear_assignment_is_optimal(n, m, seed):
+    g = np.random.RandomState(seed)
+    cost = g.rand(n, m)
+    cost[g.rand(n, m) < 0.2] = np.inf                          # gated pairs (fuse_motion)
+    for thr in (0.9, 0.4):
+        matches, ua, ub = A.linear_assignment(cost.copy(), thresh=thr)
+        assert sorted(map(tuple, matches.tolist())) == _brute(np.where(np.isinf(cost), 1e9, cost), thr)
+        assert sorted(ua.tolist() + matches[:, 0].tolist()) == list(range(n))
+        assert sorted(ub.tolist() + matches[:, 1].tolist()) == list(range(m))
+        assert all(cost[i, j] <= thr for i, j in matches)
+
+
+def test_linear_assignment_edges():
+    m, ua, ub = A.linear_assignment(np.zeros((0, 4)), 0.9)
+    assert m.shape == (0, 2) and ua == () and ub == (0, 1, 2, 3)
+    m, ua, ub = A.linear_assignment(np.full((2, 3), np.inf), 0.9)
+    assert m.shape == (0, 2) and ua.tolist() == [0, 1] and ub.tolist() == [0, 1, 2]
+    total, x, y = A.lapjv(np.array([[0.1, 0.8], [0.7, 0.2]]))          # square, no limit: plain assignment
+    assert x.tolist() == [0, 1] and y.tolist() == [0, 1] and abs(total - 0.3) < 1e-12
+    with pytest.raises(ValueError):
+        A.lapjv(np.zeros((2, 3)))
+    m, _, _ = A.linear_assignment(np.array([[0.5]]), thresh=0.0)       # tracker.py:1000: nuScenes IoU stage
+    assert m.shape == (0, 2)
+
+
+def test_bbox_overlaps_plus_one_convention():
+    a = np.array([[0, 0, 9, 9], [5, 5, 14, 14], [20, 20, 29, 29], [0, 0, 0, 0]], dtype=np.float64)
+    b = np.array([[0, 0, 9, 9], [10, 0, 19, 9], [9, 9, 9, 9]], dtype=np.float64)
+    got = A.bbox_overlaps(a, b)
+
+    def one(p, q):
+        iw = min(p[2], q[2]) - max(p[0], q[0]) + 1
+        ih = min(p[3], q[3]) - max(p[1], q[1]) + 1
+        if iw <= 0 or ih <= 0:
+            return 0.0
+        ua = (p[2] - p[0] + 1) * (p[3] - p[1] + 1) + (q[2] - q[0] + 1) * (q[3] - q[1] + 1) - iw * ih
+        return iw * ih / ua
+    want = np.array([[one(p, q) for q in b] for p in a])
+    assert np.array_equal(got, want)
+    assert got[0, 0] == 1.0 and got[0, 1] == 0.0 and got[0, 2] == 1.0 / 100 and got[2].max() == 0.0
+    assert A.bbox_overlaps(np.zeros((0, 4)), b).shape == (0, 3)
+
+
+def test_compat_modules_expose_the_two_entry_points():
+    import importlib.util
+    root = os.path.join(os.path.dirname(GOLD), "..", "deft_amd", "compat")
+    for name, attr in (("lap", "lapjv"), ("cython_bbox", "bbox_overlaps")):
+        spec = importlib.util.spec_from_file_location("_compat_" + name, os.path.join(root, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert getattr(mod, attr) is getattr(A, attr)

@@ -80,3 +80,32 @@ def test_motion_bank_slots(emu_lib):
     assert again == s[0] and float(bank.last[again].abs().sum()) == 0.0 and float(bank.h[again].abs().sum()) == 0.0
     with pytest.raises(AssertionError):
         bank.step([s[1], s[1]], np.zeros((2, 4)) + 5.0, 2)       # one row per track and launch
+
+
+def test_accelerate_binds_and_restores(emu_lib):
+    """deft_amd.tracker.accelerate on a stand-in for the reference's utils.tracker module."""
+    import types
+    import deft_oracle as O
+    from deft_amd import association
+    matching = types.SimpleNamespace(fuse_motion=1, fuse_motion_ddd=2, linear_assignment=3, bbox_ious=4)
+
+    class Tracker:
+        def get_similarity(self):
+            return "ref"
+
+    class STrack:
+        def update_lstm_features(self, tlwh):
+            return "ref"
+
+        def update_lstm_features_ddd(self, b):
+            return "ref"
+    RT = types.SimpleNamespace(Tracker=Tracker, FeatureRecorder=object, STrack=STrack, matching=matching)
+    ref_get = Tracker.get_similarity
+    kf = integrate.KalmanFilterLSTM(_opt(), O.synth_lstm_state_dict("mot"), device="cpu", lib=emu_lib)
+    undo = DT.accelerate(RT, kf)
+    assert Tracker.get_similarity is DT.get_similarity and RT.FeatureRecorder is DT.FeatureRecorder
+    assert matching.fuse_motion is association.fuse_motion and matching.bbox_ious is association.bbox_overlaps
+    assert isinstance(STrack.__dict__["future_predictions"], property)
+    undo()
+    assert Tracker.get_similarity is ref_get and RT.FeatureRecorder is object and matching.linear_assignment == 3
+    assert "future_predictions" not in STrack.__dict__ and STrack().update_lstm_features(None) == "ref"

@@ -212,10 +212,13 @@ def test_reference_tracker_with_lstm_seam(emu_lib):
         ref_get, ref_rec = RT.Tracker.get_similarity, RT.FeatureRecorder
         RT.Tracker.get_similarity = DT.get_similarity
         RT.FeatureRecorder = DT.FeatureRecorder                   # Tracker.__init__ (tracker.py:651) builds it by this name
+        from deft_amd import association
+        unbind = association.bind(RT.matching)                    # vectorised fuse_motion / linear_assignment / IoU
         try:
             batched = run(lambda o: integrate.KalmanFilterLSTM(o, lsd, device="cpu", lib=emu_lib))
         finally:
             undo()
+            unbind()
             RT.Tracker.get_similarity, RT.FeatureRecorder = ref_get, ref_rec
         assert bank.launches <= T, "one motion launch per frame, not one per track"
         assert "future_predictions" not in RT.STrack.__dict__
@@ -231,5 +234,70 @@ def test_reference_tracker_with_lstm_seam(emu_lib):
                     assert np.abs(np.array(a[4][k]) - np.array(b[4][k])).max() <= 1e-3 * max(1.0, np.abs(a[4][k]).max())
     finally:
         RT.KalmanFilterLSTM = ref_cls
+        torch.set_grad_enabled(True)
+        sys.modules.pop("dcn_v2", None)
+
+
+def test_reference_tracker_with_vectorised_association(emu_lib):
+    """The reference's default 2-D configuration (opts.py:478: Kalman filter, no LSTM): its Tracker as written
+    against the same Tracker with the per-frame forms bound in -- recorder mirror (one affinity chain per frame),
+    device-side get_similarity, vectorised fuse_motion / linear_assignment / IoU (deft_amd.association)."""
+    import deft_oracle as O
+    import make_golden as MG
+    import ref_import
+    import ref_shims
+    from deft_amd import association, integrate, tracker as DT
+    ref_shims.install()
+    ref_import.install_stubs(MG.OracleDCN)
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        from opts import opts
+        from utils import tracker as RT
+        from utils.basetrack import BaseTrack
+    finally:
+        sys.argv = argv
+    opt = opts().parse(["tracking", "--dataset", "mot", "--gpus", "-1"])
+    assert not opt.lstm
+    torch.set_grad_enabled(False)
+    try:
+        sd = O.synth_state_dict("mot")
+
+        class M:
+            AFE = integrate.AfeSeam(sd, opt.max_object, "cpu", emu_lib)
+        H, W, T = 32, 64, 7
+        chans = [16, 32, 64, 128, 256, 512, 64, 128, 256, 512, 64, 64, 64]
+        strides = [1, 2, 4, 8, 16, 32, 4, 8, 16, 32, 4, 4, 4]
+        g = torch.Generator().manual_seed(78)
+        fmaps = [torch.randn(1, c, H // s, W // s, generator=g) for c, s in zip(chans, strides)]
+
+        def run():
+            BaseTrack._count = 0
+            trk = RT.Tracker(opt, M, h=H, w=W)
+            log = []
+            for t in range(T):
+                dets = _moving_boxes(t)
+                if t in (3, 4):
+                    dets = dets[1:4]
+                targets = trk.update(dets, fmaps)
+                log.append(sorted((s.track_id, s.tracklet_len, s.tlwh.tolist(), s.mean.tolist()) for s in targets))
+            return log
+
+        ref = run()
+        ref_get, ref_rec = RT.Tracker.get_similarity, RT.FeatureRecorder
+        RT.Tracker.get_similarity = DT.get_similarity
+        RT.FeatureRecorder = DT.FeatureRecorder
+        unbind = association.bind(RT.matching)
+        try:
+            got = run()
+        finally:
+            unbind()
+            RT.Tracker.get_similarity, RT.FeatureRecorder = ref_get, ref_rec
+        assert max(s[1] for s in ref[-1]) >= 2
+        for fa, fb in zip(ref, got):
+            assert [(a[0], a[1]) for a in fa] == [(b[0], b[1]) for b in fb]
+            for a, b in zip(fa, fb):
+                assert np.abs(np.array(a[2]) - np.array(b[2])).max() <= 1e-6
+                assert np.abs(np.array(a[3]) - np.array(b[3])).max() <= 1e-6
+    finally:
         torch.set_grad_enabled(True)
         sys.modules.pop("dcn_v2", None)
