@@ -6,7 +6,9 @@
 // ever loads libdeft_hip.so built by hipcc for gfx950; this header is reachable
 // from tests/ alone (tests/hipemu/build_emu.sh -> tests/hipemu/_build/libdeft_emu.so).
 //
-// Model: one fiber (ucontext) per GPU thread, blocks run one after another.
+// Model: one fiber (ucontext) per GPU thread; the blocks of a launch are handed out to a few OS
+// threads (HIPEMU_THREADS, default = min(8, cores)), each running whole blocks one after another --
+// all emulator state, `__shared__` and dynamic LDS are thread_local, global atomics are real atomics.
 // Wave-level collectives (MFMA, shuffles) rendezvous the 64 lanes of a wave;
 // __syncthreads() rendezvous the block.  MFMA lane<->element maps follow
 // /opt/skills/guides/cdna_hip_programming.md §3 (gfx950):
@@ -22,14 +24,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <functional>
+#include <thread>
 #include <vector>
 
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 
 struct dim3 {
@@ -54,7 +58,7 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
-namespace hipemu { inline void* dyn_lds() { alignas(16) static char buf[160 * 1024]; return buf; } }
+namespace hipemu { inline void* dyn_lds() { alignas(16) static thread_local char buf[160 * 1024]; return buf; } }
 #define DEFT_DYN_LDS(type, var) type* var = (type*)hipemu::dyn_lds()
 
 namespace hipemu {
@@ -68,7 +72,7 @@ struct State {
     float xf[2][2][64];
     int parity = 0;
 };
-inline State& S() { static State s; return s; }
+inline State& S() { static thread_local State s; return s; }
 inline void yield(int code) {
     State& s = S();
     s.yield_code = code;
@@ -79,7 +83,7 @@ struct Fiber {
     std::vector<char> stack;
     int state = Y_NONE;
 };
-inline std::function<void()>& body() { static std::function<void()> f; return f; }
+inline std::function<void()>& body() { static thread_local std::function<void()> f; return f; }
 inline void trampoline() {
     body()();
     yield(Y_DONE);
@@ -88,7 +92,7 @@ inline void trampoline() {
 inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, dim3 bid) {
     State& s = S();
     const int nthr = block.x * block.y * block.z;
-    static std::vector<Fiber> fibers;
+    static thread_local std::vector<Fiber> fibers;
     if ((int)fibers.size() < nthr) fibers.resize(nthr);
     body() = fn;
     for (int t = 0; t < nthr; ++t) {
@@ -147,11 +151,30 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
     }
 }
 
+inline int worker_count() {
+    static const int n = [] {
+        const char* e = getenv("HIPEMU_THREADS");
+        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
+    return n;
+}
+
 template <typename F>
 inline void launch(F&& fn, dim3 grid, dim3 block) {
-    for (unsigned z = 0; z < grid.z; ++z)
-        for (unsigned y = 0; y < grid.y; ++y)
-            for (unsigned x = 0; x < grid.x; ++x) run_block(fn, grid, block, dim3(x, y, z));
+    const long long total = (long long)grid.x * grid.y * grid.z;
+    const std::function<void()> f = fn;
+    std::atomic<long long> next{0};
+    auto work = [&]() {
+        for (long long b = next.fetch_add(1); b < total; b = next.fetch_add(1))
+            run_block(f, grid, block, dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long long)grid.x * grid.y))));
+    };
+    const int nw = (int)(total < worker_count() ? total : worker_count());
+    if (nw <= 1) { work(); return; }
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nw; ++i) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
 }
 
 // wave exchange: deposit up to two floats, rendezvous, then read any lane's deposit
@@ -234,8 +257,24 @@ static inline int __shfl(int v, int src, int = 64) {
 static inline unsigned __shfl_xor(unsigned v, int mask, int = 64) { return (unsigned)__shfl_xor((int)v, mask); }
 static inline unsigned __shfl_down(unsigned v, int d, int = 64) { return (unsigned)__shfl_down((int)v, d); }
 
-template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
-template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicAdd(T* p, T v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (!__atomic_compare_exchange_n(p, &o, (T)(o + v), true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+static inline float atomicAdd(float* p, float v) {
+    unsigned* q = (unsigned*)p;
+    unsigned o = __atomic_load_n(q, __ATOMIC_RELAXED), n;
+    float f;
+    do { memcpy(&f, &o, 4); f += v; memcpy(&n, &f, 4); } while (!__atomic_compare_exchange_n(q, &o, n, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    memcpy(&f, &o, 4);
+    return f;
+}
+template <typename T> static inline T atomicMax(T* p, T v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
