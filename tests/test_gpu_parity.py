@@ -164,9 +164,49 @@ def test_full_size_properties(gpu_lib):
     assert pc.maxabs(p1.scores.cpu(), od["scores"]) <= pc.TOL
 
 
-@pytest.mark.parametrize("dataset,H,W", [("kitti_tracking", 384, 1280), ("nuscenes", 448, 800)])
+@pytest.mark.parametrize("seed", [100, 101, 102])
+def test_full_size_index_differences_are_ties(gpu_lib, seed):
+    """How far ordered top-K equality can hold between two fp32 implementations with different summation
+    orders: on arbitrary random frames at 1088x608 either the indices are identical, or every
+    difference is a tie at round-off level -- the oracle's own heat map puts the device's extra peak within
+    1e-4 (logit) of its 3x3 neighbourhood maximum or of the K-th score -- and the float outputs still agree
+    within 1e-3.  (Seed 101 is a frame where one NMS near-tie resolves to the neighbouring pixel.)"""
+    from deft_amd import engine
+    sd = O.synth_state_dict("mot")
+    H, W, K = 608, 1088, 100
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(seed))
+    plan = engine.DlaSegPlan(sd, 1, H, W, "mot", K=K, device="cuda", lib=gpu_lib)
+    plan.forward(x.cuda())
+    with torch.no_grad():
+        out, _ = O.dlaseg_forward(x, sd, "mot")
+    od = O.generic_decode(O.sigmoid_output(out), K=K)
+    gi, oi = plan.inds[0].cpu().long(), od["inds"][0]
+    gs, os_ = plan.scores[0].cpu(), od["scores"][0]
+    gb, ob = plan.bboxes[0].cpu(), od["bboxes"][0]
+    opos = {int(i): k for k, i in enumerate(oi.tolist())}
+    common = [(k, opos[int(i)]) for k, i in enumerate(gi.tolist()) if int(i) in opos]
+    assert len(common) >= K - 2
+    for k, ko in common:                                                    # same detection -> same floats
+        assert abs(float(gs[k]) - float(os_[ko])) <= 1e-5 and pc.maxabs(gb[k], ob[ko]) <= pc.TOL
+    logit = out["hm"][0, 0]
+    dev_logit = plan.dense["hm"].to_nchw().cpu()[0, 0]
+    assert pc.maxabs(dev_logit, logit) <= 2e-4
+    if torch.equal(gi, oi):
+        return
+    nb = torch.nn.functional.max_pool2d(logit[None, None], 3, 1, 1)[0, 0].reshape(-1)
+    flat = logit.reshape(-1)
+    kth = float(torch.logit(od["scores"][0, -1]))
+    for i in set(gi.tolist()) ^ set(oi.tolist()):
+        near_nms_tie = float(nb[i] - flat[i]) <= 1e-4
+        near_kth = abs(float(flat[i]) - kth) <= 1e-4
+        assert near_nms_tie or near_kth, (i, float(nb[i] - flat[i]), float(flat[i]) - kth)
+    order = flat[gi]                                                       # the device's order, scored by the oracle's map:
+    assert bool((order[:-1] >= order[1:] - 1e-4).all())                     # any reordering is between near-equal scores
+
+
+@pytest.mark.parametrize("dataset,H,W", [("kitti_tracking", 384, 1280), ("nuscenes", 448, 800), ("mot", 512, 512)])
 def test_full_size_other_configs(gpu_lib, dataset, H, W):
-    """BASELINE configs D (KITTI 1280x384) and E (nuScenes 800x448, one camera) at full size against
+    """BASELINE configs D (KITTI 1280x384), E (nuScenes 800x448, one camera) and A (512x512) at full size against
     the oracle: top-K indices ordered-equal, floats within 1e-3, embeddings within 1e-4 relative,
     plus the batched LSTM step the configs name."""
     from deft_amd import engine
