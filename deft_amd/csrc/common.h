@@ -56,4 +56,19 @@ __device__ __forceinline__ void deft_buffer_load_lds_x4(deft_rsrc_t r, float* ld
 }
 #endif
 
+// Cross-workgroup hand-over of split-K partial tiles.  The workgroups of a tile may sit on different XCDs, whose
+// L2s are not coherent with each other: partials are written and read with agent-scope accesses (sc1: write-through /
+// miss in the non-coherent levels) instead of paying a whole-L2 write-back + invalidate (`__threadfence()`) per
+// workgroup; deft_ws_publish() waits until this wave's stores have been acknowledged before the ticket is taken.
+#ifndef DEFT_WS_HOOKS          /* the unit-test SIMT emulator pre-defines these hooks */
+__device__ __forceinline__ void deft_ws_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float deft_ws_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void deft_ws_publish() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                 // gfx9 encoding: vmcnt(0) expcnt(0) lgkmcnt(0); vmcnt counts stores too
+}
+__device__ __forceinline__ int deft_ws_ticket(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void deft_ws_reset(int* p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
 static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

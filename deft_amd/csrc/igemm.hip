@@ -80,12 +80,15 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     // XCD-aware, bijective workgroup remap: block b runs on XCD b%8 (observed), so give
     // every XCD one contiguous run of tiles -- neighbouring n-tiles of an m-tile then
     // share their A rows in that XCD's private L2.
+    const int S = p.splitk > 1 ? p.splitk : 1;
     {
-        const int nwg = mtiles * ntiles;
+        const int nwg = mtiles * ntiles * S;
         const int q = nwg >> 3, r = nwg & 7;
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int split = bid % S;      // cross-workgroup split-K: the S workgroups of a tile are neighbours (same XCD)
+    bid /= S;
     const int mt = bid / ntiles, nt = bid - mt * ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -203,8 +206,24 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     // the current chunk sit between the two, so the loads fly under them. ----
     const bool uniform_tap = MODE != MODE_CONV || p.KH * p.KW == 1 || p.Cin >= 32;
     const unsigned inv_kw = (65536u + (unsigned)p.KW - 1u) / (unsigned)p.KW;
+    // this workgroup's share of the K chunks: [k_lo, k_lo + nk) of Kpad/32 (everything when S == 1)
+    const int nk_all = p.Kpad >> 5;
+    const int k_lo = (int)((long long)nk_all * split / S);
+    const int nk = (int)((long long)nk_all * (split + 1) / S) - k_lo;
     KCursor cur = {0, 0, 0};
-    int kload = 0;                                   // k offset of the next chunk to load
+    if (S > 1) {                                     // position the (tap, channel) cursor on chunk k_lo
+        if (MODE == MODE_DCN) {
+            cur.c0 = (k_lo / 9) * 32; cur.s = k_lo % 9;
+        } else if (MODE == MODE_CONV && uniform_tap) {
+            const int taps = p.KH * p.KW;
+            int tap;
+            if (taps == 1) { tap = 0; cur.c0 = k_lo * 32; }
+            else if (p.korder == 1) { tap = k_lo % taps; cur.c0 = (k_lo / taps) * 32; }
+            else { tap = (k_lo * 32) >> p.cin_log2; cur.c0 = (k_lo * 32) & (p.Cin - 1); }
+            cur.r = tap / p.KW; cur.s = tap - cur.r * p.KW;
+        }
+    }
+    int kload = k_lo * 32;                           // k offset of the next chunk to load
     f32x4 s0[GA], s1[GA], s2[GA], s3[GA], sw[GA], vb[GB];
     float sm[GA];
 
@@ -312,7 +331,6 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.Kpad >> 5;
     const int frow = lane & 31;        // row of the 32-row MFMA tile this lane feeds
     const int fk = (lane >> 5) * 16 + wk * KK;   // first of this lane's k-values in the chunk (this wave's share)
     float a[TM][KK], b[TN][KK];
@@ -408,6 +426,45 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(w - 1) * per_wk + tbase + (i * TN + j) * 1024 + r * 64];
     }
 
+    if (S > 1) {
+        // Park this workgroup's partial tile (lane-contiguous: 256 B per store instruction), make it visible
+        // device-wide, then take a ticket: the last of the tile's S workgroups adds the partials in split
+        // order 0..S-1 (its own included, re-read: the order must not depend on who arrives last).
+        const int tile_id = mt * ntiles + nt;
+        const size_t tsz = (size_t)BM * BN;
+        const int woff = ((wave % (WM * WN)) * TM * TN) * 1024 + lane;
+        float* mine = p.ws + ((size_t)tile_id * S + split) * tsz + woff;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) deft_ws_store(&mine[(i * TN + j) * 1024 + r * 64], acc[i][j][r]);
+        deft_ws_publish();
+        __syncthreads();                 // (waves wk > 0 of a split-K tile have already left)
+        int* ticket = (int*)smem;
+        if (tid == 0) ticket[0] = deft_ws_ticket(&p.ws_cnt[tile_id]);
+        __syncthreads();
+        if (ticket[0] != S - 1) return;
+        if (tid == 0) deft_ws_reset(&p.ws_cnt[tile_id]);             // ready for the next launch that shares the counters
+        const float* part = p.ws + (size_t)tile_id * S * tsz + woff;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = deft_ws_load(&part[(i * TN + j) * 1024 + r * 64]);
+        for (int sp = 1; sp < S; ++sp) {
+            part += tsz;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += deft_ws_load(&part[(i * TN + j) * 1024 + r * 64]);
+        }
+    }
+
     // epilogue: D reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31);
     // the 32 lanes of a half-wave write 32 consecutive channels of one pixel (128 B).
     // Residual loads are hoisted out of the per-element path (one uniform branch, 16
@@ -460,7 +517,7 @@ template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
 __global__ __launch_bounds__(256) void igemm_group_kernel(const DeftGemmDesc* __restrict__ descs) {
     const DeftGemmDesc p = descs[blockIdx.y];
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
-    if ((int)blockIdx.x >= mtiles * ntiles) return;
+    if ((int)blockIdx.x >= mtiles * ntiles * (p.splitk > 1 ? p.splitk : 1)) return;
     igemm_body<BM, BN, WM, WN, WK, MODE, NSTAGE>(p, mtiles, ntiles, blockIdx.x);
 }
 
@@ -481,7 +538,10 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
         hipLaunchKernelGGL((igemm_group_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>), dim3(max_tiles, ngroups), dim3(256), lds_bytes, s, group_dev);
     } else {
         const int mtiles = deft_cdiv(d.M, BM), ntiles = deft_cdiv(d.Cout, BN);
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>), dim3(mtiles * ntiles), dim3(256), lds_bytes, s, d,
+        const int S = d.splitk > 1 ? d.splitk : 1;
+        DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
+                   "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>), dim3(mtiles * ntiles * S), dim3(256), lds_bytes, s, d,
                            mtiles, ntiles);
     }
     DEFT_CHECK_LAUNCH("igemm");
@@ -493,8 +553,7 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
 // split-K tiles (WK = 2 / 4).
 template <int MODE>
 static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage, hipStream_t s,
-                          const DeftGemmDesc* group_dev = nullptr, int ngroups = 0, int max_m = 0, int max_n = 0) {
-    const int mt = group_dev ? deft_cdiv(max_m, bm) * deft_cdiv(max_n, bn) : 0;
+                          const DeftGemmDesc* group_dev = nullptr, int ngroups = 0, int mt = 0) {
 #define DEFT_TILE(BM_, BN_, WM_, WN_, WK_)                                                                   \
     if (bm == BM_ && bn == BN_)                                                                              \
         return one_stage ? launch_igemm<BM_, BN_, WM_, WN_, WK_, MODE, 1>(d, group_dev, ngroups, mt, s)      \
@@ -559,6 +618,37 @@ static void pick_conv_tile(int M, int rows_per_image, int Cout, int& bm, int& bn
     else { bm = 64; bn = 64; }
 }
 
+// split factor for a launch of `tiles` output tiles and nk K chunks: double S until the launch has two workgroups
+// per compute unit (FILL_BLOCKS), keeping >= 8 chunks per workgroup
+static int pick_splitk(long long tiles, int nk) {
+    int S = 1;
+    while (tiles * S < FILL_BLOCKS && nk / (2 * S) >= 8 && S < 32) S *= 2;
+    return S;
+}
+
+extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* splitk, long long* ws_floats, int* ws_tiles) {
+    DEFT_CHECK(d && tile && splitk && ws_floats && ws_tiles, -1, "deft_gemm_plan: null pointer");
+    DEFT_CHECK(entry == 0 || entry == 1, -2, "deft_gemm_plan: entry %d (0 = conv, 1 = dcn)", entry);
+    int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
+    if (bm == 0) {
+        if (entry == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);
+        else { bm = 64; bn = d->Cout >= 256 ? 128 : 64; }
+    }
+    const int nk = d->Kpad >> 5;
+    long long tiles = (long long)deft_cdiv(d->M, bm) * deft_cdiv(d->Cout, bn);
+    int S = (d->rowmap != nullptr) ? 1 : pick_splitk(tiles, nk);
+    if (entry == 1 && S > 1 && bn == 128) {          // few tiles: the narrower DCN tile gives twice the workgroups per split
+        bn = 64;
+        tiles = (long long)deft_cdiv(d->M, bm) * deft_cdiv(d->Cout, bn);
+        S = pick_splitk(tiles, nk);
+    }
+    *tile = (bm << 16) | bn | (d->tile & (1 << 29));
+    *splitk = S;
+    *ws_floats = S > 1 ? tiles * S * bm * bn : 0;
+    *ws_tiles = S > 1 ? (int)tiles : 0;
+    return 0;
+}
+
 extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
     if (int e = check_conv(d, "deft_conv2d_nhwc")) return e;
     hipStream_t s = (hipStream_t)stream;
@@ -570,16 +660,20 @@ extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
 
 extern "C" int deft_conv2d_group(const DeftGemmDesc* descs, const DeftGemmDesc* descs_dev, int ngroups, void* stream) {
     DEFT_CHECK(descs && descs_dev && ngroups > 0 && ngroups <= 65535, -40, "deft_conv2d_group: bad arguments");
-    int max_m = 0, max_n = 0;
-    for (int i = 0; i < ngroups; ++i) {
-        if (int e = check_conv(descs + i, "deft_conv2d_group")) return e;
-        max_m = descs[i].M > max_m ? descs[i].M : max_m;
-        max_n = descs[i].Cout > max_n ? descs[i].Cout : max_n;
-    }
     int bm = (descs[0].tile >> 16) & 0x1fff, bn = descs[0].tile & 0xffff;
     const bool one_stage = !((descs[0].tile >> 29) & 1);
-    if (bm == 0) { bm = 32; bn = 32; }   // one fixed (split-K) tile: few rows per group, result independent of the row count
-    return dispatch_igemm<MODE_CONV>(descs[0], bm, bn, one_stage, (hipStream_t)stream, descs_dev, ngroups, max_m, max_n);
+    if (bm == 0) { bm = 32; bn = 32; }   // one fixed (4 waves per tile) tile: few rows per group
+    long long max_tiles = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        if (int e = check_conv(descs + i, "deft_conv2d_group")) return e;
+        const int S = descs[i].splitk > 1 ? descs[i].splitk : 1;       // per-group cross-workgroup split (own ws / ws_cnt each)
+        DEFT_CHECK(S == 1 || (descs[i].ws && descs[i].ws_cnt && S <= 32 && (descs[i].Kpad >> 5) >= S), -102,
+                   "deft_conv2d_group: group %d splitk=%d needs ws, ws_cnt, S <= 32 and at least S K chunks", i, S);
+        const long long t = (long long)deft_cdiv(descs[i].M, bm) * deft_cdiv(descs[i].Cout, bn) * S;
+        max_tiles = t > max_tiles ? t : max_tiles;
+    }
+    DEFT_CHECK(max_tiles < (1ll << 31), -41, "deft_conv2d_group: too many tiles");
+    return dispatch_igemm<MODE_CONV>(descs[0], bm, bn, one_stage, (hipStream_t)stream, descs_dev, ngroups, (int)max_tiles);
 }
 
 extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {

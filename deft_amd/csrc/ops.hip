@@ -644,14 +644,24 @@ __global__ __launch_bounds__(256) void affinity_finish_kernel(const float* __res
     const int f = blockIdx.x, tid = threadIdx.x;
     const int t0 = row_start[f], P = row_start[f + 1] - t0;
     const float e1 = expf(1.f);
-    for (int p = tid; p < P * Q; p += 256) {
-        const float* hp = h4 + ((size_t)t0 * Q + p) * ldh;
-        float acc = b5;
-        for (int k = 0; k < C4; k += 4) {
-            const float4 v = *(const float4*)(hp + k);
-            acc += v.x * w5[k] + v.y * w5[k + 1] + v.z * w5[k + 2] + v.w * w5[k + 3];
+    // 16 lanes per pair row: each reads one float4 of the row (a 256-byte row = one coalesced request),
+    // the 16 partial dot products are combined with 4 xor-shuffles
+    const int sub = tid & 15, grp = tid >> 4;
+    for (int p0 = 0; p0 < P * Q; p0 += 16) {
+        const int p = p0 + grp;
+        float acc = 0.f;
+        if (p < P * Q) {
+            const float* hp = h4 + ((size_t)t0 * Q + p) * ldh;
+            for (int k = sub * 4; k < C4; k += 64) {
+                const float4 v = *(const float4*)(hp + k);
+                acc += v.x * w5[k] + v.y * w5[k + 1] + v.z * w5[k + 2] + v.w * w5[k + 3];
+            }
         }
-        E[p] = expf(fmaxf(acc, 0.f));
+        acc += __shfl_xor(acc, 8);
+        acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 1);
+        if (sub == 0 && p < P * Q) E[p] = expf(fmaxf(acc + b5, 0.f));
     }
     __syncthreads();
     if (tid < P) {

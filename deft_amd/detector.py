@@ -7,7 +7,6 @@ regression heads run as ONE plan of HIP launches (deft_amd.engine.DlaSegPlan) wi
 single D2H copy of the K detection records, instead of the reference's four
 `torch.cuda.synchronize()` points (detector.py:188, 534, 541, 545).
 """
-import numpy as np
 import torch
 
 from . import engine, hiplib

@@ -126,6 +126,10 @@ def pack_pair_conv_weight(w, cin_pad=None):
     return pack_conv_weight(w2, cin_pad)
 
 
+# cross-workgroup split-K for launches too small to fill the chip (DeftGemmDesc.splitk); DEFT_SPLITK=0 turns it off
+SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
+
+
 class _Plan:
     """Common machinery: device buffers + an ordered list of bound C-ABI calls."""
 
@@ -173,6 +177,33 @@ class _Plan:
         lib, ref = self.lib, C.byref(desc)
         self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
         self._gemms.append((entry, name, desc))
+        if SPLITK and entry in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc") and not desc.splitk:
+            self._plan_splitk(entry, desc)
+
+    def _plan_splitk(self, entry, desc):
+        """Launches with fewer output tiles than the chip has compute units (one frame per GPU: the 19x34 and
+        38x68 maps) split K across workgroups (DeftGemmDesc.splitk).  The library picks tile and split factor
+        (`deft_gemm_plan`); the plan owns ONE workspace + ticket array shared by all its launches (they are
+        ordered on the plan's stream), sized for the largest."""
+        tile, S, wsf, wst = C.c_int(), C.c_int(), C.c_longlong(), C.c_int()
+        rc = self.lib.cdll.deft_gemm_plan(C.byref(desc), 0 if entry == "deft_conv2d_nhwc" else 1, C.byref(tile), C.byref(S),
+                                          C.byref(wsf), C.byref(wst))
+        if rc != 0:
+            raise hiplib.DeftHipError("deft_gemm_plan failed (%d): %s" % (rc, self.lib.cdll.deft_last_error().decode()))
+        if S.value <= 1:
+            return
+        desc.tile, desc.splitk = tile.value, S.value
+        if not hasattr(self, "_split"):
+            self._split = {"descs": [], "floats": 0, "tiles": 0, "ws": None, "cnt": None}
+        sp = self._split
+        sp["descs"].append(desc)
+        if wsf.value > sp["floats"] or wst.value > sp["tiles"] or sp["ws"] is None:
+            sp["floats"], sp["tiles"] = max(sp["floats"], wsf.value), max(sp["tiles"], wst.value)
+            sp["ws"] = torch.empty(sp["floats"], dtype=torch.float32, device=self.device)
+            sp["cnt"] = torch.zeros(sp["tiles"], dtype=torch.int32, device=self.device)
+            for d in sp["descs"]:
+                d.ws, d.ws_cnt = sp["ws"].data_ptr(), sp["cnt"].data_ptr()
+        desc.ws, desc.ws_cnt = sp["ws"].data_ptr(), sp["cnt"].data_ptr()
 
     def autotune(self, reps=4, verbose=False):
         """Per-layer tile search on the GPU this plan will run on (the cuDNN-benchmark / MIOpen-find
@@ -191,6 +222,8 @@ class _Plan:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         memo = {}
         for entry, name, d in self._gemms:
+            if d.splitk > 1:               # cross-workgroup split-K launches keep their (tile, split, workspace)
+                continue
             key = (entry, d.M, d.Cout, d.Ktot, d.Cin, d.KH, d.KW, d.stride, d.H, d.W, d.ldx, d.ldy, bool(d.res), bool(d.rowmap))
             if key not in memo:
                 if d.Cout <= 32 or d.rowmap:
@@ -606,6 +639,21 @@ class AfePlan(_Plan):
             d.relu = 1; d.Q = 0; d.ldom = 0; d.tile = 0
             d.korder = conv_korder((Co, fm.C, 3, 3))
             d.rowmap = g["rowmap"].data_ptr() + 4 * (k * M * 2)
+        # few rows in total (one frame): the long-K groups (512-channel maps: 144 chunks) would be the tail of the
+        # launch -> split their K over workgroups so that every workgroup contracts ~9-16 chunks
+        tiles = [-(-M // 32) * -(-descs[k].Cout // 32) for k in range(nm)]
+        if SPLITK and sum(tiles) < 512:
+            S = [min(16, 1 << max(0, (descs[k].Kpad // 32 // 9).bit_length() - 1)) for k in range(nm)]
+            woff, coff = [0], [0]
+            for k in range(nm):
+                woff.append(woff[-1] + (tiles[k] * S[k] * 1024 if S[k] > 1 else 0))
+                coff.append(coff[-1] + (tiles[k] if S[k] > 1 else 0))
+            g["ws"] = torch.empty(max(1, woff[-1]), dtype=torch.float32, device=dev)
+            g["ws_cnt"] = torch.zeros(max(1, coff[-1]), dtype=torch.int32, device=dev)
+            for k in range(nm):
+                if S[k] > 1:
+                    descs[k].tile, descs[k].splitk = (32 << 16) | 32, S[k]
+                    descs[k].ws, descs[k].ws_cnt = g["ws"].data_ptr() + 4 * woff[k], g["ws_cnt"].data_ptr() + 4 * coff[k]
         g["descs"] = descs
         g["descs_dev"] = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         self._egroups[key] = g

@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("Tper", C.c_int), ("u0", C.c_int), ("du", C.c_int), ("v0", C.c_int), ("dv", C.c_int),
         ("stride_w", C.c_int), ("korder", C.c_int),
         ("rowmap", c_fp),
+        ("splitk", C.c_int), ("ws", c_fp), ("ws_cnt", c_fp),
     ]
 
 
@@ -56,11 +57,12 @@ _SIGS = {
     "deft_embed_blend": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp]),
     "deft_affinity_finish": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_float, c_fp] + [C.c_int] * 3 + [c_fp, c_fp]),
     "deft_lstm_step": (C.c_int, [c_fp] * 3 + [C.c_int] * 3 + [c_fp] * 8 + [c_fp]),
+    "deft_gemm_plan": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "deft_motion_step": (C.c_int, [c_fp, c_fp] + [C.c_int] * 3 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp] * 7 + [c_fp, c_fp, c_fp]),
     "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class DeftHipError(RuntimeError):

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 3
+#define DEFT_ABI_VERSION 4
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -60,6 +60,15 @@ typedef struct DeftGemmDesc {
      * of a zero accumulator).  Output row m is y + m*ldy.  Used by the embedding head, which
      * needs the selector convs only at the bilinear neighbours of the detection centres.     */
     const int* rowmap;
+    /* conv/dcn, cross-workgroup split-K for launches with too few output tiles to fill the chip (one frame per
+     * GPU: the 19x34 / 38x68 maps): splitk = S > 1 workgroups share one output tile, each contracting a contiguous
+     * 1/S of the K chunks; partial tiles go through `ws` (>= tiles * S * BM*BN floats, see deft_gemm_plan) and the
+     * workgroup that arrives last at `ws_cnt[tile]` (ints, zero before the first launch; left zero again) adds the S
+     * partials IN SPLIT ORDER and runs the epilogue -- deterministic, but a different fp32 summation order than
+     * S = 1.  0 / 1 = off.  Several launches may share ws / ws_cnt as long as they are ordered on one stream. */
+    int splitk;
+    float* ws;
+    int* ws_cnt;
 } DeftGemmDesc;
 
 int deft_version(void);
@@ -191,6 +200,13 @@ int deft_lstm_step(const float* x, float* h, float* c, int T, int nin, int nout,
                    const float* wih_t, const float* whh_t, const float* bias,
                    const float* w1_t, const float* b1, const float* w2_t, const float* b2,
                    float* pred, void* stream);
+
+/* The library's own choice of tile and split factor for a conv (entry 0) or dcn (entry 1) descriptor whose
+ * `tile` / `splitk` are 0: *tile as DeftGemmDesc.tile, *splitk (1 = no split), and the workspace the split needs:
+ * *ws_floats floats for `ws`, *ws_tiles ints for `ws_cnt`.  The caller allocates, writes tile/splitk/ws/ws_cnt into
+ * the descriptor and launches.  Splitting is chosen only when the WHOLE launch has fewer output tiles than the
+ * chip has compute units (latency mode); big batches keep S = 1 and their results do not change. */
+int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* splitk, long long* ws_floats, int* ws_tiles);
 
 /* The whole per-track motion update of one frame in ONE launch, for the T tracks matched/activated in it:
  * feature builder + LSTM step + future boxes.  Replaces, per track, STrack.update_lstm_features (tracker.py:408-480;

@@ -275,6 +275,14 @@ template <typename T> static inline T atomicMax(T* p, T v) {
     while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return o;
 }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+// split-K hand-over hooks of deft_amd/csrc/common.h (blocks run on several OS threads here)
+#define DEFT_WS_HOOKS 1
+static inline void deft_ws_store(float* p, float v) { __atomic_store((unsigned*)p, (unsigned*)&v, __ATOMIC_RELAXED); }
+static inline float deft_ws_load(const float* p) { float v; __atomic_load((const unsigned*)p, (unsigned*)&v, __ATOMIC_RELAXED); return v; }
+static inline void deft_ws_publish() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline int deft_ws_ticket(int* p) { return __atomic_fetch_add(p, 1, __ATOMIC_SEQ_CST); }
+static inline void deft_ws_reset(int* p) { __atomic_store_n(p, 0, __ATOMIC_SEQ_CST); }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }

@@ -121,3 +121,21 @@ def test_track_similarity(emu_lib):
 @pytest.mark.parametrize("dataset", ["mot", "nuscenes"])
 def test_motion_step(emu_lib, dataset):
     pc.check_motion(emu_lib, "cpu", dataset)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(bm=64, bn=64, S=4),
+    dict(bm=64, bn=64, S=3, k=3, Ci=32),                      # S does not divide the 9 chunks evenly
+    dict(bm=128, bn=64, S=2, two_stage=True),                  # LDS-DMA loop form
+    dict(bm=32, bn=32, S=4, Co=27),                            # intra-workgroup (4 waves) + cross-workgroup split
+    dict(bm=64, bn=32, S=2, Co=20, two_stage=True),
+    dict(bm=64, bn=64, S=4, k=1, Ci=320),                      # 1x1: the cursor is the flat k
+    dict(bm=64, bn=64, S=5, korder=1),                         # (channel block, tap) K order
+    dict(bm=128, bn=128, S=2, k=3, Ci=16),                     # Cin < 32: per-lane taps
+])
+def test_conv_splitk(emu_lib, kw):
+    pc.check_conv_splitk(emu_lib, "cpu", **kw)
+
+
+def test_splitk_auto(emu_lib):
+    pc.check_splitk_auto(emu_lib, "cpu")

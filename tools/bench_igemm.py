@@ -48,7 +48,6 @@ def conv_case(name, H, W, Ci, Co, k, stride, tiles):
 
 
 def dcn_case(name, H, W, Ci, Co, tiles):
-    import parity_checks as pc
     for tile in tiles:
         g = torch.Generator().manual_seed(0)
         sd = {"d.conv.weight": torch.randn(Co, Ci, 3, 3, generator=g) * 0.05, "d.conv.bias": torch.zeros(Co),
