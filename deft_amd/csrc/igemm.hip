@@ -49,7 +49,9 @@ struct KCursor {
 // its share of every chunk's 16 MFMA k-steps (intra-workgroup split-K for problems too small to
 // fill 256 CUs with bigger tiles: all four waves still stage the chunk, partial sums are
 // combined through LDS in wave order, so the result is deterministic).
-template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
+// SPLIT: cross-workgroup split-K (DeftGemmDesc.splitk > 1).  A separate instantiation: its partial-tile hand-over
+// must not cost the plain kernels a register (128x128: 104 VGPRs = 3 waves/SIMD, 136 with the hand-over = 2).
+template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE, bool SPLIT>
 __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, int ntiles, int bid) {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
@@ -80,7 +82,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     // XCD-aware, bijective workgroup remap: block b runs on XCD b%8 (observed), so give
     // every XCD one contiguous run of tiles -- neighbouring n-tiles of an m-tile then
     // share their A rows in that XCD's private L2.
-    const int S = p.splitk > 1 ? p.splitk : 1;
+    const int S = SPLIT ? p.splitk : 1;
     {
         const int nwg = mtiles * ntiles * S;
         const int q = nwg >> 3, r = nwg & 7;
@@ -211,7 +213,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     const int k_lo = (int)((long long)nk_all * split / S);
     const int nk = (int)((long long)nk_all * (split + 1) / S) - k_lo;
     KCursor cur = {0, 0, 0};
-    if (S > 1) {                                     // position the (tap, channel) cursor on chunk k_lo
+    if (SPLIT) {                                     // position the (tap, channel) cursor on chunk k_lo
         if (MODE == MODE_DCN) {
             cur.c0 = (k_lo / 9) * 32; cur.s = k_lo % 9;
         } else if (MODE == MODE_CONV && uniform_tap) {
@@ -426,7 +428,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(w - 1) * per_wk + tbase + (i * TN + j) * 1024 + r * 64];
     }
 
-    if (S > 1) {
+    if (SPLIT && S > 1) {               // (S == 1: a group of a grouped launch that is not split)
         // Park this workgroup's partial tile (lane-contiguous: 256 B per store instruction), make it visible
         // device-wide, then take a ticket: the last of the tile's S workgroups adds the partials in split
         // order 0..S-1 (its own included, re-read: the order must not depend on who arrives last).
@@ -506,43 +508,63 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE, bool SPLIT>
 __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, int ntiles) {
-    igemm_body<BM, BN, WM, WN, WK, MODE, NSTAGE>(p, mtiles, ntiles, blockIdx.x);
+    igemm_body<BM, BN, WM, WN, WK, MODE, NSTAGE, SPLIT>(p, mtiles, ntiles, blockIdx.x);
 }
 
 // grouped form: blockIdx.y picks one of several independent problems (descriptors in device
 // memory, same tile configuration); blocks beyond a problem's tile count exit at once.
-template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int WK, int NSTAGE, bool SPLIT>
 __global__ __launch_bounds__(256) void igemm_group_kernel(const DeftGemmDesc* __restrict__ descs) {
-    const DeftGemmDesc p = descs[blockIdx.y];
+    DeftGemmDesc p = descs[blockIdx.y];
+    if (SPLIT && p.splitk < 1) p.splitk = 1;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
-    if ((int)blockIdx.x >= mtiles * ntiles * (p.splitk > 1 ? p.splitk : 1)) return;
-    igemm_body<BM, BN, WM, WN, WK, MODE, NSTAGE>(p, mtiles, ntiles, blockIdx.x);
+    if ((int)blockIdx.x >= mtiles * ntiles * (SPLIT ? p.splitk : 1)) return;
+    igemm_body<BM, BN, WM, WN, WK, MODE_CONV, NSTAGE, SPLIT>(p, mtiles, ntiles, blockIdx.x);
+}
+
+template <auto KERNEL>
+static int set_lds_attr(int lds_bytes) {
+    static bool done = false;                  // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
+    if (lds_bytes <= 64 * 1024 || done) return 0;
+    hipError_t e = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    DEFT_CHECK(e == hipSuccess, -101, "igemm: hipFuncSetAttribute(%d B LDS) failed: %s", lds_bytes, hipGetErrorString(e));
+    done = true;
+    return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE>
-static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, int ngroups, int max_tiles, hipStream_t s) {
+static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, int ngroups, int max_tiles, bool group_split, hipStream_t s) {
     constexpr int lds_bytes = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE>() * 4;
-    static bool attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
-    if (lds_bytes > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        DEFT_CHECK(e == hipSuccess, -101, "igemm: hipFuncSetAttribute(%d B LDS) failed: %s", lds_bytes, hipGetErrorString(e));
-        e = hipFuncSetAttribute((const void*)igemm_group_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        DEFT_CHECK(e == hipSuccess, -101, "igemm: hipFuncSetAttribute(%d B LDS) failed: %s", lds_bytes, hipGetErrorString(e));
-        attr_set = true;
-    }
     if (group_dev != nullptr) {
-        hipLaunchKernelGGL((igemm_group_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>), dim3(max_tiles, ngroups), dim3(256), lds_bytes, s, group_dev);
+        if constexpr (MODE == MODE_CONV) {
+            if (group_split) {
+                if (int e = set_lds_attr<igemm_group_kernel<BM, BN, WM, WN, WK, NSTAGE, true>>(lds_bytes)) return e;
+                hipLaunchKernelGGL((igemm_group_kernel<BM, BN, WM, WN, WK, NSTAGE, true>), dim3(max_tiles, ngroups), dim3(256), lds_bytes, s, group_dev);
+            } else {
+                if (int e = set_lds_attr<igemm_group_kernel<BM, BN, WM, WN, WK, NSTAGE, false>>(lds_bytes)) return e;
+                hipLaunchKernelGGL((igemm_group_kernel<BM, BN, WM, WN, WK, NSTAGE, false>), dim3(max_tiles, ngroups), dim3(256), lds_bytes, s, group_dev);
+            }
+        } else {
+            DEFT_CHECK(false, -103, "igemm: grouped launches are conv only");
+        }
     } else {
         const int mtiles = deft_cdiv(d.M, BM), ntiles = deft_cdiv(d.Cout, BN);
         const int S = d.splitk > 1 ? d.splitk : 1;
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE>), dim3(mtiles * ntiles * S), dim3(256), lds_bytes, s, d,
-                           mtiles, ntiles);
+        if (S > 1) {
+            if constexpr (MODE != MODE_PAIR) {
+                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true>>(lds_bytes)) return e;
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true>), dim3(mtiles * ntiles * S), dim3(256), lds_bytes, s, d,
+                                   mtiles, ntiles);
+            }
+        } else {
+            if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false>>(lds_bytes)) return e;
+            hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false>), dim3(mtiles * ntiles), dim3(256), lds_bytes, s, d,
+                               mtiles, ntiles);
+        }
     }
     DEFT_CHECK_LAUNCH("igemm");
     return 0;
@@ -553,11 +575,11 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
 // split-K tiles (WK = 2 / 4).
 template <int MODE>
 static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage, hipStream_t s,
-                          const DeftGemmDesc* group_dev = nullptr, int ngroups = 0, int mt = 0) {
+                          const DeftGemmDesc* group_dev = nullptr, int ngroups = 0, int mt = 0, bool gsplit = false) {
 #define DEFT_TILE(BM_, BN_, WM_, WN_, WK_)                                                                   \
     if (bm == BM_ && bn == BN_)                                                                              \
-        return one_stage ? launch_igemm<BM_, BN_, WM_, WN_, WK_, MODE, 1>(d, group_dev, ngroups, mt, s)      \
-                         : launch_igemm<BM_, BN_, WM_, WN_, WK_, MODE, 2>(d, group_dev, ngroups, mt, s);
+        return one_stage ? launch_igemm<BM_, BN_, WM_, WN_, WK_, MODE, 1>(d, group_dev, ngroups, mt, gsplit, s)      \
+                         : launch_igemm<BM_, BN_, WM_, WN_, WK_, MODE, 2>(d, group_dev, ngroups, mt, gsplit, s);
     DEFT_TILE(128, 128, 2, 2, 1)
     DEFT_TILE(128, 64, 2, 2, 1)
     DEFT_TILE(128, 32, 4, 1, 1)
@@ -664,16 +686,18 @@ extern "C" int deft_conv2d_group(const DeftGemmDesc* descs, const DeftGemmDesc* 
     const bool one_stage = !((descs[0].tile >> 29) & 1);
     if (bm == 0) { bm = 32; bn = 32; }   // one fixed (4 waves per tile) tile: few rows per group
     long long max_tiles = 0;
+    bool any_split = false;
     for (int i = 0; i < ngroups; ++i) {
         if (int e = check_conv(descs + i, "deft_conv2d_group")) return e;
         const int S = descs[i].splitk > 1 ? descs[i].splitk : 1;       // per-group cross-workgroup split (own ws / ws_cnt each)
         DEFT_CHECK(S == 1 || (descs[i].ws && descs[i].ws_cnt && S <= 32 && (descs[i].Kpad >> 5) >= S), -102,
                    "deft_conv2d_group: group %d splitk=%d needs ws, ws_cnt, S <= 32 and at least S K chunks", i, S);
+        any_split |= S > 1;
         const long long t = (long long)deft_cdiv(descs[i].M, bm) * deft_cdiv(descs[i].Cout, bn) * S;
         max_tiles = t > max_tiles ? t : max_tiles;
     }
     DEFT_CHECK(max_tiles < (1ll << 31), -41, "deft_conv2d_group: too many tiles");
-    return dispatch_igemm<MODE_CONV>(descs[0], bm, bn, one_stage, (hipStream_t)stream, descs_dev, ngroups, (int)max_tiles);
+    return dispatch_igemm<MODE_CONV>(descs[0], bm, bn, one_stage, (hipStream_t)stream, descs_dev, ngroups, (int)max_tiles, any_split);
 }
 
 extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {

@@ -635,33 +635,54 @@ extern "C" int deft_embed_blend(const float* tmp, const float* bw, const int* ma
 // ---------------------------------------------------------------------------
 #define AF_MAXOBJ 112   // 112*112*4 B = 49 KB of LDS (opts.py:339 max_object = 100)
 
-__global__ __launch_bounds__(256) void affinity_finish_kernel(const float* __restrict__ h4, int ldh, int C4,
-                                                              const float* __restrict__ w5, float b5,
-                                                              const int* __restrict__ row_start, int Q, int max_object,
+// phase 1, every pair of every frame block in parallel: e = exp(relu(h4 . w5 + b5)), parked at the pair's final
+// place in `out`.  16 lanes per pair row (one float4 each: a 256-byte row is one coalesced request), 4 rows per
+// 16-lane group in flight, partial dot products combined with 4 xor-shuffles.
+__global__ __launch_bounds__(256) void affinity_pairs_kernel(const float* __restrict__ h4, int ldh, int C4,
+                                                             const float* __restrict__ w5, float b5, int TQ, int Q,
+                                                             float* __restrict__ out) {
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    float acc[4];
+    int pid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = (blockIdx.x * 4 + u) * 16 + grp;
+        pid[u] = p;
+        acc[u] = 0.f;
+        if (p < TQ) {
+            const float* hp = h4 + (size_t)p * ldh;
+            for (int k = sub * 4; k < C4; k += 64) {
+                const float4 v = *(const float4*)(hp + k);
+                acc[u] += v.x * w5[k] + v.y * w5[k + 1] + v.z * w5[k + 2] + v.w * w5[k + 3];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float a = acc[u];
+        a += __shfl_xor(a, 8);
+        a += __shfl_xor(a, 4);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 1);
+        if (sub == 0 && pid[u] < TQ) {
+            const int t = pid[u] / Q, j = pid[u] - t * Q;
+            out[(size_t)t * (Q + 1) + j] = expf(fmaxf(a + b5, 0.f));
+        }
+    }
+}
+
+// phase 2, one block per history frame: row / column sums with the analytic padding terms, max of the two
+// softmaxes, unmatched column -- in place on `out`.
+__global__ __launch_bounds__(256) void affinity_finish_kernel(const int* __restrict__ row_start, int Q, int max_object,
                                                               float* __restrict__ out) {
     __shared__ float E[AF_MAXOBJ * AF_MAXOBJ];
     __shared__ float rs[AF_MAXOBJ], csum[AF_MAXOBJ];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int t0 = row_start[f], P = row_start[f + 1] - t0;
     const float e1 = expf(1.f);
-    // 16 lanes per pair row: each reads one float4 of the row (a 256-byte row = one coalesced request),
-    // the 16 partial dot products are combined with 4 xor-shuffles
-    const int sub = tid & 15, grp = tid >> 4;
-    for (int p0 = 0; p0 < P * Q; p0 += 16) {
-        const int p = p0 + grp;
-        float acc = 0.f;
-        if (p < P * Q) {
-            const float* hp = h4 + ((size_t)t0 * Q + p) * ldh;
-            for (int k = sub * 4; k < C4; k += 64) {
-                const float4 v = *(const float4*)(hp + k);
-                acc += v.x * w5[k] + v.y * w5[k + 1] + v.z * w5[k + 2] + v.w * w5[k + 3];
-            }
-        }
-        acc += __shfl_xor(acc, 8);
-        acc += __shfl_xor(acc, 4);
-        acc += __shfl_xor(acc, 2);
-        acc += __shfl_xor(acc, 1);
-        if (sub == 0 && p < P * Q) E[p] = expf(fmaxf(acc + b5, 0.f));
+    for (int p = tid; p < P * Q; p += 256) {
+        const int i = p / Q, j = p - i * Q;
+        E[p] = out[(size_t)(t0 + i) * (Q + 1) + j];
     }
     __syncthreads();
     if (tid < P) {
@@ -689,12 +710,15 @@ __global__ __launch_bounds__(256) void affinity_finish_kernel(const float* __res
 }
 
 extern "C" int deft_affinity_finish(const float* h4, int ldh, int C4, const float* w5, float b5,
-                                    const int* row_start, int F, int Q, int max_object, float* out, void* stream) {
+                                    const int* row_start, int F, int T, int Q, int max_object, float* out, void* stream) {
     DEFT_CHECK(h4 && w5 && row_start && out, -1, "deft_affinity_finish: null pointer");
     DEFT_CHECK(Q > 0 && Q <= AF_MAXOBJ && max_object <= AF_MAXOBJ && Q <= max_object && (C4 & 3) == 0 && (ldh & 3) == 0, -2,
                "deft_affinity_finish: Q=%d max_object=%d must be <= %d", Q, max_object, AF_MAXOBJ);
     if (F <= 0) return 0;
-    hipLaunchKernelGGL(affinity_finish_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, h4, ldh, C4, w5, b5, row_start, Q, max_object, out);
+    DEFT_CHECK(T > 0 && (long long)T * Q < (1ll << 31), -3, "deft_affinity_finish: T=%d history rows in total (= row_start[F])", T);
+    hipLaunchKernelGGL(affinity_pairs_kernel, dim3(deft_cdiv((long long)T * Q, 64)), dim3(256), 0, (hipStream_t)stream, h4, ldh, C4, w5, b5, T * Q, Q, out);
+    DEFT_CHECK_LAUNCH("affinity_pairs");
+    hipLaunchKernelGGL(affinity_finish_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, row_start, Q, max_object, out);
     DEFT_CHECK_LAUNCH("affinity_finish");
     return 0;
 }

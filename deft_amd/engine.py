@@ -744,7 +744,7 @@ class AfePlan(_Plan):
         self._lin(h3, M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, h4, c4)
         out = torch.empty(T, Q + 1, dtype=torch.float32, device=dev)
         rs = torch.tensor(starts, dtype=torch.int32, device=dev)
-        self.lib.call("deft_affinity_finish", ptr(h4), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(rs), len(hist), Q,
+        self.lib.call("deft_affinity_finish", ptr(h4), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(rs), len(hist), T, Q,
                       self.max_object, ptr(out), self._stream())
         return out, starts
 
@@ -793,7 +793,7 @@ class AfePlan(_Plan):
             self._lin(b["h2"], M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, b["h3"], c3)
             self._lin(b["h3"], M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, b["h4"], c4)
             self.lib.call("deft_affinity_finish", ptr(b["h4"]), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(b["rs"]),
-                          nc * hist, K, self.max_object, C.c_void_p(b["out"].data_ptr() + 4 * c0 * hist * K * (K + 1)), self._stream())
+                          nc * hist, nc * hist * K, K, self.max_object, C.c_void_p(b["out"].data_ptr() + 4 * c0 * hist * K * (K + 1)), self._stream())
         return b["out"]
 
     @staticmethod

@@ -187,9 +187,10 @@ int deft_embed_blend(const float* tmp, const float* bw, const int* map_out, int 
  * x = relu(h4 . w5 + b5) per pair, then the dual softmax with the analytic padding
  * terms ((max_object - n) * e^0 + e^1) and the max/unmatched-column assembly
  * (AFE.py:119-150).  h4 [T*Q][ldh] (pairs ordered (t,j)), row_start [F+1] prefix of
- * history object counts (T = row_start[F]); out [T][Q+1]. */
+ * history object counts (device array; T = row_start[F] is also passed by value); out [T][Q+1].  Two launches:
+ * all T*Q pairs in parallel, then one block per history frame for the softmaxes (in place on `out`). */
 int deft_affinity_finish(const float* h4, int ldh, int C4, const float* w5, float b5,
-                         const int* row_start, int F, int Q, int max_object,
+                         const int* row_start, int F, int T, int Q, int max_object,
                          float* out, void* stream);
 
 /* One LSTM step + two Linears for T tracks at once.  Replaces the per-track
