@@ -139,3 +139,36 @@ def test_conv_splitk(emu_lib, kw):
 
 def test_splitk_auto(emu_lib):
     pc.check_splitk_auto(emu_lib, "cpu")
+
+
+def test_conv_random_shapes(emu_lib):
+    """Seeded sweep over geometry the fixed cases do not list: odd sizes, strides, paddings, channel counts that
+    are not tile multiples, every tile (incl. both loop forms), library-chosen split-K."""
+    import random
+    rnd = random.Random(20260926)
+    tiles = [pc.T(128, 128), pc.T(128, 64), pc.T(128, 32), pc.T(64, 64), pc.T(64, 128), pc.T(64, 32), pc.T(32, 32), 0]
+    for case in range(14):
+        k = rnd.choice([1, 3, 3, 5])
+        Ci = rnd.choice([4, 8, 16, 32, 64, 128]) if k > 1 else rnd.choice([4, 12, 36, 64, 100, 256])
+        Co = rnd.choice([1, 5, 16, 27, 33, 64, 96, 130])
+        stride = rnd.choice([1, 1, 2])
+        pad = rnd.choice([0, k // 2])
+        H = rnd.randint(max(k, 3), 13); W = rnd.randint(max(k, 3), 15)
+        N = rnd.randint(1, 3)
+        tile = rnd.choice(tiles)
+        if tile and rnd.random() < 0.4:
+            tile |= 1 << 29
+        if Ci < 32 and k == 5 and ((Ci * 25 + 31) // 32 * 32) // Ci > 64:
+            continue                                     # Cin < 32 supports at most 64 taps incl. K padding
+        pc.check_conv(emu_lib, "cpu", N, H, W, Ci, Co, k, stride, pad, tile, res=bool(case & 1), relu=bool(case & 2), seed=case)
+
+
+def test_dcn_random_shapes(emu_lib):
+    import random
+    rnd = random.Random(7)
+    for case in range(8):
+        Ci = rnd.choice([32, 64, 128])
+        Co = rnd.choice([8, 27, 40, 64, 100, 130])
+        N, H, W = rnd.randint(1, 2), rnd.randint(2, 9), rnd.randint(2, 11)
+        tile = rnd.choice([0, pc.T(64, 64), pc.T(64, 128), pc.T(128, 64), pc.T(64, 64) | (1 << 29)])
+        pc.check_dcn(emu_lib, "cpu", N, H, W, Ci, Co, tile=tile, seed=case, big_offsets=bool(case & 1))

@@ -327,3 +327,31 @@ def test_conv_splitk(gpu_lib, kw):
 
 def test_splitk_auto(gpu_lib):
     pc.check_splitk_auto(gpu_lib, "cuda")
+
+
+def test_conv_dcn_random_shapes(gpu_lib):
+    """The seeded geometry sweeps of tests/test_emu_kernels.py on the real kernels."""
+    import random
+    rnd = random.Random(20260926)
+    tiles = [pc.T(128, 128), pc.T(128, 64), pc.T(128, 32), pc.T(64, 64), pc.T(64, 128), pc.T(64, 32), pc.T(32, 32), 0]
+    for case in range(14):
+        k = rnd.choice([1, 3, 3, 5])
+        Ci = rnd.choice([4, 8, 16, 32, 64, 128]) if k > 1 else rnd.choice([4, 12, 36, 64, 100, 256])
+        Co = rnd.choice([1, 5, 16, 27, 33, 64, 96, 130])
+        stride = rnd.choice([1, 1, 2])
+        pad = rnd.choice([0, k // 2])
+        H = rnd.randint(max(k, 3), 13); W = rnd.randint(max(k, 3), 15)
+        N = rnd.randint(1, 3)
+        tile = rnd.choice(tiles)
+        if tile and rnd.random() < 0.4:
+            tile |= 1 << 29
+        if Ci < 32 and k == 5 and ((Ci * 25 + 31) // 32 * 32) // Ci > 64:
+            continue
+        pc.check_conv(gpu_lib, "cuda", N, H, W, Ci, Co, k, stride, pad, tile, res=bool(case & 1), relu=bool(case & 2), seed=case)
+    rnd = random.Random(7)
+    for case in range(8):
+        Ci = rnd.choice([32, 64, 128])
+        Co = rnd.choice([8, 27, 40, 64, 100, 130])
+        N, H, W = rnd.randint(1, 2), rnd.randint(2, 9), rnd.randint(2, 11)
+        tile = rnd.choice([0, pc.T(64, 64), pc.T(64, 128), pc.T(128, 64), pc.T(64, 64) | (1 << 29)])
+        pc.check_dcn(gpu_lib, "cuda", N, H, W, Ci, Co, tile=tile, seed=case, big_offsets=bool(case & 1))
