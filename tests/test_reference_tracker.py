@@ -287,10 +287,12 @@ def test_reference_tracker_with_vectorised_association(emu_lib):
         RT.Tracker.get_similarity = DT.get_similarity
         RT.FeatureRecorder = DT.FeatureRecorder
         unbind = association.bind(RT.matching)
+        M.AFE.host_copy = False                                   # affinity blocks stay on the device
         try:
             got = run()
         finally:
             unbind()
+            M.AFE.host_copy = True
             RT.Tracker.get_similarity, RT.FeatureRecorder = ref_get, ref_rec
         assert max(s[1] for s in ref[-1]) >= 2
         for fa, fb in zip(ref, got):
