@@ -169,7 +169,10 @@ def main():
                 "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                 "event_bracket_overhead_us": round(ev_over_ms * 1e3, 2),     # median bracket of the step's ~2 us kernels
                 "achieved_minus_bracket_overhead": round(ach_corr, 3),
-                "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3)}
+                "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3),
+                # the same FLOPs over the TIMED steps (sub-batches overlapped on their streams, every other kernel included)
+                "pipeline_achieved": round(gemm_fl / (dt / args.steps) / 1e12, 3),
+                "pipeline_frac": round(gemm_fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
         by = {}
         for (k, fl, e0, e1, _i, _b) in prof:
             by.setdefault(k, [0.0, 0, 0.0]); by[k][0] += e0.elapsed_time(e1); by[k][1] += 1; by[k][2] += fl
