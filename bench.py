@@ -122,6 +122,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pipe.step(images)
+    host_dt = time.perf_counter() - t0        # time the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -187,6 +188,7 @@ def main():
     if rank == 0:
         out = {"metric": "frames/sec (detect+embed+affinity) at 1088x608", "value": round(fps, 3), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "MOT17 1088x608 DLA-34 + DCNv2 + 100x500 affinity (BASELINE configs[1])",
                           "frames_per_step_per_gpu": B, "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": KDET, "history_frames": HIST,

@@ -152,13 +152,23 @@ class _Plan:
         self._keep.append(buf)
         return View(buf, N, H, W, C, ld)
 
+    _stream_cache = None       # set for the duration of run(): one torch.cuda.current_stream() query per launch list
+
     def _stream(self):
-        return hiplib.stream_ptr(self.device)
+        s = self._stream_cache
+        return s if s is not None else hiplib.stream_ptr(self.device)
 
     def add(self, kind, name, fn, flops=0.0):
         self.ops.append((kind, name, fn, flops))
 
     def run(self):
+        self._stream_cache = hiplib.stream_ptr(self.device)
+        try:
+            self._run_ops()
+        finally:
+            self._stream_cache = None
+
+    def _run_ops(self):
         if self.profile is None:
             for _, _, fn, _ in self.ops:
                 fn()

@@ -77,10 +77,12 @@ class HipLib:
                 "(hipcc --offload-arch=gfx950); deft_amd has no CPU fallback" % path)
         self.path = path
         self.cdll = C.CDLL(path)
+        self._fn = {}
         for name, (res, args) in _SIGS.items():
             fn = getattr(self.cdll, name)          # AttributeError if a symbol is not exported
             fn.restype = res
             fn.argtypes = args
+            self._fn[name] = fn
         v = self.cdll.deft_version()
         if v != ABI_VERSION:
             raise DeftHipError("libdeft_hip ABI version %d, expected %d -- rebuild: python -m deft_amd.build" % (v, ABI_VERSION))
@@ -92,7 +94,7 @@ class HipLib:
         if prof is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = getattr(self.cdll, name)(*args)
+        rc = self._fn[name](*args)
         if rc != 0:
             raise DeftHipError("%s failed (%d): %s" % (name, rc, self.cdll.deft_last_error().decode()))
         if prof is not None:
