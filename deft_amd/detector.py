@@ -29,6 +29,8 @@ class Detector(object):
         self.dataset = opt.dataset
         self.K = getattr(opt, "K", 100)
         self._plans = {}
+        self._graphs = {}          # (N,H,W) -> None after the first (eager) frame, then the captured hipGraph
+        self.hip_graphs = bool(getattr(opt, "hip_graphs", True))
         self.afe = engine.AfePlan(state_dict, getattr(opt, "max_object", 100), self.device, self.lib)
         self.img_height = 100          # detector.py:108-109
         self.img_width = 100
@@ -47,7 +49,22 @@ class Detector(object):
         assert pre_images is None and pre_hms is None, "DEFT inference never passes pre_img/pre_hm (detector.py:153,162)"
         N, _, H, W = images.shape
         plan = self._plan(N, H, W)
-        plan.forward(images.to(self.device, non_blocking=True))
+        images = images.to(self.device, non_blocking=True)
+        key = (N, H, W)
+        if not self.hip_graphs or key not in self._graphs:
+            plan.forward(images)                    # first frame of a shape: eager (sets kernel attributes, fills caches)
+            self._graphs.setdefault(key, None)
+        else:
+            # one frame per call is launch-bound on the host (~100 launches of 5-50 us): replay the plan's launch
+            # list as a hipGraph (buffers are plan-owned and static, so the capture stays valid)
+            if self._graphs[key] is None:
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
+                    plan.run()
+                self._graphs[key] = g
+            plan.image.copy_(images, non_blocking=True)
+            self._graphs[key].replay()
         d = plan.dets()
         if "dep" in d:      # _sigmoid_output, detector.py:491-493, applied at the K peaks
             d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)

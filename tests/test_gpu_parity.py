@@ -308,6 +308,18 @@ def test_detector_mirror_loads_reference_checkpoint(gpu_lib, tmp_path):
     assert (dets["inds"][0] == od["inds"][0].numpy()).all()
     for k in ("scores", "bboxes", "tracking"):
         assert pc.maxabs(torch.from_numpy(dets[k]), od[k]) <= pc.TOL, k
+    # frames 2 and 3 of the same shape replay the captured hipGraph: same bits as the eager first frame, and a
+    # different image gives that image's detections
+    for _ in range(2):
+        _, again, _ = det.process(x)
+        for k in dets:
+            assert (again[k] == dets[k]).all(), k
+    assert det._graphs[(1, 128, 160)] is not None
+    x2 = torch.randn(1, 3, 128, 160, generator=torch.Generator().manual_seed(1))
+    _, d2, _ = det.process(x2)
+    with torch.no_grad():
+        out2, _ = O.dlaseg_forward(x2, sd, "mot")
+    assert (d2["inds"][0] == O.generic_decode(O.sigmoid_output(out2), K=20)["inds"][0].numpy()).all()
     det.reset_tracking(opt)
 
 
