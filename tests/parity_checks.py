@@ -540,6 +540,13 @@ def check_seam_model(lib, device, dataset="mot", H=64, W=96):
     assert af.shape == (3, 3 + 1 + 2) and np.abs(af[:, 4:] - af[:, 3:4]).max() == 0.0
     many = model.AFE.affinity_many([e1[0, :3], e1[0, 1:5]], e1[0, 2:])
     assert np.abs(many[0] - ra).max() <= 1e-4 and many[1].shape == (4, 4)
+    # later calls of the same shape (on the GPU: a replayed hipGraph) return the same bits in fresh tensors
+    first = {h: v.clone() for h, v in model(x.to(device), None, None)[0][-1].items()}
+    again = model(x.to(device), None, None)[0][-1]
+    for h in first:
+        assert torch.equal(first[h], again[h]) and first[h].data_ptr() != again[h].data_ptr(), h
+    if model.hip_graphs:
+        assert model._graphs[(1, H, W)] is not None
 
 
 def check_seam_lstm(lib, device, dataset="mot"):
