@@ -16,6 +16,8 @@
 // as four ds_read_b128 (the k permutation is the same for A and B, so the
 // contraction is unchanged).  Exact fp32: the parity bar (bit-exact top-k,
 // 1e-3 on boxes) rules out bf16/fp8 MFMA; peak is 157.3 TFLOP/s.
+#include <cstdlib>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -643,8 +645,10 @@ static void pick_conv_tile(int M, int rows_per_image, int Cout, int& bm, int& bn
 // split factor for a launch of `tiles` output tiles and nk K chunks: double S until the launch has two workgroups
 // per compute unit (FILL_BLOCKS), keeping >= 8 chunks per workgroup
 static int pick_splitk(long long tiles, int nk) {
+    static const int fill = [] { const char* e = getenv("DEFT_SPLIT_FILL"); return e ? atoi(e) : FILL_BLOCKS; }();   // tuning aid
+    static const int minc = [] { const char* e = getenv("DEFT_SPLIT_MINCHUNKS"); return e ? atoi(e) : 8; }();
     int S = 1;
-    while (tiles * S < FILL_BLOCKS && nk / (2 * S) >= 8 && S < 32) S *= 2;
+    while (tiles * S < fill && nk / (2 * S) >= minc && S < 32) S *= 2;
     return S;
 }
 
