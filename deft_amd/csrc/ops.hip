@@ -479,6 +479,12 @@ extern "C" int deft_decode_boxes(const int* inds, const float* heads, int N, int
 // ---------------------------------------------------------------------------
 #define EM_MAXC 512
 
+// F.grid_sample's unnormalisation of a [-1,1] coordinate onto `size` pixels.  AFE.py:178 passes no align_corners:
+// torch >= 1.3 (the oracle as run today) means False; the authors' torch 1.2 environment meant True.
+__device__ __forceinline__ float grid_unnormalize(float g, int size, int align_corners) {
+    return align_corners ? (g + 1.f) / 2.f * (float)(size - 1) : ((g + 1.f) * (float)size - 1.f) / 2.f;
+}
+
 // One workgroup per (detection, frame).  Threads = 4 bilinear corners x (Co/4) output quads x
 // S k-slices: each thread accumulates 4 outputs over its slice of the 9*C contraction with
 // float4 weight loads (a quad group reads Co*4 contiguous bytes per k), the slices are then
@@ -487,14 +493,14 @@ extern "C" int deft_decode_boxes(const int* inds, const float* heads, int N, int
 __global__ __launch_bounds__(256) void embed_map_kernel(const float* __restrict__ fmap, int H, int W, int C, int ld,
                                                         const float* __restrict__ wsel_t, const float* __restrict__ bsel, int Co,
                                                         const float* __restrict__ centers, int ndet,
-                                                        float* __restrict__ out, int ldo, int col_off) {
+                                                        float* __restrict__ out, int ldo, int col_off, int align_corners) {
     __shared__ __attribute__((aligned(16))) float patch[16 * EM_MAXC];
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
     __shared__ float vals[4][64];
     const int tid = threadIdx.x, i = blockIdx.x, n = blockIdx.y;
     const float gx = centers[((size_t)n * ndet + i) * 2], gy = centers[((size_t)n * ndet + i) * 2 + 1];
-    // grid_sample: unnormalise (align_corners=False), clip to the border, bilinear corners
-    float fx = ((gx + 1.f) * W - 1.f) / 2.f, fy = ((gy + 1.f) * H - 1.f) / 2.f;
+    // grid_sample: unnormalise, clip to the border, bilinear corners
+    float fx = grid_unnormalize(gx, W, align_corners), fy = grid_unnormalize(gy, H, align_corners);
     fx = fminf((float)(W - 1), fmaxf(fx, 0.f));
     fy = fminf((float)(H - 1), fmaxf(fy, 0.f));
     const float x0f = floorf(fx), y0f = floorf(fy);
@@ -549,13 +555,13 @@ __global__ __launch_bounds__(256) void embed_map_kernel(const float* __restrict_
 
 extern "C" int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, int ld,
                               const float* wsel_t, const float* bsel, int Co,
-                              const float* centers, int ndet, float* out, int ldo, int col_off, void* stream) {
+                              const float* centers, int ndet, float* out, int ldo, int col_off, int align_corners, void* stream) {
     DEFT_CHECK(fmap && wsel_t && bsel && centers && out, -1, "deft_embed_map: null pointer");
     DEFT_CHECK(C <= EM_MAXC && (C & 3) == 0 && (ld & 3) == 0 && Co <= 64 && Co >= 4 && (Co & 3) == 0, -2,
                "deft_embed_map: C=%d (<=%d, %%4) Co=%d (4..64, %%4)", C, EM_MAXC, Co);
     if (ndet <= 0) return 0;
     hipLaunchKernelGGL(embed_map_kernel, dim3(ndet, Nf), dim3(256), 0, (hipStream_t)stream,
-                       fmap, H, W, C, ld, wsel_t, bsel, Co, centers, ndet, out, ldo, col_off);
+                       fmap, H, W, C, ld, wsel_t, bsel, Co, centers, ndet, out, ldo, col_off, align_corners);
     DEFT_CHECK_LAUNCH("embed_map");
     return 0;
 }
@@ -565,7 +571,7 @@ extern "C" int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, in
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ centers, int Nf, int ndet,
                                                          const int* __restrict__ map_hw, int nmaps,
-                                                         int* __restrict__ rowmap, float* __restrict__ bw) {
+                                                         int* __restrict__ rowmap, float* __restrict__ bw, int align_corners) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int per = Nf * ndet;
     if (t >= nmaps * per) return;
@@ -573,8 +579,8 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     const int n = d / ndet;
     const int H = map_hw[2 * k], W = map_hw[2 * k + 1];
     const float gx = centers[2 * d], gy = centers[2 * d + 1];
-    // grid_sample: unnormalise (align_corners=False), clip to the border, bilinear corners
-    float fx = ((gx + 1.f) * W - 1.f) / 2.f, fy = ((gy + 1.f) * H - 1.f) / 2.f;
+    // grid_sample: unnormalise, clip to the border, bilinear corners
+    float fx = grid_unnormalize(gx, W, align_corners), fy = grid_unnormalize(gy, H, align_corners);
     fx = fminf((float)(W - 1), fmaxf(fx, 0.f));
     fy = fminf((float)(H - 1), fmaxf(fy, 0.f));
     const float x0f = floorf(fx), y0f = floorf(fy);
@@ -594,11 +600,11 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
 }
 
 extern "C" int deft_embed_rows(const float* centers, int Nf, int ndet, const int* map_hw, int nmaps,
-                               int* rowmap, float* bw, void* stream) {
+                               int* rowmap, float* bw, int align_corners, void* stream) {
     DEFT_CHECK(centers && map_hw && rowmap && bw && nmaps > 0, -1, "deft_embed_rows: bad arguments");
     if (Nf * ndet <= 0) return 0;
     hipLaunchKernelGGL(embed_rows_kernel, dim3(deft_cdiv((long long)nmaps * Nf * ndet, 256)), dim3(256), 0, (hipStream_t)stream,
-                       centers, Nf, ndet, map_hw, nmaps, rowmap, bw);
+                       centers, Nf, ndet, map_hw, nmaps, rowmap, bw, align_corners);
     DEFT_CHECK_LAUNCH("embed_rows");
     return 0;
 }

@@ -572,9 +572,12 @@ class DlaSegPlan(_Plan):
 class AfePlan(_Plan):
     """Embedding extraction at detection centres + pairwise affinity (AFE.py:88-213)."""
 
-    def __init__(self, sd, max_object=100, device="cuda", lib=None):
+    def __init__(self, sd, max_object=100, device="cuda", lib=None, align_corners=False):
+        """align_corners: how grid_sample (AFE.py:178, no flag passed) maps [-1,1] onto pixels -- False = torch >= 1.3
+        (the reference as it runs today; the oracle), True = the torch 1.2 behaviour of the authors' environment."""
         super().__init__(device, lib)
         self.max_object = max_object
+        self.align_corners = bool(align_corners)
         nsel = 13
         self.sel, self.sel_t = [], []
         off = 0
@@ -685,7 +688,7 @@ class AfePlan(_Plan):
         g = self._embed_group(fmaps, Nf, ndet)
         s = self._stream()
         nm = len(self.sel)
-        self.lib.call("deft_embed_rows", ptr(centers), Nf, ndet, ptr(g["map_hw"]), nm, ptr(g["rowmap"]), ptr(g["bw"]), s)
+        self.lib.call("deft_embed_rows", ptr(centers), Nf, ndet, ptr(g["map_hw"]), nm, ptr(g["rowmap"]), ptr(g["bw"]), int(self.align_corners), s)
         self.lib.call("deft_conv2d_group", g["descs"], C.c_void_p(g["descs_dev"].data_ptr()), nm, s)
         self.lib.call("deft_embed_blend", ptr(g["tmp"]), ptr(g["bw"]), ptr(g["map_out"]), nm, Nf, ndet, ptr(out), self.D, s)
         return out
@@ -700,7 +703,7 @@ class AfePlan(_Plan):
         for fm, (wp, K, b, Co, Cc, off), wt in zip(fmaps, self.sel, self.sel_t):
             assert fm.C == Cc and fm.N == Nf
             self.lib.call("deft_embed_map", C.c_void_p(fm.addr), Nf, fm.H, fm.W, fm.C, fm.ld, ptr(wt), ptr(b), Co,
-                          ptr(centers), ndet, ptr(out), self.D, off, s)
+                          ptr(centers), ndet, ptr(out), self.D, off, int(self.align_corners), s)
         return out
 
     def _lin(self, x, M, Cin, ldx, wp, Kpad, Cout, scale, shift, relu, y, ldy):

@@ -52,8 +52,8 @@ _SIGS = {
     "deft_peak_rows": (C.c_int, [c_fp] + [C.c_int] * 4 + [c_fp, c_fp]),
     "deft_heads_finish": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_int, c_fp, c_fp]),
     "deft_decode_boxes": (C.c_int, [c_fp, c_fp] + [C.c_int] * 8 + [c_fp] * 4),
-    "deft_embed_map": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp]),
-    "deft_embed_rows": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),
+    "deft_embed_map": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "deft_embed_rows": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, C.c_int, c_fp]),
     "deft_embed_blend": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp]),
     "deft_affinity_finish": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_float, c_fp] + [C.c_int] * 4 + [c_fp, c_fp]),
     "deft_lstm_step": (C.c_int, [c_fp] * 3 + [C.c_int] * 3 + [c_fp] * 8 + [c_fp]),

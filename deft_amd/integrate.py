@@ -98,8 +98,8 @@ class DCN(nn.Module):
 class AfeSeam:
     """Stands in for `model.AFE` (AFE.py:18): the two methods the tracker calls."""
 
-    def __init__(self, state_dict, max_object=100, device="cuda", lib=None):
-        self.plan = engine.AfePlan(state_dict, max_object, device, _lib(lib))
+    def __init__(self, state_dict, max_object=100, device="cuda", lib=None, align_corners=False):
+        self.plan = engine.AfePlan(state_dict, max_object, device, _lib(lib), align_corners=align_corners)
         self.device = self.plan.device
         self.max_object = max_object
         self.host_copy = True       # affinity_many also returns the blocks as numpy (the reference's recorder layout)

@@ -162,16 +162,17 @@ int deft_decode_boxes(const int* inds, const float* heads, int N, int K, int Wm,
 
 /* Embedding head for one feature map: ReLU(3x3 selector conv) evaluated only at the
  * 4 bilinear neighbours of each detection centre, then the grid_sample blend
- * (bilinear, padding_mode=border, align_corners=False).  Replaces
+ * (bilinear, padding_mode=border; align_corners: 0 = torch >= 1.3 default, what AFE.py:178 means today and what the
+ * oracle is pinned to, 1 = the torch 1.2 behaviour of the authors' environment).  Replaces
  * AFE_module.forward_selector_stacker1 (AFE.py:162-188) for one (map, selector) pair.
  * fmap NHWC [Nf,H,W,C]; wsel_t [9*C][Co] (k=(r*3+s)*C+c); centers [Nf][ndet][2] (x,y in
  * [-1,1]); out[(n*ndet+i)*ldo + col_off + o]. */
 int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, int ld,
                    const float* wsel_t, const float* bsel, int Co,
-                   const float* centers, int ndet, float* out, int ldo, int col_off, void* stream);
+                   const float* centers, int ndet, float* out, int ldo, int col_off, int align_corners, void* stream);
 
 /* Embedding head, fused over all maps (AFE.py:162-188), step 1: for every (map k, frame n, detection
- * i) turn the centre (x,y in [-1,1], grid_sample align_corners=False, border padding) into the four
+ * i) turn the centre (x,y in [-1,1], grid_sample with the given align_corners, border padding) into the four
  * bilinear corner pixels -> rowmap[k][(n*ndet+i)*4+q] (DeftGemmDesc.rowmap format, q = 2*dy+dx;
  * corners outside the map are unused rows) and the four blend weights bw[k][n*ndet+i][4] (0 for
  * unused corners).  map_hw [nmaps][2] = (H, W) per map, device memory.
@@ -179,7 +180,7 @@ int deft_embed_map(const float* fmap, int Nf, int H, int W, int C, int ld,
  * out[(n*ndet+i)*ldo + col_off_k + o] = sum_q bw[k][..][q] * tmp_k[((n*ndet+i)*4+q)*ldt_k + o].
  * map_out [nmaps][4] = (float offset of tmp_k inside tmp, ldt_k, Co_k, col_off_k), device memory. */
 int deft_embed_rows(const float* centers, int Nf, int ndet, const int* map_hw, int nmaps,
-                    int* rowmap, float* bw, void* stream);
+                    int* rowmap, float* bw, int align_corners, void* stream);
 int deft_embed_blend(const float* tmp, const float* bw, const int* map_out, int nmaps, int Nf, int ndet,
                      float* out, int ldo, void* stream);
 

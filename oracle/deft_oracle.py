@@ -249,15 +249,16 @@ def convert_detection(boxes, h, w):
     return torch.from_numpy(c.astype(float)).float().view(1, -1, 1, 1, 2)
 
 
-def afe_extract(fmaps, centers, sd):
+def afe_extract(fmaps, centers, sd, align_corners=False):
     """AFE.forward_feature_extracter AFE.py:88-92 -> forward_selector_stacker1
     AFE.py:162-188: ReLU(3x3 selector conv) on all 13 maps, bilinear grid_sample
-    (border padding, align_corners default False on torch>=1.3) at each centre."""
+    (border padding) at each centre.  AFE.py:178 passes no align_corners: False on torch >= 1.3
+    (what the reference computes today and what the fixtures pin); True reproduces torch 1.2."""
     srcs = [F.relu(F.conv2d(x, sd["AFE.selector.%d.weight" % k], sd["AFE.selector.%d.bias" % k], 1, 1))
             for k, x in enumerate(fmaps)]
     N = centers.shape[1]
     grid = centers.view(1, N, 1, 2)
-    res = [F.grid_sample(s, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    res = [F.grid_sample(s, grid, mode="bilinear", padding_mode="border", align_corners=align_corners)
            .squeeze(3).permute(0, 2, 1) for s in srcs]                  # each [1,N,C]
     return torch.cat(res, 2)
 

@@ -248,7 +248,7 @@ def check_embed(lib, device, plan, ora_maps, sd, golden_tag=None, ndet=12):
     return afe, emb
 
 
-def check_embed_map(lib, device, Cc, Co, Hm=7, Wm=9, ndet=6, Nf=2, seed=0):
+def check_embed_map(lib, device, Cc, Co, Hm=7, Wm=9, ndet=6, Nf=2, seed=0, align_corners=False):
     """One (map, selector) pair of the embedding head vs conv2d + relu + grid_sample."""
     from deft_amd.hiplib import ptr, stream_ptr
     g = torch.Generator().manual_seed(seed)
@@ -263,15 +263,15 @@ def check_embed_map(lib, device, Cc, Co, Hm=7, Wm=9, ndet=6, Nf=2, seed=0):
     out = torch.zeros(Nf, ndet, Co + 8, device=dev)
     xd, wd, bd, cd = x.to(dev), wt.to(dev), b.to(dev), cen.to(dev).contiguous()     # keep the device copies alive
     lib.call("deft_embed_map", ptr(xd), Nf, Hm, Wm, Cc, Cc, ptr(wd), ptr(bd), Co,
-             ptr(cd), ndet, ptr(out), Co + 8, 4, stream_ptr(dev))
+             ptr(cd), ndet, ptr(out), Co + 8, 4, int(align_corners), stream_ptr(dev))
     src = F.relu(F.conv2d(fm, w, b, 1, 1))
-    ref = F.grid_sample(src, cen.view(Nf, ndet, 1, 2), mode="bilinear", padding_mode="border", align_corners=False)
+    ref = F.grid_sample(src, cen.view(Nf, ndet, 1, 2), mode="bilinear", padding_mode="border", align_corners=align_corners)
     ref = ref.squeeze(3).permute(0, 2, 1)
     assert maxabs(out[..., 4:4 + Co], ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert float(out[..., :4].abs().max()) == 0.0 and float(out[..., 4 + Co:].abs().max()) == 0.0
 
 
-def check_embed_fused(lib, device, Nf=2, ndet=7, seed=0):
+def check_embed_fused(lib, device, Nf=2, ndet=7, seed=0, align_corners=False):
     """Fused embedding head (deft_embed_rows -> deft_conv2d_group on sparse rows -> deft_embed_blend)
     over maps of different C / size / Co, against conv2d + relu + grid_sample and against the
     per-map entry point deft_embed_map."""
@@ -280,6 +280,7 @@ def check_embed_fused(lib, device, Nf=2, ndet=7, seed=0):
     plan = engine._Plan(device, lib)
     afe = engine.AfePlan.__new__(engine.AfePlan)
     engine._Plan.__init__(afe, device, lib)
+    afe.align_corners = align_corners
     afe.sel, afe.sel_t, fmaps, refs_in = [], [], [], []
     off = 0
     for (Cc, Hm, Wm, Co) in cfg:
@@ -302,7 +303,7 @@ def check_embed_fused(lib, device, Nf=2, ndet=7, seed=0):
     col = 0
     for (fm, w, b), (Cc, Hm, Wm, Co) in zip(refs_in, cfg):
         src = F.relu(F.conv2d(fm, w, b, 1, 1))
-        ref = F.grid_sample(src, cen.view(Nf, ndet, 1, 2), mode="bilinear", padding_mode="border", align_corners=False)
+        ref = F.grid_sample(src, cen.view(Nf, ndet, 1, 2), mode="bilinear", padding_mode="border", align_corners=align_corners)
         ref = ref.squeeze(3).permute(0, 2, 1)
         tol = 2e-5 * max(1.0, float(ref.abs().max()))
         assert maxabs(out[..., col:col + Co], ref) <= tol, ("embed_fused", Cc, Hm, Wm, Co)

@@ -172,3 +172,9 @@ def test_dcn_random_shapes(emu_lib):
         N, H, W = rnd.randint(1, 2), rnd.randint(2, 9), rnd.randint(2, 11)
         tile = rnd.choice([0, pc.T(64, 64), pc.T(64, 128), pc.T(128, 64), pc.T(64, 64) | (1 << 29)])
         pc.check_dcn(emu_lib, "cpu", N, H, W, Ci, Co, tile=tile, seed=case, big_offsets=bool(case & 1))
+
+
+def test_embed_align_corners_switch(emu_lib):
+    """grid_sample(align_corners=True): the torch 1.2 behaviour of the authors' environment."""
+    pc.check_embed_map(emu_lib, "cpu", 64, 48, align_corners=True)
+    pc.check_embed_fused(emu_lib, "cpu", align_corners=True)
