@@ -136,6 +136,9 @@ class _Plan:
     def __init__(self, device, lib=None):
         self.device = torch.device(device)
         self.lib = lib if lib is not None else hiplib.get_lib()
+        if (self.device.type == "cuda") == bool(getattr(self.lib, "host_pointers", False)):
+            raise hiplib.DeftHipError("deft_amd runs on an MI355X only: device %s with %s (there is no CPU path)"
+                                      % (self.device, self.lib.path))
         self.ops = []          # (kind, name, callable, flops)
         self._gemms = []       # (entry, name, descriptor) of every implicit-GEMM launch, for autotune()
         self._keep = []        # tensors / descriptors kept alive

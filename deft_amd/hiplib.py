@@ -83,6 +83,8 @@ class HipLib:
             fn.restype = res
             fn.argtypes = args
             self._fn[name] = fn
+        # a build whose kernels run on host memory (the unit-test build of the same sources) exports this marker
+        self.host_pointers = hasattr(self.cdll, "deft_host_pointers")
         v = self.cdll.deft_version()
         if v != ABI_VERSION:
             raise DeftHipError("libdeft_hip ABI version %d, expected %d -- rebuild: python -m deft_amd.build" % (v, ABI_VERSION))

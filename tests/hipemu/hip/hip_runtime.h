@@ -29,6 +29,10 @@
 #include <thread>
 #include <vector>
 
+// marks this build for the loader: its "device" pointers are host pointers (deft_amd/hiplib.py refuses to run the
+// real library on CPU tensors, and this build on GPU tensors)
+extern "C" __attribute__((weak, visibility("default"))) int deft_host_pointers(void) { return 1; }
+
 #define __global__
 #define __device__
 #define __host__

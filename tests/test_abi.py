@@ -88,3 +88,15 @@ def test_error_conventions(emu_lib):
         emu_lib.call("deft_topk", ptr(x), ptr(x.int()), ptr(x.int()), 1, 4, 0, 4, ptr(x), ptr(x.int()), ptr(x.int()), None)
     with pytest.raises(hiplib.DeftHipError, match="nin="):
         emu_lib.call("deft_lstm_step", *([ptr(x)] * 3), 1, 40, 20, *([ptr(x)] * 8), None)
+
+
+def test_real_library_refuses_cpu_tensors():
+    """The product library on a CPU device must fail loudly, not dereference host pointers on the GPU."""
+    from deft_amd import engine, hiplib
+    so = os.path.join(ROOT, "deft_amd", "lib", "libdeft_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("libdeft_hip.so not built")
+    lib = hiplib.HipLib(so)
+    assert not lib.host_pointers
+    with pytest.raises(hiplib.DeftHipError):
+        engine._Plan("cpu", lib)
