@@ -630,7 +630,8 @@ static int check_conv(const DeftGemmDesc* d, const char* who) {
 
 // automatic tile choice for a conv problem of M rows x Cout columns.  The split-K tile changes
 // the fp32 summation order, so whether it is used depends on the rows PER IMAGE only: results
-// are then bit-identical whatever the batch size (the WK = 1 tiles all sum in the same order).
+// are then bit-identical whatever the batch size (the WK = 1 tiles all sum in the same order) -- as long as no
+// cross-workgroup split (DeftGemmDesc.splitk, chosen for launches with few tiles) is in play.
 static void pick_conv_tile(int M, int rows_per_image, int Cout, int& bm, int& bn) {
     const long long m128 = deft_cdiv(M, 128);
     if (Cout <= 32) {
