@@ -33,10 +33,13 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 // dynamic-LDS layout (floats): As[NSTAGE][BM*36] | Bs[NSTAGE][BN*36] | DCN sampling records [9][BM][8] + masks [9][BM];
 // with intra-workgroup split-K (WK > 1) the same region is reused after the K loop for the
 // partial accumulators of the wk > 0 waves: [(WK-1)][32x32 tiles of the block][16][64].
-template <int BM, int BN, int WK, int NSTAGE, int MODE>
+// PREC = 1 (fp32 through the bf16 matrix cores): the staged chunk is three bf16 planes (hi, mid, lo) of
+// [rows][32 + 8 pad] instead of one fp32 image.
+#define LDB 40
+template <int BM, int BN, int WK, int NSTAGE, int MODE, int PREC = 0>
 constexpr int igemm_lds_floats() {
     constexpr int ld = (MODE == MODE_CONV && NSTAGE == 2) ? 32 : LDS_STRIDE;      // LDS-DMA image is unpadded
-    constexpr int stage = NSTAGE * (BM + BN) * ld + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
+    constexpr int stage = (PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
     constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
     return stage > red ? stage : red;
 }
@@ -53,8 +56,27 @@ struct KCursor {
 // combined through LDS in wave order, so the result is deterministic).
 // SPLIT: cross-workgroup split-K (DeftGemmDesc.splitk > 1).  A separate instantiation: its partial-tile hand-over
 // must not cost the plain kernels a register (128x128: 104 VGPRs = 3 waves/SIMD, 136 with the hand-over = 2).
-template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE, bool SPLIT>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x = hi + mid + lo with three bf16 pieces (8 + 8 + 8 mantissa bits: exact for fp32).
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r1 = v[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[e] = hh; m[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
+    }
+}
+
+// PREC: 0 = v_mfma_f32_32x32x2_f32 (a k-ordered fp32 fmaf chain); 1 = every fp32 product as six
+// v_mfma_f32_32x32x16_bf16 products of the operands' bf16 pieces (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid:
+// everything down to 2^-24 relative), fp32 accumulation -- the error of an fp32 chain (tools/probe/split_bf16_loop.hip:
+// 5.9e-6 vs 6.8e-6 max abs at K = 512) at 16/6 of the fp32 MFMA rate.  WK = 1 tiles, 1-stage loop.
+template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE, bool SPLIT, int PREC = 0>
 __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, int ntiles, int bid) {
+    static_assert(PREC == 0 || (WK == 1 && NSTAGE == 1), "split-bf16 path: WK = 1 tiles, 1-stage loop");
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int GA = BM / 32;  // f32x4 groups per thread, A tile
@@ -73,7 +95,9 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     DEFT_DYN_LDS(float, smem);
     float* const As = smem;
     float* const Bs = smem + NSTAGE * BM * LD;
-    float* const prm = Bs + NSTAGE * BN * LD;   // DCN only
+    float* const prm = PREC ? smem + 3 * (BM + BN) * LDB / 2 : Bs + NSTAGE * BN * LD;   // DCN only
+    __bf16* const Ap = (__bf16*)smem;            // PREC = 1: A planes [3][BM][LDB], then B planes [3][BN][LDB]
+    __bf16* const Bp = Ap + 3 * BM * LDB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -321,10 +345,26 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 const f32x4 t = s0[i] + s1[i];
                 v = f32x4{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)};
             }
-            *(f32x4*)&as[32 * i * LDS_STRIDE] = v;
+            if (PREC) {
+                bf16x4 h, m, l;
+                split3(v, h, m, l);
+                __bf16* ap = Ap + (rbase + 32 * i) * LDB + g * 4;
+                *(bf16x4*)ap = h; *(bf16x4*)(ap + BM * LDB) = m; *(bf16x4*)(ap + 2 * BM * LDB) = l;
+            } else {
+                *(f32x4*)&as[32 * i * LDS_STRIDE] = v;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < GB; ++i) *(f32x4*)&bs[32 * i * LDS_STRIDE] = vb[i];
+        for (int i = 0; i < GB; ++i) {
+            if (PREC) {
+                bf16x4 h, m, l;
+                split3(vb[i], h, m, l);
+                __bf16* bp = Bp + (rbase + 32 * i) * LDB + g * 4;
+                *(bf16x4*)bp = h; *(bf16x4*)(bp + BN * LDB) = m; *(bf16x4*)(bp + 2 * BN * LDB) = l;
+            } else {
+                *(f32x4*)&bs[32 * i * LDS_STRIDE] = vb[i];
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -371,6 +411,36 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         __builtin_amdgcn_sched_barrier(0);       // nothing of finish_store() may be scheduled above the MFMAs
     };
 
+    // PREC = 1: the two K = 16 halves of the chunk; a lane's fragment = 8 consecutive k of its row (k group lane>>5)
+    auto split_chunk = [&]() {
+        const int fkg = (lane >> 5) * 8;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            bf16x8 pa[TM][3], pb[TN][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) pa[i][pl] = *(const bf16x8*)(Ap + pl * BM * LDB + ((wm * TM + i) * 32 + frow) * LDB + kh * 16 + fkg);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) pb[j][pl] = *(const bf16x8*)(Bp + pl * BN * LDB + ((wn * TN + j) * 32 + frow) * LDB + kh * 16 + fkg);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];                                           // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][2], pb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     if (NSTAGE == 1) {
         // one LDS stage, two barriers per chunk:  store chunk kt | barrier | issue loads kt+1,
         // fragments + MFMAs of chunk kt | barrier
@@ -379,8 +449,12 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
             finish_store(0);
             __syncthreads();
             if (kt + 1 < nk) issue_loads();
-            read_frags(0);
-            mfma_chunk();
+            if (PREC) {
+                split_chunk();
+            } else {
+                read_frags(0);
+                mfma_chunk();
+            }
             __syncthreads();  // all waves finished reading this chunk
         }
     } else {
@@ -510,9 +584,9 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE, bool SPLIT>
+template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE, bool SPLIT, int PREC = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(DeftGemmDesc p, int mtiles, int ntiles) {
-    igemm_body<BM, BN, WM, WN, WK, MODE, NSTAGE, SPLIT>(p, mtiles, ntiles, blockIdx.x);
+    igemm_body<BM, BN, WM, WN, WK, MODE, NSTAGE, SPLIT, PREC>(p, mtiles, ntiles, blockIdx.x);
 }
 
 // grouped form: blockIdx.y picks one of several independent problems (descriptors in device
@@ -556,6 +630,24 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
         const int S = d.splitk > 1 ? d.splitk : 1;
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
+        if constexpr (WK == 1 && NSTAGE == 1) {
+            if (d.prec == 1) {                   // fp32 through the bf16 matrix cores (DeftGemmDesc.prec)
+                constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 1>() * 4;
+                if (S > 1) {
+                    if constexpr (MODE != MODE_PAIR) {
+                        if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true, 1>>(lds_p)) return e;
+                        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true, 1>), dim3(mtiles * ntiles * S), dim3(256), lds_p, s, d,
+                                           mtiles, ntiles);
+                    }
+                } else {
+                    if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 1>>(lds_p)) return e;
+                    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 1>), dim3(mtiles * ntiles), dim3(256), lds_p, s, d,
+                                       mtiles, ntiles);
+                }
+                DEFT_CHECK_LAUNCH("igemm");
+                return 0;
+            }
+        }
         if (S > 1) {
             if constexpr (MODE != MODE_PAIR) {
                 if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true>>(lds_bytes)) return e;

@@ -126,6 +126,10 @@ def pack_pair_conv_weight(w, cin_pad=None):
     return pack_conv_weight(w2, cin_pad)
 
 
+# arithmetic of the implicit-GEMM contractions (DeftGemmDesc.prec): 0 = fp32 MFMA (a k-ordered fmaf chain),
+# 1 = fp32 through the bf16 matrix cores (three bf16 pieces per operand, six products, fp32 accumulation)
+PREC = int(_os.environ.get("DEFT_PREC", "0"))
+
 # cross-workgroup split-K for launches too small to fill the chip (DeftGemmDesc.splitk); DEFT_SPLITK=0 turns it off
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
 
@@ -186,6 +190,7 @@ class _Plan:
 
     # ---- op builders -------------------------------------------------------
     def gemm(self, entry, name, desc, flops):
+        desc.prec = PREC
         self._keep.append(desc)
         lib, ref = self.lib, C.byref(desc)
         self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
@@ -719,7 +724,7 @@ class AfePlan(_Plan):
         d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, Cout, ldy, 0
         d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
         d.Ktot, d.Kpad, d.cin_log2, d.M = Cin, Kpad, 0, M
-        d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0
+        d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0; d.prec = PREC
         self.lib.call("deft_conv2d_nhwc", C.byref(d), self._stream())
 
     def affinity(self, hist, cur):
@@ -752,7 +757,7 @@ class AfePlan(_Plan):
         d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, c2, c2, 0
         d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
         d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
-        d.relu = 1; d.Q = Q; d.ldom = 0; d.tile = 0
+        d.relu = 1; d.Q = Q; d.ldom = 0; d.tile = 0; d.prec = PREC
         self.lib.call("deft_pair_layer", C.byref(d), self._stream())
         h3 = torch.empty(M, c3, dtype=torch.float32, device=dev)
         self._lin(h2, M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, h3, c3)
@@ -803,7 +808,7 @@ class AfePlan(_Plan):
             d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, c2, c2, 0
             d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
             d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
-            d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0
+            d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0; d.prec = PREC
             d.Tper, d.u0, d.du, d.v0, d.dv = hist * K, (g0 + c0 - hist) * K, K, (g0 + c0) * K, K
             self.lib.call("deft_pair_layer", C.byref(d), self._stream())
             self._lin(b["h2"], M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, b["h3"], c3)

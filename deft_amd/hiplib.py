@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("Tper", C.c_int), ("u0", C.c_int), ("du", C.c_int), ("v0", C.c_int), ("dv", C.c_int),
         ("stride_w", C.c_int), ("korder", C.c_int),
         ("rowmap", c_fp),
-        ("splitk", C.c_int), ("ws", c_fp), ("ws_cnt", c_fp),
+        ("splitk", C.c_int), ("ws", c_fp), ("ws_cnt", c_fp), ("prec", C.c_int),
     ]
 
 
@@ -62,7 +62,7 @@ _SIGS = {
     "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class DeftHipError(RuntimeError):

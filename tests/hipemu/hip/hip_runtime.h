@@ -73,7 +73,7 @@ struct State {
     ucontext_t sched, *cur = nullptr;
     int yield_code = 0;
     // wave exchange buffers: [parity][slot][lane]
-    float xf[2][2][64];
+    float xf[2][16][64];
     int parity = 0;
 };
 inline State& S() { static thread_local State s; return s; }
@@ -217,6 +217,25 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float acc = c[r];
         for (int k = 0; k < 2; ++k) acc = fmaf(A[row + 32 * k], B[col + 32 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+// 32x32x16 bf16 (gfx950): lane l feeds row/col l&31 with the 8 consecutive k of group l>>5; C/D as 32x32x2.
+// Products of bf16 values are exact in fp32; the hardware's internal summation order is not specified, here k-ordered.
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
+    hipemu::State& s = hipemu::S();
+    const int p = s.parity ^ 1, lane = s.lane;
+    for (int e = 0; e < 8; ++e) { s.xf[p][e][lane] = (float)a[e]; s.xf[p][8 + e][lane] = (float)b[e]; }
+    hipemu::yield(hipemu::Y_WAVE);
+    hipemu::State& t = hipemu::S();
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kg = 0; kg < 2; ++kg)
+            for (int e = 0; e < 8; ++e) acc = fmaf(t.xf[p][e][row + 32 * kg], t.xf[p][8 + e][col + 32 * kg], acc);
         c[r] = acc;
     }
     return c;
