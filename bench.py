@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 dense (no sparsity); the split path spends 6 bf16 products per fp32 product
 H, W, KDET, HIST = 608, 1088, 100, 5
 
 
@@ -94,8 +95,9 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from deft_amd import hiplib, synth
+    from deft_amd import engine, hiplib, synth
     from deft_amd.pipeline import HipCompute, FramePipeline
+    engine_prec = engine.PREC
     lib = hiplib.get_lib()                      # no fallback: raises if the HIP extension is missing
     sd = synth.synth_state_dict("mot")
     B = args.batch
@@ -165,7 +167,15 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(sum(b for (k, _, _, _, _i, b) in prof if k in GEMM) / max(1, n_launch)),
-                "kernel": "igemm_kernel<*> (fp32 MFMA implicit GEMM: conv / DCNv2 / pair loaders)",
+                "kernel": "igemm_kernel<*> (implicit GEMM with fp32 results: conv / DCNv2 / pair loaders)",
+                # what the contraction runs on.  prec 1: each fp32 operand = 3 bf16 pieces, each fp32 product = 6 bf16 MFMA
+                # products, fp32 accumulation (error of an fp32 chain); BN < 64 tiles and prec 0: the fp32 MFMA instruction.
+                # `peak` stays the fp32 MFMA peak (what an fp32 result is priced against); the split path's own ceiling
+                # is the bf16 dense peak / 6.
+                "arithmetic": ("fp32 via 3 x bf16 operand split, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product (tiles with BN >= 64); "
+                               "v_mfma_f32_32x32x2_f32 elsewhere") if engine_prec == 1 else "v_mfma_f32_32x32x2_f32",
+                "peak_split_bf16": round(BF16_MFMA_PEAK_TF / 6, 1) if engine_prec == 1 else None,
+                "frac_of_split_peak": round(ach / (BF16_MFMA_PEAK_TF / 6), 4) if engine_prec == 1 else None,
                 "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
                 "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                 "event_bracket_overhead_us": round(ev_over_ms * 1e3, 2),     # median bracket of the step's ~2 us kernels
@@ -191,7 +201,7 @@ def main():
                "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "MOT17 1088x608 DLA-34 + DCNv2 + 100x500 affinity (BASELINE configs[1])",
-                          "frames_per_step_per_gpu": B, "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": KDET, "history_frames": HIST,
+                          "contraction": "split-bf16 x6, fp32 accumulate" if engine_prec == 1 else "fp32 MFMA", "frames_per_step_per_gpu": B, "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": KDET, "history_frames": HIST,
                           "parallelism": "frames sharded dp%d, 1 all-gather/step" % world},
                "roofline": roof, "cpu_baseline": cpu}
     # RCCL prints its version banner through C stdio on every rank; it would otherwise be flushed at process exit,

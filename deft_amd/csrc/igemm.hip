@@ -14,8 +14,10 @@
 // v_mfma_f32_32x32x2_f32 contracts two k per instruction; the k index a lane
 // half h feeds at step kk is k = 16*h + kk, so every lane reads its 16 k-values
 // as four ds_read_b128 (the k permutation is the same for A and B, so the
-// contraction is unchanged).  Exact fp32: the parity bar (bit-exact top-k,
-// 1e-3 on boxes) rules out bf16/fp8 MFMA; peak is 157.3 TFLOP/s.
+// contraction is unchanged).  The parity bar (bit-exact top-k, 1e-3 on boxes)
+// rules out plain bf16/fp8 MFMA; fp32 accuracy comes either from the fp32 MFMA
+// (prec 0, peak 157.3 TFLOP/s) or from six bf16 MFMA products per fp32 product
+// with fp32 accumulation (prec 1, see igemm_body).
 #include <cstdlib>
 
 #include "common.h"
@@ -630,7 +632,7 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
         const int S = d.splitk > 1 ? d.splitk : 1;
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
-        if constexpr (WK == 1 && NSTAGE == 1) {
+        if constexpr (WK == 1 && NSTAGE == 1 && BN >= 64) {      // BN = 32: the operand split is amortised over too few columns
             if (d.prec == 1) {                   // fp32 through the bf16 matrix cores (DeftGemmDesc.prec)
                 constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 1>() * 4;
                 if (S > 1) {

@@ -128,7 +128,7 @@ def pack_pair_conv_weight(w, cin_pad=None):
 
 # arithmetic of the implicit-GEMM contractions (DeftGemmDesc.prec): 0 = fp32 MFMA (a k-ordered fmaf chain),
 # 1 = fp32 through the bf16 matrix cores (three bf16 pieces per operand, six products, fp32 accumulation)
-PREC = int(_os.environ.get("DEFT_PREC", "0"))
+PREC = int(_os.environ.get("DEFT_PREC", "1"))
 
 # cross-workgroup split-K for launches too small to fill the chip (DeftGemmDesc.splitk); DEFT_SPLITK=0 turns it off
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"

@@ -178,3 +178,22 @@ def test_embed_align_corners_switch(emu_lib):
     """grid_sample(align_corners=True): the torch 1.2 behaviour of the authors' environment."""
     pc.check_embed_map(emu_lib, "cpu", 64, 48, align_corners=True)
     pc.check_embed_fused(emu_lib, "cpu", align_corners=True)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_both_contraction_arithmetics(emu_lib, prec):
+    """DeftGemmDesc.prec: 0 = fp32 MFMA (k-ordered fmaf chain), 1 = six bf16 MFMA products per fp32 product with fp32
+    accumulation (the default).  The same conv / DCN / pair-MLP checks against the oracle with either."""
+    import deft_oracle as O
+    from deft_amd import engine
+    saved, engine.PREC = engine.PREC, prec
+    try:
+        pc.check_conv(emu_lib, "cpu", 1, 10, 12, 64, 64, 3, 1, 1, pc.T(128, 64), res=True)
+        pc.check_conv(emu_lib, "cpu", 2, 6, 10, 448, 128, 1, 1, 0, pc.T(128, 128))
+        pc.check_conv(emu_lib, "cpu", 1, 9, 7, 16, 40, 3, 2, 1, pc.T(64, 64))          # Cin < 32: per-lane taps
+        pc.check_conv_splitk(emu_lib, "cpu", bm=64, bn=64, S=4)
+        pc.check_dcn(emu_lib, "cpu", 1, 9, 11, 64, 64)
+        pc.check_dcn(emu_lib, "cpu", 2, 5, 6, 128, 130, tile=pc.T(64, 128), big_offsets=True)
+        pc.check_affinity(emu_lib, "cpu", O.synth_state_dict("mot"))
+    finally:
+        engine.PREC = saved
