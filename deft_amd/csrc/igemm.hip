@@ -255,8 +255,6 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     }
     int kload = k_lo * 32;                           // k offset of the next chunk to load
     f32x4 s0[GA], s1[GA], s2[GA], s3[GA], sw[GA], vb[GB];
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 vbp[GB][3];                                // PREC = 1: the weights arrive split (three bf16x4 per k-slot)
     float sm[GA];
 
     int dma_stage = 0;                               // DMA form: LDS stage the next issue_loads() fills
@@ -312,13 +310,6 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
 #pragma unroll
             for (int i = 0; i < GB; ++i)
                 deft_buffer_load_lds_x4(rx2, Bs + dma_stage * BN * 32 + (wave * 8 + 32 * i) * 32, wo + (unsigned)(32 * i * p.Kpad * 4));
-        } else if (PREC) {
-            // weights packed as bf16 planes [CoutPad][3][Kpad] (engine.split_planes): no split work for B in the loop
-            const __bf16* wp = (const __bf16*)p.w + (size_t)(n0 + rbase) * 3 * p.Kpad + kload + g * 4;
-#pragma unroll
-            for (int i = 0; i < GB; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) vbp[i][pl] = *(const f32x2*)(wp + (size_t)(32 * i * 3 + pl) * p.Kpad);
         } else {
             const float* wp = p.w + (unsigned)((n0 + rbase) * p.Kpad + kload + g * 4);
 #pragma unroll
@@ -368,8 +359,10 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
             if (PREC) {
+                bf16x4 h, m, l;
+                split3(vb[i], h, m, l);
                 __bf16* bp = Bp + (rbase + 32 * i) * LDB + g * 4;
-                *(f32x2*)bp = vbp[i][0]; *(f32x2*)(bp + BN * LDB) = vbp[i][1]; *(f32x2*)(bp + 2 * BN * LDB) = vbp[i][2];
+                *(bf16x4*)bp = h; *(bf16x4*)(bp + BN * LDB) = m; *(bf16x4*)(bp + 2 * BN * LDB) = l;
             } else {
                 *(f32x4*)&bs[32 * i * LDS_STRIDE] = vb[i];
             }
@@ -639,9 +632,6 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
         const int S = d.splitk > 1 ? d.splitk : 1;
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
-        DEFT_CHECK(d.prec == 0 || (d.prec == 1 && WK == 1 && NSTAGE == 1 && BN >= 64), -104,
-                   "igemm: prec=%d (weights as bf16 planes) needs a 1-stage tile with BN >= 64 and one wave per sub-tile, got %dx%d%s",
-                   d.prec, BM, BN, NSTAGE == 2 ? " 2-stage" : "");
         if constexpr (WK == 1 && NSTAGE == 1 && BN >= 64) {      // BN = 32: the operand split is amortised over too few columns
             if (d.prec == 1) {                   // fp32 through the bf16 matrix cores (DeftGemmDesc.prec)
                 constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 1>() * 4;

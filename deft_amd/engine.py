@@ -134,17 +134,6 @@ PREC = int(_os.environ.get("DEFT_PREC", "1"))
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
 
 
-def split_planes(w_packed):
-    """Packed fp32 weights [CoutPad][Kpad] -> bf16 planes [CoutPad][3][Kpad] (hi, mid, lo: w = hi + mid + lo exactly,
-    the split the kernels apply to activations; DeftGemmDesc.prec = 1)."""
-    w = w_packed.float()
-    hi = w.to(torch.bfloat16)
-    r1 = w - hi.float()
-    mid = r1.to(torch.bfloat16)
-    lo = (r1 - mid.float()).to(torch.bfloat16)
-    return torch.stack([hi, mid, lo], 1).contiguous()
-
-
 class _Plan:
     """Common machinery: device buffers + an ordered list of bound C-ABI calls."""
 
@@ -156,44 +145,13 @@ class _Plan:
                                       % (self.device, self.lib.path))
         self.ops = []          # (kind, name, callable, flops)
         self._gemms = []       # (entry, name, descriptor) of every implicit-GEMM launch, for autotune()
-        self._by_ptr = {}      # device address -> tensor, for every tensor made by dev()
-        self._wsplit = {}      # packed fp32 weight address -> its bf16 planes (prec 1)
         self._keep = []        # tensors / descriptors kept alive
         self.profile = None    # when set to a list, run() appends (name, kind, flops, ms)
 
     def dev(self, t):
         t = t.contiguous().to(self.device)
         self._keep.append(t)
-        self._by_ptr[t.data_ptr()] = t
         return t
-
-    def _arith(self, entry, d):
-        """Choose the contraction arithmetic of one descriptor (DeftGemmDesc.prec) and point d.w at the weights in
-        the matching format: bf16 planes (split once here, cached) when the tile the launch will use runs the
-        split-bf16 path, the packed fp32 matrix otherwise.  Re-callable after a tile change."""
-        if getattr(d, "_w_fp32", None) is not None:
-            d.w = d._w_fp32
-        d.prec = 0
-        w = self._by_ptr.get(d.w)
-        if PREC != 1 or w is None or w.dtype != torch.float32:
-            return
-        bm, bn = (d.tile >> 16) & 0x1fff, d.tile & 0xffff
-        if bm == 0 and entry != "deft_pair_layer":
-            tile, S, wsf, wst = C.c_int(), C.c_int(), C.c_longlong(), C.c_int()
-            if self.lib.cdll.deft_gemm_plan(C.byref(d), 0 if entry == "deft_conv2d_nhwc" else 1, C.byref(tile), C.byref(S),
-                                            C.byref(wsf), C.byref(wst)) != 0:
-                return
-            bm, bn = (tile.value >> 16) & 0x1fff, tile.value & 0xffff
-        if bm == 0:
-            bm, bn = 128, 64                                   # pair layer: 128x128 or 128x64
-        if bn < 64 or bm not in (64, 128) or (d.tile >> 29) & 1:
-            return
-        key = d.w
-        if key not in self._wsplit:
-            self._wsplit[key] = split_planes(w)
-        d._w_fp32 = d.w
-        d.w = self._wsplit[key].data_ptr()
-        d.prec = 1
 
     def alloc(self, N, H, W, C, ld=None):
         ld = _rup(C, 4) if ld is None else ld
@@ -232,7 +190,7 @@ class _Plan:
 
     # ---- op builders -------------------------------------------------------
     def gemm(self, entry, name, desc, flops):
-        self._arith(entry, desc)
+        desc.prec = PREC
         self._keep.append(desc)
         lib, ref = self.lib, C.byref(desc)
         self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
@@ -295,7 +253,6 @@ class _Plan:
                 best, best_t = d.tile, None
                 for t in opts:
                     d.tile = t
-                    self._arith(entry, d)                                   # the arithmetic (and weight format) follows the tile
                     try:
                         lib.call(entry, C.byref(d), s)                      # warm-up + validity
                     except hiplib.DeftHipError:
@@ -312,7 +269,6 @@ class _Plan:
                     print("autotune %-28s M=%d N=%d K=%d -> %dx%d %s (%.3f ms)" % (name, d.M, d.Cout, d.Ktot, (best >> 16) & 0x1fff, best & 0xffff,
                                                                             "2st" if best & two else "1st", best_t or 0.0))
             d.tile = memo[key]
-            self._arith(entry, d)
 
     def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0,
              true_cin=None, korder=None):
@@ -768,8 +724,7 @@ class AfePlan(_Plan):
         d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, Cout, ldy, 0
         d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
         d.Ktot, d.Kpad, d.cin_log2, d.M = Cin, Kpad, 0, M
-        d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0
-        self._arith("deft_conv2d_nhwc", d)
+        d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0; d.prec = PREC
         self.lib.call("deft_conv2d_nhwc", C.byref(d), self._stream())
 
     def affinity(self, hist, cur):
@@ -802,8 +757,7 @@ class AfePlan(_Plan):
         d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, c2, c2, 0
         d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
         d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
-        d.relu = 1; d.Q = Q; d.ldom = 0; d.tile = 0
-        self._arith("deft_pair_layer", d)
+        d.relu = 1; d.Q = Q; d.ldom = 0; d.tile = 0; d.prec = PREC
         self.lib.call("deft_pair_layer", C.byref(d), self._stream())
         h3 = torch.empty(M, c3, dtype=torch.float32, device=dev)
         self._lin(h2, M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, h3, c3)
@@ -854,8 +808,7 @@ class AfePlan(_Plan):
             d.OH, d.OW, d.Cout, d.ldy, d.ldr = 1, 1, c2, c2, 0
             d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
             d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
-            d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0
-            self._arith("deft_pair_layer", d)
+            d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0; d.prec = PREC
             d.Tper, d.u0, d.du, d.v0, d.dv = hist * K, (g0 + c0 - hist) * K, K, (g0 + c0) * K, K
             self.lib.call("deft_pair_layer", C.byref(d), self._stream())
             self._lin(b["h2"], M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, b["h3"], c3)

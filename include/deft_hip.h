@@ -72,10 +72,8 @@ typedef struct DeftGemmDesc {
     /* arithmetic of the contraction: 0 = v_mfma_f32_32x32x2_f32, bitwise a k-ordered fp32 fmaf chain; 1 = every fp32
      * operand split into three bf16 pieces and every product formed as six v_mfma_f32_32x32x16_bf16 products (all
      * terms down to 2^-24 relative), fp32 accumulation: the accuracy of an fp32 chain at 16/6 of the fp32 MFMA rate.
-     * With prec = 1 `w` points to the weights ALREADY split: bf16 [CoutPad][3][Kpad] (plane 0 = hi, 1 = mid, 2 = lo of the
-     * packed fp32 matrix; same K order), so only the activations are split inside the K loop.  Available on the tiles
-     * with one wave per output sub-tile, BN >= 64 and the 1-stage loop (error otherwise): the 128x32 / 64x32 / 32x32 tiles
-     * and the 2-stage form run prec = 0 (measured no faster there). */
+     * Honoured by the tiles with one wave per output sub-tile, BN >= 64 and the 1-stage loop (the 128x32 / 64x32 /
+     * 32x32 tiles and the 2-stage form stay on the fp32 instruction: measured no faster there). */
     int prec;
 } DeftGemmDesc;
 

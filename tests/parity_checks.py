@@ -139,7 +139,6 @@ def _deform_tiled(plan, p, xv, tile):
     kind, name, fn, fl = plan.ops[-1]
     d = plan._gemms[-1][2]          # the dcn descriptor
     d.tile, d.splitk = tile, 0
-    plan._arith("deft_dcn_v2_nhwc", d)               # arithmetic / weight format follow the tile
     if engine.SPLITK:
         plan._plan_splitk("deft_dcn_v2_nhwc", d)     # the split factor and workspace follow the tile
     return out
@@ -675,7 +674,6 @@ def _force_split(plan, d, S, bm, bn):
     cnt = torch.zeros(tiles, dtype=torch.int32, device=plan.device)
     plan._keep += [ws, cnt]
     d.tile, d.splitk, d.ws, d.ws_cnt = (bm << 16) | bn | (d.tile & (1 << 29)), S, ws.data_ptr(), cnt.data_ptr()
-    plan._arith("deft_conv2d_nhwc", d)
     return cnt
 
 
