@@ -22,15 +22,13 @@ class Detector(object):
             state_dict = {k[7:] if k.startswith("module.") else k: v for k, v in ck["state_dict"].items()}  # model.py:49-53
         self.opt = opt
         self.device = torch.device("cuda" if getattr(opt, "gpus", [0])[0] >= 0 else "cpu")
-        if self.device.type != "cuda":
-            raise hiplib.DeftHipError("deft_amd.Detector needs an MI355X (no CPU path)")
-        self.lib = hiplib.get_lib()
+        self.lib = hiplib.get_lib()            # the plans below refuse a CPU device with the HIP library (no CPU path)
         self.sd = state_dict
         self.dataset = opt.dataset
         self.K = getattr(opt, "K", 100)
         self._plans = {}
         self._graphs = {}          # (N,H,W) -> None after the first (eager) frame, then the captured hipGraph
-        self.hip_graphs = bool(getattr(opt, "hip_graphs", True))
+        self.hip_graphs = bool(getattr(opt, "hip_graphs", True)) and self.device.type == "cuda"
         self.afe = engine.AfePlan(state_dict, getattr(opt, "max_object", 100), self.device, self.lib)
         self.img_height = 100          # detector.py:108-109
         self.img_width = 100

@@ -267,6 +267,9 @@ def accelerate(tracker_module, kf=None):
     undos = [association.bind(RT.matching)]
     if kf is not None:
         undos.append(install_batched_motion(RT.STrack, MotionBank(kf)))
+        ref_kf = RT.KalmanFilterLSTM                    # tracker.py:144, 301, 661 build it by this name (gating_distance)
+        RT.KalmanFilterLSTM = type(kf)
+        undos.append(lambda: setattr(RT, "KalmanFilterLSTM", ref_kf))
 
     def undo():
         for u in undos:

@@ -58,3 +58,49 @@ def install():
     mod("sklearn.utils.linear_assignment_", linear_assignment=None)
     if not hasattr(np, "float"):
         np.float = float      # tracker.py:163, 886; matching.py:67-73 use the alias removed in numpy 1.24
+
+
+class _Anything:
+    """Import-time stand-in for classes the reference's detector.py names but the 2-D path never touches."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, name):
+        return _Anything()
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+
+def get_affine_transform_3pt(src, dst):
+    """cv2.getAffineTransform: the 2x3 matrix M with M @ [x, y, 1] = (x', y') for three point pairs (float64 solve)."""
+    src = np.asarray(src, dtype=np.float64); dst = np.asarray(dst, dtype=np.float64)
+    A = np.concatenate([src, np.ones((3, 1))], 1)
+    return np.linalg.solve(A, dst).T
+
+
+def install_detector_stubs():
+    """What `src/lib/detector.py` imports at module level beyond the tracker's needs: progress,
+    pyquaternion, nuscenes.*, pycocotools (via dataset_factory) as names only, and a functional
+    cv2.getAffineTransform (utils/image.py:get_affine_transform; post-processing of the 2-D datasets)."""
+    def mod(name, **kw):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in kw.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    mod("progress"); mod("progress.bar", Bar=_Anything)
+    mod("pyquaternion", Quaternion=_Anything)
+    mod("nuscenes", NuScenes=_Anything)
+    for n, attrs in (("nuscenes.utils", {}), ("nuscenes.utils.data_classes", {"Box": _Anything}), ("nuscenes.eval", {}),
+                     ("nuscenes.eval.common", {}), ("nuscenes.eval.common.data_classes", {"EvalBoxes": _Anything}),
+                     ("nuscenes.eval.common.config", {}), ("nuscenes.eval.tracking", {}),
+                     ("nuscenes.eval.tracking.data_classes", {"TrackingBox": _Anything}), ("nuscenes.eval.tracking.evaluate", {}),
+                     ("nuscenes.eval.detection", {}), ("nuscenes.eval.detection.data_classes", {"DetectionBox": _Anything}),
+                     ("nuscenes.eval.detection.evaluate", {})):
+        mod(n, **attrs)
+    coco = mod("pycocotools.coco", COCO=_Anything)
+    mod("pycocotools.cocoeval", COCOeval=_Anything)
+    mod("pycocotools", coco=coco)
+    mod("cv2", getAffineTransform=get_affine_transform_3pt)

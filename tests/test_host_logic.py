@@ -99,13 +99,14 @@ def test_accelerate_binds_and_restores(emu_lib):
 
         def update_lstm_features_ddd(self, b):
             return "ref"
-    RT = types.SimpleNamespace(Tracker=Tracker, FeatureRecorder=object, STrack=STrack, matching=matching)
+    RT = types.SimpleNamespace(Tracker=Tracker, FeatureRecorder=object, STrack=STrack, matching=matching, KalmanFilterLSTM=dict)
     ref_get = Tracker.get_similarity
     kf = integrate.KalmanFilterLSTM(_opt(), O.synth_lstm_state_dict("mot"), device="cpu", lib=emu_lib)
     undo = DT.accelerate(RT, kf)
     assert Tracker.get_similarity is DT.get_similarity and RT.FeatureRecorder is DT.FeatureRecorder
     assert matching.fuse_motion is association.fuse_motion and matching.bbox_ious is association.bbox_overlaps
-    assert isinstance(STrack.__dict__["future_predictions"], property)
+    assert isinstance(STrack.__dict__["future_predictions"], property) and RT.KalmanFilterLSTM is integrate.KalmanFilterLSTM
     undo()
+    assert RT.KalmanFilterLSTM is dict
     assert Tracker.get_similarity is ref_get and RT.FeatureRecorder is object and matching.linear_assignment == 3
     assert "future_predictions" not in STrack.__dict__ and STrack().update_lstm_features(None) == "ref"

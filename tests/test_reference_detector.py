@@ -1,0 +1,92 @@
+"""-m "not gpu" (build container only: needs /root/reference).  The literal drop-in of BASELINE.json's north star:
+`from detector import Detector` as src/test.py:19 does it, resolved to THIS repository's detector.py (a subclass of the
+reference's Detector), against the reference's own Detector -- same checkpoint file, same pre-processed frames through
+`Detector.run(...)` (pre-processed branch, test.py:213), including the reference's post-processing and its Tracker.  The HIP
+kernels run through the SIMT emulator (DEFT_HIP_LIB)."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HAVE_REF = os.path.isdir("/root/reference/src/lib")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = [pytest.mark.skipif(not HAVE_REF, reason="/root/reference only exists in the build container"), pytest.mark.slow]
+
+
+def _frame(seed, H, W):
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(seed))
+    c = np.array([W / 2.0, H / 2.0], dtype=np.float32)
+    s = float(max(H, W))
+    meta = {"c": c, "s": np.float32(s), "height": H, "width": W, "out_height": H // 4, "out_width": W // 4,
+            "inp_height": H, "inp_width": W, "calib": np.eye(3, 4, dtype=np.float32)}
+    batch = lambda v: torch.from_numpy(np.asarray(v)[None])                  # the DataLoader's batch dimension (test.py:106-112)
+    return {"image": [torch.zeros(H, W, 3)], "images": {1.0: [x]}, "meta": {1.0: {k: batch(v) for k, v in meta.items()}}}
+
+
+def test_detector_shim_matches_reference_detector(emu_lib, tmp_path, monkeypatch):
+    import deft_oracle as O
+    import make_golden as MG
+    import ref_import
+    import ref_shims
+    ref_shims.install()
+    ref_import.install_stubs(MG.OracleDCN)
+    ref_shims.install_detector_stubs()
+    monkeypatch.setenv("DEFT_HIP_LIB", emu_lib.path)
+    from deft_amd import hiplib
+    monkeypatch.setattr(hiplib, "_lib", emu_lib)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)       # detector.py:188, 534 call it unconditionally
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        from opts import opts
+        from dataset.dataset_factory import dataset_factory
+        from utils.basetrack import BaseTrack
+        spec = importlib.util.spec_from_file_location("detector", os.path.join(ROOT, "detector.py"))   # what `import detector` finds first
+        shim = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(shim)
+    finally:
+        sys.argv = argv
+    RD = sys.modules["deft_reference_detector"]
+    assert issubclass(shim.Detector, RD.Detector) and shim.NUSCENES_TRACKING_NAMES is RD.NUSCENES_TRACKING_NAMES
+
+    sd = dict(O.synth_state_dict("mot"))
+    # random regression heads give boxes with negative extent (the tracker's Kalman filter then fails on both sides):
+    # bias the amodal l/t/r/b head so that boxes are ~10 x 16 map pixels around the centre
+    sd["ltrb_amodal.2.weight"] = sd["ltrb_amodal.2.weight"] * 0.05
+    sd["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
+    ck = str(tmp_path / "model_mot.pth")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in sd.items()}}, ck)
+    H, W = 64, 96
+    opt = opts().parse(["tracking", "--dataset", "mot", "--gpus", "-1", "--load_model", ck, "--K", "8", "--ltrb_amodal",
+                        "--input_h", str(H), "--input_w", str(W)])
+    opt = opts().update_dataset_info_and_set_heads(opt, dataset_factory[opt.test_dataset])
+    opt.out_thresh = 0.0                                         # random-weight scores are 0.01 .. 0.2: keep the K detections
+    torch.set_grad_enabled(False)
+    try:
+        def run(cls):
+            BaseTrack._count = 0
+            det = cls(opt)
+            try:
+                det.reset_tracking(opt)                         # test.py:199, once per video
+                det.img_height, det.img_width = H, W             # test.py:163-164
+                log = []
+                for t in range(3):
+                    targets = det.run(_frame(10 + t, H, W), image_info={})
+                    log.append(sorted((s.track_id, [float(v) for v in s.tlwh], float(s.score)) for s in targets))
+            finally:
+                if hasattr(det, "_undo_tracker"):
+                    det._undo_tracker()                         # leave the reference's tracker module as found (other tests)
+            return log
+
+        ref = run(RD.Detector)
+        got = run(shim.Detector)
+        assert sum(len(f) for f in ref) >= 8
+        for fa, fb in zip(ref, got):
+            assert [a[0] for a in fa] == [b[0] for b in fb]
+            for a, b in zip(fa, fb):
+                assert np.abs(np.array(a[1]) - np.array(b[1])).max() <= 1e-3 and abs(a[2] - b[2]) <= 1e-4
+    finally:
+        torch.set_grad_enabled(True)
+        sys.modules.pop("dcn_v2", None)
