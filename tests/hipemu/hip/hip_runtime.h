@@ -6,9 +6,10 @@
 // ever loads libdeft_hip.so built by hipcc for gfx950; this header is reachable
 // from tests/ alone (tests/hipemu/build_emu.sh -> tests/hipemu/_build/libdeft_emu.so).
 //
-// Model: one fiber (ucontext) per GPU thread; the blocks of a launch are handed out to a few OS
-// threads (HIPEMU_THREADS, default = min(8, cores)), each running whole blocks one after another --
-// all emulator state, `__shared__` and dynamic LDS are thread_local, global atomics are real atomics.
+// Model: one fiber per GPU thread (hand-written x86-64 stack switch; ucontext elsewhere); the blocks of a launch
+// are handed out to a persistent pool of OS threads (HIPEMU_THREADS, default = min(8, cores)), each running whole
+// blocks one after another -- all emulator state, `__shared__` and dynamic LDS are thread_local, global atomics
+// are real atomics.
 // Wave-level collectives (MFMA, shuffles) rendezvous the 64 lanes of a wave;
 // __syncthreads() rendezvous the block.  MFMA lane<->element maps follow
 // /opt/skills/guides/cdna_hip_programming.md §3 (gfx950):
@@ -25,7 +26,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -65,12 +68,29 @@ static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; 
 namespace hipemu { inline void* dyn_lds() { alignas(16) static thread_local char buf[160 * 1024]; return buf; } }
 #define DEFT_DYN_LDS(type, var) type* var = (type*)hipemu::dyn_lds()
 
+// Fiber switch.  ucontext's swapcontext saves/restores the signal mask with two system calls per switch, which
+// dominated the emulator's run time; on x86-64 a fiber switch here is six pushes, a stack-pointer swap and six pops.
+#if defined(__x86_64__)
+#define HIPEMU_ASM_SWITCH 1
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+__asm__(".text\n.weak hipemu_switch\n.type hipemu_switch,@function\nhipemu_switch:\n"
+        "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+        "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+        "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+        ".size hipemu_switch, .-hipemu_switch\n");
+#endif
+
 namespace hipemu {
 enum Yield { Y_NONE = 0, Y_WAVE = 1, Y_BLOCK = 2, Y_DONE = 3 };
 struct State {
     dim3 tid, bid, bdim, gdim;
     int lane = 0, wave = 0;
+#ifdef HIPEMU_ASM_SWITCH
+    void* sched_sp = nullptr;
+    void** cur_sp = nullptr;
+#else
     ucontext_t sched, *cur = nullptr;
+#endif
     int yield_code = 0;
     // wave exchange buffers: [parity][slot][lane]
     float xf[2][16][64];
@@ -80,17 +100,25 @@ inline State& S() { static thread_local State s; return s; }
 inline void yield(int code) {
     State& s = S();
     s.yield_code = code;
+#ifdef HIPEMU_ASM_SWITCH
+    hipemu_switch(s.cur_sp, s.sched_sp);
+#else
     swapcontext(s.cur, &s.sched);
+#endif
 }
 struct Fiber {
+#ifdef HIPEMU_ASM_SWITCH
+    void* sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     std::vector<char> stack;
     int state = Y_NONE;
 };
 inline std::function<void()>& body() { static thread_local std::function<void()> f; return f; }
 inline void trampoline() {
     body()();
-    yield(Y_DONE);
+    for (;;) yield(Y_DONE);          // a finished fiber is never resumed; never return into the fabricated frame
 }
 
 inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, dim3 bid) {
@@ -102,11 +130,21 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
     for (int t = 0; t < nthr; ++t) {
         Fiber& f = fibers[t];
         if (f.stack.empty()) f.stack.resize(256 * 1024);
+#ifdef HIPEMU_ASM_SWITCH
+        // fabricated frame: six callee-saved registers (zero) below the return address = trampoline; the slot of the
+        // return address is 16-byte aligned, so the trampoline starts with the stack as after a call
+        uintptr_t top = ((uintptr_t)(f.stack.data() + f.stack.size()) & ~(uintptr_t)15) - 16;
+        void** frame = (void**)top;
+        frame[0] = (void*)(void (*)())trampoline;
+        for (int r = 1; r <= 6; ++r) frame[-r] = nullptr;
+        f.sp = (void*)(frame - 6);
+#else
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack.data();
         f.ctx.uc_stack.ss_size = f.stack.size();
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())trampoline, 0);
+#endif
         f.state = Y_NONE;
     }
     const int nwave = (nthr + 63) / 64;
@@ -117,8 +155,13 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
         s.bid = bid; s.bdim = block; s.gdim = grid;
         s.lane = t & 63; s.wave = t >> 6;
         s.parity = wparity[t >> 6];
+#ifdef HIPEMU_ASM_SWITCH
+        s.cur_sp = &f.sp;
+        hipemu_switch(&s.sched_sp, f.sp);
+#else
         s.cur = &f.ctx;
         swapcontext(&s.sched, &f.ctx);
+#endif
         f.state = s.yield_code;
     };
     for (;;) {
@@ -164,21 +207,59 @@ inline int worker_count() {
     return n;
 }
 
+// Worker threads live for the whole process: their thread_local fiber stacks (512 x 256 KB each) are then allocated
+// and faulted in once, not once per launch.
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    const std::function<void()>* job = nullptr;
+    long long gen = 0;
+    int pending = 0;
+    bool stop = false;
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this] {
+            long long seen = 0;
+            for (;;) {
+                const std::function<void()>* j;
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return stop || gen != seen; });
+                    if (stop) return;
+                    seen = gen; j = job;
+                }
+                (*j)();
+                std::lock_guard<std::mutex> lk(m);
+                if (--pending == 0) done_cv.notify_one();
+            }
+        });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void run(const std::function<void()>& work) {
+        { std::lock_guard<std::mutex> lk(m); job = &work; pending = (int)th.size(); ++gen; }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+};
+inline Pool& pool() { static Pool p(worker_count() - 1); return p; }
+
 template <typename F>
 inline void launch(F&& fn, dim3 grid, dim3 block) {
     const long long total = (long long)grid.x * grid.y * grid.z;
     const std::function<void()> f = fn;
     std::atomic<long long> next{0};
-    auto work = [&]() {
+    const std::function<void()> work = [&]() {
         for (long long b = next.fetch_add(1); b < total; b = next.fetch_add(1))
             run_block(f, grid, block, dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long long)grid.x * grid.y))));
     };
-    const int nw = (int)(total < worker_count() ? total : worker_count());
-    if (nw <= 1) { work(); return; }
-    std::vector<std::thread> pool;
-    for (int i = 1; i < nw; ++i) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
+    if (total < 4 || worker_count() <= 1) { work(); return; }
+    pool().run(work);
 }
 
 // wave exchange: deposit up to two floats, rendezvous, then read any lane's deposit
