@@ -391,3 +391,22 @@ def test_both_contraction_arithmetics(gpu_lib, prec):
         pc.check_affinity(gpu_lib, "cuda", O.synth_state_dict("mot"))
     finally:
         engine.PREC = saved
+
+
+def test_split_is_exact_identity_conv(gpu_lib):
+    """prec = 1: the three-way bf16 split of an fp32 operand is exact and the matrix core adds the pieces without
+    loss -- a 1x1 conv with an identity weight matrix returns its input bit for bit (60 binades, full mantissas)."""
+    from deft_amd import engine
+    assert engine.PREC == 1
+    g = torch.Generator().manual_seed(5)
+    C = 64
+    x = torch.randn(1, C, 6, 8, generator=g) * torch.exp2(torch.randint(-30, 30, (1, C, 6, 8), generator=g).float())
+    x[0, 0, 0, 0] = 1.0 + 2.0 ** -23; x[0, 1, 0, 0] = -(2.0 - 2.0 ** -23); x[0, 2, 0, 0] = 0.0
+    plan = engine._Plan("cuda", gpu_lib)
+    xv = plan.alloc(1, 6, 8, C); pc.fill_view(xv, x)
+    wp, K = engine.pack_conv_weight(torch.eye(C).view(C, C, 1, 1), C)
+    out = plan.conv("id", xv, plan.dev(wp), K, 1, 1, 1, 0, C, None, None, False, tile=pc.T(64, 64))
+    assert plan._gemms[-1][2].prec == 1
+    plan.run()
+    torch.cuda.synchronize()
+    assert torch.equal(out.to_nchw().cpu(), x)
