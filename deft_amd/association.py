@@ -43,8 +43,11 @@ def lapjv(cost, extend_cost=False, cost_limit=np.inf, return_cost=True):
         raise ValueError("Square cost array expected. If cost is intentionally non-square, pass extend_cost=True.")
     x = np.full(n, -1, dtype=int); y = np.full(m, -1, dtype=int)
     if n and m:
-        finite = cost[np.isfinite(cost)]
-        fill = cost_limit / 2.0 if cost_limit < np.inf else (finite.max() + 1 if finite.size else 1.0)
+        if cost_limit < np.inf:
+            fill = cost_limit / 2.0
+        else:
+            finite = cost[np.isfinite(cost)]
+            fill = finite.max() + 1 if finite.size else 1.0
         ext = np.full((n + m, n + m), fill)
         ext[n:, m:] = 0
         ext[:n, :m] = cost
