@@ -2,6 +2,7 @@
 emulator in tests/hipemu, checked through the C ABI against the oracle.  These
 validate indexing / fragment layouts / host packing before GPU time is spent; the
 real-hardware parity tests are in test_gpu_parity.py."""
+import numpy as np
 import pytest
 import torch
 
@@ -216,3 +217,29 @@ def test_split_is_exact_identity_conv(emu_lib):
     assert plan._gemms[-1][2].prec == 1
     plan.run()
     assert torch.equal(out.to_nchw(), x)
+
+
+def test_track_similarity_random_sweep(emu_lib):
+    """Random node lists (0..9 nodes per track, random frames / rows / decay factors) for both node-selection rules:
+    the device medians must equal numpy's on the decayed blocks bit for bit."""
+    import deft_oracle as O
+    from deft_amd import tracker as DT
+    rnd = np.random.RandomState(42)
+    for trial in range(6):
+        frame = 60 + trial
+        prev = sorted(rnd.choice(np.arange(frame - 55, frame), size=rnd.randint(3, 12), replace=False).tolist())
+        ndet = int(rnd.randint(1, 9))
+        raw = {p: rnd.rand(int(rnd.randint(1, 7)), ndet + 1).astype(np.float32) for p in prev}
+        deltas = {p: float(rnd.choice([1.0, 0.3, pow(0.01, (frame - p) / 3.0)])) for p in prev}
+        tracks_nodes = []
+        for _ in range(int(rnd.randint(1, 9))):
+            n = int(rnd.randint(0, 10))
+            fr = sorted(rnd.choice(prev, size=min(n, len(prev)), replace=False).tolist())
+            tracks_nodes.append([(f, int(rnd.randint(raw[f].shape[0]))) for f in fr])
+        pool = [pc.SimpleNamespaceNodes(nodes) for nodes in tracks_nodes]
+        for ds in ("mot", "nuscenes"):
+            me = pc._similarity_harness(emu_lib, "cpu", raw, deltas, ds)
+            me.recorder._dev = (frame,) + me.recorder._pack
+            got = DT.get_similarity(me, frame, pool, ndet)
+            want = O.track_similarity({p: raw[p] * deltas[p] for p in prev}, tracks_nodes, frame, ndet, ds)
+            assert np.array_equal(got, want), (trial, ds)
