@@ -35,6 +35,20 @@ void deft_set_error(const char* fmt, ...);
 // memcpy through a private (scratch) alloca that SROA does not split
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x = hi + mid + lo with three bf16 pieces (8 + 8 + 8 mantissa bits, round-to-nearest-even each: exact for fp32).
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r1 = v[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[e] = hh; m[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
+    }
+}
+
 // Raw buffer loads (SRD in SGPRs + 32-bit byte offset in a VGPR).  An offset >= num_records
 // returns 0 from the hardware: im2col zero padding / invalid tile rows cost one v_cndmask on
 // the OFFSET instead of a select on the loaded data (which would pull the s_waitcnt vmcnt in
@@ -54,6 +68,20 @@ __device__ __forceinline__ f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byt
 __device__ __forceinline__ void deft_buffer_load_lds_x4(deft_rsrc_t r, float* lds_wave_base, unsigned byte_off) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)byte_off, 0, 0, 0);
 }
+// the same with a wave-uniform byte offset in an SGPR (soffset: not part of the hardware's range check, so the
+// out-of-range trick stays on voff alone) -- a chunk cursor then costs no VALU
+__device__ __forceinline__ void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* lds_wave_base, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+// Pipeline barrier of the LDS-DMA loops: wait until at most N of THIS wave's DMA pieces are still in flight, then
+// rendezvous the workgroup (raw s_barrier: __syncthreads() would drain vmcnt to 0 while a DMA is outstanding).  The
+// empty asm statements keep the compiler from moving LDS accesses across it.
+#define DEFT_PIPE_BARRIER(N)                                            \
+    do {                                                                \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");        \
+        __builtin_amdgcn_s_barrier();                                   \
+        asm volatile("" ::: "memory");                                  \
+    } while (0)
 #endif
 
 // Cross-workgroup hand-over of split-K partial tiles.  The workgroups of a tile may sit on different XCDs, whose
@@ -63,12 +91,26 @@ __device__ __forceinline__ void deft_buffer_load_lds_x4(deft_rsrc_t r, float* ld
 #ifndef DEFT_WS_HOOKS          /* the unit-test SIMT emulator pre-defines these hooks */
 __device__ __forceinline__ void deft_ws_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float deft_ws_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the split-K hand-over relies on gfx950 sc1 (write-through / L2-served) accesses and gfx9 vmcnt semantics"
+#endif
+// The protocol is the hardware one of MI355X_MICROARCH.md (Workgroup dispatch ...: 'sc1 stores AND sc1 loads'): every
+// partial is an sc1 (write-through) store, each wave waits until its stores are acknowledged (vmcnt counts stores on
+// gfx9; inline asm so that no compiler pass can drop or move the wait), the workgroup rendezvous, ONE lane takes the
+// ticket with a relaxed agent-scope atomic, and the last arriver reads every partial with sc1 (L2-served) loads -- no
+// L2 write-back / L1 invalidate per workgroup.  Agent-scope release/acquire fences instead were measured 1.3-4x slower
+// on these 19x34 / 38x68 launches.
 __device__ __forceinline__ void deft_ws_publish() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);                 // gfx9 encoding: vmcnt(0) expcnt(0) lgkmcnt(0); vmcnt counts stores too
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ int deft_ws_ticket(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void deft_ws_reset(int* p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
 static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// igemm3.hip (pre-split operands, DeftGemmDesc.x3): validation, tile choice and launch, called from deft_conv2d_nhwc
+int deft_p3_check(const DeftGemmDesc* d, const char* who);
+void deft_p3_pick_tile(const DeftGemmDesc* d, int* bm, int* bn);
+int deft_p3_dispatch(const DeftGemmDesc* d, hipStream_t s);

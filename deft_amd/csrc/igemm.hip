@@ -23,9 +23,6 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// native 4-vector for all staging traffic: HIP's f32x4 is a struct whose plain copies lower to
-// memcpy through a private (scratch) alloca that SROA does not split
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 
@@ -58,20 +55,6 @@ struct KCursor {
 // combined through LDS in wave order, so the result is deterministic).
 // SPLIT: cross-workgroup split-K (DeftGemmDesc.splitk > 1).  A separate instantiation: its partial-tile hand-over
 // must not cost the plain kernels a register (128x128: 104 VGPRs = 3 waves/SIMD, 136 with the hand-over = 2).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-// x = hi + mid + lo with three bf16 pieces (8 + 8 + 8 mantissa bits: exact for fp32).
-__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 hh = (__bf16)v[e];
-        const float r1 = v[e] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        h[e] = hh; m[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
-    }
-}
-
 // PREC: 0 = v_mfma_f32_32x32x2_f32 (a k-ordered fp32 fmaf chain); 1 = every fp32 product as six
 // v_mfma_f32_32x32x16_bf16 products of the operands' bf16 pieces (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid:
 // everything down to 2^-24 relative), fp32 accumulation -- the error of an fp32 chain (tools/probe/split_bf16_loop.hip:
@@ -690,7 +673,7 @@ static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage,
 
 static int check_common(const DeftGemmDesc* d, const char* who) {
     DEFT_CHECK(d != nullptr, -1, "%s: null descriptor", who);
-    DEFT_CHECK(d->x && d->w && d->y, -2, "%s: null x/w/y pointer", who);
+    DEFT_CHECK((d->x || d->x3) && d->w && (d->y || d->y3), -2, "%s: null x/w/y pointer", who);
     DEFT_CHECK(d->M > 0 && d->Cout > 0, -3, "%s: empty problem M=%d Cout=%d", who, d->M, d->Cout);
     DEFT_CHECK(d->Kpad > 0 && (d->Kpad & 31) == 0 && d->Ktot <= d->Kpad, -4, "%s: Kpad=%d must be a multiple of 32 >= Ktot=%d", who, d->Kpad, d->Ktot);
     DEFT_CHECK((d->ldx & 3) == 0 && (((size_t)d->x) & 15) == 0 && (((size_t)d->w) & 15) == 0, -5, "%s: x/w must be 16-byte aligned, ldx %% 4 == 0", who);
@@ -752,7 +735,8 @@ extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* 
     DEFT_CHECK(entry == 0 || entry == 1, -2, "deft_gemm_plan: entry %d (0 = conv, 1 = dcn)", entry);
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     if (bm == 0) {
-        if (entry == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);
+        if (entry == 0 && d->x3 != nullptr) deft_p3_pick_tile(d, &bm, &bn);
+        else if (entry == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);
         else { bm = 64; bn = d->Cout >= 256 ? 128 : 64; }
     }
     const int nk = d->Kpad >> 5;
@@ -773,6 +757,11 @@ extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* 
 extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
     if (int e = check_conv(d, "deft_conv2d_nhwc")) return e;
     hipStream_t s = (hipStream_t)stream;
+    if (d->x3 != nullptr) {                 // pre-split operands: the LDS-DMA kernel (igemm3.hip)
+        if (int e = deft_p3_check(d, "deft_conv2d_nhwc")) return e;
+        return deft_p3_dispatch(d, s);
+    }
+    DEFT_CHECK(d->y3 == nullptr, -9, "deft_conv2d_nhwc: y3 (P3 output) needs the pre-split path (x3)");
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);

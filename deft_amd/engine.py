@@ -74,8 +74,10 @@ def _bn_fold(sd, p):
 
 
 import os as _os
-KORDER_BLOCK = _os.environ.get("DEFT_KORDER", "0") == "1"     # pack k>1 convs with Cin % 32 == 0 in (channel block, tap, channel)
-# order (DeftGemmDesc.korder = 1).  Measured neutral on MI355X for the dense convs (A/B in one process, tools/bench_igemm.py), so off.
+KORDER_BLOCK = _os.environ.get("DEFT_KORDER", "1") == "1"     # pack k>1 convs with Cin % 32 == 0 in (channel block, tap, channel)
+# order (DeftGemmDesc.korder = 1): the KH*KW shifted reads of a 32-channel block follow each other, so only the first comes
+# from HBM.  Neutral for the register-staged loop of igemm.hip (instruction-bound); what lets the LDS-DMA loop of igemm3.hip
+# run from L2 instead of HBM (tools/probe/dma_rate.hip: 54 vs 10 B/clk/CU).
 
 
 def conv_korder(w_shape, cin_pad=None):
@@ -130,6 +132,16 @@ def pack_pair_conv_weight(w, cin_pad=None):
 # 1 = fp32 through the bf16 matrix cores (three bf16 pieces per operand, six products, fp32 accumulation)
 PREC = int(_os.environ.get("DEFT_PREC", "1"))
 
+# pre-split operands (DeftGemmDesc.x3 / w3 / y3, igemm3.hip): convs whose input has Cin % 32 == 0 read the three bf16
+# pieces of activations and weights straight into LDS; producers write the pieces next to the fp32 map.  DEFT_P3=0: off
+# (the operand split stays in the K loop of igemm.hip).  Results are bit-identical either way.
+P3 = _os.environ.get("DEFT_P3", "1") != "0"
+P3_MIN_COUT = int(_os.environ.get("DEFT_P3_MIN_COUT", "64"))
+_T = lambda bm, bn: (bm << 16) | bn
+P3_3STAGE = 1 << 29
+P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAGE, _T(128, 64), _T(128, 64) | P3_3STAGE, _T(256, 64),
+            _T(64, 64), _T(64, 64) | P3_3STAGE}       # igemm3.hip deft_p3_dispatch; a forced tile outside this set keeps the conv on igemm.hip
+
 # cross-workgroup split-K for launches too small to fill the chip (DeftGemmDesc.splitk); DEFT_SPLITK=0 turns it off
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
 
@@ -143,6 +155,10 @@ class _Plan:
         if (self.device.type == "cuda") == bool(getattr(self.lib, "host_pointers", False)):
             raise hiplib.DeftHipError("deft_amd runs on an MI355X only: device %s with %s (there is no CPU path)"
                                       % (self.device, self.lib.path))
+        self._p3 = {}          # id(fp32 buffer) -> bf16 tensor holding its three-piece (P3) form
+        self._p3_cover = {}    # id(fp32 buffer) -> [(ch_lo, ch_hi, producing descriptor or None)] channel ranges with valid P3 data
+        self._p3_used = set()  # id(descriptor) of producers whose P3 output some conv reads
+        self._w3 = {}          # packed fp32 weight data_ptr -> P3 weight image
         self.ops = []          # (kind, name, callable, flops)
         self._gemms = []       # (entry, name, descriptor) of every implicit-GEMM launch, for autotune()
         self._keep = []        # tensors / descriptors kept alive
@@ -187,6 +203,60 @@ class _Plan:
                 self.profile.append((name, kind, flops, e0, e1))
             else:
                 fn()
+
+    # ---- pre-split (P3) bookkeeping ----------------------------------------
+    def p3_capable(self, v):
+        return v.ld % 32 == 0 and (v.c0 % v.ld) % 32 == 0 and v.C % 32 == 0
+
+    def p3_addr(self, v):
+        """Address of view v inside the P3 companion of its buffer (allocated on first use)."""
+        assert self.p3_capable(v)
+        t = self._p3.get(id(v.buf))
+        if t is None:
+            t = torch.zeros(v.buf.numel() * 3, dtype=torch.bfloat16, device=self.device)
+            self._p3[id(v.buf)] = t
+        pix, ch = divmod(v.c0, v.ld)
+        return t.data_ptr() + 2 * (pix * 3 * v.ld + (ch // 32) * 96)
+
+    def _p3_input(self, name, v):
+        """P3 address of an input view; channel ranges no producer has written in P3 form yet are converted now
+        (deft_split_planes, one pass over the view) -- the op list is in program order, so the producer has run."""
+        ch = v.c0 % v.ld
+        need = [(ch, ch + v.C)]
+        for lo, hi, d in self._p3_cover.get(id(v.buf), []):
+            nxt = []
+            for a, b in need:
+                if hi <= a or lo >= b:
+                    nxt.append((a, b)); continue
+                if d is not None:
+                    self._p3_used.add(id(d))
+                if a < lo: nxt.append((a, lo))
+                if hi < b: nxt.append((hi, b))
+            need = nxt
+        addr = self.p3_addr(v)
+        if need:
+            lib = self.lib
+            a = (C.c_void_p(v.addr), C.c_void_p(addr), C.c_longlong(v.N * v.H * v.W), v.C, v.ld, v.ld)
+            self.add("deft_split_planes", name + ".p3", lambda: lib.call("deft_split_planes", *a, self._stream()))
+            self._p3_cover.setdefault(id(v.buf), []).append((ch, ch + v.C, None))
+        return addr
+
+    def weights_p3(self, w_packed):
+        """P3 image of a packed fp32 weight matrix (deft_split_weights, once per matrix)."""
+        key = w_packed.data_ptr()
+        if key not in self._w3:
+            w3 = torch.empty(w_packed.numel() * 3, dtype=torch.bfloat16, device=self.device)
+            self.lib.call("deft_split_weights", ptr(w_packed), C.c_void_p(w3.data_ptr()), w_packed.shape[0], w_packed.shape[1],
+                          hiplib.stream_ptr(self.device))
+            self._w3[key] = w3
+            self._keep.append(w_packed)
+        return self._w3[key]
+
+    def finalize_p3(self):
+        """Drop the P3 outputs nobody reads (call once the whole launch list is built)."""
+        for entry, name, d in self._gemms:
+            if d.y3 and id(d) not in self._p3_used:
+                d.y3 = None
 
     # ---- op builders -------------------------------------------------------
     def gemm(self, entry, name, desc, flops):
@@ -271,7 +341,7 @@ class _Plan:
             d.tile = memo[key]
 
     def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0,
-             true_cin=None, korder=None):
+             true_cin=None, korder=None, p3=None):
         OH = (x.H + 2 * pad - KH) // stride + 1
         OW = (x.W + 2 * pad - KW) // stride + 1
         if out is None:
@@ -293,6 +363,14 @@ class _Plan:
         d.M = x.N * OH * OW
         d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = tile
         d.korder = conv_korder((Cout, x.C, KH, KW)) if korder is None else korder
+        if (P3 and PREC == 1 and p3 is not False and tile in P3_TILES and self.p3_capable(x) and KH * KW <= 32 and K == w_packed.shape[1]
+                and Cout >= P3_MIN_COUT and Cout % 8 == 0 and out.ld % 4 == 0 and (out.c0 % 4) == 0 and (KH * KW == 1 or x.C & (x.C - 1) == 0)):
+            d.x3, d.ldx3 = self._p3_input(name, x), x.ld
+            d.w3 = self.weights_p3(w_packed).data_ptr()
+            if Cout % 32 == 0 and self.p3_capable(out):
+                d.y3, d.ldy3 = self.p3_addr(out), out.ld
+                ch = out.c0 % out.ld
+                self._p3_cover.setdefault(id(out.buf), []).append((ch, ch + Cout, d))
         cin = x.C if true_cin is None else true_cin
         d.flop_k = KH * KW * cin
         self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * Cout * KH * KW * cin)
@@ -357,6 +435,7 @@ class DlaSegPlan(_Plan):
         self._build_base(x4)
         self._build_neck()
         self._build_heads(dense_heads)
+        self.finalize_p3()
 
     # ---- weights -----------------------------------------------------------
     def _conv_bn(self, name, x, wkey, bnkey, KH, stride, pad, relu, out=None, res=None, cin_pad=None):

@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("stride_w", C.c_int), ("korder", C.c_int),
         ("rowmap", c_fp),
         ("splitk", C.c_int), ("ws", c_fp), ("ws_cnt", c_fp), ("prec", C.c_int),
+        ("x3", c_fp), ("w3", c_fp), ("y3", c_fp), ("ldx3", C.c_int), ("ldy3", C.c_int),
     ]
 
 
@@ -59,10 +60,12 @@ _SIGS = {
     "deft_lstm_step": (C.c_int, [c_fp] * 3 + [C.c_int] * 3 + [c_fp] * 8 + [c_fp]),
     "deft_gemm_plan": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "deft_motion_step": (C.c_int, [c_fp, c_fp] + [C.c_int] * 3 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp] * 7 + [c_fp, c_fp, c_fp]),
+    "deft_split_planes": (C.c_int, [c_fp, c_fp, C.c_longlong, C.c_int, C.c_int, C.c_int, c_fp]),
+    "deft_split_weights": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
     "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class DeftHipError(RuntimeError):

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 5
+#define DEFT_ABI_VERSION 6
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -75,6 +75,23 @@ typedef struct DeftGemmDesc {
      * Honoured by the tiles with one wave per output sub-tile, BN >= 64 and the 1-stage loop (the 128x32 / 64x32 /
      * 32x32 tiles and the 2-stage form stay on the fp32 instruction: measured no faster there). */
     int prec;
+    /* conv, pre-split operands ("P3" format; prec = 1 only).  x3 != NULL selects the LDS-DMA kernel (igemm3.hip): the
+     * input map and the weights are read as their three bf16 pieces straight into LDS -- no operand split and no
+     * register staging in the K loop; results are bit-identical to the prec = 1 path above (same pieces, same six
+     * products, same k order).  Layouts (bf16 elements):
+     *   map   element (pixel p, channel c, piece q in {hi, mid, lo}) at  p*3*ld + (c/32)*96 + q*32 + c%32,
+     *         ld = channels per pixel of the underlying (concat) buffer, ld % 32 == 0; x3 / y3 point at the first
+     *         channel block of the view (channel offsets are multiples of 32);
+     *   w3    [CoutPad/64][Kpad/32][64 rows][12 slots of 8 bf16]: 64 output channels x one 32-wide K chunk, slot
+     *         (piece q, k-slot s) of row r stored at slot q*4 + (s ^ ((r >> 2) & 3)) -- the LDS image of the
+     *         chunk, copied verbatim (deft_split_weights builds it from the packed fp32 matrix `w`).
+     * Needs Cin % 32 == 0, Kpad == Ktot, KH*KW <= 32, no rowmap, Cout % 8 == 0, ldy % 4 == 0.
+     * y3 (nullable): the output is ALSO written in P3 form (pixel stride ldy3 channels) for a following conv;
+     * y may then be NULL when no fp32 consumer exists.  y3 is honoured by the P3 kernel only. */
+    const void* x3;
+    const void* w3;
+    void* y3;
+    int ldx3, ldy3;
 } DeftGemmDesc;
 
 int deft_version(void);
@@ -242,6 +259,15 @@ int deft_motion_step(const int* slot, const double* box, int T, int dim, int fra
  * mean of the two middle values for an even count), a zero row for a track without nodes. */
 int deft_track_similarity(const float* sim, int rows, int Q, const int* node_row, const float* node_scale,
                           const int* node_cnt, int T, int L, float* out, void* stream);
+
+/* fp32 -> P3 (three bf16 pieces, DeftGemmDesc.x3 layout) for maps produced by kernels without a P3 epilogue.
+ * x [rows][ldx] fp32 (C channels used, C % 32 == 0), y3 [rows][3*ldy3] bf16.  The split is exact:
+ * hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round-to-nearest-even each. */
+int deft_split_planes(const float* x, void* y3, long long rows, int C, int ldx, int ldy3, void* stream);
+
+/* Packed fp32 weights [CoutPad(128)][Kpad] (DeftGemmDesc.w) -> the P3 weight image (DeftGemmDesc.w3),
+ * CoutPad * Kpad * 3 bf16.  Done once per layer at load time. */
+int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpad, void* stream);
 
 #ifdef __cplusplus
 }

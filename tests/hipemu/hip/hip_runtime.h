@@ -407,4 +407,10 @@ static inline void deft_buffer_load_lds_x4(deft_rsrc_t r, float* lds_wave_base, 
     const hipemu_f32x4 v = deft_buffer_load_x4(r, byte_off);
     memcpy(lds_wave_base + 4 * hipemu::S().lane, &v, 16);
 }
+static inline void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* lds_wave_base, unsigned voff, unsigned soff) {
+    hipemu_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (voff < 0x7FFFFFFFu - 15u) memcpy(&v, r.base + voff + soff, 16);      // range check on voff alone, like the hardware
+    memcpy((char*)lds_wave_base + 16 * hipemu::S().lane, &v, 16);
+}
+#define DEFT_PIPE_BARRIER(N) __syncthreads()      /* the emulator's DMA is synchronous */
 static inline void __builtin_amdgcn_sched_barrier(int) {}

@@ -754,3 +754,165 @@ def stable_frame(sd, dataset, H, W, K=100, seed0=0, delta=2e-4, trials=4, max_tr
         if stable:
             return seed, x, out, maps, od
     raise AssertionError("no well-conditioned frame in %d seeds" % max_tries)
+
+
+# ---------------------------------------------------------------------------
+# pre-split operands (DeftGemmDesc.x3 / w3 / y3, igemm3.hip)
+def p3_to_float(plan, v):
+    """fp32 value of a view's P3 companion: hi + mid + lo, [N,H,W,C]."""
+    t = plan._p3[id(v.buf)].view(-1, v.ld // 32, 3, 32).float().sum(2)           # exact: the pieces do not overlap
+    pix, ch = divmod(v.c0, v.ld)
+    return t.reshape(-1, v.ld)[pix:pix + v.N * v.H * v.W, ch:ch + v.C].reshape(v.N, v.H, v.W, v.C)
+
+
+def check_conv_p3(lib, device, N, H, W, Ci, Cm, Co, k, stride, tile=0, tile2=0, seed=0, splitk=0):
+    """conv(Ci->Cm, k x k, stride) -> conv(Cm->Co, 3x3) + residual, both on the pre-split path, against the same chain
+    with the operand split in the K loop (igemm.hip, prec 1): BIT-identical outputs; the first conv hands its output
+    to the second in P3 form through its epilogue (no converter pass), and that P3 map equals the fp32 map exactly."""
+    assert engine.PREC == 1 and engine.P3
+    saved_splitk, engine.SPLITK = engine.SPLITK, False            # (an automatic cross-workgroup split would change the summation order)
+    try:
+        return _check_conv_p3(lib, device, N, H, W, Ci, Cm, Co, k, stride, tile, tile2, seed, splitk)
+    finally:
+        engine.SPLITK = saved_splitk
+
+
+def _check_conv_p3(lib, device, N, H, W, Ci, Cm, Co, k, stride, tile, tile2, seed, splitk):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g) * 3.0
+    w1 = torch.randn(Cm, Ci, k, k, generator=g) * (1.0 / (Ci * k * k) ** 0.5)
+    w2 = torch.randn(Co, Cm, 3, 3, generator=g) * (1.0 / (Cm * 9) ** 0.5)
+    s1, b1 = torch.rand(Cm, generator=g) + 0.5, torch.randn(Cm, generator=g)
+    s2, b2 = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    pad = k // 2
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = torch.randn(N, Co, OH, OW, generator=g)
+    outs = []
+    for p3 in (False, None):
+        plan = engine._Plan(device, lib)
+        xv = plan.alloc(N, H, W, Ci); fill_view(xv, x)
+        rv = plan.alloc(N, OH, OW, Co); fill_view(rv, r)
+        wp1, K1 = engine.pack_conv_weight(w1); wp2, K2 = engine.pack_conv_weight(w2)
+        cat = plan.alloc(N, OH, OW, Cm + 32)                      # the first conv writes a channel slice of a wider buffer
+        t = plan.conv("c1", xv, plan.dev(wp1), K1, k, k, stride, pad, Cm, plan.dev(s1), plan.dev(b1), True, out=cat.sub(32, Cm),
+                      tile=tile if p3 is None else 0, p3=p3)
+        o = plan.conv("c2", t, plan.dev(wp2), K2, 3, 3, 1, 1, Co, plan.dev(s2), plan.dev(b2), True, res=rv,
+                      tile=tile2 if p3 is None else 0, p3=p3)
+        if p3 is None:
+            d1, d2 = plan._gemms[0][2], plan._gemms[1][2]
+            assert d1.x3 and d2.x3 and d1.y3, "the pre-split path was not taken"
+            assert [op[0] for op in plan.ops].count("deft_split_planes") == 1      # the input only; c1 -> c2 goes through the epilogue
+            if splitk:
+                for d in (d1, d2):
+                    _force_split(plan, d, splitk, (d.tile >> 16) & 0x1fff, d.tile & 0xffff)
+        plan.finalize_p3()
+        plan.run()
+        if p3 is None:
+            assert torch.equal(p3_to_float(plan, t).cpu(), t.to_nchw().permute(0, 2, 3, 1).cpu()), "P3 epilogue output != fp32 output"
+            assert float(cat.buf.view(N, OH, OW, cat.ld)[..., :32].abs().max()) == 0.0
+        outs.append((t.to_nchw().cpu(), o.to_nchw().cpu()))
+    ref1 = F.relu(F.conv2d(x, w1, None, stride, pad) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    assert maxabs(outs[1][0], ref1) <= 2e-5 * max(1.0, float(ref1.abs().max()))
+    if not splitk:
+        assert torch.equal(outs[0][0], outs[1][0]), ("first conv differs from the in-loop split path", maxabs(outs[0][0], outs[1][0]))
+        assert torch.equal(outs[0][1], outs[1][1]), ("second conv differs from the in-loop split path", maxabs(outs[0][1], outs[1][1]))
+    else:
+        assert maxabs(outs[0][1], outs[1][1]) <= 2e-5 * max(1.0, float(outs[0][1].abs().max()))
+    return maxabs(outs[1][0], ref1)
+
+
+# ---------------------------------------------------------------------------
+# top-K index parity on arbitrary frames
+def compare_topk_with_oracle(plan, out, K):
+    """Device decode of frame 0 of `plan` against the oracle's head maps `out` of the same frame.  Returns
+    (indices_identical, max abs heat-map logit error).  When the ordered indices differ, every difference must be a
+    round-off tie: the oracle's OWN heat map puts the index within 1e-4 (logit) of its 3x3 neighbourhood maximum or of
+    the K-th score, the device's order is non-increasing in the oracle's scores up to 1e-4, and every detection both
+    sides report carries the same floats (scores 1e-5, boxes 1e-3)."""
+    od = O.generic_decode(O.sigmoid_output(out), K=K)
+    gi, oi = plan.inds[0].cpu().long(), od["inds"][0]
+    gc, oc = plan.clses[0].cpu().long(), od["clses"][0].long()
+    gs, os_ = plan.scores[0].cpu(), od["scores"][0]
+    gb, ob = plan.bboxes[0].cpu(), od["bboxes"][0]
+    logit = out["hm"][0]                                         # [C, h, w]
+    dev_logit = plan.dense["hm"].to_nchw().cpu()[0]
+    err = maxabs(dev_logit, logit)
+    assert err <= 2e-4, err
+    hw = logit.shape[1] * logit.shape[2]
+    gk, ok_ = (gc * hw + gi).tolist(), (oc * hw + oi).tolist()   # (class, pixel) keys
+    opos = {k: n for n, k in enumerate(ok_)}
+    common = [(n, opos[k]) for n, k in enumerate(gk) if k in opos]
+    assert len(common) >= K - 3, len(common)
+    for n, no in common:                                         # same detection -> same floats
+        assert abs(float(gs[n]) - float(os_[no])) <= 1e-5 and maxabs(gb[n], ob[no]) <= TOL
+    if gk == ok_:
+        return True, err
+    nb = F.max_pool2d(logit[None], 3, 1, 1)[0].reshape(-1)
+    flat = logit.reshape(-1)
+    kth = float(torch.logit(od["scores"][0, -1]))
+    for k in set(gk) ^ set(ok_):
+        near_nms_tie = float(nb[k] - flat[k]) <= 1e-4
+        near_kth = abs(float(flat[k]) - kth) <= 1e-4
+        assert near_nms_tie or near_kth, (k, float(nb[k] - flat[k]), float(flat[k]) - kth)
+    order = flat[torch.tensor(gk)]                               # the device's order, scored by the oracle's map
+    assert bool((order[:-1] >= order[1:] - 1e-4).all())
+    return False, err
+
+
+def peaked_head(sd, H, W, nblobs, seed=11):
+    """A final feature map and hm-head weights that give a heat map like a trained CenterNet's: `nblobs` Gaussian bumps
+    with distinct amplitudes (peak logits spread over [-2, 6]) on the prior_bias = -4.6 background (base_model.py:91-92,
+    opts.py:151), plus low-level feature noise.  -> (feat [1,64,h,w], state_dict with the hm head replaced)."""
+    g = torch.Generator().manual_seed(seed)
+    h, w = H // 4, W // 4
+    rows = max(1, int((nblobs * h / w) ** 0.5))
+    cols = -(-nblobs // rows)
+    ch, cw = h // rows, w // cols
+    assert ch >= 8 and cw >= 8, "blobs too dense for this map"
+    amp = torch.linspace(2.6, 10.6, nblobs)[torch.randperm(nblobs, generator=g)]       # peak logit = -4.6 + amp
+    amp = amp + (torch.rand(nblobs, generator=g) - 0.5) * 0.02
+    yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    bump = torch.zeros(h, w)
+    for b in range(nblobs):
+        r, c = divmod(b, cols)
+        cy = r * ch + 3 + int(torch.randint(0, ch - 6, (1,), generator=g))
+        cx = c * cw + 3 + int(torch.randint(0, cw - 6, (1,), generator=g))
+        sig = 1.2 + 0.6 * float(torch.rand(1, generator=g))
+        bump += amp[b] * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sig * sig))
+    v = torch.rand(64, generator=g) + 0.2
+    v = v / v.norm()
+    feat = (bump[None] * v[:, None, None] + 0.02 * torch.rand(64, h, w, generator=g)).unsqueeze(0)
+    sd2 = dict(sd)
+    u = torch.rand(256, generator=g) + 0.5
+    w0 = torch.randn(256, 64, 3, 3, generator=g) * 0.01
+    w0[:, :, 1, 1] += u[:, None] * v[None, :]                     # the centre tap reads the blob direction
+    w2 = (torch.rand(1, 256, 1, 1, generator=g) + 0.5)
+    w2 = w2 / float((w2.view(-1) * u).sum())                      # so that logit ~= -4.6 + bump
+    sd2["hm.0.weight"], sd2["hm.0.bias"] = w0, torch.zeros(256)
+    sd2["hm.2.weight"], sd2["hm.2.bias"] = w2, torch.full((1,), -4.6)
+    return feat, sd2
+
+
+def check_peaked_heatmap(lib, device, H, W, K=100, nblobs=140, seed=11):
+    """hm head + sigmoid + 3x3 NMS + top-K + decode on a peaked heat map: ORDERED index equality with the oracle, no tie
+    allowance.  The fixture is well-conditioned by construction, which is asserted on the oracle alone first."""
+    sd = O.synth_state_dict("mot")
+    feat, sd2 = peaked_head(sd, H, W, nblobs, seed)
+    with torch.no_grad():
+        out = {hd: O.head_forward(feat, sd2, hd) for hd in O.HEADS["mot"]}
+    od = O.generic_decode(O.sigmoid_output(out), K=K)
+    assert float(od["scores"][0, -1]) > 0.05, "fewer than K blob peaks"
+    gq = torch.Generator().manual_seed(99)
+    for _ in range(3):                                            # the oracle's own order survives +-2e-4 logit noise
+        o2 = dict(out)
+        o2["hm"] = out["hm"] + (torch.rand(out["hm"].shape, generator=gq) * 2 - 1) * 2e-4
+        assert torch.equal(O.generic_decode(O.sigmoid_output(o2), K=K)["inds"], od["inds"])
+    plan = engine.DlaSegPlan(sd2, 1, H, W, "mot", K=K, device=device, lib=lib)
+    fill_view(plan.feat, feat)
+    first = min(i for i, op in enumerate(plan.ops) if op[1].startswith("hm.0"))
+    plan.ops = plan.ops[first:]                                   # heads + decode only, on the synthetic feature map
+    plan.run()
+    assert torch.equal(plan.inds[0].cpu().long(), od["inds"][0]), "ordered top-K indices differ on a peaked heat map"
+    assert maxabs(plan.scores.cpu(), od["scores"]) <= 1e-5
+    assert maxabs(plan.bboxes.cpu(), od["bboxes"]) <= TOL
+    return plan, od

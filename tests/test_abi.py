@@ -26,7 +26,7 @@ def test_gfx950_library_exports_every_symbol():
     lib = hiplib.HipLib(so)                                # binds every symbol; raises if one is missing
     for name in _declared():
         assert hasattr(lib.cdll, name)
-    assert lib.cdll.deft_version() == 5
+    assert lib.cdll.deft_version() == 6
     # the code object is gfx950-only (no other offload arch, no host fallback path)
     blob = open(so, "rb").read()
     assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
@@ -51,7 +51,7 @@ def test_gemm_desc_layout_matches_header():
     body = src[src.index("typedef struct DeftGemmDesc {"):src.index("} DeftGemmDesc;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
-    for decl in re.findall(r"(?:const float\*|float\*|const int\*|int\*|int)\s+([^;]+);", body):
+    for decl in re.findall(r"(?:const float\*|float\*|const int\*|int\*|const void\*|void\*|int)\s+([^;]+);", body):
         names += [n.strip() for n in decl.split(",")]
     assert names == [n for n, _ in GemmDesc._fields_]
 

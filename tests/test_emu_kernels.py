@@ -243,3 +243,26 @@ def test_track_similarity_random_sweep(emu_lib):
             got = DT.get_similarity(me, frame, pool, ndet)
             want = O.track_similarity({p: raw[p] * deltas[p] for p in prev}, tracks_nodes, frame, ndet, ds)
             assert np.array_equal(got, want), (trial, ds)
+
+
+# pre-split operands (igemm3.hip): bit-identical to the in-loop split of igemm.hip, P3 epilogue output exact
+@pytest.mark.parametrize("args", [
+    (1, 9, 11, 64, 64, 128, 3, 1, T(128, 64), T(128, 128)),
+    (2, 10, 12, 32, 64, 64, 3, 2, T(64, 64), T(256, 64)),
+    (1, 7, 9, 96, 128, 64, 1, 1, T(256, 128), T(128, 64) | (1 << 29)),        # 1x1 with Cin not a power of two; 3 LDS stages
+    (1, 7, 9, 64, 128, 256, 3, 1, T(128, 128) | (1 << 29), T(128, 256)),
+    (1, 5, 6, 64, 64, 64, 3, 1, T(64, 64) | (1 << 29), 0),                    # nk = 18 / auto tile
+    (1, 4, 5, 32, 64, 64, 1, 1, 0, T(64, 64)),                                # single-chunk K (nk == 1) feeding a 3x3
+])
+def test_conv_presplit(emu_lib, args):
+    pc.check_conv_p3(emu_lib, "cpu", *args)
+
+
+def test_conv_presplit_splitk(emu_lib):
+    pc.check_conv_p3(emu_lib, "cpu", 1, 7, 9, 64, 64, 128, 3, 1, T(128, 64), T(128, 128), splitk=3)
+    pc.check_conv_p3(emu_lib, "cpu", 1, 7, 9, 128, 128, 64, 3, 1, T(256, 128), T(64, 64) | (1 << 29), splitk=4)
+
+
+def test_peaked_heatmap_ordered_topk(emu_lib):
+    """Small-map version of the GPU test: a peaked heat map must give the oracle's ordered top-K outright."""
+    pc.check_peaked_heatmap(emu_lib, "cpu", 64, 96, K=5, nblobs=6)

@@ -1,4 +1,6 @@
 """-m gpu: parity of the HIP path (through the C ABI) against the oracle on a real MI355X."""
+import os
+
 import pytest
 import torch
 
@@ -7,6 +9,7 @@ import parity_checks as pc
 from parity_checks import T
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("args", [
@@ -189,29 +192,66 @@ def test_full_size_index_differences_are_ties(gpu_lib, seed):
     plan.forward(x.cuda())
     with torch.no_grad():
         out, _ = O.dlaseg_forward(x, sd, "mot")
-    od = O.generic_decode(O.sigmoid_output(out), K=K)
-    gi, oi = plan.inds[0].cpu().long(), od["inds"][0]
-    gs, os_ = plan.scores[0].cpu(), od["scores"][0]
-    gb, ob = plan.bboxes[0].cpu(), od["bboxes"][0]
-    opos = {int(i): k for k, i in enumerate(oi.tolist())}
-    common = [(k, opos[int(i)]) for k, i in enumerate(gi.tolist()) if int(i) in opos]
-    assert len(common) >= K - 2
-    for k, ko in common:                                                    # same detection -> same floats
-        assert abs(float(gs[k]) - float(os_[ko])) <= 1e-5 and pc.maxabs(gb[k], ob[ko]) <= pc.TOL
-    logit = out["hm"][0, 0]
-    dev_logit = plan.dense["hm"].to_nchw().cpu()[0, 0]
-    assert pc.maxabs(dev_logit, logit) <= 2e-4
-    if torch.equal(gi, oi):
-        return
-    nb = torch.nn.functional.max_pool2d(logit[None, None], 3, 1, 1)[0, 0].reshape(-1)
-    flat = logit.reshape(-1)
-    kth = float(torch.logit(od["scores"][0, -1]))
-    for i in set(gi.tolist()) ^ set(oi.tolist()):
-        near_nms_tie = float(nb[i] - flat[i]) <= 1e-4
-        near_kth = abs(float(flat[i]) - kth) <= 1e-4
-        assert near_nms_tie or near_kth, (i, float(nb[i] - flat[i]), float(flat[i]) - kth)
-    order = flat[gi]                                                       # the device's order, scored by the oracle's map:
-    assert bool((order[:-1] >= order[1:] - 1e-4).all())                     # any reordering is between near-equal scores
+    pc.compare_topk_with_oracle(plan, out, K)
+
+
+@pytest.mark.parametrize("dataset,H,W,nseeds", [("mot", 608, 1088, 64), ("kitti_tracking", 384, 1280, 16), ("nuscenes", 448, 800, 16)])
+def test_topk_seed_sweep_both_arithmetics(gpu_lib, dataset, H, W, nseeds):
+    """the top-K index claim as a measured property of BOTH contraction arithmetics (prec 0 = fp32 MFMA,
+    prec 1 = split bf16, the default) on ARBITRARY frames (no stable_frame selection): every frame either reproduces the
+    oracle's ordered top-100 indices or differs only at <= 1e-4 logit ties (compare_topk_with_oracle), and the default
+    arithmetic does not mismatch more often than the fp32 MFMA beyond counting noise.  The rates go to
+    gpurun_out/topk_sweep_<dataset>.json (copied to profiles/)."""
+    import json
+    from deft_amd import engine
+    sd = O.synth_state_dict(dataset)
+    plans = {}
+    saved = engine.PREC
+    try:
+        for prec in (0, 1):
+            engine.PREC = prec
+            plans[prec] = engine.DlaSegPlan(sd, 1, H, W, dataset, K=100, device="cuda", lib=gpu_lib)
+            assert all(d.prec == prec for _, _, d in plans[prec]._gemms)
+    finally:
+        engine.PREC = saved
+    torch.set_num_threads(max(1, (os.cpu_count() or 8)))
+    diff = {0: [], 1: []}
+    worst = {0: 0.0, 1: 0.0}
+    for seed in range(1000, 1000 + nseeds):
+        x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(seed))
+        with torch.no_grad():
+            out, _ = O.dlaseg_forward(x, sd, dataset)
+        for prec in (0, 1):
+            plans[prec].forward(x.cuda())
+            same, err = pc.compare_topk_with_oracle(plans[prec], out, 100)
+            worst[prec] = max(worst[prec], err)
+            if not same:
+                diff[prec].append(seed)
+    rep = {"dataset": dataset, "H": H, "W": W, "frames": nseeds, "K": 100,
+           "frames_with_tie_level_index_differences": {"prec0_fp32_mfma": len(diff[0]), "prec1_split_bf16": len(diff[1])},
+           "seeds": {"prec0": diff[0], "prec1": diff[1]}, "max_abs_logit_error": {"prec0": worst[0], "prec1": worst[1]},
+           "every_difference_is_a_tie_below_logit": 1e-4}
+    print(json.dumps(rep))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "topk_sweep_%s.json" % dataset), "w"), indent=1)
+    except OSError:
+        pass
+    # the default arithmetic is not worse than the fp32 MFMA (binomial counting noise allowed: the events are rare and independent)
+    assert len(diff[1]) <= len(diff[0]) + max(2, len(diff[0]) // 2), rep
+    assert worst[1] <= 2e-4 and worst[0] <= 2e-4
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_peaked_heatmap_ordered_topk(gpu_lib, prec):
+    """A heat map shaped like a trained detector's (sparse Gaussian blobs on the -4.6 prior, base_model.py:91-92) through the
+    real hm head + NMS + top-K at config B's map size: ordered index equality with the oracle must hold OUTRIGHT."""
+    from deft_amd import engine
+    saved, engine.PREC = engine.PREC, prec
+    try:
+        pc.check_peaked_heatmap(gpu_lib, "cuda", 608, 1088, K=100, nblobs=140)
+    finally:
+        engine.PREC = saved
 
 
 @pytest.mark.parametrize("dataset,H,W", [("kitti_tracking", 384, 1280), ("nuscenes", 448, 800), ("mot", 512, 512)])
@@ -391,6 +431,29 @@ def test_both_contraction_arithmetics(gpu_lib, prec):
         pc.check_affinity(gpu_lib, "cuda", O.synth_state_dict("mot"))
     finally:
         engine.PREC = saved
+
+
+@pytest.mark.parametrize("args", [
+    (1, 9, 11, 64, 64, 128, 3, 1, pc.T(128, 64), pc.T(128, 128)),
+    (2, 10, 12, 32, 64, 64, 3, 2, pc.T(64, 64), pc.T(256, 64)),
+    (1, 7, 9, 96, 128, 64, 1, 1, pc.T(256, 128), pc.T(128, 64) | (1 << 29)),
+    (1, 7, 9, 64, 128, 256, 3, 1, pc.T(128, 128) | (1 << 29), pc.T(128, 256)),
+    (3, 38, 68, 256, 256, 256, 3, 1, pc.T(256, 128), pc.T(128, 128)),         # many tiles, long K: every stage of the ring in use
+    (2, 76, 136, 128, 128, 128, 3, 2, 0, pc.T(128, 128) | (1 << 29)),
+    (1, 152, 272, 64, 64, 256, 3, 1, pc.T(256, 64), pc.T(128, 256)),
+    (1, 19, 34, 512, 512, 512, 1, 1, pc.T(64, 64), pc.T(64, 64) | (1 << 29)),
+])
+def test_conv_presplit(gpu_lib, args):
+    """DeftGemmDesc.x3 (igemm3.hip: operands pre-split into bf16 pieces, LDS-DMA pipeline) is BIT-identical to the
+    in-loop split of igemm.hip on the hardware, for every tile and both ring depths."""
+    pc.check_conv_p3(gpu_lib, "cuda", *args)
+    torch.cuda.synchronize()
+
+
+def test_conv_presplit_splitk(gpu_lib):
+    pc.check_conv_p3(gpu_lib, "cuda", 1, 19, 34, 512, 512, 256, 3, 1, pc.T(128, 128), pc.T(256, 128), splitk=4)
+    pc.check_conv_p3(gpu_lib, "cuda", 1, 7, 9, 128, 128, 64, 3, 1, pc.T(256, 128), pc.T(64, 64) | (1 << 29), splitk=4)
+    torch.cuda.synchronize()
 
 
 def test_split_is_exact_identity_conv(gpu_lib):
