@@ -76,6 +76,12 @@ __device__ __forceinline__ void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* ld
 // Pipeline barrier of the LDS-DMA loops: wait until at most N of THIS wave's DMA pieces are still in flight, then
 // rendezvous the workgroup (raw s_barrier: __syncthreads() would drain vmcnt to 0 while a DMA is outstanding).  The
 // empty asm statements keep the compiler from moving LDS accesses across it.
+#define DEFT_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define DEFT_PIPE_BARRIER_ONLY()              \
+    do {                                      \
+        __builtin_amdgcn_s_barrier();         \
+        asm volatile("" ::: "memory");        \
+    } while (0)
 #define DEFT_PIPE_BARRIER(N)                                            \
     do {                                                                \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");        \
@@ -110,7 +116,74 @@ __device__ __forceinline__ void deft_ws_reset(int* p) { __hip_atomic_store(p, 0,
 
 static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- LDS-transposed epilogue shared by the MFMA kernels ----------------------------------------------------------
+// Phase 1: every wave parks its TM x TN grid of 32x32 accumulators, scaled and shifted, in the LDS tile T[BM][LDT]
+// (D reg r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31: a half-wave writes 32 consecutive floats).
+typedef float deft_f32x16 __attribute__((ext_vector_type(16)));
+template <int TM, int TN>
+__device__ __forceinline__ void deft_epilogue_stage(float* T, int LDT, const deft_f32x16 (&acc)[TM][TN], int wm, int wn, int lane,
+                                                    const DeftGemmDesc& p, int n0) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cl = (wn * TN + j) * 32 + (lane & 31);
+        const int co = n0 + cl;
+        const int coc = co < p.Cout ? co : p.Cout - 1;
+        const float sc = p.scale ? p.scale[coc] : 1.f;
+        const float sh = p.shift ? p.shift[coc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float* tp = T + ((wm * TM + i) * 32 + 4 * (lane >> 5)) * LDT + cl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tp[((r & 3) + 8 * (r >> 2)) * LDT] = acc[i][j][r] * sc + sh;
+        }
+    }
+}
+// Phase 2 (after a barrier): every thread owns 8 consecutive channels of an output row: residual (16-byte loads), ReLU,
+// fp32 store (p.y, nullable) and the three bf16 pieces (p.y3, nullable) as 16-byte stores.  row_to_m(row) -> the output
+// row (pixel index) of tile row `row`, or -1.
+template <int BM, int BN, int NT, typename RowFn>
+__device__ __forceinline__ void deft_epilogue_rows(const float* T, const DeftGemmDesc& p, int n0, int tid, RowFn row_to_m) {
+    constexpr int LDT = BN + 4, G = BN / 8, NI = (BM * G + NT - 1) / NT;
+    const bool has_res = p.res != nullptr;
+#pragma unroll 2
+    for (int it = 0; it < NI; ++it) {
+        const int item = it * NT + tid;
+        const int row = item / G, c8 = item - row * G;
+        const int co = n0 + c8 * 8;
+        if (row >= BM || co >= p.Cout) continue;
+        const long long ml = row_to_m(row);
+        if (ml < 0) continue;
+        const size_t m = (size_t)ml;
+        const float* tp = T + row * LDT + c8 * 8;
+        f32x4 v0 = *(const f32x4*)tp, v1 = *(const f32x4*)(tp + 4);
+        if (has_res) {
+            const float* rp = p.res + m * p.ldr + co;
+            v0 += *(const f32x4*)rp;
+            v1 += *(const f32x4*)(rp + 4);
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+        }
+        if (p.y != nullptr) {
+            float* yp = p.y + m * p.ldy + co;
+            *(f32x4*)yp = v0;
+            *(f32x4*)(yp + 4) = v1;
+        }
+        if (p.y3 != nullptr) {
+            bf16x4 h0, m0_, l0, h1, m1, l1;
+            split3(v0, h0, m0_, l0);
+            split3(v1, h1, m1, l1);
+            __bf16* yp = (__bf16*)p.y3 + m * p.ldy3 * 3 + (co >> 5) * 96 + (co & 31);
+            *(bf16x8*)yp = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *(bf16x8*)(yp + 32) = __builtin_shufflevector(m0_, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *(bf16x8*)(yp + 64) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+}
+
 // igemm3.hip (pre-split operands, DeftGemmDesc.x3): validation, tile choice and launch, called from deft_conv2d_nhwc
 int deft_p3_check(const DeftGemmDesc* d, const char* who);
 void deft_p3_pick_tile(const DeftGemmDesc* d, int* bm, int* bn);
 int deft_p3_dispatch(const DeftGemmDesc* d, hipStream_t s);
+int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s);

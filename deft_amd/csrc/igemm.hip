@@ -22,7 +22,7 @@
 
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef deft_f32x16 f32x16;
 
 enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 
@@ -35,10 +35,12 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 // PREC = 1 (fp32 through the bf16 matrix cores): the staged chunk is three bf16 planes (hi, mid, lo) of
 // [rows][32 + 8 pad] instead of one fp32 image.
 #define LDB 40
+// PREC = 2: as 1, with the weights pre-split (DeftGemmDesc.w3): their chunk image goes global -> LDS by DMA into one of two
+// [BN][192 B] stages (layout and swizzle of igemm3.hip) -- no staging registers, no split arithmetic, no ds_write for B.
 template <int BM, int BN, int WK, int NSTAGE, int MODE, int PREC = 0>
 constexpr int igemm_lds_floats() {
     constexpr int ld = (MODE == MODE_CONV && NSTAGE == 2) ? 32 : LDS_STRIDE;      // LDS-DMA image is unpadded
-    constexpr int stage = (PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
+    constexpr int stage = (PREC == 2 ? (3 * BM * LDB * 2 + 2 * BN * 192) / 4 : PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
     constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
     return stage > red ? stage : red;
 }
@@ -62,6 +64,7 @@ struct KCursor {
 template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE, bool SPLIT, int PREC = 0>
 __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, int ntiles, int bid) {
     static_assert(PREC == 0 || (WK == 1 && NSTAGE == 1), "split-bf16 path: WK = 1 tiles, 1-stage loop");
+    static_assert(PREC != 2 || BN % 64 == 0, "pre-split weights come in 64-row blocks");
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int GA = BM / 32;  // f32x4 groups per thread, A tile
@@ -80,9 +83,11 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     DEFT_DYN_LDS(float, smem);
     float* const As = smem;
     float* const Bs = smem + NSTAGE * BM * LD;
-    float* const prm = PREC ? smem + 3 * (BM + BN) * LDB / 2 : Bs + NSTAGE * BN * LD;   // DCN only
-    __bf16* const Ap = (__bf16*)smem;            // PREC = 1: A planes [3][BM][LDB], then B planes [3][BN][LDB]
+    constexpr bool BDMA = PREC == 2;
+    float* const prm = BDMA ? smem + (3 * BM * LDB * 2 + 2 * BN * 192) / 4 : PREC ? smem + 3 * (BM + BN) * LDB / 2 : Bs + NSTAGE * BN * LD;   // DCN only
+    __bf16* const Ap = (__bf16*)smem;            // PREC >= 1: A planes [3][BM][LDB], then B planes [3][BN][LDB] (PREC 2: two DMA stages [BN][192 B])
     __bf16* const Bp = Ap + 3 * BM * LDB;
+    char* const Bd = (char*)(Ap + 3 * BM * LDB);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -240,6 +245,16 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     f32x4 s0[GA], s1[GA], s2[GA], s3[GA], sw[GA], vb[GB];
     float sm[GA];
 
+    // PREC 2: this wave's pieces of the weight chunk image (1 KB each; piece j of the tile = 64-row block j / 12)
+    constexpr int NBP = BDMA ? BN * 3 / 64 : 1;
+    const deft_rsrc_t rw3 = deft_make_rsrc(BDMA ? p.w3 : (const void*)p.w);
+    unsigned vB3[NBP];
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+        const int j = wave + i * 4;
+        vB3[i] = (unsigned)(((n0 >> 6) + j / 12) * (p.Kpad >> 5) * 12 + j % 12) * 1024u + (unsigned)lane * 16u;
+    }
+    int bdma_stage = 0;                              // PREC 2: the B stage the next issue_loads() fills
     int dma_stage = 0;                               // DMA form: LDS stage the next issue_loads() fills
     auto issue_loads = [&]() {
         if (MODE == MODE_CONV) {
@@ -288,7 +303,13 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 s1[i] = deft_buffer_load_x4(rx2, (unsigned)r1[i] + kb);
             }
         }
-        if (DMA) {
+        if (BDMA) {
+            const unsigned soff = (unsigned)(kload >> 5) * 12288u;
+#pragma unroll
+            for (int i = 0; i < NBP; ++i)
+                deft_buffer_load_lds_x4s(rw3, Bd + bdma_stage * BN * 192 + (wave + i * 4) * 1024, vB3[i], soff);
+            bdma_stage ^= 1;
+        } else if (DMA) {
             const unsigned wo = (unsigned)(((n0 + rbase) * p.Kpad + kload + gs * 4) * 4);
 #pragma unroll
             for (int i = 0; i < GB; ++i)
@@ -341,7 +362,9 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         }
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
-            if (PREC) {
+            if (BDMA) {
+                // weights arrive by DMA
+            } else if (PREC) {
                 bf16x4 h, m, l;
                 split3(vb[i], h, m, l);
                 __bf16* bp = Bp + (rbase + 32 * i) * LDB + g * 4;
@@ -397,8 +420,10 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     };
 
     // PREC = 1: the two K = 16 halves of the chunk; a lane's fragment = 8 consecutive k of its row (k group lane>>5)
-    auto split_chunk = [&]() {
+    auto split_chunk = [&](int bstage) {
         const int fkg = (lane >> 5) * 8;
+        const char* const bdr = Bd + bstage * BN * 192 + (wn * TN * 32 + frow) * 192;
+        const int bsw = (frow >> 2) & 3;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             bf16x8 pa[TM][3], pb[TN][3];
@@ -407,7 +432,9 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
 #pragma unroll
                 for (int i = 0; i < TM; ++i) pa[i][pl] = *(const bf16x8*)(Ap + pl * BM * LDB + ((wm * TM + i) * 32 + frow) * LDB + kh * 16 + fkg);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) pb[j][pl] = *(const bf16x8*)(Bp + pl * BN * LDB + ((wn * TN + j) * 32 + frow) * LDB + kh * 16 + fkg);
+                for (int j = 0; j < TN; ++j)
+                    pb[j][pl] = BDMA ? *(const bf16x8*)(bdr + j * 32 * 192 + pl * 64 + ((kh * 2 + (lane >> 5)) ^ bsw) * 16)
+                                     : *(const bf16x8*)(Bp + pl * BN * LDB + ((wn * TN + j) * 32 + frow) * LDB + kh * 16 + fkg);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -432,10 +459,11 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         issue_loads();
         for (int kt = 0; kt < nk; ++kt) {
             finish_store(0);
+            if (BDMA) DEFT_WAIT_VM(0);           // this wave's pieces of chunk kt's weight image have landed (the barrier publishes everybody's)
             __syncthreads();
-            if (kt + 1 < nk) issue_loads();
+            if (kt + 1 < nk) issue_loads();      // (PREC 2: the weight DMA of chunk kt+1 goes to the stage last read in iteration kt-1)
             if (PREC) {
-                split_chunk();
+                split_chunk(kt & 1);
             } else {
                 read_frags(0);
                 mfma_chunk();
@@ -528,6 +556,18 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         }
     }
 
+    // P3 output requested (DCN only: the staging region is always big enough for the tile there): the LDS-transposed
+    // epilogue of common.h, which also writes the three bf16 pieces for a following pre-split conv
+    if constexpr (MODE == MODE_DCN && WK == 1) {
+        if (p.y3 != nullptr) {
+            float* const T = smem;
+            __syncthreads();
+            deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
+            __syncthreads();
+            deft_epilogue_rows<BM, BN, 256>(T, p, n0, tid, [&](int row) -> long long { return m0 + row < p.M ? (long long)(m0 + row) : -1; });
+            return;
+        }
+    }
     // epilogue: D reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31);
     // the 32 lanes of a half-wave write 32 consecutive channels of one pixel (128 B).
     // Residual loads are hoisted out of the per-element path (one uniform branch, 16
@@ -616,6 +656,13 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
         if constexpr (WK == 1 && NSTAGE == 1 && BN >= 64) {      // BN = 32: the operand split is amortised over too few columns
+            if (d.prec == 1 && d.w3 != nullptr && S == 1) {      // ... with the weights pre-split: their chunks arrive by DMA (PREC 2)
+                constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 2>() * 4;
+                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 2>>(lds_p)) return e;
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 2>), dim3(mtiles * ntiles), dim3(256), lds_p, s, d, mtiles, ntiles);
+                DEFT_CHECK_LAUNCH("igemm");
+                return 0;
+            }
             if (d.prec == 1) {                   // fp32 through the bf16 matrix cores (DeftGemmDesc.prec)
                 constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 1>() * 4;
                 if (S > 1) {
@@ -759,7 +806,7 @@ extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d->x3 != nullptr) {                 // pre-split operands: the LDS-DMA kernel (igemm3.hip)
         if (int e = deft_p3_check(d, "deft_conv2d_nhwc")) return e;
-        return deft_p3_dispatch(d, s);
+        return d->p3_kernel == 1 ? deft_p3h_dispatch(d, s) : deft_p3_dispatch(d, s);
     }
     DEFT_CHECK(d->y3 == nullptr, -9, "deft_conv2d_nhwc: y3 (P3 output) needs the pre-split path (x3)");
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
@@ -797,6 +844,8 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->Ktot == 9 * d->Cin && d->Kpad == d->Ktot, -23, "deft_dcn_v2_nhwc: Ktot/Kpad mismatch");
     DEFT_CHECK(d->OH == d->H && d->OW == d->W && d->M == d->N * d->H * d->W, -24, "deft_dcn_v2_nhwc: geometry mismatch");
     DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -25, "deft_dcn_v2_nhwc: input exceeds 2 GiB (split the batch)");
+    DEFT_CHECK(d->y3 == nullptr || ((d->Cout & 31) == 0 && (d->ldy3 & 31) == 0 && d->ldy3 >= d->Cout && (d->ldy & 3) == 0 && (((size_t)d->y3 | (size_t)d->y) & 15) == 0), -26,
+               "deft_dcn_v2_nhwc: y3 needs Cout %% 32 == 0, ldy3 %% 32 == 0, ldy %% 4 == 0, 16-byte aligned outputs");
     hipStream_t s = (hipStream_t)stream;
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);

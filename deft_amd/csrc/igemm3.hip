@@ -19,7 +19,7 @@
 // activation was split once per tap and per n-tile).
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef deft_f32x16 f32x16;
 
 #define P3_ROW 192            // bytes per staged row: 3 pieces x 32 bf16
 #define P3_WBLK 12288         // 64 weight rows of one chunk
@@ -251,61 +251,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
         }
     }
 
-    // ---- epilogue, phase 1: acc*scale + shift into the LDS tile T[BM][BN + 4] (D reg r of lane l is row (r&3) +
-    // 8*(r>>2) + 4*(l>>5), col l&31: a half-wave writes 32 consecutive floats) ----
-    constexpr int LDT = BN + 4;
+    // ---- epilogue through LDS (common.h) ----
     float* const T = (float*)smem;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int cl = (wn * TN + j) * 32 + (lane & 31);
-        const int co = n0 + cl;
-        const int coc = co < p.Cout ? co : p.Cout - 1;
-        const float sc = p.scale ? p.scale[coc] : 1.f;
-        const float sh = p.shift ? p.shift[coc] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float* tp = T + ((wm * TM + i) * 32 + 4 * (lane >> 5)) * LDT + cl;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tp[((r & 3) + 8 * (r >> 2)) * LDT] = acc[i][j][r] * sc + sh;
-        }
-    }
+    deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
     __syncthreads();
-    // ---- phase 2: every thread owns 8 consecutive channels of a pixel ----
-    constexpr int G = BN / 8;                      // channel groups per tile row
-    constexpr int NI = BM * G / NT;
-    const bool has_res = p.res != nullptr;
-#pragma unroll 2
-    for (int it = 0; it < NI; ++it) {
-        const int item = it * NT + tid;
-        const int row = item / G, c8 = item - row * G;
-        const int m = m0 + row, co = n0 + c8 * 8;
-        if (m >= p.M || co >= p.Cout) continue;
-        const float* tp = T + row * LDT + c8 * 8;
-        f32x4 v0 = *(const f32x4*)tp, v1 = *(const f32x4*)(tp + 4);
-        if (has_res) {
-            const float* rp = p.res + (size_t)m * p.ldr + co;
-            v0 += *(const f32x4*)rp;
-            v1 += *(const f32x4*)(rp + 4);
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
-        }
-        if (p.y != nullptr) {
-            float* yp = p.y + (size_t)m * p.ldy + co;
-            *(f32x4*)yp = v0;
-            *(f32x4*)(yp + 4) = v1;
-        }
-        if (p.y3 != nullptr) {
-            bf16x4 h0, m0_, l0, h1, m1, l1;
-            split3(v0, h0, m0_, l0);
-            split3(v1, h1, m1, l1);
-            __bf16* yp = (__bf16*)p.y3 + (size_t)m * p.ldy3 * 3 + (co >> 5) * 96 + (co & 31);
-            *(bf16x8*)yp = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-            *(bf16x8*)(yp + 32) = __builtin_shufflevector(m0_, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-            *(bf16x8*)(yp + 64) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-    }
+    deft_epilogue_rows<BM, BN, NT>(T, p, n0, tid, [&](int row) -> long long { return m0 + row < p.M ? (long long)(m0 + row) : -1; });
 }
 
 template <auto KERNEL>
@@ -441,5 +391,280 @@ extern "C" int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpa
     const long long tot = (long long)CoutPad * (Kpad >> 5) * 12;
     hipLaunchKernelGGL(split_weights_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, CoutPad, Kpad);
     DEFT_CHECK_LAUNCH("split_weights");
+    return 0;
+}
+
+// =====================================================================================================================
+// Halo-tile form for 3x3 / stride 1 / pad 1 convs (DeftGemmDesc.p3_kernel = 1).
+//
+// The im2col form above re-stages every input pixel once per tap (9 x 192 B per pixel and 32 channels through the
+// CU's load path); counters on the hardware put that loop at 0.36-0.44 MFMA busy with the rest spent ISSUING DMA pieces
+// and fragment reads, one workgroup per CU.  Here a workgroup owns a TH x 32 patch of output pixels, stages the
+// (TH+2) x 34 input patch of 16 channels ONCE (zero border = conv padding, by out-of-range DMA lanes) and reads the A
+// fragments of all nine taps out of it: tap (r, s) is a row offset r*34 + s into the staged patch.  Per interval
+// (one tap x 16 channels = one MFMA k-step) the workgroup streams only the BN x 96 B weight slice (3-stage ring) and
+// 1/9 of a patch: 14 KB instead of 48 KB per 128 x 128 x 32 -- and fits two workgroups per CU (76 KB of LDS), whose
+// barriers, DMA issue and epilogues overlap each other's MFMAs.
+//   LDS rows are 96 B (3 pieces x 16 k = 6 slots of 16 B); slot (piece q, k-group g) of row R sits at q*2 + (g ^ ((R >> 3) & 1)):
+//   conflict-free ds_read_b128 for any 32 consecutive rows at any offset.
+//   K order: (16-channel block, tap) -- fp32 round-off differs from the (32-channel block, tap) order of the other kernels.
+// =====================================================================================================================
+#define P3H_TW 32
+#define P3H_HW 34
+
+template <int TH, int BN>
+constexpr int p3h_lds_bytes(int nsb) {
+    const int apieces = ((TH + 2) * P3H_HW * 6 + 63) / 64;
+    const int stage = 2 * apieces * 1024 + nsb * BN * 96;
+    const int tile = TH * 32 * (BN + 4) * 4;
+    return stage > tile ? stage : tile;
+}
+
+__device__ __forceinline__ void p3_wait_vm(int n) {
+    switch (n) {            // the immediate must be a constant: n is wave-uniform
+    case 0: DEFT_WAIT_VM(0); break;
+    case 1: DEFT_WAIT_VM(1); break;
+    case 2: DEFT_WAIT_VM(2); break;
+    case 3: DEFT_WAIT_VM(3); break;
+    case 4: DEFT_WAIT_VM(4); break;
+    case 5: DEFT_WAIT_VM(5); break;
+    case 6: DEFT_WAIT_VM(6); break;
+    case 7: DEFT_WAIT_VM(7); break;
+    case 8: DEFT_WAIT_VM(8); break;
+    case 9: DEFT_WAIT_VM(9); break;
+    case 10: DEFT_WAIT_VM(10); break;
+    case 11: DEFT_WAIT_VM(11); break;
+    default: DEFT_WAIT_VM(12); break;
+    }
+}
+
+template <int TH, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int NSB = 3;
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int BM = TH * 32;
+    constexpr int TM = TH / WM, TN = BN / (WN * 32);
+    constexpr int HP = (TH + 2) * P3H_HW;              // staged input pixels
+    constexpr int ASLOTS = HP * 6;
+    constexpr int NAP = (ASLOTS + 63) / 64;            // A pieces per 16-channel block
+    constexpr int NA = (NAP + NW - 1) / NW;
+    constexpr int NBI = BN * 6 / 64;                   // B pieces per interval
+    constexpr int NB = (NBI + NW - 1) / NW;
+    constexpr int ABYTES = NAP * 1024, BBYTES = BN * 96;
+    static_assert(TM >= 1 && TN >= 1 && TH % WM == 0 && BN % (WN * 32) == 0 && (BN * 6) % 64 == 0, "tile shape");
+
+    DEFT_DYN_LDS(char, smem);
+    char* const Abase = smem;
+    char* const Bbase = smem + 2 * ABYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = bid % ntiles; bid /= ntiles;
+    const int txi = bid % tiles_x; bid /= tiles_x;
+    const int tyi = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int y0 = tyi * TH, x0 = txi * P3H_TW, n0 = nt * BN;
+
+    const deft_rsrc_t rx = deft_make_rsrc(p.x3);
+    const deft_rsrc_t rw = deft_make_rsrc(p.w3);
+    const unsigned pb = (unsigned)p.ldx3 * 6u;
+    const int nC16 = p.Cin >> 4;
+
+    // ---- loader state: all of it fixed for the whole K loop (the 16-channel block and the tap move by SGPR offsets) ----
+    unsigned offA[NA];
+    int pa_w = 0;                                       // A pieces this wave issues per block
+#pragma unroll
+    for (int ia = 0; ia < NA; ++ia) {
+        const int jp = wave + ia * NW;
+        offA[ia] = DEFT_OOB;
+        if (jp < NAP) {
+            ++pa_w;
+            const int P = jp * 64 + lane;
+            if (P < ASLOTS) {
+                const int hp = P / 6, ps = P - hp * 6;
+                const int q = ps >> 1, g = (ps & 1) ^ ((hp >> 3) & 1);
+                const int hy = hp / P3H_HW, hx = hp - hy * P3H_HW;
+                const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    offA[ia] = (unsigned)((n * p.H + iy) * p.W + ix) * pb + (unsigned)(q * 64 + g * 16);
+            }
+        }
+    }
+    unsigned vB[NB];
+    int pb_w = 0;
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+        const int jb = wave + ib * NW;
+        vB[ib] = 0;
+        if (jb < NBI) {
+            ++pb_w;
+            // stage byte b is row (n0 + b / 96) of the weight matrix: 64-row block (n0 + b/96) / 64, byte (..% 64) * 96 + b % 96 of its slice
+            const unsigned byte = (unsigned)(n0 & 63) * 96u + (unsigned)jb * 1024u;     // offset inside the first block of the tile
+            vB[ib] = (unsigned)((n0 >> 6) + (int)(byte / 6144u)) * (unsigned)(nC16 * 9) * 6144u + byte % 6144u + (unsigned)lane * 16u;
+        }
+    }
+
+    auto issueA = [&](int c16) {
+        char* const as = Abase + (c16 & 1) * ABYTES;
+        const unsigned soff = (unsigned)(c16 >> 1) * 192u + (unsigned)(c16 & 1) * 32u;
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) {
+            const int jp = wave + ia * NW;
+            if (NAP % NW == 0 || jp < NAP) deft_buffer_load_lds_x4s(rx, as + jp * 1024, offA[ia], soff);
+        }
+    };
+    auto issueB = [&](int it, int stage) {
+        char* const bs = Bbase + stage * BBYTES;
+        const unsigned soff = (unsigned)it * 6144u;        // it = c16 * 9 + tap: the (block, tap) slices of a 64-row block are consecutive
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+            const int jb = wave + ib * NW;
+            if (NBI % NW == 0 || jb < NBI) deft_buffer_load_lds_x4s(rw, bs + jb * 1024, vB[ib], soff);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fg = lane >> 5;
+    int boff[TN];                                        // byte offset of this lane's B fragment row, slot of piece 0
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + frow;
+        boff[j] = row * 96 + ((fg ^ ((row >> 3) & 1)) * 16);
+    }
+
+    pa_w = __builtin_amdgcn_readfirstlane(pa_w);      // wave-uniform by construction; tell the compiler (scalar branches in p3_wait_vm)
+    pb_w = __builtin_amdgcn_readfirstlane(pb_w);
+    const int nI = nC16 * 9;
+    issueA(0);
+    issueB(0, 0);
+    if (nI > 1) issueB(1, 1);
+    int c16 = 0, tap = 0, bst = 0;
+    bool a_after = false;                                // were A pieces issued after the B slice we are about to wait for?
+    for (int it = 0; it < nI; ++it) {
+        const int keep = (it + 1 < nI ? pb_w : 0) + (a_after ? pa_w : 0);
+        p3_wait_vm(keep);
+        DEFT_PIPE_BARRIER_ONLY();
+        a_after = false;
+        if (tap == 0 && c16 + 1 < nC16) { issueA(c16 + 1); a_after = true; }
+        if (it + 2 < nI) issueB(it + 2, bst >= 1 ? bst - 1 : 2);          // (bst + 2) % 3
+        // ---- one MFMA k-step: tap (r, s) of 16 channels ----
+        {
+            const int r = tap / 3, s = tap - 3 * r;
+            const char* const as = Abase + (c16 & 1) * ABYTES;
+            const char* const bs = Bbase + bst * BBYTES;
+            bf16x8 pa[TM][3], pb_[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int hr = (wm * TM + i + r) * P3H_HW + frow + s;
+                const char* ap = as + hr * 96 + ((fg ^ ((hr >> 3) & 1)) * 16);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pa[i][q] = *(const bf16x8*)(ap + q * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pb_[j][q] = *(const bf16x8*)(bs + boff[j] + q * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb_[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][2], pb_[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb_[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        bst = bst == 2 ? 0 : bst + 1;
+        if (++tap == 9) { tap = 0; ++c16; }
+    }
+    __syncthreads();
+
+    // ---- epilogue through LDS (common.h): tile row (ty, tx) -> output pixel, clipped at the map border ----
+    float* const T = (float*)smem;
+    deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
+    __syncthreads();
+    deft_epilogue_rows<BM, BN, NT>(T, p, n0, tid, [&](int row) -> long long {
+        const int y = y0 + (row >> 5), x = x0 + (row & 31);
+        return (y < p.H && x < p.W) ? (long long)(n * p.H + y) * p.W + x : -1;
+    });
+}
+
+template <int TH, int BN, int WM, int WN>
+static int launch_p3h(const DeftGemmDesc& d, hipStream_t s) {
+    constexpr int lds = p3h_lds_bytes<TH, BN>(3);
+    const int tiles_x = deft_cdiv(d.W, P3H_TW), tiles_y = deft_cdiv(d.H, TH), ntiles = deft_cdiv(d.Cout, BN);
+    const long long grid = (long long)d.N * tiles_x * tiles_y * ntiles;
+    DEFT_CHECK(grid < (1ll << 31), -70, "conv3h: too many tiles");
+    if (int e = p3_set_lds_attr<conv3h_kernel<TH, BN, WM, WN>>(lds)) return e;
+    hipLaunchKernelGGL((conv3h_kernel<TH, BN, WM, WN>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, s, d, tiles_x, tiles_y, ntiles);
+    DEFT_CHECK_LAUNCH("conv3h");
+    return 0;
+}
+
+// `tile` for the halo form: (TH << 16) | BN, 0 = automatic
+int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s) {
+    DEFT_CHECK(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->OH == d->H && d->OW == d->W && d->korder == 1 && d->splitk <= 1, -71,
+               "deft_conv2d_nhwc: the halo form (p3_kernel = 1) is 3x3 / stride 1 / pad 1, korder 1, no split-K");
+    int th = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
+    if (th == 0) {
+        th = 4;
+        bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+    }
+#define P3H_TILE(TH_, BN_, WM_, WN_) \
+    if (th == TH_ && bn == BN_) return launch_p3h<TH_, BN_, WM_, WN_>(*d, s);
+    P3H_TILE(4, 128, 2, 2)
+    P3H_TILE(4, 64, 4, 1)
+    P3H_TILE(4, 32, 4, 1)
+    P3H_TILE(8, 128, 4, 2)
+    P3H_TILE(8, 64, 4, 2)
+#undef P3H_TILE
+    DEFT_CHECK(false, -15, "conv3h: unsupported tile %dx32 x %d", th, bn);
+    return -15;
+}
+
+// one thread per 16-byte slot of the halo-form weight image [CoutPad/64][Cin/16][9][64 rows][6 slots]
+__global__ __launch_bounds__(256) void split_weights_h_kernel(const float* __restrict__ w, __bf16* __restrict__ w3, int CoutPad, int Kpad) {
+    const int nC16 = Kpad / 144;                                         // Kpad = 9 * Cin
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)CoutPad * nC16 * 9 * 6) return;
+    const int ps = (int)(i % 6);
+    long long t = i / 6;
+    const int r = (int)(t & 63); t >>= 6;
+    const int tap = (int)(t % 9); t /= 9;
+    const int c16 = (int)(t % nC16), blk = (int)(t / nC16);
+    const int q = ps >> 1, g = (ps & 1) ^ ((r >> 3) & 1);
+    const float* wp = w + (size_t)(blk * 64 + r) * Kpad + ((c16 >> 1) * 9 + tap) * 32 + (c16 & 1) * 16 + g * 8;     // korder 1
+    bf16x4 pc[2][3];
+    split3(*(const f32x4*)wp, pc[0][0], pc[0][1], pc[0][2]);
+    split3(*(const f32x4*)(wp + 4), pc[1][0], pc[1][1], pc[1][2]);
+    *(bf16x8*)(w3 + i * 8) = __builtin_shufflevector(pc[0][q], pc[1][q], 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+extern "C" int deft_split_weights_halo(const float* w, void* w3, int CoutPad, int Kpad, void* stream) {
+    DEFT_CHECK(w && w3 && CoutPad > 0 && (CoutPad & 63) == 0 && Kpad > 0 && Kpad % 288 == 0, -1,
+               "deft_split_weights_halo: need CoutPad %% 64 == 0 and Kpad = 9 * Cin with Cin %% 32 == 0 (%d, %d)", CoutPad, Kpad);
+    const long long tot = (long long)CoutPad * (Kpad / 144) * 9 * 6;
+    hipLaunchKernelGGL(split_weights_h_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, CoutPad, Kpad);
+    DEFT_CHECK_LAUNCH("split_weights_halo");
     return 0;
 }

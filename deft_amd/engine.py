@@ -137,6 +137,18 @@ PREC = int(_os.environ.get("DEFT_PREC", "1"))
 # (the operand split stays in the K loop of igemm.hip).  Results are bit-identical either way.
 P3 = _os.environ.get("DEFT_P3", "1") != "0"
 P3_MIN_COUT = int(_os.environ.get("DEFT_P3_MIN_COUT", "64"))
+BDMA = _os.environ.get("DEFT_BDMA", "1") != "0"             # igemm.hip prec-1 launches with >= 128 output columns read pre-split weights by DMA
+# (DeftGemmDesc.w3 without x3).  Measured in the pipeline (profiles/r2_*): pair layer 170 -> 189 TFLOP/s, 128-column 1x1 convs +3..6 %;
+# 64-column tiles and the DCN lose (the second weight stage costs them a workgroup per CU), so they keep splitting weights in the loop.
+BDMA_DCN = _os.environ.get("DEFT_BDMA_DCN", "0") == "1"
+P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
+P3_HALO_WASTE = float(_os.environ.get("DEFT_P3_HALO_WASTE", "1.25"))   # ... when its 4 x 32 pixel tiles cover the map with at most this much padding
+
+
+def halo_waste(H, W):
+    return (-(-H // 4) * 4) * (-(-W // 32) * 32) / float(H * W)
+
+
 _T = lambda bm, bn: (bm << 16) | bn
 P3_3STAGE = 1 << 29
 P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAGE, _T(128, 64), _T(128, 64) | P3_3STAGE, _T(256, 64),
@@ -144,6 +156,32 @@ P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAG
 
 # cross-workgroup split-K for launches too small to fill the chip (DeftGemmDesc.splitk); DEFT_SPLITK=0 turns it off
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
+
+
+class _P3Out:
+    """A producer's optional P3 (three bf16 pieces) output: written only if some pre-split conv reads it (`used`)."""
+
+    def __init__(self, addr, ld, desc=None):
+        self.addr, self.ld, self.desc, self.used = addr, ld, desc, False
+
+
+def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
+    """Which kernel a conv runs on when its input is available as bf16 pieces: ("halo", tile) = 3x3 / stride 1 on halo tiles
+    (igemm3.hip conv3h), ("im2col", tile) = the LDS-DMA chunk loop (igemm3_kernel), None = igemm.hip (operand split in
+    the K loop).  Measured per layer shape on MI355X with tools/bench_p3.py (profiles/r2_bench_p3.log): the halo form
+    wins where its 4 x 32 pixel tiles cover the map with little padding, the im2col form on the small deep maps; 1x1 convs
+    and Cout <= 64 stride-2 convs are HBM- or issue-bound and gain nothing from the 6-byte pieces."""
+    if KH * KW == 1 or Cin % 32 or Cout % 8:
+        return None
+    if (KH, KW, stride, pad) == (3, 3, 1, 1) and korder == 1 and P3_HALO and halo_waste(H, W) <= P3_HALO_WASTE and (Cout >= 128 or Cout <= 32):
+        return ("halo", 0)
+    if Cout < 128 or Cin < 64 or stride != 1:
+        return None                     # in the pipeline (inputs L2-warm) the 64-column and the stride-2 layers are no faster on 6-byte pieces
+    tile = _T(128, 256) if Cout >= 256 else _T(256, 128)
+    bm, bn = tile >> 16, tile & 0xffff
+    if -(-M // bm) * -(-Cout // bn) < 256:
+        tile = 0                        # few tiles (one frame per GPU): the library picks tile and split factor (deft_gemm_plan)
+    return ("im2col", tile)
 
 
 class _Plan:
@@ -157,7 +195,7 @@ class _Plan:
                                       % (self.device, self.lib.path))
         self._p3 = {}          # id(fp32 buffer) -> bf16 tensor holding its three-piece (P3) form
         self._p3_cover = {}    # id(fp32 buffer) -> [(ch_lo, ch_hi, producing descriptor or None)] channel ranges with valid P3 data
-        self._p3_used = set()  # id(descriptor) of producers whose P3 output some conv reads
+        self._p3_outs = []     # _P3Out records of every producer that can write a P3 copy of its output
         self._w3 = {}          # packed fp32 weight data_ptr -> P3 weight image
         self.ops = []          # (kind, name, callable, flops)
         self._gemms = []       # (entry, name, descriptor) of every implicit-GEMM launch, for autotune()
@@ -229,7 +267,7 @@ class _Plan:
                 if hi <= a or lo >= b:
                     nxt.append((a, b)); continue
                 if d is not None:
-                    self._p3_used.add(id(d))
+                    d.used = True
                 if a < lo: nxt.append((a, lo))
                 if hi < b: nxt.append((hi, b))
             need = nxt
@@ -241,22 +279,32 @@ class _Plan:
             self._p3_cover.setdefault(id(v.buf), []).append((ch, ch + v.C, None))
         return addr
 
-    def weights_p3(self, w_packed):
-        """P3 image of a packed fp32 weight matrix (deft_split_weights, once per matrix)."""
-        key = w_packed.data_ptr()
+    def weights_p3(self, w_packed, halo=False):
+        """P3 image of a packed fp32 weight matrix (deft_split_weights / deft_split_weights_halo, once per matrix)."""
+        key = (w_packed.data_ptr(), halo)
         if key not in self._w3:
             w3 = torch.empty(w_packed.numel() * 3, dtype=torch.bfloat16, device=self.device)
-            self.lib.call("deft_split_weights", ptr(w_packed), C.c_void_p(w3.data_ptr()), w_packed.shape[0], w_packed.shape[1],
-                          hiplib.stream_ptr(self.device))
+            self.lib.call("deft_split_weights_halo" if halo else "deft_split_weights", ptr(w_packed), C.c_void_p(w3.data_ptr()),
+                          w_packed.shape[0], w_packed.shape[1], hiplib.stream_ptr(self.device))
             self._w3[key] = w3
             self._keep.append(w_packed)
         return self._w3[key]
 
+    def p3_output(self, out, desc=None):
+        """Register `out` as producible in P3 form -> _P3Out (its `used` flag is set when a pre-split conv reads it) or None."""
+        if not (P3 and PREC == 1 and self.p3_capable(out)):
+            return None
+        h = _P3Out(self.p3_addr(out), out.ld, desc)
+        ch = out.c0 % out.ld
+        self._p3_cover.setdefault(id(out.buf), []).append((ch, ch + out.C, h))
+        self._p3_outs.append(h)
+        return h
+
     def finalize_p3(self):
         """Drop the P3 outputs nobody reads (call once the whole launch list is built)."""
-        for entry, name, d in self._gemms:
-            if d.y3 and id(d) not in self._p3_used:
-                d.y3 = None
+        for h in self._p3_outs:
+            if h.desc is not None:
+                h.desc.y3, h.desc.ldy3 = (h.addr, h.ld) if h.used else (None, 0)
 
     # ---- op builders -------------------------------------------------------
     def gemm(self, entry, name, desc, flops):
@@ -265,7 +313,7 @@ class _Plan:
         lib, ref = self.lib, C.byref(desc)
         self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
         self._gemms.append((entry, name, desc))
-        if SPLITK and entry in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc") and not desc.splitk:
+        if SPLITK and entry in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc") and not desc.splitk and not desc.p3_kernel:
             self._plan_splitk(entry, desc)
 
     def _plan_splitk(self, entry, desc):
@@ -297,8 +345,11 @@ class _Plan:
         """Per-layer tile search on the GPU this plan will run on (the cuDNN-benchmark / MIOpen-find
         step of the reference stack, done once per plan): every implicit-GEMM launch is timed alone
         with each candidate (tile, loop form) and the fastest is written into its descriptor.
-        Only result-identical candidates are tried: the WK = 1 tiles all accumulate in the same
-        order, so tuning never changes an output bit; split-K layers keep their tile."""
+        Only result-identical candidates are tried, so tuning never changes an output bit
+        (tests/test_gpu_parity.py::test_autotune_keeps_every_bit): with prec 0 every WK = 1 tile and both loop forms are the
+        same k-ordered fp32 chain; with prec 1 only the 1-stage BN >= 64 tiles implement the split-bf16 arithmetic
+        (launch_igemm falls back to the fp32 MFMA for the 2-stage form and BN = 32), so only those are candidates.
+        Launches on the pre-split kernels (x3) and cross-workgroup split-K launches keep their configuration."""
         if self.device.type != "cuda":
             return
         T = lambda bm, bn: (bm << 16) | bn
@@ -310,7 +361,7 @@ class _Plan:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         memo = {}
         for entry, name, d in self._gemms:
-            if d.splitk > 1:               # cross-workgroup split-K launches keep their (tile, split, workspace)
+            if d.splitk > 1 or d.x3:       # cross-workgroup split-K launches keep their (tile, split, workspace); so do the x3 kernels
                 continue
             key = (entry, d.M, d.Cout, d.Ktot, d.Cin, d.KH, d.KW, d.stride, d.H, d.W, d.ldx, d.ldy, bool(d.res), bool(d.rowmap))
             if key not in memo:
@@ -319,7 +370,7 @@ class _Plan:
                     if d.Cout <= 32 and -(-(d.OH * d.OW) // 128) >= 256:
                         opts = [T(128, 32), T(128, 32) | two]
                 else:
-                    opts = [t | st for t in cands[entry] for st in (0, two)]
+                    opts = [t | st for t in cands[entry] for st in ((0,) if d.prec == 1 else (0, two))]
                 best, best_t = d.tile, None
                 for t in opts:
                     d.tile = t
@@ -341,7 +392,7 @@ class _Plan:
             d.tile = memo[key]
 
     def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0,
-             true_cin=None, korder=None, p3=None):
+             true_cin=None, korder=None, p3=None, true_cout=None):
         OH = (x.H + 2 * pad - KH) // stride + 1
         OW = (x.W + 2 * pad - KW) // stride + 1
         if out is None:
@@ -363,17 +414,34 @@ class _Plan:
         d.M = x.N * OH * OW
         d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = tile
         d.korder = conv_korder((Cout, x.C, KH, KW)) if korder is None else korder
-        if (P3 and PREC == 1 and p3 is not False and tile in P3_TILES and self.p3_capable(x) and KH * KW <= 32 and K == w_packed.shape[1]
-                and Cout >= P3_MIN_COUT and Cout % 8 == 0 and out.ld % 4 == 0 and (out.c0 % 4) == 0 and (KH * KW == 1 or x.C & (x.C - 1) == 0)):
+        # ---- pre-split operands: which kernel (p3: None = by shape, False = never, "halo" / "im2col" = forced by a test) ----
+        choice = None
+        if P3 and PREC == 1 and p3 is not False and self.p3_capable(x) and K == w_packed.shape[1] and out.ld % 4 == 0 and out.c0 % 4 == 0 \
+                and Cout % 8 == 0 and (KH * KW == 1 or x.C & (x.C - 1) == 0) and KH * KW <= 32:
+            if p3 == "halo":
+                assert (KH, KW, stride, pad) == (3, 3, 1, 1) and d.korder == 1, "halo form needs 3x3 / stride 1 / pad 1 and korder 1"
+                choice = ("halo", tile)
+            elif p3 in ("im2col", True):
+                choice = ("im2col", tile) if tile in P3_TILES else None
+            elif tile == 0:
+                choice = p3_choice(KH, KW, stride, pad, x.C, Cout, x.H, x.W, d.M, d.korder)
+            elif tile in P3_TILES and Cout >= P3_MIN_COUT:
+                choice = ("im2col", tile)          # a forced igemm3 tile
+        if choice is not None:
+            halo = choice[0] == "halo"
+            d.tile = choice[1]
             d.x3, d.ldx3 = self._p3_input(name, x), x.ld
-            d.w3 = self.weights_p3(w_packed).data_ptr()
-            if Cout % 32 == 0 and self.p3_capable(out):
-                d.y3, d.ldy3 = self.p3_addr(out), out.ld
-                ch = out.c0 % out.ld
-                self._p3_cover.setdefault(id(out.buf), []).append((ch, ch + Cout, d))
+            d.p3_kernel = 1 if halo else 0
+            d.w3 = self.weights_p3(w_packed, halo).data_ptr()
+            if Cout % 32 == 0:
+                h = self.p3_output(out, d)
+                if h is not None:
+                    d.y3, d.ldy3 = h.addr, h.ld
+        if choice is None and BDMA and PREC == 1 and Cout >= 128:
+            d.w3 = self.weights_p3(w_packed).data_ptr()         # igemm.hip: weight chunks by DMA, activations split in the loop
         cin = x.C if true_cin is None else true_cin
         d.flop_k = KH * KW * cin
-        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * Cout * KH * KW * cin)
+        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * (Cout if true_cout is None else true_cout) * KH * KW * cin)
         return out
 
     def conv_pair(self, name, x, w_packed, K, KH, KW, pad, Cout, scale2, shift2, relu, true_k):
@@ -413,7 +481,9 @@ class _Plan:
         lib = self.lib
         a = (C.c_void_p(x.addr), ptr(wup), C.c_void_p(skip.addr), C.c_void_p(out.addr),
              x.N, x.H, x.W, x.C, f, x.ld, skip.ld, out.ld)
-        self.add("deft_upsample_add", name, lambda: lib.call("deft_upsample_add", *a, self._stream()))
+        h = self.p3_output(out)                       # written in P3 form too if a pre-split conv reads it (decided by run time)
+        self.add("deft_upsample_add", name, lambda: lib.call("deft_upsample_add", *a, C.c_void_p(h.addr) if h is not None and h.used else None,
+                                                             h.ld if h is not None else 0, self._stream()))
         return out
 
 
@@ -514,11 +584,13 @@ class DlaSegPlan(_Plan):
             wm, Km = pack_dcn_weight(sd[p + ".conv.weight"])
             alpha, beta = _bn_fold(sd, p + ".actf.0")
             shift = sd[p + ".conv.bias"].float() * alpha + beta
-            self._wcache[key] = (self.dev(wo), Ko, self.dev(sd[p + ".conv.conv_offset_mask.bias"].float()),
-                                 self.dev(wm), Km, self.dev(alpha), self.dev(shift))
+            bo = torch.zeros(32); bo[:27] = sd[p + ".conv.conv_offset_mask.bias"].float()
+            self._wcache[key] = (self.dev(wo), Ko, self.dev(bo), self.dev(wm), Km, self.dev(alpha), self.dev(shift))
         wo, Ko, bo, wm, Km, alpha, shift = self._wcache[key]
-        om = self.alloc(x.N, x.H, x.W, 27, ld=32)
-        self.conv(p + ".offset", x, wo, Ko, 3, 3, 1, 1, 27, None, bo, False, out=om)
+        # offset/mask conv as a 32-column problem (27 channels + 5 zero columns: zero weight rows, zero bias) so that it can run
+        # on the pre-split halo kernel, which writes 8 channels per thread; the DCN reads channels 0..26 (ldom = 32)
+        om = self.alloc(x.N, x.H, x.W, 32, ld=32)
+        self.conv(p + ".offset", x, wo, Ko, 3, 3, 1, 1, 32, None, bo, False, out=om, true_cout=27)
         out = self.alloc(x.N, x.H, x.W, cout)
         d = GemmDesc()
         d.x = x.addr; d.x2 = om.addr; d.w = wm.data_ptr()
@@ -530,6 +602,12 @@ class DlaSegPlan(_Plan):
         d.cin_log2 = int(math.log2(cin))
         d.M = x.N * x.H * x.W
         d.relu = 1; d.Q = 0; d.ldom = om.ld; d.tile = 0
+        if BDMA_DCN and PREC == 1:
+            d.w3 = self.weights_p3(wm).data_ptr()
+        if cout % 32 == 0 and out.ld % 4 == 0:
+            h = self.p3_output(out, d)               # pruned by finalize_p3() when no pre-split conv reads it
+            if h is not None:
+                d.y3, d.ldy3 = h.addr, h.ld
         self.gemm("deft_dcn_v2_nhwc", p + ".dcn", d, 2.0 * d.M * cout * 9 * cin)
         return out
 
@@ -804,6 +882,8 @@ class AfePlan(_Plan):
         d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
         d.Ktot, d.Kpad, d.cin_log2, d.M = Cin, Kpad, 0, M
         d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0; d.prec = PREC
+        if BDMA and PREC == 1 and Cout >= 128:
+            d.w3 = self.weights_p3(wp).data_ptr()
         self.lib.call("deft_conv2d_nhwc", C.byref(d), self._stream())
 
     def affinity(self, hist, cur):
@@ -837,6 +917,8 @@ class AfePlan(_Plan):
         d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
         d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
         d.relu = 1; d.Q = Q; d.ldom = 0; d.tile = 0; d.prec = PREC
+        if BDMA and PREC == 1:
+            d.w3 = self.weights_p3(w2).data_ptr()
         self.lib.call("deft_pair_layer", C.byref(d), self._stream())
         h3 = torch.empty(M, c3, dtype=torch.float32, device=dev)
         self._lin(h2, M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, h3, c3)
@@ -888,6 +970,8 @@ class AfePlan(_Plan):
             d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
             d.Ktot, d.Kpad, d.cin_log2, d.M = 512, 512, 0, M
             d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0; d.prec = PREC
+            if BDMA and PREC == 1:
+                d.w3 = self.weights_p3(w2).data_ptr()
             d.Tper, d.u0, d.du, d.v0, d.dv = hist * K, (g0 + c0 - hist) * K, K, (g0 + c0) * K, K
             self.lib.call("deft_pair_layer", C.byref(d), self._stream())
             self._lin(b["h2"], M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, b["h3"], c3)

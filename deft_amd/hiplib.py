@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
         ("stride_w", C.c_int), ("korder", C.c_int),
         ("rowmap", c_fp),
         ("splitk", C.c_int), ("ws", c_fp), ("ws_cnt", c_fp), ("prec", C.c_int),
-        ("x3", c_fp), ("w3", c_fp), ("y3", c_fp), ("ldx3", C.c_int), ("ldy3", C.c_int),
+        ("x3", c_fp), ("w3", c_fp), ("y3", c_fp), ("ldx3", C.c_int), ("ldy3", C.c_int), ("p3_kernel", C.c_int),
     ]
 
 
@@ -46,7 +46,7 @@ _SIGS = {
     "deft_nchw_to_nhwc": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
     "deft_nhwc_to_nchw": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
     "deft_maxpool2x2": (C.c_int, [c_fp, c_fp] + [C.c_int] * 6 + [c_fp]),
-    "deft_upsample_add": (C.c_int, [c_fp] * 4 + [C.c_int] * 8 + [c_fp]),
+    "deft_upsample_add": (C.c_int, [c_fp] * 4 + [C.c_int] * 8 + [c_fp, C.c_int, c_fp]),
     "deft_hm_peaks": (C.c_int, [c_fp] + [C.c_int] * 6 + [c_fp] * 3 + [C.c_int, c_fp]),
     "deft_topk": (C.c_int, [c_fp] * 3 + [C.c_int] * 4 + [c_fp] * 3 + [c_fp]),
     "deft_heads_at_peaks": (C.c_int, [c_fp] + [C.c_int] * 5 + [c_fp, C.c_int] + [c_fp] * 5 + [C.c_int] * 2 + [c_fp, c_fp]),
@@ -62,6 +62,7 @@ _SIGS = {
     "deft_motion_step": (C.c_int, [c_fp, c_fp] + [C.c_int] * 3 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp] * 7 + [c_fp, c_fp, c_fp]),
     "deft_split_planes": (C.c_int, [c_fp, c_fp, C.c_longlong, C.c_int, C.c_int, C.c_int, c_fp]),
     "deft_split_weights": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
+    "deft_split_weights_halo": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
     "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)

@@ -87,11 +87,18 @@ typedef struct DeftGemmDesc {
      *         chunk, copied verbatim (deft_split_weights builds it from the packed fp32 matrix `w`).
      * Needs Cin % 32 == 0, Kpad == Ktot, KH*KW <= 32, no rowmap, Cout % 8 == 0, ldy % 4 == 0.
      * y3 (nullable): the output is ALSO written in P3 form (pixel stride ldy3 channels) for a following conv;
-     * y may then be NULL when no fp32 consumer exists.  y3 is honoured by the P3 kernel only. */
+     * y may then be NULL when no fp32 consumer exists.  y3 is honoured by the pre-split conv kernels and by deft_dcn_v2_nhwc. */
     const void* x3;
-    const void* w3;
+    const void* w3;      /* without x3 (conv / dcn / pair on igemm.hip, prec = 1): only the weights are pre-split -- their chunk images are
+                            copied to LDS by DMA, the activations are still split in the K loop (honoured by the BN >= 64 tiles, S = 1) */
     void* y3;
     int ldx3, ldy3;
+    /* which pre-split kernel: 0 = im2col chunks (any conv the x3 rules admit); 1 = halo tiles, 3x3 / stride 1 / pad 1 only:
+     * a workgroup stages a (TH+2) x 34 input patch once per 16 channels and takes all nine taps out of it (1/7 of the
+     * im2col form's activation traffic through the CU's load path).  w3 must then be the halo-form image
+     * (deft_split_weights_halo), korder 1, no split-K; `tile` = (TH << 16) | BN, 0 = automatic.  K order (16-channel block,
+     * tap): same pieces and products as the other forms, another fp32 summation order. */
+    int p3_kernel;
 } DeftGemmDesc;
 
 int deft_version(void);
@@ -136,9 +143,10 @@ int deft_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, int ld
 /* Depthwise ConvTranspose2d(k=2f, stride f, pad f/2) + skip add:
  * y = up(x) + skip  -- IDAUp.forward dla.py:696-699 (`upsample(project(l[i])) + l[i-1]`).
  * x is [N,H,W,C]; skip and y are [N,f*H,f*W,C]; wup is the module's weight transposed to
- * [2f*2f][C] (tap-major, so 4 channels of one tap are one 16-byte load). */
+ * [2f*2f][C] (tap-major, so 4 channels of one tap are one 16-byte load).  y3 (nullable): the result also as its three
+ * bf16 pieces (DeftGemmDesc.x3 layout, pixel stride ldy3 channels) for a following pre-split conv. */
 int deft_upsample_add(const float* x, const float* wup, const float* skip, float* y,
-                      int N, int H, int W, int C, int f, int ldx, int lds, int ldy, void* stream);
+                      int N, int H, int W, int C, int f, int ldx, int lds, int ldy, void* y3, int ldy3, void* stream);
 
 /* sigmoid + 3x3 peak NMS + candidate compaction (detector.py:488, utils.py:69-74).
  * hm: NHWC [N,H,W,C] (ld): logits when apply_sigmoid != 0, already-sigmoid'ed scores
@@ -268,6 +276,10 @@ int deft_split_planes(const float* x, void* y3, long long rows, int C, int ldx, 
 /* Packed fp32 weights [CoutPad(128)][Kpad] (DeftGemmDesc.w) -> the P3 weight image (DeftGemmDesc.w3),
  * CoutPad * Kpad * 3 bf16.  Done once per layer at load time. */
 int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpad, void* stream);
+
+/* The same for the halo form (DeftGemmDesc.p3_kernel = 1): `w` must be packed with korder 1, Kpad = 9 * Cin;
+ * image [CoutPad/64][Cin/16][9 taps][64 rows][6 slots of 8 bf16]. */
+int deft_split_weights_halo(const float* w, void* w3, int CoutPad, int Kpad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -413,4 +413,7 @@ static inline void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* lds_wave_base, 
     memcpy((char*)lds_wave_base + 16 * hipemu::S().lane, &v, 16);
 }
 #define DEFT_PIPE_BARRIER(N) __syncthreads()      /* the emulator's DMA is synchronous */
+#define DEFT_PIPE_BARRIER_ONLY() __syncthreads()
+#define DEFT_WAIT_VM(N) ((void)0)
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }

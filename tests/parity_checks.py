@@ -31,7 +31,7 @@ def fill_view(v, x_nchw):
 
 
 # ---------------------------------------------------------------------------
-def check_conv(lib, device, N, H, W, Ci, Co, k, stride, pad, tile, res=False, relu=True, seed=0):
+def check_conv(lib, device, N, H, W, Ci, Co, k, stride, pad, tile, res=False, relu=True, seed=0, p3=None):
     g = torch.Generator().manual_seed(seed)
     plan = engine._Plan(device, lib)
     x = torch.randn(N, Ci, H, W, generator=g)
@@ -49,8 +49,12 @@ def check_conv(lib, device, N, H, W, Ci, Co, k, stride, pad, tile, res=False, re
         r = torch.randn(N, Co, OH, OW, generator=g)
         rv = plan.alloc(N, OH, OW, Co)
         fill_view(rv, r)
-    out = plan.conv("c", xv, plan.dev(wp), K, k, k, stride, pad, Co, plan.dev(scale), plan.dev(shift), relu, res=rv, tile=tile)
+    out = plan.conv("c", xv, plan.dev(wp), K, k, k, stride, pad, Co, plan.dev(scale), plan.dev(shift), relu, res=rv, tile=tile, p3=p3)
+    if p3 == "halo":
+        assert plan._gemms[-1][2].p3_kernel == 1 and plan._gemms[-1][2].x3
     plan.run()
+    if p3 == "halo" and plan._gemms[-1][2].y3:
+        assert torch.equal(p3_to_float(plan, out).cpu(), out.to_nchw().permute(0, 2, 3, 1).cpu()), "P3 epilogue output != fp32 output"
     ref = F.conv2d(x, w, None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if res:
         ref = ref + r
@@ -765,6 +769,14 @@ def p3_to_float(plan, v):
     return t.reshape(-1, v.ld)[pix:pix + v.N * v.H * v.W, ch:ch + v.C].reshape(v.N, v.H, v.W, v.C)
 
 
+def refresh_p3(plan, v):
+    """Re-derive the P3 companion of a view whose fp32 data a test has overwritten."""
+    import ctypes as C
+    if id(v.buf) in plan._p3:
+        plan.lib.call("deft_split_planes", C.c_void_p(v.addr), C.c_void_p(plan.p3_addr(v)), C.c_longlong(v.N * v.H * v.W), v.C, v.ld, v.ld,
+                      plan._stream())
+
+
 def check_conv_p3(lib, device, N, H, W, Ci, Cm, Co, k, stride, tile=0, tile2=0, seed=0, splitk=0):
     """conv(Ci->Cm, k x k, stride) -> conv(Cm->Co, 3x3) + residual, both on the pre-split path, against the same chain
     with the operand split in the K loop (igemm.hip, prec 1): BIT-identical outputs; the first conv hands its output
@@ -795,9 +807,9 @@ def _check_conv_p3(lib, device, N, H, W, Ci, Cm, Co, k, stride, tile, tile2, see
         wp1, K1 = engine.pack_conv_weight(w1); wp2, K2 = engine.pack_conv_weight(w2)
         cat = plan.alloc(N, OH, OW, Cm + 32)                      # the first conv writes a channel slice of a wider buffer
         t = plan.conv("c1", xv, plan.dev(wp1), K1, k, k, stride, pad, Cm, plan.dev(s1), plan.dev(b1), True, out=cat.sub(32, Cm),
-                      tile=tile if p3 is None else 0, p3=p3)
+                      tile=tile if p3 is None else 0, p3=p3 if p3 is False else "im2col")
         o = plan.conv("c2", t, plan.dev(wp2), K2, 3, 3, 1, 1, Co, plan.dev(s2), plan.dev(b2), True, res=rv,
-                      tile=tile2 if p3 is None else 0, p3=p3)
+                      tile=tile2 if p3 is None else 0, p3=p3 if p3 is False else "im2col")
         if p3 is None:
             d1, d2 = plan._gemms[0][2], plan._gemms[1][2]
             assert d1.x3 and d2.x3 and d1.y3, "the pre-split path was not taken"
@@ -909,6 +921,7 @@ def check_peaked_heatmap(lib, device, H, W, K=100, nblobs=140, seed=11):
         assert torch.equal(O.generic_decode(O.sigmoid_output(o2), K=K)["inds"], od["inds"])
     plan = engine.DlaSegPlan(sd2, 1, H, W, "mot", K=K, device=device, lib=lib)
     fill_view(plan.feat, feat)
+    refresh_p3(plan, plan.feat)                                   # (the plan's DCN epilogue wrote the pieces of ITS feature map)
     first = min(i for i, op in enumerate(plan.ops) if op[1].startswith("hm.0"))
     plan.ops = plan.ops[first:]                                   # heads + decode only, on the synthetic feature map
     plan.run()
@@ -916,3 +929,44 @@ def check_peaked_heatmap(lib, device, H, W, K=100, nblobs=140, seed=11):
     assert maxabs(plan.scores.cpu(), od["scores"]) <= 1e-5
     assert maxabs(plan.bboxes.cpu(), od["bboxes"]) <= TOL
     return plan, od
+
+
+def check_weight_dma_identical(lib, device, seed=0):
+    """igemm.hip with the weights pre-split and DMA'd (DeftGemmDesc.w3 without x3) gives the SAME BITS as with the weights
+    split in the K loop: conv (two tiles, K padding), DCN (incl. its P3 epilogue) and the pair layer."""
+    assert engine.PREC == 1
+    outs = []
+    for bdma in (False, True):
+        saved = engine.BDMA, engine.P3_HALO, engine.BDMA_DCN
+        engine.BDMA, engine.P3_HALO, engine.BDMA_DCN = bdma, False, bdma
+        try:
+            g = torch.Generator().manual_seed(seed)
+            plan = engine._Plan(device, lib)
+            x = torch.randn(2, 64, 9, 13, generator=g)
+            xv = plan.alloc(2, 9, 13, 64); fill_view(xv, x)
+            res = []
+            for (co, k, tile) in ((128, 3, T(64, 64)), (200, 1, T(128, 128)), (136, 3, T(128, 64))):
+                w = torch.randn(co, 64, k, k, generator=g) * 0.1
+                wp, K = engine.pack_conv_weight(w)
+                o = plan.conv("c", xv, plan.dev(wp), K, k, k, 1, k // 2, co, None, None, True, tile=tile, p3=False)
+                assert bool(plan._gemms[-1][2].w3) == bdma
+                res.append(o)
+            sd = {"d.conv.weight": torch.randn(64, 64, 3, 3, generator=g) * 0.05, "d.conv.bias": torch.randn(64, generator=g) * 0.1,
+                  "d.conv.conv_offset_mask.weight": torch.randn(27, 64, 3, 3, generator=g) * 0.02,
+                  "d.conv.conv_offset_mask.bias": torch.randn(27, generator=g) * 0.5,
+                  "d.actf.0.weight": torch.rand(64, generator=g) + 0.5, "d.actf.0.bias": torch.randn(64, generator=g) * 0.2,
+                  "d.actf.0.running_mean": torch.randn(64, generator=g) * 0.2, "d.actf.0.running_var": torch.rand(64, generator=g) + 0.5}
+            dplan = engine.DlaSegPlan.__new__(engine.DlaSegPlan)
+            engine._Plan.__init__(dplan, device, lib)
+            dplan.sd = sd; dplan._wcache = {}
+            xd = dplan.alloc(2, 9, 13, 64); fill_view(xd, x)
+            od = dplan._deform("d", xd)
+            dd = dplan._gemms[-1][2]
+            assert bool(dd.w3) == bdma and dd.y3                       # the DCN also writes its output as bf16 pieces ...
+            plan.run(); dplan.run()
+            assert torch.equal(p3_to_float(dplan, od).cpu(), od.to_nchw().permute(0, 2, 3, 1).cpu())   # ... which equal the fp32 map exactly
+            outs.append([r.to_nchw().cpu() for r in res] + [od.to_nchw().cpu()])
+        finally:
+            engine.BDMA, engine.P3_HALO, engine.BDMA_DCN = saved
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), maxabs(a, b)

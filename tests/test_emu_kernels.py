@@ -266,3 +266,17 @@ def test_conv_presplit_splitk(emu_lib):
 def test_peaked_heatmap_ordered_topk(emu_lib):
     """Small-map version of the GPU test: a peaked heat map must give the oracle's ordered top-K outright."""
     pc.check_peaked_heatmap(emu_lib, "cpu", 64, 96, K=5, nblobs=6)
+
+
+# halo-tile form of the 3x3 / stride 1 convs (DeftGemmDesc.p3_kernel = 1): ragged map edges, every tile shape
+@pytest.mark.parametrize("args", [
+    (1, 8, 32, 32, 64, 3, 1, 1, 0), (2, 9, 37, 64, 128, 3, 1, 1, 0), (1, 5, 70, 64, 64, 3, 1, 1, T(4, 64)),
+    (1, 6, 33, 32, 32, 3, 1, 1, T(4, 32)), (1, 10, 40, 64, 128, 3, 1, 1, T(8, 128)), (1, 9, 31, 128, 64, 3, 1, 1, T(8, 64)),
+    (1, 4, 20, 64, 200, 3, 1, 1, T(4, 128)),
+])
+def test_conv_halo(emu_lib, args):
+    pc.check_conv(emu_lib, "cpu", *args, res=True, relu=True, p3="halo")
+
+
+def test_weight_dma_identical(emu_lib):
+    pc.check_weight_dma_identical(emu_lib, "cpu")

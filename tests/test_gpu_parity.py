@@ -450,6 +450,47 @@ def test_conv_presplit(gpu_lib, args):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("args", [
+    (1, 8, 32, 32, 64, 3, 1, 1, 0), (2, 9, 37, 64, 128, 3, 1, 1, 0), (1, 5, 70, 64, 64, 3, 1, 1, pc.T(4, 64)),
+    (1, 6, 33, 32, 32, 3, 1, 1, pc.T(4, 32)), (1, 10, 40, 64, 128, 3, 1, 1, pc.T(8, 128)), (1, 9, 31, 128, 64, 3, 1, 1, pc.T(8, 64)),
+    (1, 4, 20, 64, 200, 3, 1, 1, pc.T(4, 128)),
+    (3, 76, 136, 128, 128, 3, 1, 1, 0), (2, 152, 272, 64, 64, 3, 1, 1, 0), (2, 152, 272, 64, 256, 3, 1, 1, pc.T(8, 128)), (4, 38, 68, 256, 32, 3, 1, 1, 0),
+])
+def test_conv_halo(gpu_lib, args):
+    """Halo-tile form of the 3x3 / stride 1 convs (DeftGemmDesc.p3_kernel = 1) against torch conv2d: ragged edges, all tile
+    shapes, and full-size maps (every LDS stage and both workgroups of a CU in flight)."""
+    pc.check_conv(gpu_lib, "cuda", *args, res=True, relu=True, p3="halo")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_autotune_keeps_every_bit(gpu_lib, prec):
+    """_Plan.autotune() may only pick among result-identical kernels -- outputs before and after tuning are
+    bit-identical for both contraction arithmetics."""
+    from deft_amd import engine
+    saved, engine.PREC = engine.PREC, prec
+    try:
+        sd = O.synth_state_dict("mot")
+        plan = engine.DlaSegPlan(sd, 2, 128, 160, "mot", K=20, device="cuda", lib=gpu_lib)
+        x = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(3)).cuda()
+        plan.forward(x); torch.cuda.synchronize()
+        before = [fm.to_nchw().clone() for fm in plan.fmaps] + [plan.dense["hm"].to_nchw().clone(), plan.bboxes.clone()]
+        tiles0 = [d.tile for _, _, d in plan._gemms]
+        plan.autotune(reps=1)
+        plan.forward(x); torch.cuda.synchronize()
+        after = [fm.to_nchw() for fm in plan.fmaps] + [plan.dense["hm"].to_nchw(), plan.bboxes]
+        assert tiles0 != [d.tile for _, _, d in plan._gemms], "autotune changed nothing: the test would be vacuous"
+        for a, b in zip(before, after):
+            assert torch.equal(a, b)
+    finally:
+        engine.PREC = saved
+
+
+def test_weight_dma_identical(gpu_lib):
+    pc.check_weight_dma_identical(gpu_lib, "cuda")
+    torch.cuda.synchronize()
+
+
 def test_conv_presplit_splitk(gpu_lib):
     pc.check_conv_p3(gpu_lib, "cuda", 1, 19, 34, 512, 512, 256, 3, 1, pc.T(128, 128), pc.T(256, 128), splitk=4)
     pc.check_conv_p3(gpu_lib, "cuda", 1, 7, 9, 128, 128, 64, 3, 1, pc.T(256, 128), pc.T(64, 64) | (1 << 29), splitk=4)

@@ -47,28 +47,36 @@ def case(name, H, W, Ci, Co, k, stride, tiles, res=False):
         rv = None
         if res:
             rv = plan.alloc(B, (H - 1) // stride + 1, (W - 1) // stride + 1, Co); rv.buf.fill_(0.25)
+        halo = isinstance(tile, tuple)
         out = plan.conv("c", xv, plan.dev(wp), K, k, k, stride, k // 2, Co, plan.dev(sc), plan.dev(sh), True, res=rv,
-                        tile=0 if tile is None else tile, p3=False if tile is None else None)
+                        tile=0 if tile is None else (tile[1] if halo else tile), p3=False if tile is None else ("halo" if halo else "im2col"))
         plan.finalize_p3()                       # nobody reads the P3 output here: fp32 epilogue only, like the igemm.hip launch
         plan.run(); torch.cuda.synchronize()
         if tile is None:
             ref = out.buf.clone()
-        same = "ref" if tile is None else ("bit-identical" if torch.equal(out.buf, ref) else "DIFFERS %.3e" % float((out.buf - ref).abs().max()))
+        same = "ref" if tile is None else ("bit-identical" if torch.equal(out.buf, ref) else "max diff %.3e" % float((out.buf - ref).abs().max()))
         plan.ops = [plan.ops[-1]]
         fl = plan.ops[-1][3]
         ms = timeit(plan)
         d = plan._gemms[-1][2]
-        label = "igemm.hip (in-loop split)" if tile is None else "P3 %3dx%-3d %dst" % ((tile >> 16) & 0x1fff, tile & 0xffff, 3 if tile & S3 else 2) if tile else "P3 auto"
+        if halo:
+            label = "P3 halo %dx32 x %d" % (tile[1] >> 16, tile[1] & 0xffff)
+        else:
+            label = "igemm.hip (in-loop split)" if tile is None else "P3 %3dx%-3d %dst" % ((tile >> 16) & 0x1fff, tile & 0xffff, 3 if tile & S3 else 2) if tile else "P3 auto"
         print("%-30s %-28s %7.3f ms %6.1f TF/s  %s" % (name, label, ms, fl / ms / 1e9, same), flush=True)
 
 
-ALL = [T(256, 128), T(128, 128), T(128, 128) | S3, T(128, 256)]
-N64 = [T(256, 64), T(128, 64), T(128, 64) | S3, T(64, 64), T(64, 64) | S3]
-case("3x3 64->64 @152x272", 152, 272, 64, 64, 3, 1, N64, res=True)
-case("3x3 128->128 @76x136", 76, 136, 128, 128, 3, 1, ALL, res=True)
-case("3x3 256->256 @38x68", 38, 68, 256, 256, 3, 1, ALL, res=True)
-case("3x3 512->512 @19x34", 19, 34, 512, 512, 3, 1, ALL + [T(64, 64) | S3])
-case("head 3x3 64->256 @152x272", 152, 272, 64, 256, 3, 1, ALL)
+ALL = [T(256, 128), T(128, 128), T(128, 256)]
+N64 = [T(256, 64), T(128, 64), T(64, 64)]
+H128 = [("h", T(4, 128)), ("h", T(8, 128))]
+H64 = [("h", T(4, 64)), ("h", T(8, 64))]
+case("3x3 64->64 @152x272", 152, 272, 64, 64, 3, 1, N64 + H64, res=True)
+case("3x3 128->128 @76x136", 76, 136, 128, 128, 3, 1, ALL + H128, res=True)
+case("3x3 256->256 @38x68", 38, 68, 256, 256, 3, 1, ALL + H128, res=True)
+case("3x3 512->512 @19x34", 19, 34, 512, 512, 3, 1, ALL + H128)
+case("head 3x3 64->256 @152x272", 152, 272, 64, 256, 3, 1, ALL + H128)
+case("offset 3x3 64->32 @152x272", 152, 272, 64, 32, 3, 1, [("h", T(4, 32))])
+case("offset 3x3 128->32 @76x136", 76, 136, 128, 32, 3, 1, [("h", T(4, 32))])
 case("1x1 1280->512 @19x34", 19, 34, 1280, 512, 1, 1, ALL)
 case("1x1 448->128 @76x136", 76, 136, 448, 128, 1, 1, ALL)
 case("1x1 128->64 @152x272", 152, 272, 128, 64, 1, 1, N64)
