@@ -1,24 +1,33 @@
 #!/usr/bin/env python
 """Benchmark of DEFT's per-frame hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--config A|B|D|E] [--batch B]
 
-A "step" = one batch of B synthetic 1088x608 frames per GPU through
-DLA-34 + DCNv2 neck + hm head + decode (K=100) + sparse regression heads +
-embedding head (100 detections) + 100x500 affinity (5 history frames x 100).
-Inputs are resident in HBM when the timed region starts.  With N>1 (launched by
-torch.distributed.run, one rank per GPU) consecutive frames are sharded over the
-ranks and one RCCL all-gather of the embedding records per step provides the
-cross-rank history (deft_amd/pipeline.py); `value` is whole-job frames/s.
+A "step" = one batch of B synthetic frames per GPU through DLA-34 + DCNv2 neck + hm head + decode (K=100) + sparse
+regression heads + embedding head + affinity against the history frames (+ the batched LSTM motion update where the
+config names it).  Inputs are resident in HBM when the timed region starts.  With N>1 (launched by
+torch.distributed.run, one rank per GPU) consecutive frames are sharded over the ranks and one RCCL all-gather of the
+embedding records per step provides the cross-rank history (deft_amd/pipeline.py); `value` is whole-job frames/s.
+
+Configs (BASELINE.json `configs`): B (default, the metric's configuration) MOT17 1088x608 + 100x500 affinity;
+A 512x512 + 32x128 affinity; D KITTI 1280x384 + 30x150 affinity + LSTM motion update; E nuScenes 800x448, one camera
+per GPU (replicas: no collective) + 3-D LSTM motion update.
 
 Extra objects in the JSON line:
-  roofline      the implicit-GEMM kernel family (conv + DCNv2 launches of the step),
-                algorithmic FLOPs (2*M*Cout*K of each conv, no padding) / measured
-                launch time (HIP events on the launch stream) vs the FP32-MFMA peak.
-  cpu_baseline  the oracle (PyTorch-CPU restatement pinned against the reference
-                modules) timed on this box's host cores on a bounded sample.
+  roofline        the implicit-GEMM kernel family (conv / DCNv2 / pair launches of the step): algorithmic FLOPs
+                  (2*M*Cout*K per launch, no padding) / launch time (HIP events on the launch stream) against the
+                  TIME-WEIGHTED ceiling of the instructions each launch issues (bf16 dense / 6 = 416.7 TFLOP/s for
+                  the split-bf16 launches, 157.3 for the fp32-MFMA launches); the fp32-priced figure is kept as
+                  `frac_of_fp32_mfma_peak`.
+  cpu_baseline    the oracle (PyTorch-CPU restatement pinned against the reference modules) on this box's host cores:
+                  one full-size warm-up frame, then the median of 5 timed frames.
+  sustained       the same step loop continued until the GPU has been busy >= 5 s (not part of `value`).
+  latency_mode    one frame per step per GPU, hipGraph replay (what every GPU runs in BASELINE configs[2] / [4]).
+  value_incl_pcie the step loop fed from pinned host memory (double-buffered H2D of fresh frames on a copy stream) with the
+                  detections and affinity blocks copied back every step.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -32,49 +41,72 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 dense (no sparsity); the split path spends 6 bf16 products per fp32 product
-H, W, KDET, HIST = 608, 1088, 100, 5
+SPLIT_PEAK_TF = BF16_MFMA_PEAK_TF / 6
+KDET = 100
+
+CONFIGS = {
+    "A": dict(dataset="mot", H=512, W=512, ndet=32, hist=4, lstm=False, replicas=False,
+              workload="512x512 DLA-34 + DCNv2 + 32x128 affinity (BASELINE configs[0], GPU side)"),
+    "B": dict(dataset="mot", H=608, W=1088, ndet=100, hist=5, lstm=False, replicas=False,
+              workload="MOT17 1088x608 DLA-34 + DCNv2 + 100x500 affinity (BASELINE configs[1])"),
+    "D": dict(dataset="kitti_tracking", H=384, W=1280, ndet=30, hist=5, lstm=True, replicas=False,
+              workload="KITTI 1280x384 2D tracking, DLA-34 + DCNv2 + 30x150 affinity + LSTM motion update (BASELINE configs[3])"),
+    "E": dict(dataset="nuscenes", H=448, W=800, ndet=30, hist=5, lstm=True, replicas=True,
+              workload="nuScenes 800x448, one camera per GPU (replicas), DLA-34 + DCNv2 + 30x150 affinity + 3-D LSTM motion update (BASELINE configs[4])"),
+}
 
 
-def cpu_baseline(frames=3, budget_s=25.0):
-    """kind=port: oracle/deft_oracle.py on the host cores (GPU not used).  Bounded: stops
-    after `budget_s` seconds of CPU work (at least one timed frame)."""
+def cpu_baseline(cfg, frames=5):
+    """kind=port: oracle/deft_oracle.py on the host cores (GPU not used): one full-size warm-up frame, then the median of
+    `frames` timed frames of the same config."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import deft_oracle as O
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(ncpu, 32)))     # ATen's CPU convs stop scaling (and thrash) far below 256 threads
-    sd = O.synth_state_dict("mot")
+    H, W, nd, hist, ds = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"], cfg["dataset"]
+    sd = O.synth_state_dict(ds)
+    lsd = O.synth_lstm_state_dict("mot" if ds != "nuscenes" else "nuscenes") if cfg["lstm"] and hasattr(O, "synth_lstm_state_dict") else None
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 3, H, W, generator=g)
-    hist = [torch.rand(1, KDET, 416, generator=g) * 3 for _ in range(HIST)]
+    D = sum(sd["AFE.selector.%d.weight" % k].shape[0] for k in range(13))
+    hists = [torch.rand(1, nd, D, generator=g) * 3 for _ in range(hist)]
     t_all = []
+
+    def frame():
+        out, maps = O.dlaseg_forward(x, sd, ds)
+        dets = O.generic_decode(O.sigmoid_output(out), K=KDET)
+        b = dets["bboxes"][0, :nd]
+        c = torch.stack([(b[:, 0] + b[:, 2]) / (W / 4) - 1, (b[:, 1] + b[:, 3]) / (H / 4) - 1], 1).view(1, nd, 1, 1, 2)
+        emb = O.afe_extract(maps, c, sd)
+        for hx in hists:
+            O.afe_affinity(hx, emb, sd, 100)
+        if lsd is not None:
+            nin = lsd["lstm.weight_ih_l0"].shape[1]
+            h = torch.zeros(1, 1, 128); c0 = torch.zeros(1, 1, 128)
+            for _ in range(nd):                                     # the reference steps the LSTM once per matched track
+                O.lstm_predict(h, c0, torch.randn(1, 1, nin, generator=g), lsd)
     with torch.no_grad():
-        O.dlaseg_forward(torch.randn(1, 3, 128, 160, generator=g), sd, "mot")       # small warm-up (thread pool, allocator)
-        t_begin = time.time()
-        for it in range(frames):
+        frame()                                                     # full-size warm-up (thread pool, allocator, oneDNN primitives)
+        for _ in range(frames):
             t0 = time.time()
-            out, maps = O.dlaseg_forward(x, sd, "mot")
-            dets = O.generic_decode(O.sigmoid_output(out), K=KDET)
-            b = dets["bboxes"][0]
-            c = torch.stack([(b[:, 0] + b[:, 2]) / (W / 4) - 1, (b[:, 1] + b[:, 3]) / (H / 4) - 1], 1).view(1, KDET, 1, 1, 2)
-            emb = O.afe_extract(maps, c, sd)
-            for hx in hist:
-                O.afe_affinity(hx, emb, sd, 100)
+            frame()
             t_all.append(time.time() - t0)
-            if time.time() - t_begin > budget_s:
-                break
     t = sorted(t_all)[len(t_all) // 2]
-    return {"value": round(1.0 / t, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d frame(s) of 1088x608, median (DLA-34+DCNv2+decode+embed(100)+5x(100x100) affinity), small warm-up, %d threads" % (len(t_all), torch.get_num_threads())}
+    return {"value": round(1.0 / t, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "1 full-size warm-up + median of %d frames of %dx%d (DLA-34+DCNv2+decode+embed(%d)+%dx(%dx%d) affinity%s), %d threads"
+                      % (len(t_all), W, H, nd, hist, nd, nd, " + %d LSTM steps" % nd if lsd is not None else "", torch.get_num_threads())}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip sustained / latency_mode / value_incl_pcie (profiling runs)")
     ap.add_argument("--autotune", action="store_true", help="per-layer tile search at plan-build time (engine._Plan.autotune)")
     ap.add_argument("--graphs", action="store_true", help="replay each sub-batch's launch list as a captured hipGraph")
     ap.add_argument("--verbose", action="store_true")
@@ -82,6 +114,8 @@ def main():
                     help="profiling aid: same sub-batch plans, launched back to back on one stream (per-kernel durations "
                          "comparable with the roofline's per-launch HIP events)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    H, W, NDET, HIST = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,17 +133,39 @@ def main():
     from deft_amd.pipeline import HipCompute, FramePipeline
     engine_prec = engine.PREC
     lib = hiplib.get_lib()                      # no fallback: raises if the HIP extension is missing
-    sd = synth.synth_state_dict("mot")
+    sd = synth.synth_state_dict(cfg["dataset"])
     B = args.batch
-    comp = HipCompute(sd, B, H, W, "mot", K=KDET, device=dev, lib=lib, streams=args.streams)
+    comp = HipCompute(sd, B, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=args.streams, ndet=NDET)
     comp.serialize = args.serialize
-    pipe = FramePipeline(comp, B, KDET, comp.D, history=HIST, device=dev)
+    gather = not cfg["replicas"]                # config E: one camera stream per GPU, no cross-GPU state at all
+    pipe = FramePipeline(comp, B, NDET, comp.D, history=HIST, device=dev, exchange=gather)
     g = torch.Generator().manual_seed(1000 + rank)
     images = torch.randn(B, 3, H, W, generator=g).to(dev)      # resident in HBM before timing
 
+    motion = None
+    if cfg["lstm"]:                             # batched LSTM motion update of the frame's matched tracks (tracker.py:408-580), in the step
+        lsd = synth.synth_lstm_state_dict("nuscenes" if cfg["dataset"] == "nuscenes" else "mot")
+        lp = engine.LstmPlan(lsd, dev, lib)
+        T = B * NDET
+        dim = 7 if lp.nin == 18 else 4
+        motion = {"plan": lp, "slot": torch.arange(T, dtype=torch.int32, device=dev), "h": torch.zeros(T, 128, device=dev),
+                  "c": torch.zeros(T, 128, device=dev), "last": torch.zeros(T, 9, dtype=torch.float64, device=dev), "frame": 0,
+                  "box3d": (torch.rand(T, 7, generator=g, dtype=torch.float64) * 4 + 1).to(dev), "dim": dim}
+
+    def step(imgs):
+        outs = pipe.step(imgs)
+        if motion is not None:
+            motion["frame"] += 1
+            if motion["dim"] == 4:              # tlwh of the frame's detections, float64 like the reference's STrack
+                bb = torch.cat([p.bboxes[:, :NDET] for p in comp.plans], 0).reshape(-1, 4).double() * 4.0
+                box = torch.stack([bb[:, 0], bb[:, 1], bb[:, 2] - bb[:, 0], bb[:, 3] - bb[:, 1]], 1).contiguous()
+            else:
+                box = motion["box3d"]
+            motion["out"] = motion["plan"].motion_step(motion["slot"], box, motion["frame"], motion["h"], motion["c"], motion["last"])
+        return outs
+
     if args.autotune:                                    # plan-build time, outside the timed region
         comp.autotune(images, verbose=args.verbose and rank == 0)
-
     if args.graphs:
         comp.capture(images)
 
@@ -119,11 +175,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        pipe.step(images)
+        step(images)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pipe.step(images)
+        step(images)
     host_dt = time.perf_counter() - t0        # time the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     sync()
     dt = time.perf_counter() - t0
@@ -134,48 +190,129 @@ def main():
     frames = args.steps * B * world
     fps = frames / dt
 
+    extras = {}
+    if not args.no_extras:
+        # ---- sustained: keep stepping until the GPU has been busy for >= 5 s in total (the timed region above is what `value`
+        #      reports; an outside sampler needs more than a second of load to see it) ----
+        n_more = max(0, int((5.0 - dt) / max(dt / args.steps, 1e-6)) + 1) if dt < 5.0 else 0
+        if n_more:
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(n_more):
+                step(images)
+            sync()
+            d1 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([d1], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); d1 = float(t.item())
+            extras["sustained"] = {"steps": n_more, "seconds": round(d1, 3), "value": round(n_more * B * world / d1, 3), "unit": "frames/s"}
+        # ---- fed from host memory: pinned, double-buffered H2D of FRESH frames on a copy stream + D2H of detections and affinity ----
+        if world == 1:
+            nb = 2
+            host = [torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(7 + i)).pin_memory() for i in range(nb)]
+            devb = [torch.empty(B, 3, H, W, device=dev) for _ in range(nb)]
+            cs = torch.cuda.Stream(device=dev)
+            ev_in = [torch.cuda.Event() for _ in range(nb)]
+            ev_free = [torch.cuda.Event() for _ in range(nb)]
+            aff_host = torch.empty(B, HIST * NDET, NDET + 1).pin_memory()
+            det_host = torch.empty(B, KDET, 6).pin_memory()
+            main = torch.cuda.current_stream(dev)
+
+            def feed(i):
+                with torch.cuda.stream(cs):
+                    cs.wait_event(ev_free[i % nb])
+                    devb[i % nb].copy_(host[i % nb], non_blocking=True)
+                    ev_in[i % nb].record(cs)
+            for e in ev_free:
+                e.record(main)
+            nst = max(4, min(args.steps, 25))
+            feed(0)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(nst):
+                if i + 1 < nst:
+                    feed(i + 1)                                      # next step's frames travel while this step computes
+                main.wait_event(ev_in[i % nb])
+                outs = step(devb[i % nb])
+                ev_free[i % nb].record(main)
+                blk = [o for o in outs if o is not None]
+                if blk:
+                    aff_host[:len(blk)].copy_(torch.stack(blk), non_blocking=True)
+                k = 0
+                for p in comp.plans:
+                    det_host[k:k + p.N, :, 0].copy_(p.scores, non_blocking=True)
+                    det_host[k:k + p.N, :, 1].copy_(p.inds, non_blocking=True)
+                    det_host[k:k + p.N, :, 2:6].copy_(p.bboxes, non_blocking=True)
+                    k += p.N
+            sync()
+            d1 = time.perf_counter() - t1
+            extras["value_incl_pcie"] = round(nst * B / d1, 3)
+            extras["pcie"] = {"steps": nst, "h2d_bytes_per_step": B * 3 * H * W * 4, "d2h_bytes_per_step": aff_host.numel() * 4 + det_host.numel() * 4,
+                              "note": "fp32 frames from pinned host memory, double-buffered on a copy stream; per-step D2H of detections and affinity blocks"}
+        # ---- latency mode: one frame per step per GPU, hipGraph replay (BASELINE configs[2]: 8 frames/batch over 8 GPUs = one per GPU) ----
+        comp1 = HipCompute(sd, 1, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=1, ndet=NDET)
+        pipe1 = FramePipeline(comp1, 1, NDET, comp1.D, history=HIST, device=dev, exchange=gather)
+        comp1.capture(images[:1])
+        for _ in range(HIST + 3):
+            pipe1.step(images[:1])
+        sync()
+        n1 = 100
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            pipe1.step(images[:1])
+        sync()
+        d1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([d1], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); d1 = float(t.item())
+        extras["latency_mode"] = {"frames_per_step_per_gpu": 1, "hip_graphs": True, "steps": n1, "ms_per_step": round(d1 / n1 * 1e3, 3),
+                                  "value": round(n1 * world / d1, 3), "unit": "frames/s",
+                                  "workload": "one frame per GPU per step" + (", 1 all-gather/step" if world > 1 and gather else "")}
+        del comp1, pipe1
+
     # ---- roofline of the dominant kernel family: one profiled step, HIP events per launch
     #      (torch events on the stream every kernel is launched on) ----
     roof = None
     prof = []
     gr, comp.graphs = comp.graphs, None          # per-launch events need eager launches
     ser, comp.serialize = comp.serialize, True   # same sub-batch plans, back to back on one stream: per-launch events
-    pipe.step(images)                            # un-profiled step queued first: the host then runs AHEAD of the GPU, so the
+    step(images)                                 # un-profiled step queued first: the host then runs AHEAD of the GPU, so the
     if rank == 0:                                # event intervals below hold kernel time, not Python launch latency
         lib.profile = prof
-    pipe.step(images)                            # EVERY rank runs the step (it contains the all-gather); rank 0 records
+    step(images)                                 # EVERY rank runs the step (it contains the all-gather); rank 0 records
     comp.serialize = ser
     comp.graphs = gr
     torch.cuda.synchronize()
     lib.profile = None
     if rank == 0:
         GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer")
-        gemm_ms = sum(e0.elapsed_time(e1) for (k, _, e0, e1, _i, _b) in prof if k in GEMM)
-        gemm_fl = sum(fl for (k, fl, _, _, _i, _b) in prof if k in GEMM)
-        n_launch = sum(1 for p in prof if p[0] in GEMM)
-        all_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1, _i, _b) in prof)
+        rows = [(k, fl, e0.elapsed_time(e1), info, b, ceil) for (k, fl, e0, e1, info, b, ceil) in prof]
+        gemm = [r for r in rows if r[0] in GEMM]
+        gemm_ms = sum(r[2] for r in gemm)
+        gemm_fl = sum(r[1] for r in gemm)
+        n_launch = len(gemm)
+        all_ms = sum(r[2] for r in rows)
         # fixed cost of one (event, launch, event) bracket: the smallest kernels of the step (a few us of real work)
-        tiny = sorted(e0.elapsed_time(e1) for (k, _, e0, e1, _i, _b) in prof if k in ("deft_peak_rows", "deft_embed_rows", "deft_decode_boxes"))
+        tiny = sorted(r[2] for r in rows if r[0] in ("deft_peak_rows", "deft_embed_rows", "deft_decode_boxes"))
         ev_over_ms = tiny[len(tiny) // 2] if tiny else 0.0
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
         ach_corr = gemm_fl / (max(gemm_ms - n_launch * ev_over_ms, 1e-6) * 1e-3) / 1e12
+        # ceiling of the instructions each launch issues: split-bf16 launches 2500/6, fp32-MFMA launches 157.3 (hiplib marks each call)
+        peak_w = sum(r[2] * r[5] for r in gemm) / max(gemm_ms, 1e-9)
+        split_ms = sum(r[2] for r in gemm if r[5] > FP32_MFMA_PEAK_TF)
+        worst = max((r[1] / (r[2] * 1e-3) / 1e12 / r[5], r[3]) for r in gemm)
         traffic, tsrc = None, None                    # HBM bytes per launch from the committed PMC passes of this build, if any
-        tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if os.path.exists(tfile):
+        tfile = os.path.join(ROOT, "profiles", "r2_traffic.json")
+        if os.path.exists(tfile) and args.config == "B":
             tj = json.load(open(tfile))
-            traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
-        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
-                "algorithmic_bytes_per_launch": round(sum(b for (k, _, _, _, _i, b) in prof if k in GEMM) / max(1, n_launch)),
-                "kernel": "igemm_kernel<*> (implicit GEMM with fp32 results: conv / DCNv2 / pair loaders)",
-                # what the contraction runs on.  prec 1: each fp32 operand = 3 bf16 pieces, each fp32 product = 6 bf16 MFMA
-                # products, fp32 accumulation (error of an fp32 chain); BN < 64 tiles and prec 0: the fp32 MFMA instruction.
-                # `peak` stays the fp32 MFMA peak (what an fp32 result is priced against); the split path's own ceiling
-                # is the bf16 dense peak / 6.
-                "arithmetic": ("fp32 via 3 x bf16 operand split, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product (tiles with BN >= 64); "
-                               "v_mfma_f32_32x32x2_f32 elsewhere") if engine_prec == 1 else "v_mfma_f32_32x32x2_f32",
-                "peak_split_bf16": round(BF16_MFMA_PEAK_TF / 6, 1) if engine_prec == 1 else None,
-                "frac_of_split_peak": round(ach / (BF16_MFMA_PEAK_TF / 6), 4) if engine_prec == 1 else None,
+            traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, FETCH x2)"
+        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak_w, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
+                "kernel": "implicit-GEMM family: igemm_kernel / igemm3_kernel / conv3h_kernel (conv, DCNv2, pair loaders; fp32 results)",
+                "peak_note": "time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split-bf16 kernels (2500 / 6 = 416.7 TFLOP/s: "
+                             "3 bf16 pieces per operand, 6 v_mfma_f32_32x32x16_bf16 per fp32 product), the rest on v_mfma_f32_32x32x2_f32 (157.3)"
+                             % (100.0 * split_ms / max(gemm_ms, 1e-9)),
+                "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4),
+                "max_per_launch_frac": round(worst[0], 4), "max_per_launch_frac_shape": worst[1],
                 "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
                 "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                 "event_bracket_overhead_us": round(ev_over_ms * 1e3, 2),     # median bracket of the step's ~2 us kernels
@@ -183,30 +320,35 @@ def main():
                 "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3),
                 # the same FLOPs over the TIMED steps (sub-batches overlapped on their streams, every other kernel included)
                 "pipeline_achieved": round(gemm_fl / (dt / args.steps) / 1e12, 3),
-                "pipeline_frac": round(gemm_fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+                "pipeline_frac": round(gemm_fl / (dt / args.steps) / 1e12 / peak_w, 4)}
         by = {}
-        for (k, fl, e0, e1, _i, _b) in prof:
-            by.setdefault(k, [0.0, 0, 0.0]); by[k][0] += e0.elapsed_time(e1); by[k][1] += 1; by[k][2] += fl
+        for r in rows:
+            by.setdefault(r[0], [0.0, 0, 0.0]); by[r[0]][0] += r[2]; by[r[0]][1] += 1; by[r[0]][2] += r[1]
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
-            json.dump({"by_entry_ms_launches_flops": by, "calls": [(k, fl, e0.elapsed_time(e1), info) for (k, fl, e0, e1, info, _b) in prof]}, f)
+            json.dump({"by_entry_ms_launches_flops": by, "calls": [(r[0], r[1], r[2], r[3], r[5]) for r in rows]}, f)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(cfg)
 
     if rank == 0:
-        out = {"metric": "frames/sec (detect+embed+affinity) at 1088x608", "value": round(fps, 3), "unit": "frames/s",
+        what = "detect+embed+affinity" + ("+LSTM" if cfg["lstm"] else "")
+        out = {"metric": "frames/sec (%s) at %dx%d" % (what, W, H), "value": round(fps, 3), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
+               "timed_seconds": round(dt, 3), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "MOT17 1088x608 DLA-34 + DCNv2 + 100x500 affinity (BASELINE configs[1])",
-                          "contraction": "split-bf16 x6, fp32 accumulate" if engine_prec == 1 else "fp32 MFMA", "frames_per_step_per_gpu": B, "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": KDET, "history_frames": HIST,
-                          "parallelism": "frames sharded dp%d, 1 all-gather/step" % world},
+               "config": {"workload": cfg["workload"], "config": args.config,
+                          "contraction": "split-bf16 x6, fp32 accumulate" if engine_prec == 1 else "fp32 MFMA", "frames_per_step_per_gpu": B,
+                          "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": NDET, "history_frames": HIST,
+                          "lstm_motion_update_in_step": bool(cfg["lstm"]),
+                          "parallelism": ("single GPU (no collective)" if world == 1 else
+                                          ("%d independent replicas (one camera stream per GPU, no collective)" % world if cfg["replicas"]
+                                           else "frames sharded dp%d, 1 all-gather/step" % world))},
                "roofline": roof, "cpu_baseline": cpu}
+        out.update(extras)
     # RCCL prints its version banner through C stdio on every rank; it would otherwise be flushed at process exit,
     # AFTER the JSON line.  Flush it everywhere first, then rank 0 prints the JSON as the last stdout line.
-    import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:

@@ -769,11 +769,11 @@ static void pick_conv_tile(int M, int rows_per_image, int Cout, int& bm, int& bn
 
 // split factor for a launch of `tiles` output tiles and nk K chunks: double S until the launch has two workgroups
 // per compute unit (FILL_BLOCKS), keeping >= 8 chunks per workgroup
-static int pick_splitk(long long tiles, int nk) {
+static int pick_splitk(long long tiles, int nk, int wgs_per_cu = 2) {
     static const int fill = [] { const char* e = getenv("DEFT_SPLIT_FILL"); return e ? atoi(e) : FILL_BLOCKS; }();   // tuning aid
     static const int minc = [] { const char* e = getenv("DEFT_SPLIT_MINCHUNKS"); return e ? atoi(e) : 8; }();
     int S = 1;
-    while (tiles * S < fill && nk / (2 * S) >= minc && S < 32) S *= 2;
+    while (tiles * S < fill * wgs_per_cu / 2 && nk / (2 * S) >= minc && S < 32) S *= 2;
     return S;
 }
 
@@ -788,7 +788,9 @@ extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* 
     }
     const int nk = d->Kpad >> 5;
     long long tiles = (long long)deft_cdiv(d->M, bm) * deft_cdiv(d->Cout, bn);
-    int S = (d->rowmap != nullptr) ? 1 : pick_splitk(tiles, nk);
+    // the 8-wave tiles of the pre-split kernel hold a whole CU each: one workgroup per CU fills the chip
+    const int per_cu = (entry == 0 && d->x3 != nullptr && bm * bn >= 256 * 128) ? 1 : 2;
+    int S = (d->rowmap != nullptr) ? 1 : pick_splitk(tiles, nk, per_cu);
     if (entry == 1 && S > 1 && bn == 128) {          // few tiles: the narrower DCN tile gives twice the workgroups per split
         bn = 64;
         tiles = (long long)deft_cdiv(d->M, bm) * deft_cdiv(d->Cout, bn);

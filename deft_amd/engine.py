@@ -142,6 +142,8 @@ BDMA = _os.environ.get("DEFT_BDMA", "1") != "0"             # igemm.hip prec-1 l
 # 64-column tiles and the DCN lose (the second weight stage costs them a workgroup per CU), so they keep splitting weights in the loop.
 BDMA_DCN = _os.environ.get("DEFT_BDMA_DCN", "0") == "1"
 P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
+P3_MIN_TILES = int(_os.environ.get("DEFT_P3_MIN_TILES", "512"))   # ... and give every CU two workgroups (latency mode: 2.39 ms/frame on igemm.hip
+# with split-K vs 2.88 on the pre-split kernels, profiles/r2_latency_ab.txt); the im2col form (one 8-wave workgroup per CU) needs half as many
 P3_HALO_WASTE = float(_os.environ.get("DEFT_P3_HALO_WASTE", "1.25"))   # ... when its 4 x 32 pixel tiles cover the map with at most this much padding
 
 
@@ -174,13 +176,15 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
     if KH * KW == 1 or Cin % 32 or Cout % 8:
         return None
     if (KH, KW, stride, pad) == (3, 3, 1, 1) and korder == 1 and P3_HALO and halo_waste(H, W) <= P3_HALO_WASTE and (Cout >= 128 or Cout <= 32):
-        return ("halo", 0)
+        bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+        if (M // (H * W)) * -(-H // 4) * -(-W // 32) * -(-Cout // bn) >= P3_MIN_TILES:
+            return ("halo", 0)
     if Cout < 128 or Cin < 64 or stride != 1:
         return None                     # in the pipeline (inputs L2-warm) the 64-column and the stride-2 layers are no faster on 6-byte pieces
     tile = _T(128, 256) if Cout >= 256 else _T(256, 128)
     bm, bn = tile >> 16, tile & 0xffff
-    if -(-M // bm) * -(-Cout // bn) < 256:
-        tile = 0                        # few tiles (one frame per GPU): the library picks tile and split factor (deft_gemm_plan)
+    if -(-M // bm) * -(-Cout // bn) < P3_MIN_TILES // 2:
+        return None                     # few tiles (one frame per GPU): igemm.hip's smaller tiles + cross-workgroup split-K fill the chip better
     return ("im2col", tile)
 
 
@@ -441,6 +445,7 @@ class _Plan:
             d.w3 = self.weights_p3(w_packed).data_ptr()         # igemm.hip: weight chunks by DMA, activations split in the loop
         cin = x.C if true_cin is None else true_cin
         d.flop_k = KH * KW * cin
+        d.flop_n = 0 if true_cout is None else true_cout
         self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * (Cout if true_cout is None else true_cout) * KH * KW * cin)
         return out
 

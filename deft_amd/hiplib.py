@@ -21,6 +21,7 @@ class GemmDesc(C.Structure):
     """Mirror of DeftGemmDesc (include/deft_hip.h).  `flop_k` (python-side only) overrides
     Ktot in the algorithmic FLOP count when input channels are padding (the 3->4 image)."""
     flop_k = 0
+    flop_n = 0          # likewise for output columns that are padding (the 27 -> 32 offset/mask conv)
     _fields_ = [
         ("x", c_fp), ("x2", c_fp), ("w", c_fp), ("scale", c_fp), ("shift", c_fp), ("res", c_fp), ("y", c_fp),
         ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("ldx", C.c_int),
@@ -113,6 +114,7 @@ class HipLib:
                 rows_in = d.M * d.KH * d.KW if d.rowmap else d.N * d.H * d.W
                 return 4.0 * (min(rows_in, d.N * d.H * d.W) * d.Cin + d.M * d.Cout * (2 if d.res else 1) + d.Cout * d.Ktot
                               + (d.M * 27 if name == "deft_dcn_v2_nhwc" else 0))
+            ceil = 157.3            # TFLOP/s ceiling of the instructions the launch issues: v_mfma_f32_32x32x2_f32 ...
             if name == "deft_conv2d_group":
                 ds = args[0]
                 fl = sum(2.0 * ds[i].M * ds[i].Cout * ds[i].Ktot for i in range(args[2]))
@@ -120,10 +122,30 @@ class HipLib:
                 info = "group of %d" % args[2]
             elif name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer"):
                 d = args[0]._obj
-                fl = 2.0 * d.M * d.Cout * (d.flop_k if d.flop_k else d.Ktot)
+                fl = 2.0 * d.M * (d.flop_n if d.flop_n else d.Cout) * (d.flop_k if d.flop_k else d.Ktot)
                 nbytes = alg_bytes(d)
                 info = "M=%d N=%d K=%d %dx%d s%d @%dx%d" % (d.M, d.Cout, d.Ktot, d.KH, d.KW, d.stride, d.H, d.W)
-            prof.append((name, fl, e0, e1, info, nbytes))
+                if self.split_arithmetic(name, d):
+                    ceil = 2500.0 / 6   # ... or six v_mfma_f32_32x32x16_bf16 per fp32 product (bf16 dense peak / 6)
+                    info += " split" + (" halo" if d.p3_kernel else (" x3" if d.x3 else ""))
+            prof.append((name, fl, e0, e1, info, nbytes, ceil))
+
+    def split_arithmetic(self, name, d):
+        """Does this launch run on the bf16 matrix instructions (prec 1 honoured)?  The pre-split kernels always do; igemm.hip
+        only on its 1-stage tiles with BN >= 64 (launch_igemm) -- the tile is the library's own choice when tile == 0."""
+        if d.prec != 1:
+            return False
+        if d.x3:
+            return True
+        tile = d.tile
+        if (tile & 0xffff) == 0:
+            if name == "deft_pair_layer":
+                return True                                  # 128 x 128 or 128 x 64
+            t, s, wf, wt = C.c_int(), C.c_int(), C.c_longlong(), C.c_int()
+            if self.cdll.deft_gemm_plan(C.byref(d), 0 if name == "deft_conv2d_nhwc" else 1, C.byref(t), C.byref(s), C.byref(wf), C.byref(wt)) != 0:
+                return False
+            tile = t.value
+        return (tile & 0xffff) >= 64 and not (tile >> 29) & 1
 
 
 _lib = None

@@ -25,16 +25,18 @@ class HipCompute:
     embedding exchange, so the hardware overlaps one sub-batch's kernel tails (partially
     filled last wave of workgroups) and barrier stalls with the other's workgroups."""
 
-    def __init__(self, sd, batch, H, W, dataset="mot", K=100, max_object=100, device="cuda", lib=None, streams=1):
+    def __init__(self, sd, batch, H, W, dataset="mot", K=100, max_object=100, device="cuda", lib=None, streams=1, ndet=None):
+        """ndet: embeddings are extracted for the first `ndet` (<= K) decoded detections of every frame (default K)."""
         assert batch % streams == 0
+        ndet = K if ndet is None else ndet
         self.device = torch.device(device)
         self.nstream, self.sub = streams, batch // streams
         self.plans = [engine.DlaSegPlan(sd, self.sub, H, W, dataset, K=K, device=device, lib=lib) for _ in range(streams)]
         self.plan = self.plans[0]
         self.afe = engine.AfePlan(sd, max_object, device, lib)
         self.D = self.afe.D
-        self.K = K
-        self.emb = torch.zeros(batch, K, self.D, dtype=torch.float32, device=self.device)
+        self.K, self.ndet = K, ndet
+        self.emb = torch.zeros(batch, ndet, self.D, dtype=torch.float32, device=self.device)
         if streams > 1:
             self.side = [torch.cuda.Stream(device=self.device) for _ in range(streams)]
             self.ev_main = torch.cuda.Event()
@@ -60,12 +62,12 @@ class HipCompute:
         self.graphs = []
         for s_, p in enumerate(self.plans):
             sl = slice(s_ * self.sub, (s_ + 1) * self.sub)
-            p.forward(images[sl]); self.afe.extract(p.fmaps, p.centers, out=self.emb[sl])      # warm-up: attributes, caches
+            p.forward(images[sl]); self.afe.extract(p.fmaps, p.centers if self.ndet == self.K else p.centers[:, :self.ndet], out=self.emb[sl])      # warm-up: attributes, caches
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side[s_ % len(side)]):
                 p.run()
-                self.afe.extract(p.fmaps, p.centers, out=self.emb[sl])
+                self.afe.extract(p.fmaps, p.centers if self.ndet == self.K else p.centers[:, :self.ndet], out=self.emb[sl])
             self.graphs.append(g)
         torch.cuda.synchronize(self.device)
 
@@ -77,7 +79,7 @@ class HipCompute:
             self.graphs[s_].replay()
         else:
             p.forward(images[sl])
-            self.afe.extract(p.fmaps, p.centers, out=self.emb[sl])
+            self.afe.extract(p.fmaps, p.centers if self.ndet == self.K else p.centers[:, :self.ndet], out=self.emb[sl])
 
     serialize = False      # profiling aid: run the sub-batch plans one after the other on the current stream
 
@@ -117,18 +119,20 @@ class HipCompute:
 
 
 class FramePipeline:
-    def __init__(self, compute, batch, K, D, history=5, device="cuda", group=None):
+    def __init__(self, compute, batch, K, D, history=5, device="cuda", group=None, exchange=True):
+        """exchange=False: every rank is an independent replica with its own stream (BASELINE configs[4]: one nuScenes camera per
+        GPU, convert_nuScenes.py:173-175) -- no collective at all, even inside a process group."""
         self.c, self.batch, self.K, self.D, self.history = compute, batch, K, D, history
         self.device = torch.device(device)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = dist.get_world_size(group) if exchange and dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         # ring of the last `history` frames of the GLOBAL stream order, then this step's frames
         self.tail = torch.zeros(history, K, D, dtype=torch.float32, device=self.device)
         self.tail_valid = 0
         self.gathered = torch.zeros(self.world * batch, K, D, dtype=torch.float32, device=self.device)
         # test hook: run the collective even in a 1-rank group (exercises the RCCL path on a 1-GPU box)
-        self.force_gather = bool(dist.is_available() and dist.is_initialized() and self.world == 1)
+        self.force_gather = bool(exchange and dist.is_available() and dist.is_initialized() and self.world == 1)
 
     def step(self, images):
         """images [batch,3,H,W]: this rank's frames  (global frame index within the step =

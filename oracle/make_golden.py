@@ -352,6 +352,121 @@ def run_association():
     print("  association fixtures written (reference fuse_motion / fuse_motion_ddd)")
 
 
+def run_detector_trace(lstm):
+    """The reference's OWN `Detector.run` (detector.py:112-344: pre-processed branch of src/test.py:213, its post-processing, its
+    Tracker) over 6 synthetic frames with the reference model on CPU, and a TRACE of every call it makes into the seams this
+    repository replaces -- what went in and what came out:
+        process()                               frame -> decoded detections (K rows)
+        model.AFE.forward_feature_extracter     detection centres -> embeddings
+        FeatureRecorder.update                  -> the frame's (decayed) similarity blocks against every stored frame
+        Tracker.get_similarity                  (tracks' node lists, #detections) -> the tracks x detections matrix
+        STrack.update_lstm_features (lstm)      (track, tlwh, frame) -> LSTM features and future boxes
+    plus the tracks it returns.  tests replay the trace against the HIP path on cuda:0 in the same order
+    (tests/test_gpu_parity.py::test_composed_dropin_replays_reference_trace) -- the GPU box has no /root/reference."""
+    sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+    import importlib
+    import ref_shims
+    ref_shims.install()
+    ref_import.install_stubs(OracleDCN)
+    ref_shims.install_detector_stubs()
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        from opts import opts
+        from dataset.dataset_factory import dataset_factory
+        from utils import tracker as RT
+        from utils.basetrack import BaseTrack
+        RD = importlib.import_module("detector")
+    finally:
+        sys.argv = argv
+    tag = "mot_lstm" if lstm else "mot"
+    sd = dict(O.synth_state_dict("mot"))
+    sd["ltrb_amodal.2.weight"] = sd["ltrb_amodal.2.weight"] * 0.05           # boxes of ~10 x 16 map pixels (random heads give negative extents)
+    sd["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
+    ck = os.path.join(GOLD, "_trace_ck.pth")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in sd.items()}}, ck)
+    H, W, K, T = 64, 96, 8, 6
+    opt = opts().parse(["tracking", "--dataset", "mot", "--gpus", "-1", "--load_model", ck, "--K", str(K), "--ltrb_amodal",
+                        "--input_h", str(H), "--input_w", str(W)])
+    opt = opts().update_dataset_info_and_set_heads(opt, dataset_factory[opt.test_dataset])
+    opt.out_thresh = 0.0
+    opt.lstm = bool(lstm)
+    fix = {"H": H, "W": W, "K": K, "T": T, "lstm": int(lstm), "seeds": np.arange(10, 10 + T)}
+    real_sync, torch.cuda.synchronize = torch.cuda.synchronize, (lambda *a, **k: None)          # detector.py:188, 534 call it unconditionally
+    lsd = O.synth_lstm_state_dict("mot")
+    saved = (RD.Detector.process, RT.Tracker.get_similarity, RT.STrack.update_lstm_features, RT.KalmanFilterLSTM)
+    cur = {"t": 0, "gs": 0, "mo": 0}
+    try:
+        if lstm:
+            class KF(saved[3]):
+                def __init__(self, o):
+                    super().__init__(o)
+                    self.model.load_state_dict(lsd, strict=True); self.model.eval()
+            RT.KalmanFilterLSTM = KF
+            RT.STrack.shared_kalman_lstm = KF(opt)
+
+        def process(self, images, *a, **k):
+            r = saved[0](self, images, *a, **k)
+            for key, v in r[1].items():
+                fix["t%d_det_%s" % (cur["t"], key)] = np.asarray(v.detach().cpu() if torch.is_tensor(v) else v)
+            return r
+
+        def get_similarity(self, frame_index, strack_pool, num_detections):
+            out = saved[1](self, frame_index, strack_pool, num_detections)
+            k = "t%d_gs%d" % (cur["t"], cur["gs"]); cur["gs"] += 1
+            fix[k + "_out"] = np.asarray(out, np.float64)
+            fix[k + "_args"] = np.array([frame_index, num_detections])
+            fix[k + "_nodes"] = np.array([[tk, n.frame_index, n.id] for tk, trk in enumerate(strack_pool) for n in trk.nodes], np.int64).reshape(-1, 3)
+            fix[k + "_ntracks"] = np.array(len(strack_pool))
+            return out
+
+        def update_lstm_features(self, tlwh):
+            box = np.asarray(tlwh, np.float64).copy()
+            saved[2](self, tlwh)
+            k = "t%d_mo%d" % (cur["t"], cur["mo"]); cur["mo"] += 1
+            fix[k + "_in"] = np.r_[float(self.track_id), float(self.frame_id), box]
+            fix[k + "_fut"] = np.stack([np.asarray(self.future_predictions[q]) for q in sorted(self.future_predictions)])
+            fix[k + "_h"] = self.hn.reshape(-1).numpy().copy()
+        RD.Detector.process, RT.Tracker.get_similarity, RT.STrack.update_lstm_features = process, get_similarity, update_lstm_features
+        BaseTrack._count = 0
+        det = RD.Detector(opt)
+        det.reset_tracking(opt)
+        det.img_height, det.img_width = H, W
+        afe = det.tracker.model.AFE
+        real_ffe = afe.forward_feature_extracter
+
+        def ffe(fm, centers):
+            e = real_ffe(fm, centers)
+            fix["t%d_centers" % cur["t"]] = centers.detach().cpu().numpy(); fix["t%d_emb" % cur["t"]] = e.detach().cpu().numpy()
+            return e
+        afe.forward_feature_extracter = ffe
+        with torch.no_grad():
+            for t in range(T):
+                cur.update(t=t, gs=0, mo=0)
+                x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(10 + t))
+                c = np.array([W / 2.0, H / 2.0], dtype=np.float32)
+                meta = {"c": c, "s": np.float32(max(H, W)), "height": H, "width": W, "out_height": H // 4, "out_width": W // 4,
+                        "inp_height": H, "inp_width": W, "calib": np.eye(3, 4, dtype=np.float32)}
+                batch = lambda v: torch.from_numpy(np.asarray(v)[None])
+                targets = det.run({"image": [torch.zeros(H, W, 3)], "images": {1.0: [x]}, "meta": {1.0: {k: batch(v) for k, v in meta.items()}}}, image_info={})
+                fix["t%d_tracks" % t] = np.array(sorted([s.track_id] + [float(v) for v in s.tlwh] + [float(s.score)] for s in targets), np.float64).reshape(-1, 6)
+                fr = det.tracker.frame_id
+                fix["t%d_frame_id" % t] = np.array(fr)
+                sims = det.tracker.recorder.all_similarity.get(fr, {})
+                fix["t%d_sim_prev" % t] = np.array(sorted(sims), np.int64)
+                for p in sims:
+                    fix["t%d_sim_%d" % (t, p)] = np.asarray(sims[p], np.float32)
+                fix["t%d_boxes" % t] = np.asarray(det.tracker.recorder.all_boxes.get(fr, np.zeros((0, 4))), np.float64)
+                fix["t%d_ngs" % t] = np.array(cur["gs"]); fix["t%d_nmo" % t] = np.array(cur["mo"])
+        ntr = sum(len(fix["t%d_tracks" % t]) for t in range(T))
+        assert ntr >= 12, "the synthetic stream must produce tracks"
+    finally:
+        RD.Detector.process, RT.Tracker.get_similarity, RT.STrack.update_lstm_features, RT.KalmanFilterLSTM = saved
+        torch.cuda.synchronize = real_sync
+        os.remove(ck)
+    np.savez_compressed(os.path.join(GOLD, "detector_trace_%s.npz" % tag), **fix)
+    print("  detector trace [%s]: %d frames, %d track rows, %d seam records" % (tag, T, ntr, len(fix)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -367,4 +482,6 @@ if __name__ == "__main__":
     run_motion("nuscenes")
     run_track_similarity()
     run_association()
+    run_detector_trace(lstm=False)
+    run_detector_trace(lstm=True)
     print("golden fixtures written to", os.path.abspath(GOLD))

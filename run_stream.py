@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Drive ONE video stream over the GPUs of a node with deft_amd.stream.ShardedStream (BASELINE configs[2]: consecutive frames
+sharded one per GPU; two small all-gathers per step over RCCL/xGMI; association on rank 0).
+
+    python run_stream.py --frames 16                          # one GPU (no collective)
+    python run_stream.py --frames 16 --force-dist --check     # one GPU, the collectives run through a 1-rank RCCL group and are
+                                                              # checked against the direct path (used by the -m gpu test)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_stream.py --frames 64
+
+Synthetic weights / frames (no dataset here).  With the reference's src/lib on PYTHONPATH (and its third-party imports
+available) rank 0 runs the reference's own `Tracker` from the gathered records; otherwise the run stops after the exchange
+(records + affinity blocks on every rank), which is everything that involves the GPUs.  Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", default="608x1088")
+    ap.add_argument("--dets", type=int, default=30, help="detections kept per frame (random weights: a score threshold is meaningless)")
+    ap.add_argument("--force-dist", action="store_true", help="run the collectives in a 1-rank process group")
+    ap.add_argument("--check", action="store_true", help="compare records / blocks with a second, collective-free stream")
+    args = ap.parse_args()
+    H, W = [int(v) for v in args.size.split("x")]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=dev)
+    from deft_amd import integrate, synth
+    from deft_amd.stream import ShardedStream
+    torch.set_grad_enabled(False)
+    sd = synth.synth_state_dict("mot")
+    model = integrate.DeftModel(sd, "mot", K=100, max_object=100, device=dev)
+
+    def detect(x):
+        out, fmaps = model(x.to(dev), None, None)
+        o = dict(out[-1]); o["hm"] = o["hm"].sigmoid()
+        dets = {k: v.detach().cpu() for k, v in integrate.generic_decode(o, K=100).items()}
+        res = [{"score": float(dets["scores"][0, i]), "class": int(dets["clses"][0, i]) + 1,
+                "bbox": dets["bboxes"][0, i].numpy().astype(np.float32) * 4.0} for i in range(args.dets)]     # down_ratio 4 (opts.py:138-143)
+        return res, fmaps
+
+    tracker = None
+    if rank == 0:
+        try:                                              # the reference's Tracker, when its tree is importable
+            argv, sys.argv = sys.argv, ["test.py", "tracking"]
+            from opts import opts
+            from utils import tracker as RT
+            sys.argv = argv
+            tracker = RT.Tracker(opts().parse(["tracking", "--dataset", "mot"]), model, h=H, w=W)
+        except Exception:
+            sys.argv = sys.argv if sys.argv[0] != "test.py" else [__file__]
+    st = ShardedStream(detect, model.AFE, model.AFE.plan.D, tracker=tracker, dataset="mot", kmax=100, img_h=H, img_w=W, batch=1, device=dev,
+                       force_collective=args.force_dist, snapshot=lambda tg: [(int(t.track_id), [float(v) for v in t.tlwh]) for t in tg])
+    ref = ShardedStream(detect, model.AFE, model.AFE.plan.D, dataset="mot", kmax=100, img_h=H, img_w=W, batch=1, device=dev) if args.check else None
+    if ref is not None:
+        ref.collective, ref.world, ref.rank = False, 1, 0
+    ok, ntracks = True, 0
+    nsteps = args.frames // world
+    frames = [torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(500 + t)) for t in range(nsteps * world)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(nsteps):
+        out = st.step([frames[s * world + rank]])
+        ntracks += sum(len(tg) for _, tg in out)
+        if ref is not None and world == 1:
+            ref.step([frames[s]])
+            ok &= torch.equal(st.all_rec, ref.rec) and torch.equal(st.all_blk, ref.blk)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"frames": nsteps * world, "world": world, "size": "%dx%d" % (W, H), "collectives": bool(st.collective),
+                          "backend": dist.get_backend() if dist.is_initialized() else None, "ms_per_frame": round(dt / (nsteps * world) * 1e3, 3),
+                          "bytes_gathered_per_step": st.bytes_gathered // max(nsteps, 1), "reference_tracker": tracker is not None,
+                          "track_outputs": ntracks, "check": ("ok" if ok else "MISMATCH") if args.check else None}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -970,3 +970,88 @@ def check_weight_dma_identical(lib, device, seed=0):
             engine.BDMA, engine.P3_HALO, engine.BDMA_DCN = saved
     for a, b in zip(*outs):
         assert torch.equal(a, b), maxabs(a, b)
+
+
+# ---------------------------------------------------------------------------
+# composed drop-in against a trace of the reference's own Detector.run (oracle/make_golden.py run_detector_trace)
+def check_detector_trace(lib, device, tag):
+    """Replays, in the reference's call order, every call its `Detector.run` made into the seams this repository replaces
+    (6 frames; fixture tests/golden/detector_trace_<tag>.npz written from the reference's own Detector / Tracker): fused
+    `Detector.process` (hipGraph replay from the second frame on a GPU), embedding extraction at the reference's detection
+    centres, the recorder's similarity blocks, the device-side tracks x detections medians, and (lstm) the batched motion
+    update -- all through the C ABI on `device`, each against what the reference computed at that point."""
+    from types import SimpleNamespace
+    from deft_amd import hiplib, integrate, tracker as DT
+    from deft_amd.detector import Detector
+    f = np.load(os.path.join(GOLD, "detector_trace_%s.npz" % tag))
+    H, W, K, T, lstm = int(f["H"]), int(f["W"]), int(f["K"]), int(f["T"]), bool(int(f["lstm"]))
+    sd = dict(O.synth_state_dict("mot"))
+    sd["ltrb_amodal.2.weight"] = sd["ltrb_amodal.2.weight"] * 0.05
+    sd["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
+    saved_lib, hiplib._lib = hiplib._lib, lib                       # Detector() asks hiplib.get_lib()
+    try:
+        opt = SimpleNamespace(dataset="mot", K=K, max_object=100, gpus=[0 if device != "cpu" else -1], hip_graphs=True, depth_scale=1.0)
+        det = Detector(opt, sd)
+        seam = integrate.AfeSeam(sd, 100, device, lib)
+        model = SimpleNamespace(AFE=seam)
+        rec = DT.FeatureRecorder("mot")
+        trk = SimpleNamespace(recorder=rec, dataset="mot", model=model)
+        bank, slots = None, {}
+        if lstm:
+            bank = DT.MotionBank(engine.LstmPlan(O.synth_lstm_state_dict("mot"), device, lib))
+        worst = {"det": 0.0, "emb": 0.0, "sim": 0.0, "gs": 0.0, "motion": 0.0}
+        for t in range(T):
+            x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(int(f["seeds"][t])))
+            _, dets, fmaps = det.process(x)
+            real = f["t%d_det_scores" % t][0] > 0          # fewer than K peaks on this small map: the rest are score-0 fillers whose
+            assert real.sum() >= K - 2                     # index torch.topk leaves unspecified (ours: 0); nothing downstream reads them
+            assert np.array_equal(dets["clses"][0][real].astype(np.int64), f["t%d_det_clses" % t][0][real].astype(np.int64))
+            assert float(np.abs(dets["scores"][0][~real]).max() if (~real).any() else 0.0) == 0.0
+            for key, tol in (("scores", 1e-5), ("bboxes", TOL), ("bboxes_amodal", TOL), ("cts", TOL), ("tracking", TOL)):
+                e = float(np.abs(dets[key][0][real].astype(np.float64) - f["t%d_det_%s" % (t, key)][0][real].astype(np.float64)).max())
+                assert e <= tol, (t, key, e)
+                worst["det"] = max(worst["det"], e)
+            centers = torch.from_numpy(f["t%d_centers" % t])
+            emb = seam.forward_feature_extracter(fmaps, centers)
+            ref_emb = f["t%d_emb" % t]
+            e = float(np.abs(emb.cpu().numpy() - ref_emb).max() / max(1.0, np.abs(ref_emb).max()))
+            assert e <= 1e-4, (t, "emb", e)
+            worst["emb"] = max(worst["emb"], e)
+            fr = int(f["t%d_frame_id" % t])
+            rec.update(model, fr, emb.data, f["t%d_boxes" % t])
+            assert sorted(rec.all_similarity[fr]) == [int(p) for p in f["t%d_sim_prev" % t]]
+            for p in rec.all_similarity[fr]:
+                e = float(np.abs(np.asarray(rec.all_similarity[fr][p]) - f["t%d_sim_%d" % (t, p)]).max())
+                assert e <= 1e-4, (t, "sim", p, e)
+                worst["sim"] = max(worst["sim"], e)
+            for k in range(int(f["t%d_ngs" % t])):
+                key = "t%d_gs%d" % (t, k)
+                fi, nd = [int(v) for v in f[key + "_args"]]
+                pool = [SimpleNamespace(nodes=[]) for _ in range(int(f[key + "_ntracks"]))]
+                for tk, nf, ni in f[key + "_nodes"]:
+                    pool[int(tk)].nodes.append(SimpleNamespace(frame_index=int(nf), id=int(ni)))
+                out = DT.get_similarity(trk, fi, pool, nd)
+                ref = f[key + "_out"]
+                assert out.shape == ref.shape and out.dtype == np.float64, (out.shape, ref.shape)
+                e = float(np.abs(out - ref).max()) if ref.size else 0.0
+                assert e <= 1e-4, (t, "get_similarity", k, e)
+                worst["gs"] = max(worst["gs"], e)
+            nmo = int(f["t%d_nmo" % t])
+            if lstm and nmo:
+                ins = np.stack([f["t%d_mo%d_in" % (t, k)] for k in range(nmo)])
+                assert len(set(ins[:, 0])) == nmo and len(set(ins[:, 1])) == 1          # one update per track, one frame id
+                for tid in ins[:, 0]:
+                    if tid not in slots:
+                        slots[tid] = bank.alloc()
+                _, pred = bank.step([slots[tid] for tid in ins[:, 0]], ins[:, 2:6], int(ins[0, 1]))
+                for k in range(nmo):
+                    ref = f["t%d_mo%d_fut" % (t, k)]
+                    e = float(np.abs(pred[k] - ref).max() / max(1.0, np.abs(ref).max()))
+                    assert e <= 1e-4, (t, "motion", k, e)
+                    worst["motion"] = max(worst["motion"], e)
+        if lstm:
+            assert bank.launches == sum(1 for t in range(T) if int(f["t%d_nmo" % t])) and worst["motion"] > 0     # one launch per frame
+        assert sum(int(f["t%d_ngs" % t]) for t in range(T)) >= T - 1 and worst["sim"] > 0
+        return worst
+    finally:
+        hiplib._lib = saved_lib

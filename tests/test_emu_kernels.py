@@ -280,3 +280,10 @@ def test_conv_halo(emu_lib, args):
 
 def test_weight_dma_identical(emu_lib):
     pc.check_weight_dma_identical(emu_lib, "cpu")
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("tag", ["mot", "mot_lstm"])
+def test_composed_dropin_replays_reference_trace(emu_lib, tag):
+    """The reference's own Detector.run, traced (tests/golden/detector_trace_*.npz), replayed through the composed HIP path."""
+    print(pc.check_detector_trace(emu_lib, "cpu", tag))

@@ -486,6 +486,46 @@ def test_autotune_keeps_every_bit(gpu_lib, prec):
         engine.PREC = saved
 
 
+@pytest.mark.parametrize("tag", ["mot", "mot_lstm"])
+def test_composed_dropin_replays_reference_trace(gpu_lib, tag):
+    """the COMPOSED drop-in on the hardware.  tests/golden/detector_trace_*.npz is a trace of the reference's own
+    `Detector.run` (its pre-processed branch, post-processing and Tracker; written by oracle/make_golden.py where /root/reference
+    exists): every call it made into the seams this repository replaces, with inputs and outputs.  Replayed here on cuda:0 in
+    the same order -- fused Detector.process with hipGraph replay, embeddings at the reference's centres, recorder blocks,
+    device-side similarity medians, batched LSTM motion update -- each against the reference's value at that point."""
+    worst = pc.check_detector_trace(gpu_lib, "cuda", tag)
+    torch.cuda.synchronize()
+    print(worst)
+
+
+def test_sharded_stream_over_rccl(gpu_lib):
+    """the `nccl` (RCCL) branch of the sharded tracker stream on the 1-GPU box -- run_stream.py with a
+    1-rank process group: both collectives run on device buffers, and the gathered records / affinity blocks must equal the
+    collective-free path bit for bit.  (The 2-rank logic, with the reference's Tracker on rank 0, is tests/test_stream_dist.py.)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_stream.py"), "--frames", "5", "--size", "128x160", "--dets", "12", "--force-dist", "--check"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["check"] == "ok" and rep["collectives"] and rep["backend"] == "nccl" and rep["bytes_gathered_per_step"] > 0
+
+
+def test_frame_pipeline_over_rccl(gpu_lib):
+    """The throughput pipeline's all-gather through a 1-rank RCCL group (DEFT_FORCE_DIST=1): bench.py must complete and report."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DEFT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "A", "--batch", "4", "--streams", "1", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["value"] > 0 and rep["n_gpus"] == 1
+
+
 def test_weight_dma_identical(gpu_lib):
     pc.check_weight_dma_identical(gpu_lib, "cuda")
     torch.cuda.synchronize()

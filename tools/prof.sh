@@ -7,7 +7,7 @@
 set -u
 TAG=$1; shift
 ONE=""
-if [ $# -eq 0 ]; then set -- python bench.py --no-cpu-baseline --steps 6 --warmup 2; ONE="--serialize"; fi
+if [ $# -eq 0 ]; then set -- python bench.py --no-cpu-baseline --no-extras --steps 6 --warmup 2; ONE="--serialize"; fi
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
