@@ -205,49 +205,45 @@ def main():
             if world > 1:
                 t = torch.tensor([d1], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); d1 = float(t.item())
             extras["sustained"] = {"steps": n_more, "seconds": round(d1, 3), "value": round(n_more * B * world / d1, 3), "unit": "frames/s"}
-        # ---- fed from host memory: pinned, double-buffered H2D of FRESH frames on a copy stream + D2H of detections and affinity ----
+        # ---- fed from host memory: uint8 camera frames (1920x1080 for MOT17, else the network size) from pinned staging buffers,
+        #      double-buffered H2D on a copy stream, warp + normalise ON THE DEVICE (deft_preprocess_u8, detector.py:377-395), and the
+        #      detections + affinity blocks copied back every step ----
         if world == 1:
-            nb = 2
-            host = [torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(7 + i)).pin_memory() for i in range(nb)]
-            devb = [torch.empty(B, 3, H, W, device=dev) for _ in range(nb)]
-            cs = torch.cuda.Stream(device=dev)
-            ev_in = [torch.cuda.Event() for _ in range(nb)]
-            ev_free = [torch.cuda.Event() for _ in range(nb)]
+            from deft_amd.preprocess import FrameFeeder
+            sh, sw = (1080, 1920) if args.config == "B" else (H, W)
+            compu = HipCompute(sd, B, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=args.streams, ndet=NDET)
+            compu.use_u8(sh, sw)
+            pipeu = FramePipeline(compu, B, NDET, compu.D, history=HIST, device=dev, exchange=gather)
+            feeder = FrameFeeder(B, sh, sw, dev)
+            fresh = [torch.randint(0, 256, (B, sh, sw, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7 + i)) for i in range(2)]
             aff_host = torch.empty(B, HIST * NDET, NDET + 1).pin_memory()
             det_host = torch.empty(B, KDET, 6).pin_memory()
-            main = torch.cuda.current_stream(dev)
-
-            def feed(i):
-                with torch.cuda.stream(cs):
-                    cs.wait_event(ev_free[i % nb])
-                    devb[i % nb].copy_(host[i % nb], non_blocking=True)
-                    ev_in[i % nb].record(cs)
-            for e in ev_free:
-                e.record(main)
+            for i in range(HIST + 2):                                # warm-up into the steady state (history ring full)
+                k = feeder.push(fresh[i % 2]); pipeu.step(feeder.take(k)); feeder.release(k)
             nst = max(4, min(args.steps, 25))
-            feed(0)
             sync()
             t1 = time.perf_counter()
+            k = feeder.push(fresh[0])
             for i in range(nst):
-                if i + 1 < nst:
-                    feed(i + 1)                                      # next step's frames travel while this step computes
-                main.wait_event(ev_in[i % nb])
-                outs = step(devb[i % nb])
-                ev_free[i % nb].record(main)
-                blk = [o for o in outs if o is not None]
-                if blk:
-                    aff_host[:len(blk)].copy_(torch.stack(blk), non_blocking=True)
-                k = 0
-                for p in comp.plans:
-                    det_host[k:k + p.N, :, 0].copy_(p.scores, non_blocking=True)
-                    det_host[k:k + p.N, :, 1].copy_(p.inds, non_blocking=True)
-                    det_host[k:k + p.N, :, 2:6].copy_(p.bboxes, non_blocking=True)
-                    k += p.N
+                kn = feeder.push(fresh[(i + 1) % 2]) if i + 1 < nst else None       # next step's frames travel while this step computes
+                outs = pipeu.step(feeder.take(k))
+                feeder.release(k)
+                aff_host.copy_(torch.stack(outs), non_blocking=True)
+                j = 0
+                for p in compu.plans:
+                    det_host[j:j + p.N, :, 0].copy_(p.scores, non_blocking=True)
+                    det_host[j:j + p.N, :, 1].copy_(p.inds, non_blocking=True)
+                    det_host[j:j + p.N, :, 2:6].copy_(p.bboxes, non_blocking=True)
+                    j += p.N
+                k = kn
             sync()
             d1 = time.perf_counter() - t1
             extras["value_incl_pcie"] = round(nst * B / d1, 3)
-            extras["pcie"] = {"steps": nst, "h2d_bytes_per_step": B * 3 * H * W * 4, "d2h_bytes_per_step": aff_host.numel() * 4 + det_host.numel() * 4,
-                              "note": "fp32 frames from pinned host memory, double-buffered on a copy stream; per-step D2H of detections and affinity blocks"}
+            extras["pcie"] = {"steps": nst, "frame": "%dx%dx3 uint8" % (sw, sh), "h2d_bytes_per_step": B * sh * sw * 3,
+                              "d2h_bytes_per_step": aff_host.numel() * 4 + det_host.numel() * 4,
+                              "note": "uint8 frames from pinned host memory, double-buffered on a copy stream (host staging copy included), warp + "
+                                      "normalise on the device; per-step D2H of detections and affinity blocks"}
+            del compu, pipeu, feeder
         # ---- latency mode: one frame per step per GPU, hipGraph replay (BASELINE configs[2]: 8 frames/batch over 8 GPUs = one per GPU) ----
         comp1 = HipCompute(sd, 1, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=1, ndet=NDET)
         pipe1 = FramePipeline(comp1, 1, NDET, comp1.D, history=HIST, device=dev, exchange=gather)

@@ -33,26 +33,35 @@ def bbox_overlaps(boxes, query_boxes):
 
 
 def lapjv(cost, extend_cost=False, cost_limit=np.inf, return_cost=True):
-    """`lap.lapjv` as matching.py:48 uses it: a rectangular cost matrix is embedded in an (n+m) x (n+m) square
-    one -- cost_limit/2 (or max+1 without a limit) in the two off-diagonal blocks, 0 in the bottom-right one --
-    so a pair is only matched while it costs less than leaving both unmatched; solved exactly.  Returns
-    (total cost of the kept pairs, x, y): x[i] = column of row i or -1, y[j] = row of column j or -1."""
+    """`lap.lapjv` (third-party, absent here: parity unpinned).  With a cost_limit -- the only form the reference uses
+    (matching.py:48: extend_cost=True, cost_limit=thresh) -- the rectangular matrix is embedded in an (n+m) x (n+m) square one
+    with cost_limit/2 in the two off-diagonal blocks and 0 in the bottom-right one, so a pair is only matched while it costs
+    less than leaving both unmatched.  Without a limit lap pads to a max(n,m) square with ZEROS and matches every row of the
+    smaller side (extend_cost=True), or insists on a square matrix.  NaN costs are treated as +inf (never matched) instead of
+    raising.  Solved exactly (scipy.optimize.linear_sum_assignment).  Returns (total cost of the kept pairs, x, y):
+    x[i] = column of row i or -1, y[j] = row of column j or -1."""
     cost = np.asarray(cost, dtype=np.float64)
     n, m = cost.shape
     if n != m and not (extend_cost or cost_limit < np.inf):
         raise ValueError("Square cost array expected. If cost is intentionally non-square, pass extend_cost=True.")
     x = np.full(n, -1, dtype=int); y = np.full(m, -1, dtype=int)
     if n and m:
+        cost = np.where(np.isnan(cost), np.inf, cost)
+        finite = cost[np.isfinite(cost)]
+        big = (np.abs(finite).max() if finite.size else 1.0) * (n + m + 1) + 1.0            # stands in for +inf inside the solver
         if cost_limit < np.inf:
-            fill = cost_limit / 2.0
+            ext = np.full((n + m, n + m), cost_limit / 2.0)
+            ext[n:, m:] = 0
+            ext[:n, :m] = np.where(np.isfinite(cost), cost, max(big, cost_limit + 1.0))
+            r, c = linear_sum_assignment(ext)
+            keep = (r < n) & (c < m)
         else:
-            finite = cost[np.isfinite(cost)]
-            fill = finite.max() + 1 if finite.size else 1.0
-        ext = np.full((n + m, n + m), fill)
-        ext[n:, m:] = 0
-        ext[:n, :m] = cost
-        r, c = linear_sum_assignment(ext)
-        keep = (r < n) & (c < m)
+            k = max(n, m)
+            ext = np.zeros((k, k))
+            ext[:n, :m] = np.where(np.isfinite(cost), cost, big)
+            r, c = linear_sum_assignment(ext)
+            keep = (r < n) & (c < m)
+            keep &= np.isfinite(cost[np.minimum(r, n - 1), np.minimum(c, m - 1)])            # a forced +inf pairing is no match
         x[r[keep]] = c[keep]; y[c[keep]] = r[keep]
     total = float(cost[np.nonzero(x >= 0)[0], x[x >= 0]].sum())
     return (total, x, y) if return_cost else (x, y)

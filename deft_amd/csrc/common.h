@@ -77,14 +77,18 @@ __device__ __forceinline__ void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* ld
 // rendezvous the workgroup (raw s_barrier: __syncthreads() would drain vmcnt to 0 while a DMA is outstanding).  The
 // empty asm statements keep the compiler from moving LDS accesses across it.
 #define DEFT_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-#define DEFT_PIPE_BARRIER_ONLY()              \
-    do {                                      \
-        __builtin_amdgcn_s_barrier();         \
-        asm volatile("" ::: "memory");        \
+// lgkmcnt(0): this wave's LDS reads have RETURNED before it arrives.  The compiler may sink MFMAs (not memory operations) below
+// the barrier together with the wait for their ds_read operands; another wave's DMA into the stage those reads target would
+// then race with them (seen on the hardware as rare wrong tiles in the one-stage loop).
+#define DEFT_PIPE_BARRIER_ONLY()                                   \
+    do {                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+        __builtin_amdgcn_s_barrier();                              \
+        asm volatile("" ::: "memory");                             \
     } while (0)
 #define DEFT_PIPE_BARRIER(N)                                            \
     do {                                                                \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");        \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); \
         __builtin_amdgcn_s_barrier();                                   \
         asm volatile("" ::: "memory");                                  \
     } while (0)
@@ -112,6 +116,11 @@ __device__ __forceinline__ void deft_ws_publish() {
 }
 __device__ __forceinline__ int deft_ws_ticket(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void deft_ws_reset(int* p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
+// round-half-even double -> int (cv2's saturate_cast<int>(double) = lrint)
+#ifndef DEFT_RINT_HOOK        /* the unit-test SIMT emulator pre-defines this hook */
+__device__ __forceinline__ int deft_rint(double v) { return __double2int_rn(v); }
 #endif
 
 static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -40,7 +40,8 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 template <int BM, int BN, int WK, int NSTAGE, int MODE, int PREC = 0>
 constexpr int igemm_lds_floats() {
     constexpr int ld = (MODE == MODE_CONV && NSTAGE == 2) ? 32 : LDS_STRIDE;      // LDS-DMA image is unpadded
-    constexpr int stage = (PREC == 2 ? (3 * BM * LDB * 2 + 2 * BN * 192) / 4 : PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
+    // PREC = 3: the same with ONE weight stage, refilled after the chunk's second barrier (no extra LDS: the DCN keeps its 3 workgroups/CU)
+    constexpr int stage = (PREC >= 2 ? (3 * BM * LDB * 2 + (PREC == 2 ? 2 : 1) * BN * 192) / 4 : PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
     constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
     return stage > red ? stage : red;
 }
@@ -64,7 +65,7 @@ struct KCursor {
 template <int BM, int BN, int WM, int WN, int WK, int MODE, int NSTAGE, bool SPLIT, int PREC = 0>
 __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, int ntiles, int bid) {
     static_assert(PREC == 0 || (WK == 1 && NSTAGE == 1), "split-bf16 path: WK = 1 tiles, 1-stage loop");
-    static_assert(PREC != 2 || BN % 64 == 0, "pre-split weights come in 64-row blocks");
+    static_assert(PREC < 2 || BN % 64 == 0, "pre-split weights come in 64-row blocks");
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int GA = BM / 32;  // f32x4 groups per thread, A tile
@@ -83,8 +84,9 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     DEFT_DYN_LDS(float, smem);
     float* const As = smem;
     float* const Bs = smem + NSTAGE * BM * LD;
-    constexpr bool BDMA = PREC == 2;
-    float* const prm = BDMA ? smem + (3 * BM * LDB * 2 + 2 * BN * 192) / 4 : PREC ? smem + 3 * (BM + BN) * LDB / 2 : Bs + NSTAGE * BN * LD;   // DCN only
+    constexpr bool BDMA = PREC >= 2;
+    constexpr int NBS = PREC == 3 ? 1 : 2;               // weight stages of the DMA form
+    float* const prm = BDMA ? smem + (3 * BM * LDB * 2 + NBS * BN * 192) / 4 : PREC ? smem + 3 * (BM + BN) * LDB / 2 : Bs + NSTAGE * BN * LD;   // DCN only
     __bf16* const Ap = (__bf16*)smem;            // PREC >= 1: A planes [3][BM][LDB], then B planes [3][BN][LDB] (PREC 2: two DMA stages [BN][192 B])
     __bf16* const Bp = Ap + 3 * BM * LDB;
     char* const Bd = (char*)(Ap + 3 * BM * LDB);
@@ -304,11 +306,13 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
             }
         }
         if (BDMA) {
-            const unsigned soff = (unsigned)(kload >> 5) * 12288u;
+            if (NBS == 2) {
+                const unsigned soff = (unsigned)(kload >> 5) * 12288u;
 #pragma unroll
-            for (int i = 0; i < NBP; ++i)
-                deft_buffer_load_lds_x4s(rw3, Bd + bdma_stage * BN * 192 + (wave + i * 4) * 1024, vB3[i], soff);
-            bdma_stage ^= 1;
+                for (int i = 0; i < NBP; ++i)
+                    deft_buffer_load_lds_x4s(rw3, Bd + bdma_stage * BN * 192 + (wave + i * 4) * 1024, vB3[i], soff);
+                bdma_stage ^= 1;
+            }
         } else if (DMA) {
             const unsigned wo = (unsigned)(((n0 + rbase) * p.Kpad + kload + gs * 4) * 4);
 #pragma unroll
@@ -336,6 +340,13 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         } else if (MODE == MODE_DCN) {               // (channel block, tap) order: tap fastest
             if (++cur.s == 9) { cur.s = 0; cur.c0 += 32; }
         }
+    };
+    int kb_next = k_lo;                                 // PREC 3: chunk whose weight image the next issue_b() fetches
+    auto issue_b = [&]() {
+        const unsigned soff = (unsigned)kb_next * 12288u;
+#pragma unroll
+        for (int i = 0; i < NBP; ++i) deft_buffer_load_lds_x4s(rw3, Bd + (wave + i * 4) * 1024, vB3[i], soff);
+        ++kb_next;
     };
     auto finish_store = [&](int stage) {
         float* as = As + stage * BM * LDS_STRIDE + rbase * LDS_STRIDE + g * 4;
@@ -457,18 +468,20 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         // one LDS stage, two barriers per chunk:  store chunk kt | barrier | issue loads kt+1,
         // fragments + MFMAs of chunk kt | barrier
         issue_loads();
+        if (BDMA && NBS == 1) issue_b();
         for (int kt = 0; kt < nk; ++kt) {
             finish_store(0);
             if (BDMA) DEFT_WAIT_VM(0);           // this wave's pieces of chunk kt's weight image have landed (the barrier publishes everybody's)
             __syncthreads();
             if (kt + 1 < nk) issue_loads();      // (PREC 2: the weight DMA of chunk kt+1 goes to the stage last read in iteration kt-1)
             if (PREC) {
-                split_chunk(kt & 1);
+                split_chunk(NBS == 2 ? (kt & 1) : 0);
             } else {
                 read_frags(0);
                 mfma_chunk();
             }
             __syncthreads();  // all waves finished reading this chunk
+            if (BDMA && NBS == 1 && kt + 1 < nk) issue_b();      // PREC 3: refill the single weight stage; lands under the next finish_store()
         }
     } else {
         // two LDS stages, ONE barrier per chunk.  Iteration kt: issue the loads of chunk kt+1,
@@ -656,10 +669,11 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
         if constexpr (WK == 1 && NSTAGE == 1 && BN >= 64) {      // BN = 32: the operand split is amortised over too few columns
-            if (d.prec == 1 && d.w3 != nullptr && S == 1) {      // ... with the weights pre-split: their chunks arrive by DMA (PREC 2)
-                constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 2>() * 4;
-                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 2>>(lds_p)) return e;
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 2>), dim3(mtiles * ntiles), dim3(256), lds_p, s, d, mtiles, ntiles);
+            if (d.prec == 1 && d.w3 != nullptr && S == 1) {      // ... with the weights pre-split: their chunks arrive by DMA
+                constexpr int PB = MODE == MODE_DCN ? 3 : 2;     // DCN: one weight stage (LDS as before: 3 workgroups/CU); else two
+                constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, PB>() * 4;
+                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, PB>>(lds_p)) return e;
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, PB>), dim3(mtiles * ntiles), dim3(256), lds_p, s, d, mtiles, ntiles);
                 DEFT_CHECK_LAUNCH("igemm");
                 return 0;
             }
@@ -784,7 +798,7 @@ extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* 
     if (bm == 0) {
         if (entry == 0 && d->x3 != nullptr) deft_p3_pick_tile(d, &bm, &bn);
         else if (entry == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);
-        else { bm = 64; bn = d->Cout >= 256 ? 128 : 64; }
+        else { bm = 64; bn = d->Cout >= 128 ? 128 : 64; }
     }
     const int nk = d->Kpad >> 5;
     long long tiles = (long long)deft_cdiv(d->M, bm) * deft_cdiv(d->Cout, bn);
@@ -796,7 +810,7 @@ extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* 
         tiles = (long long)deft_cdiv(d->M, bm) * deft_cdiv(d->Cout, bn);
         S = pick_splitk(tiles, nk);
     }
-    *tile = (bm << 16) | bn | (d->tile & (1 << 29));
+    *tile = (bm << 16) | bn | (d->tile & (3 << 29));
     *splitk = S;
     *ws_floats = S > 1 ? tiles * S * bm * bn : 0;
     *ws_tiles = S > 1 ? (int)tiles : 0;
@@ -852,7 +866,7 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) {             // BM = 64 keeps the 9-tap sampling records at 20 KB of LDS (4 workgroups per CU)
-        bm = 64; bn = d->Cout >= 256 ? 128 : 64;      // tools/bench_igemm.py dcn
+        bm = 64; bn = d->Cout >= 128 ? 128 : 64;      // tools/bench_igemm.py dcn (r2, weights by DMA: 64x128 wins from Cout = 128)
     }
     return dispatch_igemm<MODE_DCN>(*d, bm, bn, one_stage, s);
 }

@@ -24,10 +24,13 @@ typedef deft_f32x16 f32x16;
 #define P3_ROW 192            // bytes per staged row: 3 pieces x 32 bf16
 #define P3_WBLK 12288         // 64 weight rows of one chunk
 
-template <int BM, int BN, int NS>
+// NS = 1: ONE stage and no overlap inside a workgroup -- the DMA latency of a chunk is covered by the OTHER workgroups of the CU
+// (48 KB at 128 x 128: three of them, against one for the 2-stage ring); the epilogue tile is then staged in WM passes of
+// BM / WM rows so that it does not push the LDS footprint above the stage.
+template <int BM, int BN, int NS, int WM>
 constexpr int p3_lds_bytes() {
     constexpr int stage = NS * (BM + BN) * P3_ROW;
-    constexpr int tile = BM * (BN + 4) * 4;
+    constexpr int tile = (NS == 1 ? BM / WM : BM) * (BN + 4) * 4;
     return stage > tile ? stage : tile;
 }
 
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
     constexpr int STAGE = (BM + BN) * P3_ROW;
     constexpr int PER = NA + NB;                 // DMA pieces a wave issues per chunk (vmcnt bookkeeping)
     static_assert(BM * 12 % NT == 0 && TM >= 1 && TN >= 1 && BN % 64 == 0, "tile shape");
-    static_assert(NS == 2 || (NS == 3 && NBI % NW == 0), "3 stages need the same DMA count in every wave");
+    static_assert(NS == 1 || NS == 2 || (NS == 3 && NBI % NW == 0), "3 stages need the same DMA count in every wave");
 
     DEFT_DYN_LDS(char, smem);
     const int tid = threadIdx.x;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
     const int m0 = mt * BM, n0 = nt * BN;
 
     const deft_rsrc_t rx = deft_make_rsrc(p.x3);
-    const deft_rsrc_t rw = deft_make_rsrc(p.w3);
+    const deft_rsrc_t rw = deft_make_rsrc(p.w3);       // (no tile reaches past the 128-padded weight rows: deft_p3_dispatch checks)
     const unsigned pb = (unsigned)p.ldx3 * 6u;       // bytes per pixel: 3 pieces x ld channels x 2
     const int taps = p.KH * p.KW;
 
@@ -190,7 +193,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
     // ---- K loop: NS stages, one barrier per chunk.  Iteration kt: wait until chunk kt has landed (this wave's DMA
     // pieces, then the barrier for everybody else's), refill the stage that was read in iteration kt-1 (everybody
     // has passed the barrier, so nobody reads it any more) with chunk kt+NS-1, then fragments + MFMAs of chunk kt.
-    if (NS == 2) {
+    if (NS == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            issue(0);
+            DEFT_PIPE_BARRIER(0);                              // chunk kt has landed, for everybody
+            compute(0);
+            DEFT_PIPE_BARRIER_ONLY();                          // everybody has read it: the stage may be refilled
+        }
+    } else if (NS == 2) {
         issue(0);
         for (int kt = 0; kt < nk; ++kt) {
             DEFT_PIPE_BARRIER(0);
@@ -253,9 +263,21 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
 
     // ---- epilogue through LDS (common.h) ----
     float* const T = (float*)smem;
-    deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
-    __syncthreads();
-    deft_epilogue_rows<BM, BN, NT>(T, p, n0, tid, [&](int row) -> long long { return m0 + row < p.M ? (long long)(m0 + row) : -1; });
+    if (NS == 1 && WM > 1) {
+        constexpr int BMH = BM / WM;                           // one wave row of the tile per pass: the LDS tile stays below the stage size
+#pragma unroll 1
+        for (int half = 0; half < WM; ++half) {
+            if (wm == half) deft_epilogue_stage<TM, TN>(T, BN + 4, acc, 0, wn, lane, p, n0);
+            __syncthreads();
+            const int mb = m0 + half * BMH;
+            deft_epilogue_rows<BMH, BN, NT>(T, p, n0, tid, [&](int row) -> long long { return mb + row < p.M ? (long long)(mb + row) : -1; });
+            __syncthreads();
+        }
+    } else {
+        deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
+        __syncthreads();
+        deft_epilogue_rows<BM, BN, NT>(T, p, n0, tid, [&](int row) -> long long { return m0 + row < p.M ? (long long)(m0 + row) : -1; });
+    }
 }
 
 template <auto KERNEL>
@@ -270,7 +292,7 @@ static int p3_set_lds_attr(int lds_bytes) {
 
 template <int BM, int BN, int WM, int WN, int NS>
 static int launch_p3(const DeftGemmDesc& d, hipStream_t s) {
-    constexpr int lds = p3_lds_bytes<BM, BN, NS>();
+    constexpr int lds = p3_lds_bytes<BM, BN, NS, WM>();
     const int mtiles = deft_cdiv(d.M, BM), ntiles = deft_cdiv(d.Cout, BN);
     const int S = d.splitk > 1 ? d.splitk : 1;
     DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && S <= 32 && (d.Kpad >> 5) >= S), -102,
@@ -315,13 +337,20 @@ int deft_p3_check(const DeftGemmDesc* d, const char* who) {
     return 0;
 }
 
-// `tile`: (BM << 16) | BN as igemm.hip; bit 29 selects 3 LDS stages where the tile has them.
+// `tile`: (BM << 16) | BN as igemm.hip; bit 29 selects 3 LDS stages, bit 30 ONE stage (several workgroups per CU) where the tile has them.
 int deft_p3_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
-    const bool three = (d->tile >> 29) & 1;
+    const int ns = (d->tile >> 30) & 1 ? 1 : ((d->tile >> 29) & 1 ? 3 : 2);
     if (bm == 0) deft_p3_pick_tile(d, &bm, &bn);
+    // the weight image has ceil(Cout / 128) * 128 rows (deft_split_weights of the 128-padded matrix): no tile may reach past them
+    DEFT_CHECK(bn > 0 && (long long)deft_cdiv(d->Cout, bn) * bn <= (long long)deft_cdiv(d->Cout, 128) * 128, -69,
+               "igemm3: tile width %d reaches past the padded weight matrix (Cout=%d)", bn, d->Cout);
 #define P3_TILE(BM_, BN_, WM_, WN_, NS_) \
-    if (bm == BM_ && bn == BN_ && three == (NS_ == 3)) return launch_p3<BM_, BN_, WM_, WN_, NS_>(*d, s);
+    if (bm == BM_ && bn == BN_ && ns == NS_) return launch_p3<BM_, BN_, WM_, WN_, NS_>(*d, s);
+    P3_TILE(128, 128, 2, 2, 1)
+    P3_TILE(128, 64, 2, 2, 1)
+    P3_TILE(64, 128, 2, 2, 1)
+    P3_TILE(64, 64, 2, 2, 1)
     P3_TILE(256, 128, 4, 2, 2)
     P3_TILE(128, 256, 2, 4, 2)
     P3_TILE(128, 128, 2, 2, 2)
@@ -332,7 +361,7 @@ int deft_p3_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     P3_TILE(64, 64, 2, 2, 2)
     P3_TILE(64, 64, 2, 2, 3)
 #undef P3_TILE
-    DEFT_CHECK(false, -15, "igemm3: unsupported tile %dx%d%s", bm, bn, three ? " (3 stages)" : "");
+    DEFT_CHECK(false, -15, "igemm3: unsupported tile %dx%d with %d stage(s)", bm, bn, ns);
     return -15;
 }
 
@@ -412,10 +441,10 @@ extern "C" int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpa
 #define P3H_TW 32
 #define P3H_HW 34
 
-template <int TH, int BN>
+template <int TH, int BN, int TPI>
 constexpr int p3h_lds_bytes(int nsb) {
     const int apieces = ((TH + 2) * P3H_HW * 6 + 63) / 64;
-    const int stage = 2 * apieces * 1024 + nsb * BN * 96;
+    const int stage = 2 * apieces * 1024 + nsb * TPI * BN * 96;
     const int tile = TH * 32 * (BN + 4) * 4;
     return stage > tile ? stage : tile;
 }
@@ -438,9 +467,12 @@ __device__ __forceinline__ void p3_wait_vm(int n) {
     }
 }
 
-template <int TH, int BN, int WM, int WN>
+// TPI: taps per interval (1 or 3 = one filter row).  Narrow tiles (BN = 32: the offset/mask convs) have 6 MFMAs per wave and tap --
+// with one barrier per tap they are barrier-bound; three taps per weight stage give 18 per barrier.
+template <int TH, int BN, int WM, int WN, int TPI>
 __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int tiles_x, int tiles_y, int ntiles) {
     constexpr int NSB = 3;
+    static_assert(TPI == 1 || TPI == 3, "one tap or one filter row per interval");
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int BM = TH * 32;
     constexpr int TM = TH / WM, TN = BN / (WN * 32);
@@ -448,9 +480,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     constexpr int ASLOTS = HP * 6;
     constexpr int NAP = (ASLOTS + 63) / 64;            // A pieces per 16-channel block
     constexpr int NA = (NAP + NW - 1) / NW;
-    constexpr int NBI = BN * 6 / 64;                   // B pieces per interval
+    constexpr int PPT = BN * 6 / 64;                   // B pieces per tap
+    constexpr int NBI = TPI * PPT;                     // B pieces per interval
     constexpr int NB = (NBI + NW - 1) / NW;
-    constexpr int ABYTES = NAP * 1024, BBYTES = BN * 96;
+    constexpr int ABYTES = NAP * 1024, BBYTES = TPI * BN * 96;
     static_assert(TM >= 1 && TN >= 1 && TH % WM == 0 && BN % (WN * 32) == 0 && (BN * 6) % 64 == 0, "tile shape");
 
     DEFT_DYN_LDS(char, smem);
@@ -475,7 +508,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     const int y0 = tyi * TH, x0 = txi * P3H_TW, n0 = nt * BN;
 
     const deft_rsrc_t rx = deft_make_rsrc(p.x3);
-    const deft_rsrc_t rw = deft_make_rsrc(p.w3);
+    const deft_rsrc_t rw = deft_make_rsrc(p.w3);       // (no tile reaches past the 128-padded weight rows: deft_p3_dispatch checks)
     const unsigned pb = (unsigned)p.ldx3 * 6u;
     const int nC16 = p.Cin >> 4;
 
@@ -508,8 +541,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
         if (jb < NBI) {
             ++pb_w;
             // stage byte b is row (n0 + b / 96) of the weight matrix: 64-row block (n0 + b/96) / 64, byte (..% 64) * 96 + b % 96 of its slice
-            const unsigned byte = (unsigned)(n0 & 63) * 96u + (unsigned)jb * 1024u;     // offset inside the first block of the tile
-            vB[ib] = (unsigned)((n0 >> 6) + (int)(byte / 6144u)) * (unsigned)(nC16 * 9) * 6144u + byte % 6144u + (unsigned)lane * 16u;
+            const int tl = jb / PPT, jj = jb - tl * PPT;                                   // tap of the interval, piece of its BN x 96 B slice
+            const unsigned byte = (unsigned)(n0 & 63) * 96u + (unsigned)jj * 1024u;      // offset inside the first block of the tile
+            vB[ib] = (unsigned)((n0 >> 6) + (int)(byte / 6144u)) * (unsigned)(nC16 * 9) * 6144u + byte % 6144u + (unsigned)tl * 6144u + (unsigned)lane * 16u;
         }
     }
 
@@ -524,11 +558,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     };
     auto issueB = [&](int it, int stage) {
         char* const bs = Bbase + stage * BBYTES;
-        const unsigned soff = (unsigned)it * 6144u;        // it = c16 * 9 + tap: the (block, tap) slices of a 64-row block are consecutive
+        const unsigned soff = (unsigned)(it * TPI) * 6144u;    // it * TPI = c16 * 9 + first tap: the (block, tap) slices of a 64-row block are consecutive
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
             const int jb = wave + ib * NW;
-            if (NBI % NW == 0 || jb < NBI) deft_buffer_load_lds_x4s(rw, bs + jb * 1024, vB[ib], soff);
+            if (NBI % NW == 0 || jb < NBI) deft_buffer_load_lds_x4s(rw, bs + (jb / PPT) * BN * 96 + (jb % PPT) * 1024, vB[ib], soff);
         }
     };
 
@@ -550,7 +584,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
 
     pa_w = __builtin_amdgcn_readfirstlane(pa_w);      // wave-uniform by construction; tell the compiler (scalar branches in p3_wait_vm)
     pb_w = __builtin_amdgcn_readfirstlane(pb_w);
-    const int nI = nC16 * 9;
+    const int nI = nC16 * (9 / TPI);
     issueA(0);
     issueB(0, 0);
     if (nI > 1) issueB(1, 1);
@@ -563,11 +597,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
         a_after = false;
         if (tap == 0 && c16 + 1 < nC16) { issueA(c16 + 1); a_after = true; }
         if (it + 2 < nI) issueB(it + 2, bst >= 1 ? bst - 1 : 2);          // (bst + 2) % 3
-        // ---- one MFMA k-step: tap (r, s) of 16 channels ----
-        {
-            const int r = tap / 3, s = tap - 3 * r;
+        // ---- TPI MFMA k-steps: taps (r, s) of 16 channels ----
+#pragma unroll
+        for (int ts = 0; ts < TPI; ++ts) {
+            const int tp = tap * TPI + ts;
+            const int r = tp / 3, s = tp - 3 * r;
             const char* const as = Abase + (c16 & 1) * ABYTES;
-            const char* const bs = Bbase + bst * BBYTES;
+            const char* const bs = Bbase + bst * BBYTES + ts * BN * 96;
             bf16x8 pa[TM][3], pb_[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -595,7 +631,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
                 }
         }
         bst = bst == 2 ? 0 : bst + 1;
-        if (++tap == 9) { tap = 0; ++c16; }
+        if (++tap == 9 / TPI) { tap = 0; ++c16; }
     }
     __syncthreads();
 
@@ -609,14 +645,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     });
 }
 
-template <int TH, int BN, int WM, int WN>
+template <int TH, int BN, int WM, int WN, int TPI>
 static int launch_p3h(const DeftGemmDesc& d, hipStream_t s) {
-    constexpr int lds = p3h_lds_bytes<TH, BN>(3);
+    constexpr int lds = p3h_lds_bytes<TH, BN, TPI>(3);
     const int tiles_x = deft_cdiv(d.W, P3H_TW), tiles_y = deft_cdiv(d.H, TH), ntiles = deft_cdiv(d.Cout, BN);
     const long long grid = (long long)d.N * tiles_x * tiles_y * ntiles;
     DEFT_CHECK(grid < (1ll << 31), -70, "conv3h: too many tiles");
-    if (int e = p3_set_lds_attr<conv3h_kernel<TH, BN, WM, WN>>(lds)) return e;
-    hipLaunchKernelGGL((conv3h_kernel<TH, BN, WM, WN>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, s, d, tiles_x, tiles_y, ntiles);
+    if (int e = p3_set_lds_attr<conv3h_kernel<TH, BN, WM, WN, TPI>>(lds)) return e;
+    hipLaunchKernelGGL((conv3h_kernel<TH, BN, WM, WN, TPI>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, s, d, tiles_x, tiles_y, ntiles);
     DEFT_CHECK_LAUNCH("conv3h");
     return 0;
 }
@@ -630,13 +666,15 @@ int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s) {
         th = 4;
         bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
     }
-#define P3H_TILE(TH_, BN_, WM_, WN_) \
-    if (th == TH_ && bn == BN_) return launch_p3h<TH_, BN_, WM_, WN_>(*d, s);
-    P3H_TILE(4, 128, 2, 2)
-    P3H_TILE(4, 64, 4, 1)
-    P3H_TILE(4, 32, 4, 1)
-    P3H_TILE(8, 128, 4, 2)
-    P3H_TILE(8, 64, 4, 2)
+    const int tpi = (d->tile >> 29) & 1 ? 1 : 0;                 // bit 29: force one tap per interval where the tile defaults to three
+#define P3H_TILE(TH_, BN_, WM_, WN_, TPI_) \
+    if (th == TH_ && bn == BN_ && (tpi == 0 || tpi == TPI_)) return launch_p3h<TH_, BN_, WM_, WN_, TPI_>(*d, s);
+    P3H_TILE(4, 128, 2, 2, 1)
+    P3H_TILE(4, 64, 4, 1, 1)
+    P3H_TILE(4, 32, 4, 1, 3)
+    P3H_TILE(4, 32, 4, 1, 1)
+    P3H_TILE(8, 128, 4, 2, 1)
+    P3H_TILE(8, 64, 4, 2, 1)
 #undef P3H_TILE
     DEFT_CHECK(false, -15, "conv3h: unsupported tile %dx32 x %d", th, bn);
     return -15;

@@ -58,6 +58,51 @@ extern "C" int deft_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, 
 }
 
 // ---------------------------------------------------------------------------
+// Pre-processing on the device (detector.py:346-422): cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) of the uint8 HWC
+// frame into the network input grid + ((v / 255 - mean) / std) + HWC -> NHWC(ld), ONE pass: 3 B/pixel in instead of the
+// 12 B/pixel fp32 NCHW image (and no nchw_to_nhwc pass).  cv2's fixed-point arithmetic restated (cv2 is absent here: parity
+// unpinned): source coordinates in 1/1024 px (AB_BITS = 10) from rounded per-column / per-row terms + round_delta 16, cut to 1/32 px
+// (INTER_BITS = 5); bilinear weights = products of the 1/32 fractions scaled to 2^15 (exact integers, sum 2^15); result
+// (sum + 2^14) >> 15.  The normalisation is a 3 x 256 table computed by the host in float64 like the reference's numpy expression.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ src, int sh, int sw, const double* __restrict__ minv,
+                                                            const float* __restrict__ lut, float* __restrict__ y, int N, int H, int W, int ldy) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W) return;
+    const int x = (int)(i % W);
+    const long long t = i / W;
+    const int yy = (int)(t % H), n = (int)(t / H);
+    const double* m = minv + n * 6;
+    const int X0 = deft_rint(m[0] * x * 1024.0) + deft_rint((m[1] * yy + m[2]) * 1024.0) + 16;
+    const int Y0 = deft_rint(m[3] * x * 1024.0) + deft_rint((m[4] * yy + m[5]) * 1024.0) + 16;
+    const int X = X0 >> 5, Y = Y0 >> 5;
+    const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+    const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    const unsigned char* base = src + (size_t)n * sh * sw * 3;
+    const bool x0 = (unsigned)sx < (unsigned)sw, x1 = (unsigned)(sx + 1) < (unsigned)sw, y0 = (unsigned)sy < (unsigned)sh, y1 = (unsigned)(sy + 1) < (unsigned)sh;
+    float* yp = y + (size_t)i * ldy;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int p00 = (x0 && y0) ? base[((size_t)sy * sw + sx) * 3 + c] : 0;
+        const int p01 = (x1 && y0) ? base[((size_t)sy * sw + sx + 1) * 3 + c] : 0;
+        const int p10 = (x0 && y1) ? base[((size_t)(sy + 1) * sw + sx) * 3 + c] : 0;
+        const int p11 = (x1 && y1) ? base[((size_t)(sy + 1) * sw + sx + 1) * 3 + c] : 0;
+        const int v = (w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11 + (1 << 14)) >> 15;
+        yp[c] = lut[c * 256 + v];
+    }
+    for (int c = 3; c < ldy; ++c) yp[c] = 0.f;
+}
+
+extern "C" int deft_preprocess_u8(const unsigned char* src, int N, int sh, int sw, const double* minv, const float* lut, float* y, int H, int W, int ldy, void* stream) {
+    DEFT_CHECK(src && minv && lut && y && N > 0 && sh > 0 && sw > 0 && H > 0 && W > 0 && ldy >= 3, -1, "deft_preprocess_u8: bad arguments");
+    DEFT_CHECK((long long)sh * sw * 3 < (1ll << 31), -2, "deft_preprocess_u8: source frame too large");
+    const long long tot = (long long)N * H * W;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, src, sh, sw, minv, lut, y, N, H, W, ldy);
+    DEFT_CHECK_LAUNCH("preprocess_u8");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // MaxPool2d(2,2)   (dla.py:266-267)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -651,7 +696,7 @@ extern "C" int deft_embed_blend(const float* tmp, const float* bw, const int* ma
 // ---------------------------------------------------------------------------
 #define AF_MAXOBJ 112   // 112*112*4 B = 49 KB of LDS (opts.py:339 max_object = 100)
 
-// phase 1, every pair of every frame block in parallel: e = exp(relu(h4 . w5 + b5)), parked at the pair's final
+// phase 1, every pair of every frame block in parallel: x = relu(h4 . w5 + b5), parked at the pair's final
 // place in `out`.  16 lanes per pair row (one float4 each: a 256-byte row is one coalesced request), 4 rows per
 // 16-lane group in flight, partial dot products combined with 4 xor-shuffles.
 __global__ __launch_bounds__(256) void affinity_pairs_kernel(const float* __restrict__ h4, int ldh, int C4,
@@ -682,7 +727,7 @@ __global__ __launch_bounds__(256) void affinity_pairs_kernel(const float* __rest
         a += __shfl_xor(a, 1);
         if (sub == 0 && pid[u] < TQ) {
             const int t = pid[u] / Q, j = pid[u] - t * Q;
-            out[(size_t)t * (Q + 1) + j] = expf(fmaxf(a + b5, 0.f));
+            out[(size_t)t * (Q + 1) + j] = fmaxf(a + b5, 0.f);          // the relu'd logit; the softmaxes of phase 2 subtract their maxima
         }
     }
 }
@@ -692,34 +737,47 @@ __global__ __launch_bounds__(256) void affinity_pairs_kernel(const float* __rest
 __global__ __launch_bounds__(256) void affinity_finish_kernel(const int* __restrict__ row_start, int Q, int max_object,
                                                               float* __restrict__ out) {
     __shared__ float E[AF_MAXOBJ * AF_MAXOBJ];
-    __shared__ float rs[AF_MAXOBJ], csum[AF_MAXOBJ];
+    __shared__ float rs[AF_MAXOBJ], csum[AF_MAXOBJ], rmx[AF_MAXOBJ], cmx[AF_MAXOBJ];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int t0 = row_start[f], P = row_start[f + 1] - t0;
-    const float e1 = expf(1.f);
+    if (P < 0 || P > AF_MAXOBJ || P > max_object) {
+        // row_start is DEVICE data the host entry cannot validate: a frame with more objects than the tile holds is refused
+        // loudly (NaN rows) instead of overrunning LDS
+        for (int p = tid; p < (P > 0 ? P : 0) * (Q + 1); p += 256) out[(size_t)t0 * (Q + 1) + p] = __int_as_float(0x7fc00000);
+        return;
+    }
     for (int p = tid; p < P * Q; p += 256) {
         const int i = p / Q, j = p - i * Q;
         E[p] = out[(size_t)(t0 + i) * (Q + 1) + j];
     }
     __syncthreads();
+    // F.softmax (AFE.py:136-137) subtracts the maximum of the softmax dimension: every row / column also holds the constant 1.0 of the
+    // appended unmatched entry and (max_object - n) zero paddings, so its maximum is at least 1 -- exp never overflows, whatever the logits
     if (tid < P) {
+        float m = 1.f;
+        for (int j = 0; j < Q; ++j) m = fmaxf(m, E[tid * Q + j]);
         float s = 0.f;
-        for (int j = 0; j < Q; ++j) s += E[tid * Q + j];
-        rs[tid] = s + (float)(max_object - Q) + e1;
+        for (int j = 0; j < Q; ++j) s += expf(E[tid * Q + j] - m);
+        rmx[tid] = m;
+        rs[tid] = s + (float)(max_object - Q) * expf(-m) + expf(1.f - m);
     }
     if (tid < Q) {
+        float m = 1.f;
+        for (int i = 0; i < P; ++i) m = fmaxf(m, E[i * Q + tid]);
         float s = 0.f;
-        for (int i = 0; i < P; ++i) s += E[i * Q + tid];
-        csum[tid] = s + (float)(max_object - P) + e1;
+        for (int i = 0; i < P; ++i) s += expf(E[i * Q + tid] - m);
+        cmx[tid] = m;
+        csum[tid] = s + (float)(max_object - P) * expf(-m) + expf(1.f - m);
     }
     __syncthreads();
     for (int p = tid; p < P * (Q + 1); p += 256) {
         const int i = p / (Q + 1), j = p - i * (Q + 1);
         float v;
         if (j < Q) {
-            const float e = E[i * Q + j];
-            v = fmaxf(e / rs[i], e / csum[j]);
+            const float x = E[i * Q + j];
+            v = fmaxf(expf(x - rmx[i]) / rs[i], expf(x - cmx[j]) / csum[j]);
         } else {
-            v = e1 / rs[i];
+            v = expf(1.f - rmx[i]) / rs[i];
         }
         out[(size_t)(t0 + i) * (Q + 1) + j] = v;
     }

@@ -11,9 +11,11 @@ torch is used for device memory and streams.  Reference anchors:
   AfePlan         AFE.py:88-213
   LstmPlan        kalman_filter_lstm.py:65-78
 """
+import collections
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import hiplib
@@ -139,8 +141,9 @@ P3 = _os.environ.get("DEFT_P3", "1") != "0"
 P3_MIN_COUT = int(_os.environ.get("DEFT_P3_MIN_COUT", "64"))
 BDMA = _os.environ.get("DEFT_BDMA", "1") != "0"             # igemm.hip prec-1 launches with >= 128 output columns read pre-split weights by DMA
 # (DeftGemmDesc.w3 without x3).  Measured in the pipeline (profiles/r2_*): pair layer 170 -> 189 TFLOP/s, 128-column 1x1 convs +3..6 %;
-# 64-column tiles and the DCN lose (the second weight stage costs them a workgroup per CU), so they keep splitting weights in the loop.
-BDMA_DCN = _os.environ.get("DEFT_BDMA_DCN", "0") == "1"
+# 64-column conv tiles lose (the second weight stage costs them a workgroup per CU) and keep splitting weights in the loop; the DCN uses
+# the ONE-stage form (no extra LDS, refilled after the chunk's second barrier): 11.07 -> 10.24 ms of DCN per 32-frame step.
+BDMA_DCN = _os.environ.get("DEFT_BDMA_DCN", "1") == "1"
 P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
 P3_MIN_TILES = int(_os.environ.get("DEFT_P3_MIN_TILES", "512"))   # ... and give every CU two workgroups (latency mode: 2.39 ms/frame on igemm.hip
 # with split-K vs 2.88 on the pre-split kernels, profiles/r2_latency_ab.txt); the im2col form (one 8-wave workgroup per CU) needs half as many
@@ -153,8 +156,9 @@ def halo_waste(H, W):
 
 _T = lambda bm, bn: (bm << 16) | bn
 P3_3STAGE = 1 << 29
+P3_1STAGE = 1 << 30
 P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAGE, _T(128, 64), _T(128, 64) | P3_3STAGE, _T(256, 64),
-            _T(64, 64), _T(64, 64) | P3_3STAGE}       # igemm3.hip deft_p3_dispatch; a forced tile outside this set keeps the conv on igemm.hip
+            _T(64, 64), _T(64, 64) | P3_3STAGE, _T(128, 128) | P3_1STAGE, _T(128, 64) | P3_1STAGE, _T(64, 128) | P3_1STAGE, _T(64, 64) | P3_1STAGE}       # igemm3.hip deft_p3_dispatch; a forced tile outside this set keeps the conv on igemm.hip
 
 # cross-workgroup split-K for launches too small to fill the chip (DeftGemmDesc.splitk); DEFT_SPLITK=0 turns it off
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
@@ -179,12 +183,14 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
         if (M // (H * W)) * -(-H // 4) * -(-W // 32) * -(-Cout // bn) >= P3_MIN_TILES:
             return ("halo", 0)
-    if Cout < 128 or Cin < 64 or stride != 1:
-        return None                     # in the pipeline (inputs L2-warm) the 64-column and the stride-2 layers are no faster on 6-byte pieces
-    tile = _T(128, 256) if Cout >= 256 else _T(256, 128)
-    bm, bn = tile >> 16, tile & 0xffff
-    if -(-M // bm) * -(-Cout // bn) < P3_MIN_TILES // 2:
-        return None                     # few tiles (one frame per GPU): igemm.hip's smaller tiles + cross-workgroup split-K fill the chip better
+    if Cout < 64 or Cin < 64 or stride != 1:
+        return None                     # stride-2 and 1x1 layers are no faster on 6-byte pieces (HBM- or issue-bound, tools/bench_p3.py)
+    # the ONE-stage loop with several workgroups per CU (48 / 37 KB of LDS: 3 / 4 of them) beats the 2-stage ring with one 8-wave
+    # workgroup on every shape (profiles/r2_bench_p3.log: 256->256 @38x68 179 vs 150 TFLOP/s, 64->64 @152x272 148 vs 120)
+    tile = (_T(64, 128) if Cout >= 128 else _T(128, 64)) | P3_1STAGE
+    bm, bn = (tile >> 16) & 0x1fff, tile & 0xffff
+    if -(-M // bm) * -(-Cout // bn) < P3_MIN_TILES:
+        return None                     # few tiles (one frame per GPU): igemm.hip's cross-workgroup split-K fills the chip better
     return ("im2col", tile)
 
 
@@ -230,8 +236,18 @@ class _Plan:
         self._stream_cache = hiplib.stream_ptr(self.device)
         try:
             self._run_ops()
+        except hiplib.DeftHipError:
+            self.reset_splitk()            # a launch list that stopped half way may leave split-K tickets taken: start clean next time
+            raise
         finally:
             self._stream_cache = None
+
+    def reset_splitk(self):
+        """Zero the cross-workgroup split-K ticket counters (DeftGemmDesc.ws_cnt).  They are zero after every COMPLETED launch (the
+        last arriver resets its tile's counter); only an aborted launch can leave them non-zero."""
+        sp = getattr(self, "_split", None)
+        if sp is not None and sp["cnt"] is not None:
+            sp["cnt"].zero_()
 
     def _run_ops(self):
         if self.profile is None:
@@ -504,6 +520,7 @@ class DlaSegPlan(_Plan):
         self._wcache = {}
         self.image = torch.zeros(N, 3, H, W, dtype=torch.float32, device=self.device)
         x4 = self.alloc(N, H, W, 4)
+        self._x4 = x4
         lib = self.lib
         a = (ptr(self.image), C.c_void_p(x4.addr), N, 3, H, W, 4)
         self.add("deft_nchw_to_nhwc", "image", lambda: lib.call("deft_nchw_to_nhwc", *a, self._stream()))
@@ -716,6 +733,28 @@ class DlaSegPlan(_Plan):
         self.add("deft_decode_boxes", "decode_boxes", lambda: lib.call("deft_decode_boxes", *d_, self._stream()))
 
     # ---- public --------------------------------------------------------------
+    def use_u8_input(self, sh, sw, minv=None):
+        """Switch the plan's first launch from `deft_nchw_to_nhwc` (fp32 NCHW frames, detector.py:150) to `deft_preprocess_u8`:
+        uint8 HWC frames [N, sh, sw, 3] are warped (Detector.pre_process' affine, fix_res mode), normalised and written straight
+        into the network's input buffer.  minv: dst -> src matrices [N,6] float64 (default: the reference's for sh x sw frames)."""
+        from . import preprocess as PR
+        assert self.ops[0][0] in ("deft_nchw_to_nhwc", "deft_preprocess_u8")
+        if minv is None:
+            M, _, _ = PR.input_affine(sh, sw, self.H, self.W)
+            minv = np.tile(PR.invert_affine(M)[None], (self.N, 1))
+        self.image_u8 = torch.zeros(self.N, sh, sw, 3, dtype=torch.uint8, device=self.device)
+        self._minv = self.dev(torch.from_numpy(np.ascontiguousarray(minv, np.float64)))
+        self._lut = self.dev(torch.from_numpy(PR.normalisation_table()))
+        lib, x4 = self.lib, self._x4
+        a = (ptr(self.image_u8), self.N, sh, sw, ptr(self._minv), ptr(self._lut), C.c_void_p(x4.addr), self.H, self.W, x4.ld)
+        self.ops[0] = ("deft_preprocess_u8", "image", lambda: lib.call("deft_preprocess_u8", *a, self._stream()), 0.0)
+
+    def forward_u8(self, frames_u8):
+        """frames_u8 [N, sh, sw, 3] uint8 on the device (after use_u8_input)."""
+        self.image_u8.copy_(frames_u8, non_blocking=True)
+        self.run()
+        return self
+
     def forward(self, images):
         """images [N,3,H,W] fp32 (detector.py:150).  Runs backbone + neck + hm head + decode.
         Results stay on the device: self.scores/inds/clses/cts/bboxes/head_vals, self.fmaps."""
@@ -741,6 +780,7 @@ class DlaSegPlan(_Plan):
 
 class AfePlan(_Plan):
     """Embedding extraction at detection centres + pairwise affinity (AFE.py:88-213)."""
+    EGROUP_CACHE = 8
 
     def __init__(self, sd, max_object=100, device="cuda", lib=None, align_corners=False):
         """align_corners: how grid_sample (AFE.py:178, no flag passed) maps [-1,1] onto pixels -- False = torch >= 1.3
@@ -794,9 +834,12 @@ class AfePlan(_Plan):
         copies) and the scratch of the fused embedding head."""
         key = (tuple(fm.addr for fm in fmaps), Nf, ndet)
         if not hasattr(self, "_egroups"):
-            self._egroups = {}
+            self._egroups = collections.OrderedDict()
         if key in self._egroups:
+            self._egroups.move_to_end(key)
             return self._egroups[key]
+        while len(self._egroups) >= self.EGROUP_CACHE:       # drop-in tracker path: ndet changes from frame to frame -- keep the few most
+            self._egroups.popitem(last=False)                # recent shapes (each entry owns rowmaps, scratch and split-K workspaces: MBs)
         dev = self.device
         nm = len(self.sel)
         M = Nf * ndet * 4

@@ -46,6 +46,7 @@ _SIGS = {
     "deft_pair_layer": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "deft_nchw_to_nhwc": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
     "deft_nhwc_to_nchw": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
+    "deft_preprocess_u8": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
     "deft_maxpool2x2": (C.c_int, [c_fp, c_fp] + [C.c_int] * 6 + [c_fp]),
     "deft_upsample_add": (C.c_int, [c_fp] * 4 + [C.c_int] * 8 + [c_fp, C.c_int, c_fp]),
     "deft_hm_peaks": (C.c_int, [c_fp] + [C.c_int] * 6 + [c_fp] * 3 + [C.c_int, c_fp]),
@@ -169,7 +170,7 @@ def ptr(t):
     """Device (or, under the test emulator, host) address of a tensor; None -> NULL."""
     if t is None:
         return None
-    assert t.dtype in (torch.float32, torch.int32, torch.float64), t.dtype
+    assert t.dtype in (torch.float32, torch.int32, torch.float64, torch.uint8), t.dtype
     return C.c_void_p(t.data_ptr())
 
 

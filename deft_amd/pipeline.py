@@ -42,6 +42,12 @@ class HipCompute:
             self.ev_main = torch.cuda.Event()
             self.ev_side = [torch.cuda.Event() for _ in range(streams)]
 
+    def use_u8(self, sh, sw):
+        """Feed the plans uint8 HWC frames [batch, sh, sw, 3]: warp + normalise + layout on the device (deft_preprocess_u8,
+        detector.py:377-395) instead of fp32 NCHW tensors pre-processed by the host."""
+        for p in self.plans:
+            p.use_u8_input(sh, sw)
+
     def autotune(self, images, verbose=False):
         """One-off per-layer tile search (engine._Plan.autotune) on real activations: run the
         sub-batch plans once on `images` [batch,3,H,W], then time the candidates."""
@@ -75,10 +81,10 @@ class HipCompute:
         p = self.plans[s_]
         sl = slice(s_ * self.sub, (s_ + 1) * self.sub)
         if self.graphs is not None:
-            p.image.copy_(images[sl], non_blocking=True)
+            (p.image_u8 if images.dtype == torch.uint8 else p.image).copy_(images[sl], non_blocking=True)
             self.graphs[s_].replay()
         else:
-            p.forward(images[sl])
+            p.forward_u8(images[sl]) if images.dtype == torch.uint8 else p.forward(images[sl])
             self.afe.extract(p.fmaps, p.centers if self.ndet == self.K else p.centers[:, :self.ndet], out=self.emb[sl])
 
     serialize = False      # profiling aid: run the sub-batch plans one after the other on the current stream

@@ -137,6 +137,16 @@ int deft_pair_layer(const DeftGemmDesc* d, void* stream);
 int deft_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ldy, void* stream);
 int deft_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int ldx, void* stream);
 
+/* Pre-processing of uint8 frames on the device -- Detector.pre_process (detector.py:377-395) without the host pass:
+ * cv2.warpAffine(frame, trans_input, (W, H), INTER_LINEAR) [constant 0 border] + ((v / 255 - mean) / std) + HWC -> NHWC,
+ * one kernel, written straight into the network's input buffer (replaces deft_nchw_to_nhwc on that path).
+ * src [N][sh][sw][3] uint8 (cv2 channel order); minv [N][6] double: the dst -> src matrix cv2 derives from trans_input
+ * (deft_amd.preprocess.invert_affine); lut [3][256] float: the normalisation of every uint8 level per channel, computed in
+ * float64 like the reference's numpy expression; y [N][H][W][ldy] (channels >= 3 zeroed).  cv2's fixed-point arithmetic
+ * (coordinates cut to 1/32 px, 15-bit weights) restated -- cv2 is not available here: parity unpinned. */
+int deft_preprocess_u8(const unsigned char* src, int N, int sh, int sw, const double* minv, const float* lut, float* y,
+                       int H, int W, int ldy, void* stream);
+
 /* MaxPool2d(2,2) -- Tree.downsample, dla.py:266-267, 273. */
 int deft_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, int ldx, int ldy, void* stream);
 
@@ -219,7 +229,9 @@ int deft_embed_blend(const float* tmp, const float* bw, const int* map_out, int 
  * x = relu(h4 . w5 + b5) per pair, then the dual softmax with the analytic padding
  * terms ((max_object - n) * e^0 + e^1) and the max/unmatched-column assembly
  * (AFE.py:119-150).  h4 [T*Q][ldh] (pairs ordered (t,j)), row_start [F+1] prefix of
- * history object counts (device array; T = row_start[F] is also passed by value); out [T][Q+1].  Two launches:
+ * history object counts (device array; T = row_start[F] is also passed by value; every frame's count must be <= max_object <=
+ * 112 -- a frame that violates it gets NaN rows, the kernel cannot report an error); out [T][Q+1].  The softmaxes subtract their
+ * maximum like F.softmax (finite for any logit).  Two launches:
  * all T*Q pairs in parallel, then one block per history frame for the softmaxes (in place on `out`). */
 int deft_affinity_finish(const float* h4, int ldh, int C4, const float* w5, float b5,
                          const int* row_start, int F, int T, int Q, int max_object,

@@ -379,3 +379,38 @@ def track_similarity(sim_frame, tracks_nodes, frame_index, num_detections, datas
             a = a[a.shape[0] - mm:]
         rows_out.append(np.median(a, axis=0).tolist())
     return np.array(rows_out)
+
+
+# --------------------------------------------------------------------------
+# pre-processing (detector.py:377-395): cv2.warpAffine(INTER_LINEAR, constant 0 border) + normalisation, numpy restatement
+# of cv2's fixed-point arithmetic (cv2 itself is absent here: PARITY UNPINNED; checked against a float bilinear resampling)
+# --------------------------------------------------------------------------
+def warp_affine_u8(img, M, out_w, out_h):
+    """img [h,w,3] uint8, M 2x3 forward (src -> dst) -> [out_h, out_w, 3] uint8."""
+    M = np.asarray(M, np.float64)
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    i00, i01, i10, i11 = M[1, 1] * D, -M[0, 1] * D, -M[1, 0] * D, M[0, 0] * D
+    b0, b1 = -i00 * M[0, 2] - i01 * M[1, 2], -i10 * M[0, 2] - i11 * M[1, 2]
+    xs, ys = np.arange(out_w, dtype=np.float64), np.arange(out_h, dtype=np.float64)
+    X = (np.rint(i00 * xs * 1024.0).astype(np.int64)[None, :] + np.rint((i01 * ys + b0) * 1024.0).astype(np.int64)[:, None] + 16) >> 5
+    Y = (np.rint(i10 * xs * 1024.0).astype(np.int64)[None, :] + np.rint((i11 * ys + b1) * 1024.0).astype(np.int64)[:, None] + 16) >> 5
+    sx, sy, fx, fy = X >> 5, Y >> 5, X & 31, Y & 31
+    h, w = img.shape[:2]
+    pad = np.zeros((h + 2, w + 2, 3), np.int64)
+    pad[1:-1, 1:-1] = img
+
+    def tap(yy, xx):
+        ok = (yy >= -1) & (yy <= h) & (xx >= -1) & (xx <= w)
+        return np.where(ok[..., None], pad[np.clip(yy + 1, 0, h + 1), np.clip(xx + 1, 0, w + 1)], 0)
+    w00 = ((32 - fy) * (32 - fx) * 32)[..., None]; w01 = ((32 - fy) * fx * 32)[..., None]
+    w10 = (fy * (32 - fx) * 32)[..., None]; w11 = (fy * fx * 32)[..., None]
+    v = (w00 * tap(sy, sx) + w01 * tap(sy, sx + 1) + w10 * tap(sy + 1, sx) + w11 * tap(sy + 1, sx + 1) + (1 << 14)) >> 15
+    return v.astype(np.uint8)
+
+
+def preprocess_u8(img, M, out_w, out_h, mean, std):
+    """detector.py:389-394: warp, ((x / 255. - mean) / std).astype(float32), HWC -> [1,3,H,W]."""
+    inp = warp_affine_u8(img, M, out_w, out_h)
+    x = ((inp / 255.0 - mean.reshape(1, 1, 3)) / std.reshape(1, 1, 3)).astype(np.float32)
+    return torch.from_numpy(x.transpose(2, 0, 1)[None].copy())

@@ -352,6 +352,54 @@ def run_association():
     print("  association fixtures written (reference fuse_motion / fuse_motion_ddd)")
 
 
+def run_postprocess():
+    """utils.post_process.generic_post_process (post_process.py:29-112) and utils.ddd_utils.nms (ddd_utils.py:178-245) of the
+    reference on synthetic decoded detections (MOT heads and the nuScenes 3-D heads): inputs and outputs as fixtures for
+    deft_amd.postprocess.  cv2.getAffineTransform is the float64 3-point solve of tests/ref_shims.py (cv2 is absent: unpinned)."""
+    sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+    import ref_shims
+    from types import SimpleNamespace
+    ref_shims.install()
+    ref_import.install_stubs(OracleDCN)
+    ref_shims.install_detector_stubs()
+    from utils.post_process import generic_post_process
+    from utils.ddd_utils import nms
+    g = np.random.RandomState(5)
+    fix = {}
+    for tag, ddd, (Hh, Ww, oh, ow) in (("mot", False, (1080, 1920, 152, 272)), ("nusc", True, (900, 1600, 112, 200))):
+        K = 40
+        scores = np.sort(g.rand(1, K).astype(np.float32) * 0.9)[:, ::-1].copy()
+        cts = (g.rand(1, K, 2) * np.array([ow, oh])).astype(np.float32)
+        wh = (g.rand(1, K, 2) * 30 + 2).astype(np.float32)
+        dets = {"scores": scores, "clses": g.randint(0, 10 if ddd else 1, (1, K)).astype(np.float32), "cts": cts,
+                "bboxes": np.concatenate([cts - wh / 2, cts + wh / 2], 2).astype(np.float32), "tracking": g.randn(1, K, 2).astype(np.float32) * 3}
+        calib = np.array([[1266.4, 0.0, 816.3, 0.0], [0.0, 1266.4, 491.5, 0.0], [0.0, 0.0, 1.0, 0.0]], np.float32)
+        if ddd:
+            dets.update(dep=(g.rand(1, K, 1) * 60 + 3).astype(np.float32), dim=(g.rand(1, K, 3) * 3 + 0.5).astype(np.float32),
+                        rot=g.randn(1, K, 8).astype(np.float32), amodel_offset=g.randn(1, K, 2).astype(np.float32))
+        c = np.array([Ww / 2.0, Hh / 2.0], np.float32); s = np.float32(max(Hh, Ww))
+        opt = SimpleNamespace(out_thresh=0.25)
+        ref = generic_post_process(opt, {k: v.copy() for k, v in dets.items()}, [c], [s], oh, ow, 10, [calib], Hh, Ww)[0]
+        for k, v in dets.items():
+            fix["%s_in_%s" % (tag, k)] = v
+        fix["%s_c" % tag], fix["%s_s" % tag], fix["%s_hw" % tag], fix["%s_calib" % tag] = c, s, np.array([oh, ow]), calib
+        fix["%s_n" % tag] = np.array(len(ref))
+        for key in ("score", "class", "ct", "bbox", "tracking") + (("dep", "dim", "alpha", "loc", "rot_y") if ddd else ()):
+            fix["%s_out_%s" % (tag, key)] = np.array([np.asarray(r[key]).reshape(-1) for r in ref])
+        assert 5 < len(ref) < K
+    for case, (n, ov) in enumerate(((30, 0.8), (17, 0.7), (1, 0.8), (60, 0.5))):
+        ctr = g.rand(n, 2) * 200
+        sz = g.rand(n, 2) * 60 + 10
+        boxes = np.concatenate([ctr - sz / 2, ctr + sz / 2], 1)
+        boxes[n // 2:] = boxes[:n - n // 2] + g.randn(n - n // 2, 4) * 2          # near-duplicates to suppress
+        sc = g.rand(n)
+        keep, count = nms(torch.from_numpy(boxes), torch.from_numpy(sc), overlap=ov)
+        fix["nms%d_boxes" % case], fix["nms%d_scores" % case], fix["nms%d_overlap" % case] = boxes, sc, np.array(ov)
+        fix["nms%d_keep" % case], fix["nms%d_count" % case] = keep.numpy(), np.array(count)
+    np.savez_compressed(os.path.join(GOLD, "postprocess.npz"), **fix)
+    print("  post-process fixtures written (reference generic_post_process / nms)")
+
+
 def run_detector_trace(lstm):
     """The reference's OWN `Detector.run` (detector.py:112-344: pre-processed branch of src/test.py:213, its post-processing, its
     Tracker) over 6 synthetic frames with the reference model on CPU, and a TRACE of every call it makes into the seams this
@@ -482,6 +530,7 @@ if __name__ == "__main__":
     run_motion("nuscenes")
     run_track_similarity()
     run_association()
+    run_postprocess()
     run_detector_trace(lstm=False)
     run_detector_trace(lstm=True)
     print("golden fixtures written to", os.path.abspath(GOLD))

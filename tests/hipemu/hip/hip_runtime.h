@@ -396,11 +396,11 @@ static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); re
 static inline void __builtin_amdgcn_s_setprio(int) {}
 // buffer-load hooks of deft_amd/csrc/common.h: num_records = 2^31-1, offsets >= 2^31 read as zero
 #define DEFT_BUFFER_HOOKS 1
-struct deft_rsrc_t { const char* base; };
-static inline deft_rsrc_t deft_make_rsrc(const void* base) { return deft_rsrc_t{(const char*)base}; }
+struct deft_rsrc_t { const char* base; unsigned n; };
+static inline deft_rsrc_t deft_make_rsrc(const void* base) { return deft_rsrc_t{(const char*)base, 0x7FFFFFFFu}; }
 static inline hipemu_f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off) {
     hipemu_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (byte_off < 0x7FFFFFFFu - 15u) memcpy(&v, r.base + byte_off, 16);
+    if (byte_off < r.n && byte_off + 16u <= r.n) memcpy(&v, r.base + byte_off, 16);
     return v;
 }
 static inline void deft_buffer_load_lds_x4(deft_rsrc_t r, float* lds_wave_base, unsigned byte_off) {
@@ -409,11 +409,13 @@ static inline void deft_buffer_load_lds_x4(deft_rsrc_t r, float* lds_wave_base, 
 }
 static inline void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* lds_wave_base, unsigned voff, unsigned soff) {
     hipemu_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (voff < 0x7FFFFFFFu - 15u) memcpy(&v, r.base + voff + soff, 16);      // range check on voff alone, like the hardware
+    if (voff < r.n && voff + 16u <= r.n) memcpy(&v, r.base + voff + soff, 16);      // range check on voff alone, like the hardware
     memcpy((char*)lds_wave_base + 16 * hipemu::S().lane, &v, 16);
 }
 #define DEFT_PIPE_BARRIER(N) __syncthreads()      /* the emulator's DMA is synchronous */
 #define DEFT_PIPE_BARRIER_ONLY() __syncthreads()
 #define DEFT_WAIT_VM(N) ((void)0)
+#define DEFT_RINT_HOOK 1
+static inline int deft_rint(double v) { return (int)std::nearbyint(v); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }

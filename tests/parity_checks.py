@@ -1055,3 +1055,41 @@ def check_detector_trace(lib, device, tag):
         return worst
     finally:
         hiplib._lib = saved_lib
+
+
+def check_preprocess_u8(lib, device, N=2, sh=45, sw=80, H=32, W=64, seed=0):
+    """deft_preprocess_u8 (uint8 HWC frame -> warped, normalised NHWC input of the plan) against the numpy restatement of
+    detector.py:377-395 with cv2's fixed-point warp (oracle.preprocess_u8): EXACT; and that restatement against a float bilinear
+    resampling of the same affine (within one uint8 level: the fixed-point form is cv2's, not an approximation of ours)."""
+    from deft_amd import preprocess as PR
+    from scipy.ndimage import map_coordinates
+    g = np.random.RandomState(seed)
+    frames = g.randint(0, 256, (N, sh, sw, 3)).astype(np.uint8)
+    frames[:, 5:20, 10:40] = (np.linspace(0, 255, 30)[None, None, :, None]).astype(np.uint8)          # a smooth ramp next to noise
+    sd = O.synth_state_dict("mot")
+    plan = engine.DlaSegPlan(sd, N, H, W, "mot", K=5, device=device, lib=lib)
+    plan.use_u8_input(sh, sw)
+    plan.image_u8.copy_(torch.from_numpy(frames))
+    plan.ops[0][2]()                                                  # the pre-processing launch alone
+    got = plan._x4.to_nchw().cpu()[:, :3]
+    M, c, s = PR.input_affine(sh, sw, H, W)
+    for n in range(N):
+        ref = O.preprocess_u8(frames[n], M, W, H, PR.MEAN, PR.STD)
+        assert torch.equal(got[n:n + 1], ref), maxabs(got[n:n + 1], ref)
+    assert float(plan._x4.buf.view(N, H, W, 4)[..., 3].abs().max()) == 0.0
+    # the restated fixed-point warp vs float bilinear sampling (constant-0 border) of the same inverse map
+    inv = PR.invert_affine(M)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    sx, sy = inv[0] * xx + inv[1] * yy + inv[2], inv[3] * xx + inv[4] * yy + inv[5]
+    warped = O.warp_affine_u8(frames[0], M, W, H).astype(np.float64)
+    fl = np.stack([map_coordinates(frames[0][..., ch].astype(np.float64), [sy, sx], order=1, mode="constant", cval=0.0) for ch in range(3)], -1)
+    inner = (sx > 1) & (sx < sw - 2) & (sy > 1) & (sy < sh - 2)
+    assert np.abs(warped - fl)[inner].max() <= 4.5                   # 1/32-px coordinate quantisation on white noise (gradient up to 255/px)
+    ramp = inner & (sy > 6) & (sy < 18) & (sx > 12) & (sx < 38)
+    assert ramp.sum() > 20 and np.abs(warped - fl)[ramp].max() <= 1.0 # on smooth content: within one level
+    # end to end: the plan fed with uint8 frames == the plan fed with the reference-style pre-processed fp32 tensor
+    plan.forward_u8(torch.from_numpy(frames).to(plan.device))
+    a = [plan.scores.clone(), plan.inds.clone(), plan.bboxes.clone()]
+    p2 = engine.DlaSegPlan(sd, N, H, W, "mot", K=5, device=device, lib=lib)
+    p2.forward(torch.cat([O.preprocess_u8(frames[n], M, W, H, PR.MEAN, PR.STD) for n in range(N)]).to(p2.device))
+    assert torch.equal(a[1], p2.inds) and torch.equal(a[0], p2.scores) and torch.equal(a[2], p2.bboxes)

@@ -125,3 +125,22 @@ def test_compat_modules_expose_the_two_entry_points():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         assert getattr(mod, attr) is getattr(A, attr)
+
+
+def test_lapjv_without_limit_and_nan():
+    """the no-limit form pads to a max(n,m) square with zeros like lap (every row of the smaller side is matched, also with
+    negative costs); NaN costs never match and never raise."""
+    from deft_amd import association as A
+    g = np.random.RandomState(4)
+    c = g.randn(3, 5)                                    # negative entries
+    tot, x, y = A.lapjv(c, extend_cost=True)
+    assert (x >= 0).all() and (y >= 0).sum() == 3
+    best = min(sum(c[i, p[i]] for i in range(3)) for p in __import__("itertools").permutations(range(5), 3))
+    assert abs(tot - best) <= 1e-12
+    with pytest.raises(ValueError):
+        A.lapjv(c)
+    c2 = g.rand(4, 4); c2[1, :] = np.nan; c2[2, 3] = np.nan
+    tot, x, y = A.lapjv(c2, extend_cost=True, cost_limit=0.9)
+    assert x[1] == -1 and not (x[2] == 3)
+    tot, x, y = A.lapjv(c2)
+    assert x[1] == -1 and sorted(v for v in x if v >= 0) == sorted(set(v for v in x if v >= 0))

@@ -252,7 +252,9 @@ def test_track_similarity_random_sweep(emu_lib):
     (1, 7, 9, 96, 128, 64, 1, 1, T(256, 128), T(128, 64) | (1 << 29)),        # 1x1 with Cin not a power of two; 3 LDS stages
     (1, 7, 9, 64, 128, 256, 3, 1, T(128, 128) | (1 << 29), T(128, 256)),
     (1, 5, 6, 64, 64, 64, 3, 1, T(64, 64) | (1 << 29), 0),                    # nk = 18 / auto tile
-    (1, 4, 5, 32, 64, 64, 1, 1, 0, T(64, 64)),                                # single-chunk K (nk == 1) feeding a 3x3
+    (1, 4, 5, 32, 64, 64, 1, 1, 0, T(64, 64)),
+    (2, 9, 11, 64, 128, 128, 3, 1, T(128, 128) | (1 << 30), T(128, 64) | (1 << 30)),     # one LDS stage, several workgroups per CU
+    (2, 7, 9, 64, 128, 64, 3, 2, T(64, 128) | (1 << 30), T(64, 64) | (1 << 30)),                                # single-chunk K (nk == 1) feeding a 3x3
 ])
 def test_conv_presplit(emu_lib, args):
     pc.check_conv_p3(emu_lib, "cpu", *args)
@@ -273,6 +275,7 @@ def test_peaked_heatmap_ordered_topk(emu_lib):
     (1, 8, 32, 32, 64, 3, 1, 1, 0), (2, 9, 37, 64, 128, 3, 1, 1, 0), (1, 5, 70, 64, 64, 3, 1, 1, T(4, 64)),
     (1, 6, 33, 32, 32, 3, 1, 1, T(4, 32)), (1, 10, 40, 64, 128, 3, 1, 1, T(8, 128)), (1, 9, 31, 128, 64, 3, 1, 1, T(8, 64)),
     (1, 4, 20, 64, 200, 3, 1, 1, T(4, 128)),
+    (2, 7, 40, 64, 32, 3, 1, 1, T(4, 32) | (1 << 29)),        # narrow tile, one tap per interval (default: a filter row per interval)
 ])
 def test_conv_halo(emu_lib, args):
     pc.check_conv(emu_lib, "cpu", *args, res=True, relu=True, p3="halo")
@@ -287,3 +290,7 @@ def test_weight_dma_identical(emu_lib):
 def test_composed_dropin_replays_reference_trace(emu_lib, tag):
     """The reference's own Detector.run, traced (tests/golden/detector_trace_*.npz), replayed through the composed HIP path."""
     print(pc.check_detector_trace(emu_lib, "cpu", tag))
+
+
+def test_preprocess_u8(emu_lib):
+    pc.check_preprocess_u8(emu_lib, "cpu")

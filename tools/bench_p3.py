@@ -12,6 +12,7 @@ from deft_amd import engine, hiplib  # noqa: E402
 
 T = lambda bm, bn: (bm << 16) | bn
 S3 = 1 << 29
+S1 = 1 << 30
 lib = hiplib.get_lib()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""          # run only the cases whose name contains this
@@ -41,6 +42,8 @@ def case(name, H, W, Ci, Co, k, stride, tiles, res=False):
     ref = None
     x0 = torch.randn(B * H * W * Ci, generator=g).cuda()
     for tile in [None] + tiles:
+        if tile is not None and not isinstance(tile, tuple) and -(-Co // (tile & 0xffff)) * (tile & 0xffff) > -(-Co // 128) * 128:
+            continue                                  # tile wider than the padded weight matrix
         plan = engine._Plan("cuda", lib)
         xv = plan.alloc(B, H, W, Ci)
         xv.buf.copy_(x0)
@@ -62,12 +65,12 @@ def case(name, H, W, Ci, Co, k, stride, tiles, res=False):
         if halo:
             label = "P3 halo %dx32 x %d" % (tile[1] >> 16, tile[1] & 0xffff)
         else:
-            label = "igemm.hip (in-loop split)" if tile is None else "P3 %3dx%-3d %dst" % ((tile >> 16) & 0x1fff, tile & 0xffff, 3 if tile & S3 else 2) if tile else "P3 auto"
+            label = "igemm.hip (in-loop split)" if tile is None else "P3 %3dx%-3d %dst" % ((tile >> 16) & 0x1fff, tile & 0xffff, 1 if tile & S1 else (3 if tile & S3 else 2)) if tile else "P3 auto"
         print("%-30s %-28s %7.3f ms %6.1f TF/s  %s" % (name, label, ms, fl / ms / 1e9, same), flush=True)
 
 
-ALL = [T(256, 128), T(128, 128), T(128, 256)]
-N64 = [T(256, 64), T(128, 64), T(64, 64)]
+ALL = [T(256, 128), T(128, 128), T(128, 256), T(128, 128) | S1, T(64, 128) | S1, T(128, 64) | S1]
+N64 = [T(256, 64), T(128, 64), T(64, 64), T(128, 64) | S1, T(64, 64) | S1]
 H128 = [("h", T(4, 128)), ("h", T(8, 128))]
 H64 = [("h", T(4, 64)), ("h", T(8, 64))]
 case("3x3 64->64 @152x272", 152, 272, 64, 64, 3, 1, N64 + H64, res=True)
