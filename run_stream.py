@@ -86,6 +86,12 @@ def main():
     dt = time.perf_counter() - t0
     if dist.is_initialized():
         dist.barrier()
+    try:                                   # RCCL prints its banner through C stdio; flush it BEFORE the JSON line (last line of stdout)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if rank == 0:
         print(json.dumps({"frames": nsteps * world, "world": world, "size": "%dx%d" % (W, H), "collectives": bool(st.collective),
                           "backend": dist.get_backend() if dist.is_initialized() else None, "ms_per_frame": round(dt / (nsteps * world) * 1e3, 3),

@@ -219,6 +219,11 @@ def test_topk_seed_sweep_both_arithmetics(gpu_lib, dataset, H, W, nseeds):
     finally:
         engine.PREC = saved
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 8)))      # ATen's CPU convs thrash far below the box's 256 hardware threads
+    # MOT net: heat-map logits agree to <= 1.1e-4 and every index difference is a <= 1e-4 tie.  The synthetic KITTI / nuScenes nets are an
+    # order of magnitude worse conditioned (logit range [-13, 4.6], DCN-stage maps differ by 6e-5 relative between ANY two fp32 summation
+    # orders -- the fp32-MFMA path shows the same 7e-4 as the split path, tools/probe/fmap_errors.py): there the tie level is twice the
+    # frame's own cross-implementation error
+    logit_tol, tie = (2e-4, 1e-4) if dataset == "mot" else (3e-3, None)
     diff = {0: [], 1: []}
     worst = {0: 0.0, 1: 0.0}
     for seed in range(1000, 1000 + nseeds):
@@ -227,14 +232,14 @@ def test_topk_seed_sweep_both_arithmetics(gpu_lib, dataset, H, W, nseeds):
             out, _ = O.dlaseg_forward(x, sd, dataset)
         for prec in (0, 1):
             plans[prec].forward(x.cuda())
-            same, err = pc.compare_topk_with_oracle(plans[prec], out, 100)
+            same, err = pc.compare_topk_with_oracle(plans[prec], out, 100, logit_tol=logit_tol, tie=tie)
             worst[prec] = max(worst[prec], err)
             if not same:
                 diff[prec].append(seed)
     rep = {"dataset": dataset, "H": H, "W": W, "frames": nseeds, "K": 100,
            "frames_with_tie_level_index_differences": {"prec0_fp32_mfma": len(diff[0]), "prec1_split_bf16": len(diff[1])},
            "seeds": {"prec0": diff[0], "prec1": diff[1]}, "max_abs_logit_error": {"prec0": worst[0], "prec1": worst[1]},
-           "every_difference_is_a_tie_below_logit": 1e-4}
+           "every_difference_is_a_tie_below_logit": tie if tie is not None else "2 x the frame's max |logit error|"}
     print(json.dumps(rep))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -243,7 +248,7 @@ def test_topk_seed_sweep_both_arithmetics(gpu_lib, dataset, H, W, nseeds):
         pass
     # the default arithmetic is not worse than the fp32 MFMA (binomial counting noise allowed: the events are rare and independent)
     assert len(diff[1]) <= len(diff[0]) + max(2, len(diff[0]) // 2), rep
-    assert worst[1] <= 2e-4 and worst[0] <= 2e-4
+    assert worst[1] <= logit_tol and worst[0] <= logit_tol and worst[1] <= 2.5 * worst[0] + 1e-5
 
 
 @pytest.mark.parametrize("prec", [0, 1])
@@ -522,7 +527,7 @@ def test_sharded_stream_over_rccl(gpu_lib):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "run_stream.py"), "--frames", "5", "--size", "128x160", "--dets", "12", "--force-dist", "--check"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    rep = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert rep["check"] == "ok" and rep["collectives"] and rep["backend"] == "nccl" and rep["bytes_gathered_per_step"] > 0
 
 
@@ -535,7 +540,7 @@ def test_frame_pipeline_over_rccl(gpu_lib):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "A", "--batch", "4", "--streams", "1", "--steps", "4", "--warmup", "2",
                         "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    rep = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert rep["value"] > 0 and rep["n_gpus"] == 1
 
 
