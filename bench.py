@@ -82,9 +82,9 @@ def cpu_baseline(cfg, frames=5):
             O.afe_affinity(hx, emb, sd, 100)
         if lsd is not None:
             nin = lsd["lstm.weight_ih_l0"].shape[1]
-            h = torch.zeros(1, 1, 128); c0 = torch.zeros(1, 1, 128)
+            h = torch.zeros(1, 128); c0 = torch.zeros(1, 128)
             for _ in range(nd):                                     # the reference steps the LSTM once per matched track
-                O.lstm_predict(h, c0, torch.randn(1, 1, nin, generator=g), lsd)
+                O.lstm_predict(h, c0, torch.randn(1, nin, generator=g), lsd)
     with torch.no_grad():
         frame()                                                     # full-size warm-up (thread pool, allocator, oneDNN primitives)
         for _ in range(frames):
@@ -215,7 +215,8 @@ def main():
             compu.use_u8(sh, sw)
             pipeu = FramePipeline(compu, B, NDET, compu.D, history=HIST, device=dev, exchange=gather)
             feeder = FrameFeeder(B, sh, sw, dev)
-            fresh = [torch.randint(0, 256, (B, sh, sw, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7 + i)) for i in range(2)]
+            # the decoder / camera driver of a real feeder writes straight into pinned staging buffers: no pageable -> pinned memcpy here
+            fresh = [torch.randint(0, 256, (B, sh, sw, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7 + i)).pin_memory() for i in range(2)]
             aff_host = torch.empty(B, HIST * NDET, NDET + 1).pin_memory()
             det_host = torch.empty(B, KDET, 6).pin_memory()
             for i in range(HIST + 2):                                # warm-up into the steady state (history ring full)
@@ -241,7 +242,7 @@ def main():
             extras["value_incl_pcie"] = round(nst * B / d1, 3)
             extras["pcie"] = {"steps": nst, "frame": "%dx%dx3 uint8" % (sw, sh), "h2d_bytes_per_step": B * sh * sw * 3,
                               "d2h_bytes_per_step": aff_host.numel() * 4 + det_host.numel() * 4,
-                              "note": "uint8 frames from pinned host memory, double-buffered on a copy stream (host staging copy included), warp + "
+                              "note": "uint8 frames from pinned host memory, double-buffered on a copy stream, warp + "
                                       "normalise on the device; per-step D2H of detections and affinity blocks"}
             del compu, pipeu, feeder
         # ---- latency mode: one frame per step per GPU, hipGraph replay (BASELINE configs[2]: 8 frames/batch over 8 GPUs = one per GPU) ----

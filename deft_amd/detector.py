@@ -7,6 +7,7 @@ regression heads run as ONE plan of HIP launches (deft_amd.engine.DlaSegPlan) wi
 single D2H copy of the K detection records, instead of the reference's four
 `torch.cuda.synchronize()` points (detector.py:188, 534, 541, 545).
 """
+import numpy as np
 import torch
 
 from . import engine, hiplib
@@ -72,6 +73,33 @@ class Detector(object):
             import time
             return output, dets, time.time(), plan.fmaps
         return output, dets, plan.fmaps
+
+    # ---- between process() and Tracker.update(): the reference's post-processing, vectorised (deft_amd/postprocess.py) ----
+    def post_process(self, dets, meta, scale=1):
+        """detector.py:553-575: network output grid -> original image coordinates (+ depth un-projection for the 3-D heads).
+        Returns the reference's list of per-detection dicts."""
+        from . import postprocess as PP
+        post = PP.generic_post_process(dets, meta["c"], meta["s"], meta["out_height"], meta["out_width"],
+                                       getattr(self.opt, "out_thresh", 0.0), calib=meta.get("calib"))
+        self.this_calib = meta.get("calib")
+        if scale != 1 and "bbox" in post:
+            post["bbox"] = post["bbox"] / np.float32(scale)
+        self._post = post
+        return PP.as_result_list(post)
+
+    def merge_outputs(self, detections):
+        """detector.py:577-583 (single test scale)."""
+        thr = getattr(self.opt, "out_thresh", 0.0)
+        return [d for d in detections[0] if d["score"] > thr]
+
+    def nuscenes_targets(self, results, image_info, nms=True):
+        """The nuScenes branch of Detector.run up to the tracker calls (detector.py:200-338): per tracking class the arguments of
+        `self.tracker[class_name].update(results, FeatureMaps, ddd_boxes=, depths_by_class=, ddd_org_boxes=, submission=, classe=)`."""
+        from . import postprocess as PP
+        post = {k: np.stack([np.asarray(r[k]) for r in results]) if results else np.zeros((0,)) for k in ("score", "class", "bbox", "dim", "loc", "rot_y")}
+        if not results:
+            return {n: {"results": [], "ddd_boxes": [], "depths": [], "ddd_org_boxes": [], "submission": []} for n in PP.NUSCENES_TRACKING_NAMES}
+        return PP.nuscenes_frame(post, image_info, nms=nms)
 
     def reset_tracking(self, opt):
         """detector.py:677-686 (the recorder mirror lives in deft_amd.tracker)."""

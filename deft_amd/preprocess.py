@@ -65,10 +65,13 @@ class FrameFeeder:
         if self.device.type != "cuda":
             self.dev[k].copy_(frames_u8)
             return k
-        self.host[k].copy_(frames_u8)
+        src = frames_u8
+        if not frames_u8.is_pinned():              # pageable source: stage it (a host memcpy; decoders should write into pinned memory)
+            self.host[k].copy_(frames_u8)
+            src = self.host[k]
         with torch.cuda.stream(self.copy):
             self.copy.wait_event(self.free[k])
-            self.dev[k].copy_(self.host[k], non_blocking=True)
+            self.dev[k].copy_(src, non_blocking=True)
             self.ready[k].record(self.copy)
         return k
 

@@ -124,3 +124,25 @@ def test_nuscenes_branch_against_scalar_restatement():
         if len(full):
             keep, _ = PP.greedy_nms(full[:, :4], full[:, -1], overlap=0.7 if name in ("bus", "truck") else 0.8)
             assert np.array_equal(kept, full[sorted(set(keep.tolist()))]) and np.array_equal(kept[0], full[0])
+
+
+def test_detector_mirror_post_process_methods():
+    """deft_amd.detector.Detector.post_process / merge_outputs / nuscenes_targets: the reference's method names and return
+    shapes (detector.py:553-583, 200-338) on top of the vectorised functions -- checked against the same reference fixtures."""
+    from types import SimpleNamespace
+    from deft_amd.detector import Detector
+    f = np.load(GOLD)
+    det = Detector.__new__(Detector)                     # the methods under test touch no device state
+    det.opt = SimpleNamespace(out_thresh=0.25)
+    dets = {k[8:]: f[k] for k in f.files if k.startswith("nusc_in_")}
+    oh, ow = [int(v) for v in f["nusc_hw"]]
+    meta = {"c": f["nusc_c"], "s": f["nusc_s"], "out_height": oh, "out_width": ow, "calib": f["nusc_calib"]}
+    res = det.post_process(dets, meta)
+    assert len(res) == int(f["nusc_n"]) and abs(float(res[3]["rot_y"]) - float(f["nusc_out_rot_y"][3])) <= 1e-6
+    merged = det.merge_outputs([res])
+    assert len(merged) == int((f["nusc_out_score"].reshape(-1) > 0.25).sum())
+    info = {"trans_matrix": np.eye(3, 4), "cs_record_rot": [1, 0, 0, 0], "cs_record_trans": [0, 0, 0], "pose_record_rot": [1, 0, 0, 0], "pose_record_trans": [0, 0, 0]}
+    by_class = det.nuscenes_targets(merged, info)
+    assert set(by_class) == set(__import__("deft_amd.postprocess", fromlist=["x"]).NUSCENES_TRACKING_NAMES)
+    assert sum(len(v["results"]) for v in by_class.values()) > 0
+    assert det.nuscenes_targets([], info)["car"]["results"] == []

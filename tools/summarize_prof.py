@@ -43,7 +43,7 @@ if os.path.exists(st):
             break
         out.append("| `%s` | %s | %.2f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                     float(r["AverageNs"]) / 1e3, r["Percentage"]))
-    ig = [(int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(st)) if "igemm" in r["Name"]]
+    ig = [(int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(st)) if "igemm" in r["Name"] or "conv3h" in r["Name"]]
     if ig:
         out.append("")
         out.append("All `igemm*` kernels together: %d launches, average %.1f us (compare `roofline.avg_launch_us` of the bench line; "
@@ -86,7 +86,7 @@ if os.path.exists(fe) and os.path.exists(wr):
     out.append("")
 if os.path.exists(fe) and os.path.exists(wr):
     # dominant kernel family for bench.py's roofline.traffic: HBM bytes per launch, averaged over all igemm launches
-    fk = [k for k in pf if "igemm" in k]
+    fk = [k for k in pf if "igemm" in k or "conv3h" in k]
     nl = sum(nf[k] for k in fk)
     fetch = sum(pf[k]["FETCH_SIZE"] for k in fk) * 1024.0 * 2.0          # KiB -> B, gfx950 wide-stream correction x2
     write = sum(pw.get(k, {}).get("WRITE_SIZE", 0.0) for k in fk) * 1024.0
