@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("igemm.hip", "igemm3.hip", "ops.hip")]
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("igemm.hip", "igemm3.hip", "direct.hip", "ops.hip")]
 DEPS = SRCS + [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "..", "include", "deft_hip.h")]
 OUT = os.path.join(HERE, "lib", "libdeft_hip.so")
 

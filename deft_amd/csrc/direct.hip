@@ -1,0 +1,226 @@
+// Direct (patch-in-LDS) convolution for the 16-output-channel FULL-RESOLUTION layers of DLA-34 (gfx950 only):
+//   base_layer   7x7, 3(+1 pad) -> 16, stride 1, pad 3 @ H x W      (dla.py:301-306)
+//   level0       3x3, 16 -> 16,     stride 1, pad 1 @ H x W      (dla.py:307-308, _make_conv_level :331-345)
+// together 6.2 GFLOP per 1088x608 frame on 661 504 pixels -- 16 channels wide, so an implicit GEMM has 16 (32 as pixel
+// pairs) columns and a 147 / 144-deep contraction: on igemm.hip they run on v_mfma_f32_32x32x2_f32 at 61-70 TFLOP/s with the
+// matrix pipe 62 % busy (profiles/r2_summary.md), 1/3 of it on padding.  Here a workgroup stages the (8 + KH - 1) x (32 + KW - 1)
+// fp32 input patch of an 8 x 32 output tile ONCE, splits it into the three bf16 pieces (x = hi + mid + lo, exact) on the way
+// into LDS -- one split per input element instead of one per (output pixel, tap) -- and takes every tap out of the patch as
+// a shifted fragment read feeding v_mfma_f32_16x16x32_bf16 (16 pixels x 16 output channels x 32 k): six products per
+// fp32 product, fp32 accumulation, the same arithmetic as DeftGemmDesc.prec = 1.
+//
+// K order inside one MFMA (lane l: row/col l & 15, k-group g = l >> 4 holding 8 consecutive k):
+//   Cin = 16:  step t covers taps 2t and 2t+1:  tap = 2t + (g >> 1), channels 8 (g & 1) .. +7     (3x3: 5 steps, tap 9 = zero weights)
+//   Cin = 4:   step t is window row t, 8 pixels x 4 channels: pixel 2g + (e >> 2), channel e & 3  (7x7: 7 steps, pixel 7 = zero weights)
+// The weight image w3 is [steps][3 pieces][64 lanes][8 bf16]: the B fragments, loaded lane-linearly into registers once.
+#include "common.h"
+
+typedef float dc_f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int DC_TH = 8, DC_TW = 32;
+
+template <int KH, int KW, int CIN>
+struct DcCfg {
+    static_assert(CIN == 16 || CIN == 4, "16 channels, or the 4-channel (padded RGB) image");
+    static_assert(CIN == 16 || KW <= 8, "the 4-channel form covers one window row of up to 8 pixels per MFMA");
+    static constexpr int PH = DC_TH + KH - 1;
+    static constexpr int PW = DC_TW + (CIN == 16 ? KW - 1 : 8);        // Cin = 4: an 8-pixel K step reaches pixel x + 7
+    // bytes per patch pixel and piece.  Cin = 16: 32 B of data in a 48-byte slot -- 16 lanes reading 16 B at a 48-byte stride
+    // touch every LDS bank once (at 32 bytes two lanes would share each bank)
+    static constexpr int PXB = CIN == 16 ? 48 : 8;
+    static constexpr int PLANE = PH * PW * PXB;
+    static constexpr int STEPS = CIN == 16 ? (KH * KW + 1) / 2 : KH;
+    static constexpr int LDS = 3 * PLANE;
+    static constexpr int ITEMS = CIN == 16 ? PH * PW * 4 : PH * PW;      // 16-byte global loads per patch
+    static constexpr int NI = (ITEMS + 255) / 256;
+};
+
+template <int KH, int KW, int CIN>
+__global__ __launch_bounds__(256, 3) void direct_conv_kernel(const DeftGemmDesc p, int tiles_x, int tiles_y) {
+    using C = DcCfg<KH, KW, CIN>;
+    DEFT_DYN_LDS(char, smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int bid = blockIdx.x;
+    {   // XCD-aware, bijective workgroup remap (see igemm.hip): neighbouring tiles share their halo in one XCD's L2
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int txi = bid % tiles_x; bid /= tiles_x;
+    const int tyi = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int oy0 = tyi * DC_TH, ox0 = txi * DC_TW;
+
+    // ---- weights: this lane's B fragments of every step (L2-resident, lane-linear) ----
+    const bf16x8* const wf = (const bf16x8*)p.w3;
+    bf16x8 Bf[C::STEPS][3];
+#pragma unroll
+    for (int t = 0; t < C::STEPS; ++t)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Bf[t][q] = wf[(t * 3 + q) * 64 + lane];
+
+    const int co = lane & 15;                      // epilogue constants, fetched ahead of everything that waits
+    const float sc = p.scale ? p.scale[co < p.Cout ? co : 0] : 1.f, sh = p.shift ? p.shift[co < p.Cout ? co : 0] : 0.f;
+
+    // ---- stage the patch: fp32 NHWC -> three bf16 piece planes in LDS (zero outside the image) ----
+    {
+        const deft_rsrc_t rx = deft_make_rsrc(p.x);
+        dc_f32x4 v[C::NI];
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+            const int it = i * 256 + tid;
+            const int px = CIN == 16 ? it >> 2 : it, cq = CIN == 16 ? it & 3 : 0;
+            const int py = px / C::PW, pxx = px - py * C::PW;
+            const int iy = oy0 - p.pad + py, ix = ox0 - p.pad + pxx;
+            const bool ok = it < C::ITEMS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? ((unsigned)((n * p.H + iy) * p.W + ix) * (unsigned)p.ldx + (unsigned)cq * 4u) * 4u : DEFT_OOB;
+            v[i] = deft_buffer_load_x4(rx, off);
+        }
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+            const int it = i * 256 + tid;
+            if (it < C::ITEMS) {
+                const int px = CIN == 16 ? it >> 2 : it, cq = CIN == 16 ? it & 3 : 0;
+                bf16x4 h, m, l;
+                split3(v[i], h, m, l);
+                char* const dst = smem + px * C::PXB + cq * 8;
+                *(bf16x4*)dst = h;
+                *(bf16x4*)(dst + C::PLANE) = m;
+                *(bf16x4*)(dst + 2 * C::PLANE) = l;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- contraction: wave w owns output rows 2w, 2w+1 of the tile = four 16-pixel m-tiles ----
+    dc_f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = dc_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int prow = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < C::STEPS; ++t) {
+        int a0;                                     // byte offset of this lane's 16 bytes for m-tile (row 0, x 0)
+        if (CIN == 16) {
+            int tap = 2 * t + (g >> 1);
+            tap = tap < KH * KW ? tap : KH * KW - 1;                // the padding tap of the last step: zero weights, any finite data
+            const int tr = tap / KW, ts = tap - tr * KW;
+            a0 = ((2 * wave + tr) * C::PW + prow + ts) * C::PXB + (g & 1) * 16;
+        } else {
+            a0 = ((2 * wave + t) * C::PW + prow + 2 * g) * C::PXB;
+        }
+        bf16x8 Af[4][3];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const char* const ap = smem + a0 + ((mt >> 1) * C::PW + (mt & 1) * 16) * C::PXB;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (CIN == 16) {
+                    Af[mt][q] = *(const bf16x8*)(ap + q * C::PLANE);
+                } else {                                // 8-byte aligned only: two pixels as two 8-byte reads
+                    const bf16x4 u0 = *(const bf16x4*)(ap + q * C::PLANE), u1 = *(const bf16x4*)(ap + q * C::PLANE + 8);
+                    Af[mt][q] = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+        }
+        // six products, smallest terms first (as the other split-bf16 kernels); the four m-tiles interleaved so that no MFMA
+        // waits on the one before it
+#define DC_PROD(QA, QB)                                                                                             \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[mt][QA], Bf[t][QB], acc[mt], 0, 0, 0);
+        DC_PROD(1, 1) DC_PROD(2, 0) DC_PROD(0, 2) DC_PROD(1, 0) DC_PROD(0, 1) DC_PROD(0, 0)
+#undef DC_PROD
+    }
+
+    // ---- epilogue: D reg i of lane l is pixel 4 (l >> 4) + i of the m-tile, output channel l & 15 ----
+    if (co < p.Cout) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int oy = oy0 + 2 * wave + (mt >> 1);
+            if (oy >= p.OH) continue;
+            float* const yr = p.y + (size_t)((n * p.OH + oy) * (size_t)p.OW) * p.ldy + co;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ox = ox0 + (mt & 1) * 16 + 4 * g + i;
+                if (ox < p.OW) {
+                    float r = acc[mt][i] * sc + sh;
+                    if (p.relu) r = fmaxf(r, 0.f);
+                    yr[(size_t)ox * p.ldy] = r;
+                }
+            }
+        }
+    }
+}
+
+template <int KH, int KW, int CIN>
+int launch_direct(const DeftGemmDesc& d, hipStream_t s) {
+    using C = DcCfg<KH, KW, CIN>;
+    const int tiles_x = deft_cdiv(d.OW, DC_TW), tiles_y = deft_cdiv(d.OH, DC_TH);
+    const long long grid = (long long)d.N * tiles_x * tiles_y;
+    DEFT_CHECK(grid < (1ll << 31), -70, "deft_conv_direct: too many tiles");
+    hipLaunchKernelGGL((direct_conv_kernel<KH, KW, CIN>), dim3((unsigned)grid), dim3(256), C::LDS, s, d, tiles_x, tiles_y);
+    DEFT_CHECK_LAUNCH("deft_conv_direct");
+    return 0;
+}
+
+// one thread per bf16x8 of the fragment image [steps][3][64 lanes]
+__global__ __launch_bounds__(256) void split_weights_direct_kernel(const float* __restrict__ w, __bf16* __restrict__ w3, int Cout, int Kpad, int KH, int KW,
+                                                                   int Cin, int steps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= steps * 3 * 64) return;
+    const int lane = i & 63, q = (i >> 6) % 3, t = i / 192;
+    const int co = lane & 15, g = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int k = -1;                                   // index into the packed row, k = (r*KW + s)*Cin + c
+        if (Cin == 16) {
+            const int tap = 2 * t + (g >> 1);
+            if (tap < KH * KW) k = tap * 16 + (g & 1) * 8 + e;
+        } else {
+            const int s = 2 * g + (e >> 2);
+            if (s < KW) k = (t * KW + s) * 4 + (e & 3);
+        }
+        v[e] = (k >= 0 && co < Cout) ? w[(size_t)co * Kpad + k] : 0.f;
+    }
+    bf16x4 pc[2][3];
+    split3(f32x4{v[0], v[1], v[2], v[3]}, pc[0][0], pc[0][1], pc[0][2]);
+    split3(f32x4{v[4], v[5], v[6], v[7]}, pc[1][0], pc[1][1], pc[1][2]);
+    *(bf16x8*)(w3 + (size_t)i * 8) = __builtin_shufflevector(pc[0][q], pc[1][q], 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+int direct_steps(int KH, int KW, int Cin) { return Cin == 16 ? (KH * KW + 1) / 2 : KH; }
+
+}  // namespace
+
+extern "C" int deft_conv_direct(const DeftGemmDesc* d, void* stream) {
+    DEFT_CHECK(d != nullptr && d->x && d->w3 && d->y, -1, "deft_conv_direct: null descriptor / x / w3 / y");
+    DEFT_CHECK(d->stride == 1 && (d->stride_w == 0 || d->stride_w == 1) && d->OH == d->H && d->OW == d->W && d->KH == d->KW && d->pad == d->KH / 2, -72,
+               "deft_conv_direct: stride-1 'same' convs only (KH=%d KW=%d stride=%d pad=%d)", d->KH, d->KW, d->stride, d->pad);
+    DEFT_CHECK(d->Cout >= 1 && d->Cout <= 16 && d->ldy >= d->Cout, -73, "deft_conv_direct: Cout=%d (at most 16 output channels), ldy=%d", d->Cout, d->ldy);
+    DEFT_CHECK(d->res == nullptr && d->rowmap == nullptr && d->splitk <= 1 && d->y3 == nullptr && d->x3 == nullptr, -74,
+               "deft_conv_direct: no residual / rowmap / split-K / P3 operands");
+    DEFT_CHECK((d->ldx & 3) == 0 && d->ldx >= d->Cin && (((size_t)d->x | (size_t)d->w3) & 15) == 0, -75, "deft_conv_direct: ldx %% 4, 16-byte aligned x / w3");
+    DEFT_CHECK(d->M == d->N * d->OH * d->OW && (long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -76, "deft_conv_direct: M mismatch or input exceeds 2 GiB");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->KH == 3 && d->Cin == 16) return launch_direct<3, 3, 16>(*d, s);
+    if (d->KH == 7 && d->Cin == 4) return launch_direct<7, 7, 4>(*d, s);
+    DEFT_CHECK(false, -77, "deft_conv_direct: built for 3x3 x 16 channels and 7x7 x 4 channels (KH=%d Cin=%d)", d->KH, d->Cin);
+    return -77;
+}
+
+extern "C" long long deft_direct_weight_bytes(int KH, int KW, int Cin) {
+    if (!((Cin == 16 && KH * KW >= 1) || (Cin == 4 && KW <= 8)) || KH < 1 || KW < 1) return -1;
+    return (long long)direct_steps(KH, KW, Cin) * 3 * 64 * 16;
+}
+
+extern "C" int deft_split_weights_direct(const float* w, void* w3, int Cout, int Kpad, int KH, int KW, int Cin, void* stream) {
+    DEFT_CHECK(w && w3 && Cout >= 1 && Cout <= 16 && (Cin == 16 || (Cin == 4 && KW <= 8)) && KH >= 1 && KW >= 1 && Kpad >= KH * KW * Cin, -1,
+               "deft_split_weights_direct: need Cout <= 16, Cin 16 (or 4 with KW <= 8), Kpad >= KH*KW*Cin (%d %d %d %d %d)", Cout, Kpad, KH, KW, Cin);
+    const int steps = direct_steps(KH, KW, Cin);
+    hipLaunchKernelGGL(split_weights_direct_kernel, dim3(deft_cdiv(steps * 192, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, Cout, Kpad, KH, KW, Cin, steps);
+    DEFT_CHECK_LAUNCH("split_weights_direct");
+    return 0;
+}

@@ -161,6 +161,9 @@ P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAG
             _T(64, 64), _T(64, 64) | P3_3STAGE, _T(128, 128) | P3_1STAGE, _T(128, 64) | P3_1STAGE, _T(64, 128) | P3_1STAGE, _T(64, 64) | P3_1STAGE}       # igemm3.hip deft_p3_dispatch; a forced tile outside this set keeps the conv on igemm.hip
 
 # cross-workgroup split-K for launches too small to fill the chip (DeftGemmDesc.splitk); DEFT_SPLITK=0 turns it off
+# the two 16-channel full-resolution layers (base_layer 7x7, level0 3x3) on the patch-in-LDS kernel (csrc/direct.hip) instead of the
+# pixel-pair implicit GEMM on the fp32 MFMA instruction
+DIRECT = _os.environ.get("DEFT_DIRECT", "1") != "0"
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
 
 
@@ -488,6 +491,37 @@ class _Plan:
         self.gemm("deft_conv2d_nhwc", name, d, 2.0 * x.N * OH * OW * Cout * true_k)
         return out
 
+    def conv_direct(self, name, x, w_packed, K, KH, pad, Cout, scale, shift, relu, true_cin):
+        """Stride-1 'same' conv with <= 16 output channels on the patch-in-LDS kernel (deft_conv_direct): x is fp32 NHWC with 16
+        (or, for the image, 4) channels; `w_packed` the ordinary packed fp32 matrix, re-laid once into B fragments."""
+        assert pad == KH // 2 and x.C in (4, 16) and Cout <= 16
+        out = self.alloc(x.N, x.H, x.W, Cout)
+        key = (w_packed.data_ptr(), "direct")
+        if key not in self._w3:
+            nb = self.lib.cdll.deft_direct_weight_bytes(KH, KH, x.C)
+            assert nb > 0
+            w3 = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            self.lib.call("deft_split_weights_direct", ptr(w_packed), ptr(w3), Cout, w_packed.shape[1], KH, KH, x.C, hiplib.stream_ptr(self.device))
+            self._w3[key] = w3
+            self._keep.append(w_packed)
+        d = GemmDesc()
+        d.x = x.addr; d.w = w_packed.data_ptr(); d.w3 = self._w3[key].data_ptr()
+        d.scale = scale.data_ptr() if scale is not None else None
+        d.shift = shift.data_ptr() if shift is not None else None
+        d.y = out.addr
+        d.N, d.H, d.W, d.Cin, d.ldx = x.N, x.H, x.W, x.C, x.ld
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = x.H, x.W, Cout, out.ld, 0
+        d.KH, d.KW, d.stride, d.pad = KH, KH, 1, pad
+        d.Ktot, d.Kpad = K, w_packed.shape[1]
+        d.M = x.N * x.H * x.W
+        d.relu = int(relu)
+        d.flop_k = KH * KH * true_cin
+        d.prec = 1
+        self._keep.append(d)
+        lib, ref = self.lib, C.byref(d)
+        self.add("deft_conv_direct", name, lambda: lib.call("deft_conv_direct", ref, self._stream()), 2.0 * d.M * Cout * KH * KH * true_cin)
+        return out
+
     def maxpool(self, name, x, out=None):
         if out is None:
             out = self.alloc(x.N, x.H // 2, x.W // 2, x.C)
@@ -532,6 +566,14 @@ class DlaSegPlan(_Plan):
     # ---- weights -----------------------------------------------------------
     def _conv_bn(self, name, x, wkey, bnkey, KH, stride, pad, relu, out=None, res=None, cin_pad=None):
         w = self.sd[wkey + ".weight"]
+        if (DIRECT and PREC == 1 and w.shape[0] <= 16 and stride == 1 and out is None and res is None and pad == KH // 2
+                and ((KH, x.C) in ((3, 16), (7, 4))) and x.N * ((x.H + 7) // 8) * ((x.W + 31) // 32) >= P3_MIN_TILES):
+            if ("d", wkey) not in self._wcache:
+                wp, K = pack_conv_weight(w, cin_pad)
+                alpha, beta = _bn_fold(self.sd, bnkey)
+                self._wcache[("d", wkey)] = (self.dev(wp), K, self.dev(alpha), self.dev(beta))
+            wp, K, alpha, beta = self._wcache[("d", wkey)]
+            return self.conv_direct(name, x, wp, K, KH, pad, w.shape[0], alpha, beta, relu, w.shape[1])
         if w.shape[0] <= 16 and stride == 1 and out is None and res is None and x.W % 2 == 0 and KH > 1:
             # 16-channel full-resolution layers (base_layer, level0): pixel-pair GEMM, 32 useful columns
             if wkey not in self._wcache:

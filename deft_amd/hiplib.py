@@ -65,10 +65,13 @@ _SIGS = {
     "deft_split_planes": (C.c_int, [c_fp, c_fp, C.c_longlong, C.c_int, C.c_int, C.c_int, c_fp]),
     "deft_split_weights": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
     "deft_split_weights_halo": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
+    "deft_conv_direct": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "deft_split_weights_direct": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp]),
+    "deft_direct_weight_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class DeftHipError(RuntimeError):
@@ -121,12 +124,15 @@ class HipLib:
                 fl = sum(2.0 * ds[i].M * ds[i].Cout * ds[i].Ktot for i in range(args[2]))
                 nbytes = sum(alg_bytes(ds[i]) for i in range(args[2]))
                 info = "group of %d" % args[2]
-            elif name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer"):
+            elif name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer", "deft_conv_direct"):
                 d = args[0]._obj
                 fl = 2.0 * d.M * (d.flop_n if d.flop_n else d.Cout) * (d.flop_k if d.flop_k else d.Ktot)
                 nbytes = alg_bytes(d)
                 info = "M=%d N=%d K=%d %dx%d s%d @%dx%d" % (d.M, d.Cout, d.Ktot, d.KH, d.KW, d.stride, d.H, d.W)
-                if self.split_arithmetic(name, d):
+                if name == "deft_conv_direct":
+                    ceil = 2500.0 / 6   # six v_mfma_f32_16x16x32_bf16 per fp32 product
+                    info += " split direct"
+                elif self.split_arithmetic(name, d):
                     ceil = 2500.0 / 6   # ... or six v_mfma_f32_32x32x16_bf16 per fp32 product (bf16 dense peak / 6)
                     info += " split" + (" halo" if d.p3_kernel else (" x3" if d.x3 else ""))
             prof.append((name, fl, e0, e1, info, nbytes, ceil))
@@ -162,7 +168,12 @@ def load(path):
 def get_lib():
     global _lib
     if _lib is None:
-        _lib = HipLib(os.environ.get("DEFT_HIP_LIB", LIB_PATH))     # override: A/B builds of the same HIP sources
+        lib = HipLib(os.environ.get("DEFT_HIP_LIB", LIB_PATH))     # override: A/B builds of the same HIP sources
+        if lib.host_pointers and os.environ.get("DEFT_TEST_HOST_POINTERS") != "1":
+            # the unit-test build of the kernels (the SIMT emulator under tests/) runs on host memory: never a product path -- tests hand it over
+            # explicitly (hiplib.load / the `lib=` arguments), an environment variable alone must not select it
+            raise DeftHipError("%s is the host-memory test build of the kernels, not libdeft_hip.so (deft_amd has no CPU path)" % lib.path)
+        _lib = lib
     return _lib
 
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     src = open(os.path.join(ROOT, "include", "deft_hip.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|const char\*)\s+(deft_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|long long|const char\*)\s+(deft_\w+)\s*\(", src, flags=re.M)))
 
 
 def test_header_matches_binding():
@@ -26,7 +26,7 @@ def test_gfx950_library_exports_every_symbol():
     lib = hiplib.HipLib(so)                                # binds every symbol; raises if one is missing
     for name in _declared():
         assert hasattr(lib.cdll, name)
-    assert lib.cdll.deft_version() == 6
+    assert lib.cdll.deft_version() == 7
     # the code object is gfx950-only (no other offload arch, no host fallback path)
     blob = open(so, "rb").read()
     assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
@@ -88,6 +88,17 @@ def test_error_conventions(emu_lib):
         emu_lib.call("deft_topk", ptr(x), ptr(x.int()), ptr(x.int()), 1, 4, 0, 4, ptr(x), ptr(x.int()), ptr(x.int()), None)
     with pytest.raises(hiplib.DeftHipError, match="nin="):
         emu_lib.call("deft_lstm_step", *([ptr(x)] * 3), 1, 40, 20, *([ptr(x)] * 8), None)
+
+
+def test_get_lib_refuses_the_emulator_build(emu_lib, monkeypatch):
+    """DEFT_HIP_LIB pointing at the host-memory test build must not become the product library."""
+    from deft_amd import hiplib
+    monkeypatch.setattr(hiplib, "_lib", None)
+    monkeypatch.setenv("DEFT_HIP_LIB", emu_lib.path)
+    monkeypatch.delenv("DEFT_TEST_HOST_POINTERS", raising=False)
+    with pytest.raises(hiplib.DeftHipError):
+        hiplib.get_lib()
+    assert hiplib._lib is None
 
 
 def test_real_library_refuses_cpu_tensors():

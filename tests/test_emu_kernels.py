@@ -36,6 +36,12 @@ def test_conv_pixel_pair(emu_lib, Ci, k):
     pc.check_conv_pair(emu_lib, "cpu", Ci, k)
 
 
+@pytest.mark.parametrize("Ci,k,kw", [(3, 7, {}), (16, 3, {}), (16, 3, {"N": 1, "H": 8, "W": 32, "Co": 12, "relu": False}), (3, 7, {"N": 1, "H": 19, "W": 70, "wide": True}),
+                                     (16, 3, {"wide": True, "seed": 3})])
+def test_conv_direct(emu_lib, Ci, k, kw):
+    pc.check_conv_direct(emu_lib, "cpu", Ci, k, **kw)
+
+
 def test_concat_conv(emu_lib):
     pc.check_concat_conv(emu_lib, "cpu")
 

@@ -40,6 +40,12 @@ def test_conv_pixel_pair(gpu_lib, Ci, k):
     pc.check_conv_pair(gpu_lib, "cuda", Ci, k)
 
 
+@pytest.mark.parametrize("Ci,k,kw", [(3, 7, {}), (16, 3, {}), (16, 3, {"N": 1, "H": 8, "W": 32, "Co": 12, "relu": False}), (3, 7, {"N": 1, "H": 19, "W": 70, "wide": True}),
+                                     (16, 3, {"wide": True, "seed": 3}), (16, 3, {"N": 3, "H": 152, "W": 272}), (3, 7, {"N": 2, "H": 152, "W": 272, "seed": 5})])
+def test_conv_direct(gpu_lib, Ci, k, kw):
+    pc.check_conv_direct(gpu_lib, "cuda", Ci, k, **kw)
+
+
 def test_concat_conv(gpu_lib):
     pc.check_concat_conv(gpu_lib, "cuda")
 

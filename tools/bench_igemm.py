@@ -87,6 +87,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "dcn":
     dcn_case("dcn 256->256 @38x68", 38, 68, 256, 256, DT)
     dcn_case("dcn 512->256 @19x34", 19, 34, 512, 256, DT)
     sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "dcn1":     # the two dominant DCN shapes, default tile only (ablation builds via DEFT_HIP_LIB)
+    dcn_case("dcn 64->64 @152x272", 152, 272, 64, 64, [T(64, 64)])
+    dcn_case("dcn 128->128 @76x136", 76, 136, 128, 128, [T(64, 128)])
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "small":    # few-row problems: split-K tiles vs 128x32
     N32 = [T(128, 32), T(64, 32), T(32, 32), T(64, 32) | ONE, T(32, 32) | ONE]
     conv_case("offset 3x3 64->27 @152x272", 152, 272, 64, 27, 3, 1, N32)
