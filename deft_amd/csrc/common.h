@@ -153,7 +153,47 @@ __device__ __forceinline__ void deft_epilogue_stage(float* T, int LDT, const def
 template <int BM, int BN, int NT, typename RowFn>
 __device__ __forceinline__ void deft_epilogue_rows(const float* T, const DeftGemmDesc& p, int n0, int tid, RowFn row_to_m) {
     constexpr int LDT = BN + 4, G = BN / 8, NI = (BM * G + NT - 1) / NT;
+    static_assert(G <= 64 && (G & (G - 1)) == 0, "the threads of a row are an aligned power-of-two lane group");
     const bool has_res = p.res != nullptr;
+    if (p.fold_y != nullptr) {
+        // folded 1x1 conv (DeftGemmDesc.fold_w): every lane stays active through the shuffles; invalid items contribute zeros
+        for (int it = 0; it < NI; ++it) {
+            const int item = it * NT + tid;
+            const int row = item / G, c8 = item - row * G;
+            const int co = n0 + c8 * 8;
+            const bool cok = row < BM && co < p.Cout;
+            const long long ml = row < BM ? row_to_m(row) : -1;
+            const float* tp = T + (row < BM ? row : 0) * LDT + c8 * 8;
+            f32x4 v0 = *(const f32x4*)tp, v1 = *(const f32x4*)(tp + 4);
+            if (has_res && cok && ml >= 0) {
+                const float* rp = p.res + (size_t)ml * p.ldr + co;
+                v0 += *(const f32x4*)rp;
+                v1 += *(const f32x4*)(rp + 4);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+            }
+            if (!cok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+            if (p.y != nullptr && cok && ml >= 0) {
+                float* yp = p.y + (size_t)ml * p.ldy + co;
+                *(f32x4*)yp = v0;
+                *(f32x4*)(yp + 4) = v1;
+            }
+            const int coc = cok ? co : 0;
+            for (int c2 = 0; c2 < p.fold_n; ++c2) {
+                const float* fw = p.fold_w + (size_t)c2 * p.Cout + coc;
+                const f32x4 w0 = *(const f32x4*)fw, w1 = *(const f32x4*)(fw + 4);
+                float s = v0[0] * w0[0];
+                s = fmaf(v0[1], w0[1], s); s = fmaf(v0[2], w0[2], s); s = fmaf(v0[3], w0[3], s);
+                s = fmaf(v1[0], w1[0], s); s = fmaf(v1[1], w1[1], s); s = fmaf(v1[2], w1[2], s); s = fmaf(v1[3], w1[3], s);
+#pragma unroll
+                for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o);
+                if (c8 == 0 && ml >= 0) p.fold_y[((size_t)(n0 / BN) * (size_t)p.M + (size_t)ml) * p.fold_ld + c2] = s;
+            }
+        }
+        return;
+    }
 #pragma unroll 2
     for (int it = 0; it < NI; ++it) {
         const int item = it * NT + tid;

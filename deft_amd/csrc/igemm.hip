@@ -734,7 +734,8 @@ static int dispatch_igemm(const DeftGemmDesc& d, int bm, int bn, bool one_stage,
 
 static int check_common(const DeftGemmDesc* d, const char* who) {
     DEFT_CHECK(d != nullptr, -1, "%s: null descriptor", who);
-    DEFT_CHECK((d->x || d->x3) && d->w && (d->y || d->y3), -2, "%s: null x/w/y pointer", who);
+    DEFT_CHECK((d->x || d->x3) && d->w && (d->y || d->y3 || (d->x3 && d->fold_y)), -2, "%s: null x/w/y pointer", who);
+    DEFT_CHECK(d->fold_y == nullptr || d->x3 != nullptr, -2, "%s: fold_y is honoured by the pre-split conv kernels only (x3)", who);
     DEFT_CHECK(d->M > 0 && d->Cout > 0, -3, "%s: empty problem M=%d Cout=%d", who, d->M, d->Cout);
     DEFT_CHECK(d->Kpad > 0 && (d->Kpad & 31) == 0 && d->Ktot <= d->Kpad, -4, "%s: Kpad=%d must be a multiple of 32 >= Ktot=%d", who, d->Kpad, d->Ktot);
     DEFT_CHECK((d->ldx & 3) == 0 && (((size_t)d->x) & 15) == 0 && (((size_t)d->w) & 15) == 0, -5, "%s: x/w must be 16-byte aligned, ldx %% 4 == 0", who);

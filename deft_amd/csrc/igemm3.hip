@@ -331,7 +331,10 @@ int deft_p3_check(const DeftGemmDesc* d, const char* who) {
     DEFT_CHECK((d->Cout & 7) == 0 && (d->ldy & 3) == 0 && (!d->res || (d->ldr & 3) == 0) && (((size_t)d->y | (size_t)d->res) & 15) == 0, -64,
                "%s: x3 needs Cout %% 8 == 0, ldy/ldr %% 4 == 0, y/res 16-byte aligned", who);
     DEFT_CHECK(d->y3 == nullptr || ((d->ldy3 & 31) == 0 && d->ldy3 >= d->Cout && (d->Cout & 31) == 0), -65, "%s: y3 needs Cout %% 32 == 0 and ldy3 %% 32 == 0", who);
-    DEFT_CHECK(d->y != nullptr || d->y3 != nullptr, -66, "%s: no output", who);
+    DEFT_CHECK(d->y != nullptr || d->y3 != nullptr || d->fold_y != nullptr, -66, "%s: no output", who);
+    DEFT_CHECK(d->fold_y == nullptr || (d->fold_w != nullptr && d->fold_n >= 1 && d->fold_n <= 16 && d->fold_ld >= d->fold_n && d->splitk <= 1 && (((size_t)d->fold_w) & 15) == 0
+                                        && (d->tile & 0xffff) != 0),
+               -59, "%s: fold_y needs fold_w (16-byte aligned), 1 <= fold_n <= 16, fold_ld >= fold_n, no split-K and a forced tile (the part count is ceil(Cout / BN))", who);
     DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx3 * 6 < (1ll << 31), -67, "%s: x3 map exceeds 2 GiB (split the batch)", who);
     DEFT_CHECK((long long)deft_cdiv(d->Cout, 128) * 128 * d->Kpad * 6 < (1ll << 31), -68, "%s: w3 exceeds 2 GiB", who);
     return 0;

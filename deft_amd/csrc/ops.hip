@@ -989,3 +989,23 @@ extern "C" int deft_track_similarity(const float* sim, int rows, int Q, const in
     DEFT_CHECK_LAUNCH("track_similarity");
     return 0;
 }
+
+// ---- sum of the partial maps of a folded 1x1 conv (DeftGemmDesc.fold_y) + bias ----
+__global__ __launch_bounds__(256) void fold_finish_kernel(const float* __restrict__ part, int nparts, long long M, int C, int ldp, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int ldy) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * C) return;
+    const long long m = i / C;
+    const int c = (int)(i - m * C);
+    float s = part[m * ldp + c];
+    for (int k = 1; k < nparts; ++k) s += part[((long long)k * M + m) * ldp + c];
+    y[m * ldy + c] = s + (bias ? bias[c] : 0.f);
+}
+
+extern "C" int deft_fold_finish(const float* part, int nparts, long long M, int C, int ldp, const float* bias, float* y, int ldy, void* stream) {
+    DEFT_CHECK(part && y && nparts >= 1 && M > 0 && C >= 1 && ldp >= C && ldy >= C, -1, "deft_fold_finish: bad arguments");
+    DEFT_CHECK(M * C < (1ll << 31) * 256, -2, "deft_fold_finish: too many elements");
+    hipLaunchKernelGGL(fold_finish_kernel, dim3((unsigned)deft_cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts, M, C, ldp, bias, y, ldy);
+    DEFT_CHECK_LAUNCH("fold_finish");
+    return 0;
+}

@@ -67,6 +67,17 @@ class View:
         return self.buf.view(self.N, self.H, self.W, self.ld)[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2).contiguous()
 
 
+class _LazyView(View):
+    """Geometry of a map that may never be written (conv(fold=...)): `materialize()` allocates it."""
+
+    def __init__(self, plan, N, H, W, C):
+        super().__init__(None, N, H, W, C, _rup(C, 4), 0)
+        self._plan = plan
+
+    def materialize(self):
+        return self._plan.alloc(self.N, self.H, self.W, self.C)
+
+
 def _bn_fold(sd, p):
     """Eval BatchNorm as y = x*alpha + beta, computed like ATen's CPU kernel."""
     invstd = 1.0 / torch.sqrt(sd[p + ".running_var"].float() + BN_EPS)
@@ -164,6 +175,7 @@ P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAG
 # the two 16-channel full-resolution layers (base_layer 7x7, level0 3x3) on the patch-in-LDS kernel (csrc/direct.hip) instead of the
 # pixel-pair implicit GEMM on the fp32 MFMA instruction
 DIRECT = _os.environ.get("DEFT_DIRECT", "1") != "0"
+FOLD = _os.environ.get("DEFT_FOLD", "1") != "0"       # heat-map head: the 1x1 conv folded into the epilogue of the 3x3 conv (DeftGemmDesc.fold_w)
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
 
 
@@ -336,7 +348,7 @@ class _Plan:
         lib, ref = self.lib, C.byref(desc)
         self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
         self._gemms.append((entry, name, desc))
-        if SPLITK and entry in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc") and not desc.splitk and not desc.p3_kernel:
+        if SPLITK and entry in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc") and not desc.splitk and not desc.p3_kernel and not desc.fold_y:
             self._plan_splitk(entry, desc)
 
     def _plan_splitk(self, entry, desc):
@@ -415,11 +427,14 @@ class _Plan:
             d.tile = memo[key]
 
     def conv(self, name, x, w_packed, K, KH, KW, stride, pad, Cout, scale, shift, relu, out=None, res=None, tile=0,
-             true_cin=None, korder=None, p3=None, true_cout=None):
+             true_cin=None, korder=None, p3=None, true_cout=None, fold=None):
+        """fold = (w [n][Cout] device fp32, bias [n] or None, n): a following 1x1 conv with n <= 16 outputs.  When this conv runs on
+        a pre-split kernel it is folded into the epilogue (DeftGemmDesc.fold_w) and the return value is the [N, OH, OW, n] map of
+        the 1x1 conv -- the Cout-channel map is never written; otherwise `fold` is ignored and the caller adds the 1x1 conv."""
         OH = (x.H + 2 * pad - KH) // stride + 1
         OW = (x.W + 2 * pad - KW) // stride + 1
         if out is None:
-            out = self.alloc(x.N, OH, OW, Cout)
+            out = self.alloc(x.N, OH, OW, Cout) if fold is None else _LazyView(self, x.N, OH, OW, Cout)
         assert (out.N, out.H, out.W, out.C) == (x.N, OH, OW, Cout), (name, out.H, out.W, out.C, OH, OW, Cout)
         if res is not None:
             assert (res.H, res.W, res.C) == (OH, OW, Cout), name
@@ -428,7 +443,7 @@ class _Plan:
         d.scale = scale.data_ptr() if scale is not None else None
         d.shift = shift.data_ptr() if shift is not None else None
         d.res = res.addr if res is not None else None
-        d.y = out.addr
+        d.y = out.addr if out.buf is not None else None
         d.N, d.H, d.W, d.Cin, d.ldx = x.N, x.H, x.W, x.C, x.ld
         d.OH, d.OW, d.Cout, d.ldy, d.ldr = OH, OW, Cout, out.ld, (res.ld if res is not None else 0)
         d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
@@ -450,13 +465,27 @@ class _Plan:
                 choice = p3_choice(KH, KW, stride, pad, x.C, Cout, x.H, x.W, d.M, d.korder)
             elif tile in P3_TILES and Cout >= P3_MIN_COUT:
                 choice = ("im2col", tile)          # a forced igemm3 tile
+        folded = None
+        if fold is not None:
+            if choice is not None and FOLD and res is None:
+                fw, fb, fn = fold
+                halo = choice[0] == "halo"
+                t = choice[1] if choice[1] & 0xffff else ((4 << 16) | (128 if Cout > 64 else (64 if Cout > 32 else 32)) if halo else 0)
+                if t & 0xffff:
+                    choice = (choice[0], t)
+                    nparts = -(-Cout // (t & 0xffff))
+                    part = torch.empty(nparts * d.M * fn, dtype=torch.float32, device=self.device)
+                    folded = (part, nparts, fw, fb, fn)
+            if folded is None and out.buf is None:
+                out = out.materialize()
+                d.y = out.addr; d.ldy = out.ld
         if choice is not None:
             halo = choice[0] == "halo"
             d.tile = choice[1]
             d.x3, d.ldx3 = self._p3_input(name, x), x.ld
             d.p3_kernel = 1 if halo else 0
             d.w3 = self.weights_p3(w_packed, halo).data_ptr()
-            if Cout % 32 == 0:
+            if Cout % 32 == 0 and folded is None:
                 h = self.p3_output(out, d)
                 if h is not None:
                     d.y3, d.ldy3 = h.addr, h.ld
@@ -465,7 +494,18 @@ class _Plan:
         cin = x.C if true_cin is None else true_cin
         d.flop_k = KH * KW * cin
         d.flop_n = 0 if true_cout is None else true_cout
+        if folded is not None:
+            part, nparts, fw, fb, fn = folded
+            d.y = None; d.ldy = Cout
+            d.fold_w, d.fold_y, d.fold_n, d.fold_ld = fw.data_ptr(), part.data_ptr(), fn, fn
+            self._keep += [part, fw, fb]
         self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * (Cout if true_cout is None else true_cout) * KH * KW * cin)
+        if folded is not None:
+            y2 = self.alloc(x.N, OH, OW, fn)
+            lib = self.lib
+            a = (ptr(part), nparts, C.c_longlong(d.M), fn, fn, ptr(fb), C.c_void_p(y2.addr), y2.ld)
+            self.add("deft_fold_finish", name + ".fold", lambda: lib.call("deft_fold_finish", *a, self._stream()), 2.0 * d.M * fn * Cout)
+            return y2
         return out
 
     def conv_pair(self, name, x, w_packed, K, KH, KW, pad, Cout, scale2, shift2, relu, true_k):
@@ -710,8 +750,12 @@ class DlaSegPlan(_Plan):
             c = self.heads[hd]
             w0, K0 = pack_conv_weight(sd[hd + ".0.weight"])
             w1, K1 = pack_conv_weight(sd[hd + ".2.weight"])
-            hid = self.conv(hd + ".0", self.feat, self.dev(w0), K0, 3, 3, 1, 1, 256, None, self.dev(sd[hd + ".0.bias"].float()), True)
-            self.dense[hd] = self.conv(hd + ".2", hid, self.dev(w1), K1, 1, 1, 1, 0, c, None, self.dev(sd[hd + ".2.bias"].float()), False)
+            b1 = self.dev(sd[hd + ".2.bias"].float())
+            fold = (self.dev(sd[hd + ".2.weight"].float().reshape(c, 256)), b1, c) if c <= 16 else None
+            hid = self.conv(hd + ".0", self.feat, self.dev(w0), K0, 3, 3, 1, 1, 256, None, self.dev(sd[hd + ".0.bias"].float()), True, fold=fold)
+            # (on a pre-split kernel the 1x1 conv was folded into the 3x3 conv's epilogue: `hid` is then already its output)
+            self.dense[hd] = hid if hid.C == c and fold is not None and hid.C != 256 else \
+                self.conv(hd + ".2", hid, self.dev(w1), K1, 1, 1, 1, 0, c, None, b1, False)
         hm = self.dense["hm"]
         chm = self.heads["hm"]
         lib = self.lib

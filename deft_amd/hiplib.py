@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("rowmap", c_fp),
         ("splitk", C.c_int), ("ws", c_fp), ("ws_cnt", c_fp), ("prec", C.c_int),
         ("x3", c_fp), ("w3", c_fp), ("y3", c_fp), ("ldx3", C.c_int), ("ldy3", C.c_int), ("p3_kernel", C.c_int),
+        ("fold_w", c_fp), ("fold_y", c_fp), ("fold_n", C.c_int), ("fold_ld", C.c_int),
     ]
 
 
@@ -65,6 +66,7 @@ _SIGS = {
     "deft_split_planes": (C.c_int, [c_fp, c_fp, C.c_longlong, C.c_int, C.c_int, C.c_int, c_fp]),
     "deft_split_weights": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
     "deft_split_weights_halo": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
+    "deft_fold_finish": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.c_int, C.c_int, c_fp, c_fp, C.c_int, c_fp]),
     "deft_conv_direct": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "deft_split_weights_direct": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp]),
     "deft_direct_weight_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),

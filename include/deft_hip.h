@@ -99,6 +99,15 @@ typedef struct DeftGemmDesc {
      * (deft_split_weights_halo), korder 1, no split-K; `tile` = (TH << 16) | BN, 0 = automatic.  K order (16-channel block,
      * tap): same pieces and products as the other forms, another fp32 summation order. */
     int p3_kernel;
+    /* A following 1x1 conv with few outputs folded into the epilogue of the pre-split conv kernels (x3 != NULL) -- the heat-map
+     * head's `Conv2d(256, C, 1)` after `Conv2d(64, 256, 3) + ReLU` (base_model.py:37-66): the 256-channel hidden map is neither
+     * written nor re-read.  fold_w [fold_n][Cout] fp32 (the 1x1 weights), fold_n <= 16.  Every workgroup multiplies its BN-wide
+     * slice of the finished (scaled, shifted, ReLU'd) output rows with the matching slice of fold_w and writes the partial sums to
+     * fold_y[(n_tile * M + row) * fold_ld + c]: ceil(Cout / BN) parts (force `tile` to know BN), summed -- together with the 1x1
+     * bias -- by deft_fold_finish.  y and y3 may then both be NULL.  NULL = off. */
+    const float* fold_w;
+    float* fold_y;
+    int fold_n, fold_ld;
 } DeftGemmDesc;
 
 int deft_version(void);
@@ -292,6 +301,10 @@ int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpad, void* st
 /* The same for the halo form (DeftGemmDesc.p3_kernel = 1): `w` must be packed with korder 1, Kpad = 9 * Cin;
  * image [CoutPad/64][Cin/16][9 taps][64 rows][6 slots of 8 bf16]. */
 int deft_split_weights_halo(const float* w, void* w3, int CoutPad, int Kpad, void* stream);
+
+/* y[m][c] = bias[c] + sum over the `nparts` partial maps part[(i * M + m) * ldp + c] of a folded 1x1 conv (DeftGemmDesc.fold_y),
+ * c < C; parts are added in index order (deterministic). */
+int deft_fold_finish(const float* part, int nparts, long long M, int C, int ldp, const float* bias, float* y, int ldy, void* stream);
 
 /* Direct (input patch in LDS) convolution for the 16-output-channel full-resolution layers: DLA-34's base_layer (7x7, 3 -> 16,
  * dla.py:301-306; the image as 4-channel NHWC) and level0 (3x3, 16 -> 16, dla.py:307-308), + folded BatchNorm + ReLU.

@@ -859,6 +859,36 @@ def _check_conv_p3(lib, device, N, H, W, Ci, Cm, Co, k, stride, tile, tile2, see
     return maxabs(outs[1][0], ref1)
 
 
+def check_conv_fold(lib, device, N, H, W, Ci, Cm, fn, p3, tile=0, seed=0):
+    """3x3 conv Ci -> Cm + ReLU with the following 1x1 conv Cm -> fn folded into its epilogue (DeftGemmDesc.fold_w; the heat-map
+    head, base_model.py:37-66) on the pre-split kernels: equals conv2d(relu(conv2d)) to fp32 round-off, the Cm-channel map is
+    not allocated, and the partial maps of the n-tiles are summed by deft_fold_finish."""
+    assert engine.PREC == 1 and engine.P3 and engine.FOLD
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w0 = torch.randn(Cm, Ci, 3, 3, generator=g) * (1.0 / (Ci * 9) ** 0.5)
+    b0 = torch.randn(Cm, generator=g)
+    w1 = torch.randn(fn, Cm, 1, 1, generator=g) * (1.0 / Cm ** 0.5)
+    b1 = torch.randn(fn, generator=g)
+    plan = engine._Plan(device, lib)
+    xv = plan.alloc(N, H, W, Ci); fill_view(xv, x)
+    wp0, K0 = engine.pack_conv_weight(w0)
+    nbuf = len(plan._keep)
+    out = plan.conv("h0", xv, plan.dev(wp0), K0, 3, 3, 1, 1, Cm, None, plan.dev(b0), True, tile=tile, p3=p3,
+                    fold=(plan.dev(w1.reshape(fn, Cm)), plan.dev(b1), fn))
+    d = plan._gemms[-1][2]
+    assert out.C == fn and d.fold_y and not d.y and not d.y3, "the 1x1 conv was not folded"
+    assert [op[0] for op in plan.ops][-2:] == ["deft_conv2d_nhwc", "deft_fold_finish"]
+    assert all(not (isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.numel() == N * H * W * Cm) for t in plan._keep[nbuf:]), "hidden map allocated"
+    plan.finalize_p3()
+    plan.run()
+    hid = F.relu(F.conv2d(x.double(), w0.double(), b0.double(), 1, 1))
+    ref = F.conv2d(hid, w1.double(), b1.double())
+    err = maxabs(out.to_nchw().cpu().double(), ref)
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), ("fold", N, H, W, Ci, Cm, fn, p3, tile, err)
+    return err
+
+
 # ---------------------------------------------------------------------------
 # top-K index parity on arbitrary frames
 def compare_topk_with_oracle(plan, out, K, logit_tol=2e-4, tie=1e-4):

@@ -107,6 +107,22 @@ def test_forward_embed_mot(emu_lib):
     pc.check_embed(emu_lib, "cpu", plan, ora_maps, sd)
 
 
+def test_forward_every_presplit_kernel_forced(emu_lib):
+    """The same frame with the tile-count gates off (engine.P3_MIN_TILES = 0): the direct full-resolution kernel, the halo and im2col
+    pre-split kernels and the folded heat-map head all run inside the model, against the oracle."""
+    import deft_oracle as O
+    from deft_amd import engine
+    saved, engine.P3_MIN_TILES = engine.P3_MIN_TILES, 0
+    try:
+        sd = O.synth_state_dict("mot")
+        plan, rep, _ = pc.check_forward(emu_lib, "cpu", "mot", 32, 128, sd=sd)
+        kinds = [op[0] for op in plan.ops]
+        assert kinds.count("deft_conv_direct") == 2 and kinds.count("deft_fold_finish") >= 1
+        assert any(d.p3_kernel == 1 for _, _, d in plan._gemms) and any(d.x3 and not d.p3_kernel for _, _, d in plan._gemms)
+    finally:
+        engine.P3_MIN_TILES = saved
+
+
 def test_seam_dcn_module(emu_lib):
     pc.check_seam_dcn(emu_lib, "cpu")
 
@@ -285,6 +301,13 @@ def test_peaked_heatmap_ordered_topk(emu_lib):
 ])
 def test_conv_halo(emu_lib, args):
     pc.check_conv(emu_lib, "cpu", *args, res=True, relu=True, p3="halo")
+
+
+# the heat-map head's 1x1 conv folded into the 3x3 conv's epilogue (DeftGemmDesc.fold_w): halo and im2col kernels, 1 and 2 n-tiles, ragged edges
+@pytest.mark.parametrize("args", [(1, 9, 37, 64, 256, 1, "halo", 0), (2, 5, 33, 64, 256, 3, "halo", T(4, 128)), (1, 6, 40, 64, 128, 10, "halo", T(8, 64)),
+                                  (1, 7, 19, 64, 256, 2, "im2col", T(64, 128) | (1 << 30)), (1, 6, 21, 64, 72, 1, "im2col", T(128, 64) | (1 << 30))])
+def test_conv_fold(emu_lib, args):
+    pc.check_conv_fold(emu_lib, "cpu", *args)
 
 
 def test_weight_dma_identical(emu_lib):
