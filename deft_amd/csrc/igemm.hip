@@ -41,7 +41,7 @@ template <int BM, int BN, int WK, int NSTAGE, int MODE, int PREC = 0>
 constexpr int igemm_lds_floats() {
     constexpr int ld = (MODE == MODE_CONV && NSTAGE == 2) ? 32 : LDS_STRIDE;      // LDS-DMA image is unpadded
     // PREC = 3: the same with ONE weight stage, refilled after the chunk's second barrier (no extra LDS: the DCN keeps its 3 workgroups/CU)
-    constexpr int stage = (PREC >= 2 ? (3 * BM * LDB * 2 + (PREC == 2 ? 2 : 1) * BN * 192) / 4 : PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 9 : 0);
+    constexpr int stage = (PREC >= 2 ? (3 * BM * LDB * 2 + (PREC == 2 ? 2 : 1) * BN * 192) / 4 : PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 5 : 0);
     constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
     return stage > red ? stage : red;
 }
@@ -179,17 +179,20 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
 
     // DCN: the bilinear sampling records of all (tile row, tap) pairs are computed ONCE, before the
     // K loop -- upstream DCNv2 modulated_deformable_im2col + dmcn_im2col_bilinear semantics -- into
-    // prm[tap][row][8] = {4 corner byte offsets, 4 corner weights} and msk[tap][row] = sigmoid(mask).
+    // prm[tap][row] = the four corner weights, each already multiplied by sigmoid(mask), and pof[tap][row] = the byte offset of
+    // the (clamped) top-left corner pixel with two flags in its low bits: bit 0 = the right-hand corners are one pixel further,
+    // bit 1 = the lower corners are one line further (both set away from the map border; a corner outside the map has weight
+    // 0 and reads some pixel inside it).  20 bytes per record: 11.5 KB at BM = 64 -- four 64x64 / three 64x128 workgroups per CU.
     // The K order of the DCN contraction is (32-channel block, tap, channel): all nine taps of one
     // channel block are consumed back to back, so the 4x4-pixel neighbourhood lines of that block
     // stay in the CU's 32 KB L1 across the 36 corner reads that touch them.
-    float* const msk = prm + 9 * BM * 8;
+    int* const pof = (int*)(prm + 9 * BM * 4);
     if (MODE == MODE_DCN) {
         for (int idx = tid; idx < 9 * BM; idx += 256) {
             const int tap = idx / BM, row = idx - tap * BM;
             const int m = m0 + row;
-            int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
-            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mask = 0.f;
+            int o1 = 0;
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
             if (m < p.M) {
                 const int hw = p.H * p.W;
                 const int rem = m - (m / hw) * hw;
@@ -205,18 +208,19 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                     const float hh = 1.f - lh, hw_ = 1.f - lw;
                     const int h_low = (int)hl, w_low = (int)wl;
                     const int h_high = h_low + 1, w_high = w_low + 1;
-                    mask = 1.f / (1.f + expf(-ml));
-                    const int pb = p.ldx * 4;       // records hold BYTE offsets of the corner pixels inside the image
-                    if (h_low >= 0 && w_low >= 0) { o1 = (h_low * p.W + w_low) * pb; w1 = hh * hw_; }
-                    if (h_low >= 0 && w_high <= p.W - 1) { o2 = (h_low * p.W + w_high) * pb; w2 = hh * lw; }
-                    if (h_high <= p.H - 1 && w_low >= 0) { o3 = (h_high * p.W + w_low) * pb; w3 = lh * hw_; }
-                    if (h_high <= p.H - 1 && w_high <= p.W - 1) { o4 = (h_high * p.W + w_high) * pb; w4 = lh * lw; }
+                    const float mask = 1.f / (1.f + expf(-ml));
+                    if (h_low >= 0 && w_low >= 0) w1 = hh * hw_ * mask;
+                    if (h_low >= 0 && w_high <= p.W - 1) w2 = hh * lw * mask;
+                    if (h_high <= p.H - 1 && w_low >= 0) w3 = lh * hw_ * mask;
+                    if (h_high <= p.H - 1 && w_high <= p.W - 1) w4 = lh * lw * mask;
+                    // h_low in [-1, H-1], w_low in [-1, W-1] here: clamp the four corners into the map
+                    const int hl_c = h_low < 0 ? 0 : h_low, wl_c = w_low < 0 ? 0 : w_low;
+                    const int hh_c = h_high > p.H - 1 ? p.H - 1 : h_high, wh_c = w_high > p.W - 1 ? p.W - 1 : w_high;
+                    o1 = (hl_c * p.W + wl_c) * (p.ldx * 4) | (wh_c - wl_c) | ((hh_c - hl_c) << 1);       // pixel stride is a multiple of 16 bytes
                 }
             }
-            float* pr = prm + idx * 8;
-            *(f32x4*)(pr) = f32x4{__int_as_float(o1), __int_as_float(o2), __int_as_float(o3), __int_as_float(o4)};
-            *(f32x4*)(pr + 4) = f32x4{w1, w2, w3, w4};
-            msk[idx] = mask;
+            *(f32x4*)(prm + idx * 4) = f32x4{w1, w2, w3, w4};
+            pof[idx] = o1;
         }
         __syncthreads();
     }
@@ -245,7 +249,6 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     }
     int kload = k_lo * 32;                           // k offset of the next chunk to load
     f32x4 s0[GA], s1[GA], s2[GA], s3[GA], sw[GA], vb[GB];
-    float sm[GA];
 
     // PREC 2: this wave's pieces of the weight chunk image (1 KB each; piece j of the tile = 64-row block j / 12)
     constexpr int NBP = BDMA ? BN * 3 / 64 : 1;
@@ -285,17 +288,19 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         } else if (MODE == MODE_DCN) {
             const int tap = cur.s;                       // chunk j = (channel block cur.c0/32, tap cur.s)
             const int cb4 = cur.c0 * 4;
+            const int dcn_dx = p.ldx * 4, dcn_dy = p.W * p.ldx * 4;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
-                const float* pr = prm + (tap * BM + rbase + 32 * i) * 8;
-                const f32x4 po = *(const f32x4*)pr;          // invalid corners: offset 0, weight 0
-                sw[i] = *(const f32x4*)(pr + 4);
-                sm[i] = msk[tap * BM + rbase + 32 * i];
-                const int pb = rb[i] + cb4;
-                s0[i] = deft_buffer_load_x4(rx, (unsigned)(pb + __float_as_int(po.x)));
-                s1[i] = deft_buffer_load_x4(rx, (unsigned)(pb + __float_as_int(po.y)));
-                s2[i] = deft_buffer_load_x4(rx, (unsigned)(pb + __float_as_int(po.z)));
-                s3[i] = deft_buffer_load_x4(rx, (unsigned)(pb + __float_as_int(po.w)));
+                const int rec = tap * BM + rbase + 32 * i;
+                sw[i] = *(const f32x4*)(prm + rec * 4);
+                const int po = pof[rec];
+                const int o1 = rb[i] + cb4 + (po & ~3);
+                const int o2 = o1 + ((po & 1) ? dcn_dx : 0);
+                const int dy = (po & 2) ? dcn_dy : 0;
+                s0[i] = deft_buffer_load_x4(rx, (unsigned)o1);
+                s1[i] = deft_buffer_load_x4(rx, (unsigned)o2);
+                s2[i] = deft_buffer_load_x4(rx, (unsigned)(o1 + dy));
+                s3[i] = deft_buffer_load_x4(rx, (unsigned)(o2 + dy));
             }
         } else {
             const unsigned kb = (unsigned)((kload + g * 4) * 4);
@@ -357,7 +362,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
             if (MODE == MODE_CONV) {
                 v = s0[i];
             } else if (MODE == MODE_DCN) {
-                v = (sw[i].x * s0[i] + sw[i].y * s1[i] + sw[i].z * s2[i] + sw[i].w * s3[i]) * sm[i];
+                v = sw[i].x * s0[i] + sw[i].y * s1[i] + sw[i].z * s2[i] + sw[i].w * s3[i];
             } else {
                 const f32x4 t = s0[i] + s1[i];
                 v = f32x4{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)};
@@ -866,7 +871,7 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);
-    if (bm == 0) {             // BM = 64 keeps the 9-tap sampling records at 20 KB of LDS (4 workgroups per CU)
+    if (bm == 0) {             // BM = 64: 11.5 KB of sampling records, 39 KB of LDS in all -- four 64x64 (three 64x128) workgroups per CU
         bm = 64; bn = d->Cout >= 128 ? 128 : 64;      // tools/bench_igemm.py dcn (r2, weights by DMA: 64x128 wins from Cout = 128)
     }
     return dispatch_igemm<MODE_DCN>(*d, bm, bn, one_stage, s);
