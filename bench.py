@@ -280,7 +280,7 @@ def main():
     torch.cuda.synchronize()
     lib.profile = None
     if rank == 0:
-        GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer")
+        GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer", "deft_conv_direct")
         rows = [(k, fl, e0.elapsed_time(e1), info, b, ceil) for (k, fl, e0, e1, info, b, ceil) in prof]
         gemm = [r for r in rows if r[0] in GEMM]
         gemm_ms = sum(r[2] for r in gemm)
@@ -304,9 +304,9 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak_w, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
-                "kernel": "implicit-GEMM family: igemm_kernel / igemm3_kernel / conv3h_kernel (conv, DCNv2, pair loaders; fp32 results)",
+                "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel (conv, DCNv2, pair loaders; fp32 results)",
                 "peak_note": "time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split-bf16 kernels (2500 / 6 = 416.7 TFLOP/s: "
-                             "3 bf16 pieces per operand, 6 v_mfma_f32_32x32x16_bf16 per fp32 product), the rest on v_mfma_f32_32x32x2_f32 (157.3)"
+                             "3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product), the rest on v_mfma_f32_32x32x2_f32 (157.3)"
                              % (100.0 * split_ms / max(gemm_ms, 1e-9)),
                 "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4),
                 "max_per_launch_frac": round(worst[0], 4), "max_per_launch_frac_shape": worst[1],
