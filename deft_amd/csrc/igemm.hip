@@ -574,9 +574,9 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         }
     }
 
-    // P3 output requested (DCN only: the staging region is always big enough for the tile there): the LDS-transposed
-    // epilogue of common.h, which also writes the three bf16 pieces for a following pre-split conv
-    if constexpr (MODE == MODE_DCN && WK == 1) {
+    // P3 output requested: the LDS-transposed epilogue of common.h, which also writes the three bf16 pieces for a following
+    // pre-split conv (the launch sizes the dynamic LDS for the BM x (BN + 4) tile when y3 is set: launch_igemm)
+    if constexpr ((MODE == MODE_DCN || (MODE == MODE_CONV && PREC >= 1)) && WK == 1) {
         if (p.y3 != nullptr) {
             float* const T = smem;
             __syncthreads();
@@ -645,11 +645,11 @@ __global__ __launch_bounds__(256) void igemm_group_kernel(const DeftGemmDesc* __
 
 template <auto KERNEL>
 static int set_lds_attr(int lds_bytes) {
-    static bool done = false;                  // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
-    if (lds_bytes <= 64 * 1024 || done) return 0;
+    static int cur = 64 * 1024;                // > 64 KB of dynamic LDS needs the opt-in, once per instantiation and size
+    if (lds_bytes <= cur) return 0;
     hipError_t e = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     DEFT_CHECK(e == hipSuccess, -101, "igemm: hipFuncSetAttribute(%d B LDS) failed: %s", lds_bytes, hipGetErrorString(e));
-    done = true;
+    cur = lds_bytes;
     return 0;
 }
 
@@ -671,14 +671,16 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
     } else {
         const int mtiles = deft_cdiv(d.M, BM), ntiles = deft_cdiv(d.Cout, BN);
         const int S = d.splitk > 1 ? d.splitk : 1;
+        DEFT_CHECK(d.y3 == nullptr || WK == 1, -9, "igemm: y3 (P3 output) is not available on the intra-workgroup split-K tiles (%dx%d)", BM, BN);
+        const int lds_y3 = d.y3 != nullptr ? BM * (BN + 4) * 4 : 0;          // the LDS-transposed epilogue's tile
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
         if constexpr (WK == 1 && NSTAGE == 1 && BN >= 64) {      // BN = 32: the operand split is amortised over too few columns
             if (d.prec == 1 && d.w3 != nullptr && S == 1) {      // ... with the weights pre-split: their chunks arrive by DMA
                 constexpr int PB = MODE == MODE_DCN ? 3 : 2;     // DCN: one weight stage (LDS as before: 3 workgroups/CU); else two
                 constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, PB>() * 4;
-                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, PB>>(lds_p)) return e;
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, PB>), dim3(mtiles * ntiles), dim3(256), lds_p, s, d, mtiles, ntiles);
+                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, PB>>(lds_p > lds_y3 ? lds_p : lds_y3)) return e;
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, PB>), dim3(mtiles * ntiles), dim3(256), lds_p > lds_y3 ? lds_p : lds_y3, s, d, mtiles, ntiles);
                 DEFT_CHECK_LAUNCH("igemm");
                 return 0;
             }
@@ -686,28 +688,30 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
                 constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 1>() * 4;
                 if (S > 1) {
                     if constexpr (MODE != MODE_PAIR) {
-                        if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true, 1>>(lds_p)) return e;
-                        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true, 1>), dim3(mtiles * ntiles * S), dim3(256), lds_p, s, d,
+                        if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true, 1>>(lds_p > lds_y3 ? lds_p : lds_y3)) return e;
+                        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true, 1>), dim3(mtiles * ntiles * S), dim3(256), lds_p > lds_y3 ? lds_p : lds_y3, s, d,
                                            mtiles, ntiles);
                     }
                 } else {
-                    if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 1>>(lds_p)) return e;
-                    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 1>), dim3(mtiles * ntiles), dim3(256), lds_p, s, d,
+                    if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 1>>(lds_p > lds_y3 ? lds_p : lds_y3)) return e;
+                    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 1>), dim3(mtiles * ntiles), dim3(256), lds_p > lds_y3 ? lds_p : lds_y3, s, d,
                                        mtiles, ntiles);
                 }
                 DEFT_CHECK_LAUNCH("igemm");
                 return 0;
             }
         }
+        // (from here on: the fp32-MFMA instantiations; their plain-conv form has no P3 epilogue)
+        DEFT_CHECK(d.y3 == nullptr || MODE == MODE_DCN, -9, "igemm: y3 (P3 output) needs the split-bf16 arithmetic (prec 1, a 1-stage tile with BN >= 64); tile %dx%d prec %d", BM, BN, d.prec);
         if (S > 1) {
             if constexpr (MODE != MODE_PAIR) {
-                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true>>(lds_bytes)) return e;
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true>), dim3(mtiles * ntiles * S), dim3(256), lds_bytes, s, d,
+                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true>>(lds_bytes > lds_y3 ? lds_bytes : lds_y3)) return e;
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, true>), dim3(mtiles * ntiles * S), dim3(256), lds_bytes > lds_y3 ? lds_bytes : lds_y3, s, d,
                                    mtiles, ntiles);
             }
         } else {
-            if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false>>(lds_bytes)) return e;
-            hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false>), dim3(mtiles * ntiles), dim3(256), lds_bytes, s, d,
+            if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false>>(lds_bytes > lds_y3 ? lds_bytes : lds_y3)) return e;
+            hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false>), dim3(mtiles * ntiles), dim3(256), lds_bytes > lds_y3 ? lds_bytes : lds_y3, s, d,
                                mtiles, ntiles);
         }
     }
@@ -830,7 +834,9 @@ extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
         if (int e = deft_p3_check(d, "deft_conv2d_nhwc")) return e;
         return d->p3_kernel == 1 ? deft_p3h_dispatch(d, s) : deft_p3_dispatch(d, s);
     }
-    DEFT_CHECK(d->y3 == nullptr, -9, "deft_conv2d_nhwc: y3 (P3 output) needs the pre-split path (x3)");
+    DEFT_CHECK(d->y3 == nullptr || (d->rowmap == nullptr && d->stride_w == 0 && (d->Cout & 31) == 0 && (d->ldy3 & 31) == 0 && d->ldy3 >= d->Cout && (d->ldy & 3) == 0 &&
+                                    (!d->res || (d->ldr & 3) == 0) && (((size_t)d->y3 | (size_t)d->y | (size_t)d->res) & 15) == 0 && d->y != nullptr),
+               -9, "deft_conv2d_nhwc: y3 (P3 output) needs a dense conv with Cout %% 32 == 0, ldy3 %% 32 == 0, ldy/ldr %% 4 == 0, 16-byte aligned y/y3/res");
     int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);

@@ -175,6 +175,7 @@ P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAG
 # the two 16-channel full-resolution layers (base_layer 7x7, level0 3x3) on the patch-in-LDS kernel (csrc/direct.hip) instead of the
 # pixel-pair implicit GEMM on the fp32 MFMA instruction
 DIRECT = _os.environ.get("DEFT_DIRECT", "1") != "0"
+Y3_INLOOP = _os.environ.get("DEFT_Y3_INLOOP", "1") != "0"    # piece-form output from the in-loop kernel's epilogue (else deft_split_planes)
 FOLD = _os.environ.get("DEFT_FOLD", "1") != "0"       # heat-map head: the 1x1 conv folded into the epilogue of the 3x3 conv (DeftGemmDesc.fold_w)
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
 
@@ -491,6 +492,13 @@ class _Plan:
                     d.y3, d.ldy3 = h.addr, h.ld
         if choice is None and BDMA and PREC == 1 and Cout >= 128:
             d.w3 = self.weights_p3(w_packed).data_ptr()         # igemm.hip: weight chunks by DMA, activations split in the loop
+        if choice is None and Y3_INLOOP and P3 and PREC == 1 and tile == 0 and Cout >= 64 and Cout % 32 == 0 and out.buf is not None \
+                and out.ld % 4 == 0 and out.c0 % 4 == 0 and (res is None or res.ld % 4 == 0):
+            # the in-loop kernel's split-bf16 tiles (BN >= 64: every automatic tile from Cout = 64) can write the piece form too:
+            # no deft_split_planes pass for a pre-split conv that reads this output
+            h = self.p3_output(out, d)
+            if h is not None:
+                d.y3, d.ldy3 = h.addr, h.ld
         cin = x.C if true_cin is None else true_cin
         d.flop_k = KH * KW * cin
         d.flop_n = 0 if true_cout is None else true_cout

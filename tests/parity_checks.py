@@ -859,6 +859,37 @@ def _check_conv_p3(lib, device, N, H, W, Ci, Cm, Co, k, stride, tile, tile2, see
     return maxabs(outs[1][0], ref1)
 
 
+def check_conv_inloop_y3(lib, device, N=2, H=13, W=18, Ci=32, Cm=64, Co=64, k=3, stride=2, seed=0):
+    """A conv on the in-loop kernel (igemm.hip: stride-2 / 1x1 layers) hands its output to a pre-split conv in piece form through its
+    own epilogue (DeftGemmDesc.y3 without x3): no deft_split_planes pass, the pieces equal the fp32 map exactly, results as before."""
+    assert engine.PREC == 1 and engine.P3 and engine.Y3_INLOOP
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g) * 2.0
+    w1 = torch.randn(Cm, Ci, k, k, generator=g) * (1.0 / (Ci * k * k) ** 0.5)
+    w2 = torch.randn(Co, Cm, 3, 3, generator=g) * (1.0 / (Cm * 9) ** 0.5)
+    s1, b1 = torch.rand(Cm, generator=g) + 0.5, torch.randn(Cm, generator=g)
+    s2, b2 = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    pad = k // 2
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = torch.randn(N, Cm, OH, OW, generator=g)
+    plan = engine._Plan(device, lib)
+    xv = plan.alloc(N, H, W, Ci); fill_view(xv, x)
+    rv = plan.alloc(N, OH, OW, Cm); fill_view(rv, r)
+    wp1, K1 = engine.pack_conv_weight(w1); wp2, K2 = engine.pack_conv_weight(w2)
+    t = plan.conv("c1", xv, plan.dev(wp1), K1, k, k, stride, pad, Cm, plan.dev(s1), plan.dev(b1), True, res=rv, p3=False)
+    o = plan.conv("c2", t, plan.dev(wp2), K2, 3, 3, 1, 1, Co, plan.dev(s2), plan.dev(b2), True, p3="im2col", tile=T(64, 64) | (1 << 30))
+    plan.finalize_p3()
+    d1, d2 = plan._gemms[0][2], plan._gemms[1][2]
+    assert not d1.x3 and d1.y3 and d2.x3, "expected: in-loop conv with a piece-form output feeding a pre-split conv"
+    assert "deft_split_planes" not in [op[0] for op in plan.ops]
+    plan.run()
+    assert torch.equal(p3_to_float(plan, t).cpu(), t.to_nchw().permute(0, 2, 3, 1).cpu()), "piece-form output != fp32 output"
+    ref1 = F.relu(F.conv2d(x, w1, None, stride, pad) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1) + r)
+    ref2 = F.relu(F.conv2d(ref1, w2, None, 1, 1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
+    assert maxabs(t.to_nchw(), ref1) <= 2e-5 * max(1.0, float(ref1.abs().max()))
+    assert maxabs(o.to_nchw(), ref2) <= 4e-5 * max(1.0, float(ref2.abs().max()))
+
+
 def check_conv_fold(lib, device, N, H, W, Ci, Cm, fn, p3, tile=0, seed=0):
     """3x3 conv Ci -> Cm + ReLU with the following 1x1 conv Cm -> fn folded into its epilogue (DeftGemmDesc.fold_w; the heat-map
     head, base_model.py:37-66) on the pre-split kernels: equals conv2d(relu(conv2d)) to fp32 round-off, the Cm-channel map is

@@ -310,6 +310,11 @@ def test_conv_fold(emu_lib, args):
     pc.check_conv_fold(emu_lib, "cpu", *args)
 
 
+@pytest.mark.parametrize("kw", [{}, {"k": 1, "stride": 1, "Ci": 96, "Cm": 128, "Co": 64}, {"Cm": 256, "Ci": 64, "H": 9, "W": 11}])
+def test_conv_inloop_piece_output(emu_lib, kw):
+    pc.check_conv_inloop_y3(emu_lib, "cpu", **kw)
+
+
 def test_weight_dma_identical(emu_lib):
     pc.check_weight_dma_identical(emu_lib, "cpu")
 

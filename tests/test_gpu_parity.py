@@ -557,6 +557,11 @@ def test_frame_pipeline_over_rccl(gpu_lib):
     assert rep["value"] > 0 and rep["n_gpus"] == 1
 
 
+@pytest.mark.parametrize("kw", [{}, {"k": 1, "stride": 1, "Ci": 96, "Cm": 128, "Co": 64}, {"Cm": 256, "Ci": 64, "H": 9, "W": 11}, {"N": 4, "H": 152, "W": 272, "Ci": 64, "Cm": 128, "Co": 128}])
+def test_conv_inloop_piece_output(gpu_lib, kw):
+    pc.check_conv_inloop_y3(gpu_lib, "cuda", **kw)
+
+
 def test_weight_dma_identical(gpu_lib):
     pc.check_weight_dma_identical(gpu_lib, "cuda")
     torch.cuda.synchronize()
