@@ -441,14 +441,13 @@ extern "C" int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpa
 //   conflict-free ds_read_b128 for any 32 consecutive rows at any offset.
 //   K order: (16-channel block, tap) -- fp32 round-off differs from the (32-channel block, tap) order of the other kernels.
 // =====================================================================================================================
-#define P3H_TW 32
-#define P3H_HW 34
-
-template <int TH, int BN, int TPI>
+//   Tile width TW = 32 (an MFMA row block is one tile row) or 16 (a row block is two tile rows of 16 pixels): 8 x 16 tiles cover the
+//   maps whose width is 8 mod 16 (136, 272 at config B) with 11 % / 0 % padding where 4 x 32 tiles need 18 % / 6 %.
+template <int TH, int BN, int TPI, int TW>
 constexpr int p3h_lds_bytes(int nsb) {
-    const int apieces = ((TH + 2) * P3H_HW * 6 + 63) / 64;
+    const int apieces = ((TH + 2) * (TW + 2) * 6 + 63) / 64;
     const int stage = 2 * apieces * 1024 + nsb * TPI * BN * 96;
-    const int tile = TH * 32 * (BN + 4) * 4;
+    const int tile = TH * TW * (BN + 4) * 4;
     return stage > tile ? stage : tile;
 }
 
@@ -472,13 +471,15 @@ __device__ __forceinline__ void p3_wait_vm(int n) {
 
 // TPI: taps per interval (1 or 3 = one filter row).  Narrow tiles (BN = 32: the offset/mask convs) have 6 MFMAs per wave and tap --
 // with one barrier per tap they are barrier-bound; three taps per weight stage give 18 per barrier.
-template <int TH, int BN, int WM, int WN, int TPI>
+template <int TH, int BN, int WM, int WN, int TPI, int TW>
 __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int tiles_x, int tiles_y, int ntiles) {
     constexpr int NSB = 3;
     static_assert(TPI == 1 || TPI == 3, "one tap or one filter row per interval");
+    static_assert(TW == 32 || (TW == 16 && TH % 2 == 0), "tile width 32, or 16 with an even number of rows");
     constexpr int NW = WM * WN, NT = NW * 64;
-    constexpr int BM = TH * 32;
-    constexpr int TM = TH / WM, TN = BN / (WN * 32);
+    constexpr int P3H_HW = TW + 2;                     // staged patch width
+    constexpr int BM = TH * TW;
+    constexpr int TM = BM / 32 / WM, TN = BN / (WN * 32);
     constexpr int HP = (TH + 2) * P3H_HW;              // staged input pixels
     constexpr int ASLOTS = HP * 6;
     constexpr int NAP = (ASLOTS + 63) / 64;            // A pieces per 16-channel block
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     constexpr int NBI = TPI * PPT;                     // B pieces per interval
     constexpr int NB = (NBI + NW - 1) / NW;
     constexpr int ABYTES = NAP * 1024, BBYTES = TPI * BN * 96;
-    static_assert(TM >= 1 && TN >= 1 && TH % WM == 0 && BN % (WN * 32) == 0 && (BN * 6) % 64 == 0, "tile shape");
+    static_assert(TM >= 1 && TN >= 1 && (BM / 32) % WM == 0 && BN % (WN * 32) == 0 && (BN * 6) % 64 == 0, "tile shape");
 
     DEFT_DYN_LDS(char, smem);
     char* const Abase = smem;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     const int txi = bid % tiles_x; bid /= tiles_x;
     const int tyi = bid % tiles_y;
     const int n = bid / tiles_y;
-    const int y0 = tyi * TH, x0 = txi * P3H_TW, n0 = nt * BN;
+    const int y0 = tyi * TH, x0 = txi * TW, n0 = nt * BN;
 
     const deft_rsrc_t rx = deft_make_rsrc(p.x3);
     const deft_rsrc_t rw = deft_make_rsrc(p.w3);       // (no tile reaches past the 128-padded weight rows: deft_p3_dispatch checks)
@@ -610,7 +611,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
             bf16x8 pa[TM][3], pb_[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int hr = (wm * TM + i + r) * P3H_HW + frow + s;
+                // row block (wm * TM + i) of the tile: tile row = block, column = frow (TW = 32); rows 2 * block + (frow >> 4), column frow & 15 (TW = 16)
+                const int hr = TW == 32 ? (wm * TM + i + r) * P3H_HW + frow + s
+                                        : (2 * (wm * TM + i) + (frow >> 4) + r) * P3H_HW + (frow & 15) + s;
                 const char* ap = as + hr * 96 + ((fg ^ ((hr >> 3) & 1)) * 16);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) pa[i][q] = *(const bf16x8*)(ap + q * 32);
@@ -643,43 +646,47 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
     __syncthreads();
     deft_epilogue_rows<BM, BN, NT>(T, p, n0, tid, [&](int row) -> long long {
-        const int y = y0 + (row >> 5), x = x0 + (row & 31);
+        const int y = y0 + row / TW, x = x0 + row % TW;       // (TW = 16: row block b holds tile rows 2b, 2b+1 -- the same formula)
         return (y < p.H && x < p.W) ? (long long)(n * p.H + y) * p.W + x : -1;
     });
 }
 
-template <int TH, int BN, int WM, int WN, int TPI>
+template <int TH, int BN, int WM, int WN, int TPI, int TW>
 static int launch_p3h(const DeftGemmDesc& d, hipStream_t s) {
-    constexpr int lds = p3h_lds_bytes<TH, BN, TPI>(3);
-    const int tiles_x = deft_cdiv(d.W, P3H_TW), tiles_y = deft_cdiv(d.H, TH), ntiles = deft_cdiv(d.Cout, BN);
+    constexpr int lds = p3h_lds_bytes<TH, BN, TPI, TW>(3);
+    const int tiles_x = deft_cdiv(d.W, TW), tiles_y = deft_cdiv(d.H, TH), ntiles = deft_cdiv(d.Cout, BN);
     const long long grid = (long long)d.N * tiles_x * tiles_y * ntiles;
     DEFT_CHECK(grid < (1ll << 31), -70, "conv3h: too many tiles");
-    if (int e = p3_set_lds_attr<conv3h_kernel<TH, BN, WM, WN, TPI>>(lds)) return e;
-    hipLaunchKernelGGL((conv3h_kernel<TH, BN, WM, WN, TPI>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, s, d, tiles_x, tiles_y, ntiles);
+    if (int e = p3_set_lds_attr<conv3h_kernel<TH, BN, WM, WN, TPI, TW>>(lds)) return e;
+    hipLaunchKernelGGL((conv3h_kernel<TH, BN, WM, WN, TPI, TW>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, s, d, tiles_x, tiles_y, ntiles);
     DEFT_CHECK_LAUNCH("conv3h");
     return 0;
 }
 
-// `tile` for the halo form: (TH << 16) | BN, 0 = automatic
+// `tile` for the halo form: (TH << 16) | BN, 0 = automatic (4 x 32 pixels); bit 28: tiles are 16 pixels wide (TH x 16)
 int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     DEFT_CHECK(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->OH == d->H && d->OW == d->W && d->korder == 1 && d->splitk <= 1, -71,
                "deft_conv2d_nhwc: the halo form (p3_kernel = 1) is 3x3 / stride 1 / pad 1, korder 1, no split-K");
-    int th = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
+    int th = (d->tile >> 16) & 0xfff, bn = d->tile & 0xffff;
+    const int tw = (d->tile >> 28) & 1 ? 16 : 32;
     if (th == 0) {
-        th = 4;
+        th = tw == 16 ? 8 : 4;
         bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
     }
     const int tpi = (d->tile >> 29) & 1 ? 1 : 0;                 // bit 29: force one tap per interval where the tile defaults to three
-#define P3H_TILE(TH_, BN_, WM_, WN_, TPI_) \
-    if (th == TH_ && bn == BN_ && (tpi == 0 || tpi == TPI_)) return launch_p3h<TH_, BN_, WM_, WN_, TPI_>(*d, s);
-    P3H_TILE(4, 128, 2, 2, 1)
-    P3H_TILE(4, 64, 4, 1, 1)
-    P3H_TILE(4, 32, 4, 1, 3)
-    P3H_TILE(4, 32, 4, 1, 1)
-    P3H_TILE(8, 128, 4, 2, 1)
-    P3H_TILE(8, 64, 4, 2, 1)
+#define P3H_TILE(TH_, BN_, WM_, WN_, TPI_, TW_) \
+    if (th == TH_ && tw == TW_ && bn == BN_ && (tpi == 0 || tpi == TPI_)) return launch_p3h<TH_, BN_, WM_, WN_, TPI_, TW_>(*d, s);
+    P3H_TILE(4, 128, 2, 2, 1, 32)
+    P3H_TILE(4, 64, 4, 1, 1, 32)
+    P3H_TILE(4, 32, 4, 1, 3, 32)
+    P3H_TILE(4, 32, 4, 1, 1, 32)
+    P3H_TILE(8, 128, 4, 2, 1, 32)
+    P3H_TILE(8, 64, 4, 2, 1, 32)
+    P3H_TILE(8, 128, 2, 2, 1, 16)
+    P3H_TILE(8, 64, 4, 1, 1, 16)
+    P3H_TILE(8, 32, 4, 1, 3, 16)
 #undef P3H_TILE
-    DEFT_CHECK(false, -15, "conv3h: unsupported tile %dx32 x %d", th, bn);
+    DEFT_CHECK(false, -15, "conv3h: unsupported tile %dx%d x %d", th, tw, bn);
     return -15;
 }
 

@@ -158,11 +158,15 @@ BDMA_DCN = _os.environ.get("DEFT_BDMA_DCN", "1") == "1"
 P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
 P3_MIN_TILES = int(_os.environ.get("DEFT_P3_MIN_TILES", "512"))   # ... and give every CU two workgroups (latency mode: 2.39 ms/frame on igemm.hip
 # with split-K vs 2.88 on the pre-split kernels, profiles/r2_latency_ab.txt); the im2col form (one 8-wave workgroup per CU) needs half as many
-P3_HALO_WASTE = float(_os.environ.get("DEFT_P3_HALO_WASTE", "1.25"))   # ... when its 4 x 32 pixel tiles cover the map with at most this much padding
+P3_HALO16 = _os.environ.get("DEFT_P3_HALO16", "1") != "0"   # ... as 8 x 16 pixel tiles where those pad the map less than 4 x 32
+P3_HALO_WASTE = float(_os.environ.get("DEFT_P3_HALO_WASTE", "1.2"))   # ... when its 4 x 32 pixel tiles cover the map with at most this much padding
 
 
-def halo_waste(H, W):
-    return (-(-H // 4) * 4) * (-(-W // 32) * 32) / float(H * W)
+def halo_waste(H, W, th=4, tw=32):
+    return (-(-H // th) * th) * (-(-W // tw) * tw) / float(H * W)
+
+
+P3H_W16 = 1 << 28          # halo tile flag: TH x 16 pixels instead of TH x 32
 
 
 _T = lambda bm, bn: (bm << 16) | bn
@@ -195,10 +199,16 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
     and Cout <= 64 stride-2 convs are HBM- or issue-bound and gain nothing from the 6-byte pieces."""
     if KH * KW == 1 or Cin % 32 or Cout % 8:
         return None
-    if (KH, KW, stride, pad) == (3, 3, 1, 1) and korder == 1 and P3_HALO and halo_waste(H, W) <= P3_HALO_WASTE and (Cout >= 128 or Cout <= 32):
+    if (KH, KW, stride, pad) == (3, 3, 1, 1) and korder == 1 and P3_HALO:
+        # 4 x 32 or 8 x 16 pixel tiles: whichever pads the map less (widths that are 8 mod 16 -- 136, 272 at config B -- favour 8 x 16:
+        # 128->128 @76x136 -9 %, head -5 %); 64-column tiles only as 8 x 16 (64->64 @152x272: 0.30 ms against 0.37 im2col / 0.38 as 4 x 32)
+        w32, w16 = halo_waste(H, W, 4, 32), halo_waste(H, W, 8, 16)
+        use16 = P3_HALO16 and (w16 < w32 - 0.01 or 32 < Cout <= 64)
+        th, tw, waste = (8, 16, w16) if use16 else (4, 32, w32)
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
-        if (M // (H * W)) * -(-H // 4) * -(-W // 32) * -(-Cout // bn) >= P3_MIN_TILES:
-            return ("halo", 0)
+        if waste <= P3_HALO_WASTE and (Cout >= 128 or Cout <= 32 or use16) \
+                and (M // (H * W)) * -(-H // th) * -(-W // tw) * -(-Cout // bn) >= P3_MIN_TILES:
+            return ("halo", ((th << 16) | bn | P3H_W16) if use16 else 0)
     if Cout < 64 or Cin < 64 or stride != 1:
         return None                     # stride-2 and 1x1 layers are no faster on 6-byte pieces (HBM- or issue-bound, tools/bench_p3.py)
     # the ONE-stage loop with several workgroups per CU (48 / 37 KB of LDS: 3 / 4 of them) beats the 2-stage ring with one 8-wave

@@ -297,6 +297,7 @@ def test_peaked_heatmap_ordered_topk(emu_lib):
     (1, 8, 32, 32, 64, 3, 1, 1, 0), (2, 9, 37, 64, 128, 3, 1, 1, 0), (1, 5, 70, 64, 64, 3, 1, 1, T(4, 64)),
     (1, 6, 33, 32, 32, 3, 1, 1, T(4, 32)), (1, 10, 40, 64, 128, 3, 1, 1, T(8, 128)), (1, 9, 31, 128, 64, 3, 1, 1, T(8, 64)),
     (1, 4, 20, 64, 200, 3, 1, 1, T(4, 128)),
+    (1, 9, 24, 64, 128, 3, 1, 1, T(8, 128) | (1 << 28)), (2, 16, 16, 32, 64, 3, 1, 1, T(8, 64) | (1 << 28)), (1, 11, 37, 64, 32, 3, 1, 1, T(8, 32) | (1 << 28)),   # 8 x 16 pixel tiles
     (2, 7, 40, 64, 32, 3, 1, 1, T(4, 32) | (1 << 29)),        # narrow tile, one tap per interval (default: a filter row per interval)
 ])
 def test_conv_halo(emu_lib, args):

@@ -478,6 +478,8 @@ def test_conv_presplit(gpu_lib, args):
     (1, 8, 32, 32, 64, 3, 1, 1, 0), (2, 9, 37, 64, 128, 3, 1, 1, 0), (1, 5, 70, 64, 64, 3, 1, 1, pc.T(4, 64)),
     (1, 6, 33, 32, 32, 3, 1, 1, pc.T(4, 32)), (1, 10, 40, 64, 128, 3, 1, 1, pc.T(8, 128)), (1, 9, 31, 128, 64, 3, 1, 1, pc.T(8, 64)),
     (1, 4, 20, 64, 200, 3, 1, 1, pc.T(4, 128)), (2, 7, 40, 64, 32, 3, 1, 1, pc.T(4, 32) | (1 << 29)),
+    (1, 9, 24, 64, 128, 3, 1, 1, pc.T(8, 128) | (1 << 28)), (2, 16, 16, 32, 64, 3, 1, 1, pc.T(8, 64) | (1 << 28)), (1, 11, 37, 64, 32, 3, 1, 1, pc.T(8, 32) | (1 << 28)),
+    (3, 76, 136, 128, 128, 3, 1, 1, pc.T(8, 128) | (1 << 28)), (2, 152, 272, 64, 32, 3, 1, 1, pc.T(8, 32) | (1 << 28)),      # 8 x 16 pixel tiles
     (3, 76, 136, 128, 128, 3, 1, 1, 0), (2, 152, 272, 64, 64, 3, 1, 1, 0), (2, 152, 272, 64, 256, 3, 1, 1, pc.T(8, 128)), (4, 38, 68, 256, 32, 3, 1, 1, 0),
 ])
 def test_conv_halo(gpu_lib, args):

@@ -63,12 +63,21 @@ def case(name, H, W, Ci, Co, k, stride, tiles, res=False):
         ms = timeit(plan)
         d = plan._gemms[-1][2]
         if halo:
-            label = "P3 halo %dx32 x %d" % (tile[1] >> 16, tile[1] & 0xffff)
+            label = "P3 halo %dx%d x %d" % ((tile[1] >> 16) & 0xfff, 16 if tile[1] >> 28 & 1 else 32, tile[1] & 0xffff)
         else:
             label = "igemm.hip (in-loop split)" if tile is None else "P3 %3dx%-3d %dst" % ((tile >> 16) & 0x1fff, tile & 0xffff, 1 if tile & S1 else (3 if tile & S3 else 2)) if tile else "P3 auto"
         print("%-30s %-28s %7.3f ms %6.1f TF/s  %s" % (name, label, ms, fl / ms / 1e9, same), flush=True)
 
 
+W16 = 1 << 28
+if ONLY == "tw16":                                      # 8 x 16 against 4 x 32 pixel halo tiles on the maps whose width is 8 mod 16
+    ONLY = ""
+    case("3x3 128->128 @76x136", 76, 136, 128, 128, 3, 1, [("h", T(4, 128)), ("h", T(8, 128) | W16)], res=True)
+    case("head 3x3 64->256 @152x272", 152, 272, 64, 256, 3, 1, [("h", T(4, 128)), ("h", T(8, 128) | W16)])
+    case("offset 3x3 64->32 @152x272", 152, 272, 64, 32, 3, 1, [("h", T(4, 32)), ("h", T(8, 32) | W16)])
+    case("offset 3x3 128->32 @76x136", 76, 136, 128, 32, 3, 1, [("h", T(4, 32)), ("h", T(8, 32) | W16)])
+    case("3x3 64->64 @152x272", 152, 272, 64, 64, 3, 1, [T(128, 64) | (1 << 30), ("h", T(4, 64)), ("h", T(8, 64) | W16)], res=True)
+    sys.exit(0)
 ALL = [T(256, 128), T(128, 128), T(128, 256), T(128, 128) | S1, T(64, 128) | S1, T(128, 64) | S1]
 N64 = [T(256, 64), T(128, 64), T(64, 64), T(128, 64) | S1, T(64, 64) | S1]
 H128 = [("h", T(4, 128)), ("h", T(8, 128))]
