@@ -158,6 +158,7 @@ BDMA_DCN = _os.environ.get("DEFT_BDMA_DCN", "1") == "1"
 P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
 P3_MIN_TILES = int(_os.environ.get("DEFT_P3_MIN_TILES", "512"))   # ... and give every CU two workgroups (latency mode: 2.39 ms/frame on igemm.hip
 # with split-K vs 2.88 on the pre-split kernels, profiles/r2_latency_ab.txt); the im2col form (one 8-wave workgroup per CU) needs half as many
+P3_HALO_WASTE_NARROW = float(_os.environ.get("DEFT_P3_HALO_WASTE_NARROW", "1.3"))
 P3_HALO16 = _os.environ.get("DEFT_P3_HALO16", "1") != "0"   # ... as 8 x 16 pixel tiles where those pad the map less than 4 x 32
 P3_HALO_WASTE = float(_os.environ.get("DEFT_P3_HALO_WASTE", "1.2"))   # ... when its 4 x 32 pixel tiles cover the map with at most this much padding
 
@@ -206,8 +207,11 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
         use16 = P3_HALO16 and (w16 < w32 - 0.01 or 32 < Cout <= 64)
         th, tw, waste = (8, 16, w16) if use16 else (4, 32, w32)
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
-        if waste <= P3_HALO_WASTE and (Cout >= 128 or Cout <= 32 or use16) \
-                and (M // (H * W)) * -(-H // th) * -(-W // tw) * -(-Cout // bn) >= P3_MIN_TILES:
+        # the 32-column offset/mask convs run on the fp32 instruction otherwise (intra-workgroup split-K tiles): the halo form wins with
+        # more padding and fewer tiles (256->27 @38x68, 16 frames: 0.097 -> 0.055 ms at 24 % padding and 400 tiles; @19x34 it loses)
+        narrow = Cout <= 32
+        if waste <= (P3_HALO_WASTE_NARROW if narrow else P3_HALO_WASTE) and (Cout >= 128 or narrow or use16) \
+                and (M // (H * W)) * -(-H // th) * -(-W // tw) * -(-Cout // bn) >= (P3_MIN_TILES * 3 // 4 if narrow else P3_MIN_TILES):
             return ("halo", ((th << 16) | bn | P3H_W16) if use16 else 0)
     if Cout < 64 or Cin < 64 or stride != 1:
         return None                     # stride-2 and 1x1 layers are no faster on 6-byte pieces (HBM- or issue-bound, tools/bench_p3.py)

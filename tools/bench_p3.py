@@ -70,6 +70,12 @@ def case(name, H, W, Ci, Co, k, stride, tiles, res=False):
 
 
 W16 = 1 << 28
+if ONLY == "small":                                     # offset convs of the small maps: halo tiles against the intra-workgroup split-K tiles
+    ONLY = ""
+    case("offset 3x3 256->32 @38x68", 38, 68, 256, 32, 3, 1, [("h", T(4, 32)), ("h", T(8, 32) | (1 << 28))])
+    case("offset 3x3 512->32 @19x34", 19, 34, 512, 32, 3, 1, [("h", T(4, 32)), ("h", T(8, 32) | (1 << 28))])
+    case("3x3 256->256 @38x68", 38, 68, 256, 256, 3, 1, [T(64, 128) | (1 << 30), ("h", T(8, 128) | (1 << 28))], res=True)
+    sys.exit(0)
 if ONLY == "tw16":                                      # 8 x 16 against 4 x 32 pixel halo tiles on the maps whose width is 8 mod 16
     ONLY = ""
     case("3x3 128->128 @76x136", 76, 136, 128, 128, 3, 1, [("h", T(4, 128)), ("h", T(8, 128) | W16)], res=True)
