@@ -1,7 +1,8 @@
-// Direct (patch-in-LDS) convolution for the 16-output-channel FULL-RESOLUTION layers of DLA-34 (gfx950 only):
+// Direct (patch-in-LDS) convolution for the layers of DLA-34 that READ A FULL-RESOLUTION MAP (gfx950 only):
 //   base_layer   7x7, 3(+1 pad) -> 16, stride 1, pad 3 @ H x W      (dla.py:301-306)
 //   level0       3x3, 16 -> 16,     stride 1, pad 1 @ H x W      (dla.py:307-308, _make_conv_level :331-345)
-// together 6.2 GFLOP per 1088x608 frame on 661 504 pixels -- 16 channels wide, so an implicit GEMM has 16 (32 as pixel
+//   level1       3x3, 16 -> 32,     stride 2, pad 1 @ H x W      (dla.py:309-310)
+// the first two together 6.2 GFLOP per 1088x608 frame on 661 504 pixels -- 16 channels wide, so an implicit GEMM has 16 (32 as pixel
 // pairs) columns and a 147 / 144-deep contraction: on igemm.hip they run on v_mfma_f32_32x32x2_f32 at 61-70 TFLOP/s with the
 // matrix pipe 62 % busy (profiles/r2_summary.md), 1/3 of it on padding.  Here a workgroup stages the (8 + KH - 1) x (32 + KW - 1)
 // fp32 input patch of an 8 x 32 output tile ONCE, splits it into the three bf16 pieces (x = hi + mid + lo, exact) on the way
@@ -12,24 +13,30 @@
 // K order inside one MFMA (lane l: row/col l & 15, k-group g = l >> 4 holding 8 consecutive k):
 //   Cin = 16:  step t covers taps 2t and 2t+1:  tap = 2t + (g >> 1), channels 8 (g & 1) .. +7     (3x3: 5 steps, tap 9 = zero weights)
 //   Cin = 4:   step t is window row t, 8 pixels x 4 channels: pixel 2g + (e >> 2), channel e & 3  (7x7: 7 steps, pixel 7 = zero weights)
-// The weight image w3 is [steps][3 pieces][64 lanes][8 bf16]: the B fragments, loaded lane-linearly into registers once.
+// The weight image w3 is [Cout/16 column blocks][steps][3 pieces][64 lanes][8 bf16]: the B fragments, loaded lane-linearly into registers once.
+// Stride 2 (level1): a 4 x 32 output tile from a 9 x 65 patch; wave w owns column block w & 1 (16 of the 32 output channels) and
+// output rows 2 (w >> 1), +1 -- the same four m-tiles and register budget per wave as the stride-1 form.
 #include "common.h"
 
 typedef float dc_f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int DC_TH = 8, DC_TW = 32;
+constexpr int DC_TW = 32;
 
-template <int KH, int KW, int CIN>
+template <int KH, int KW, int CIN, int STRIDE>
 struct DcCfg {
     static_assert(CIN == 16 || CIN == 4, "16 channels, or the 4-channel (padded RGB) image");
     static_assert(CIN == 16 || KW <= 8, "the 4-channel form covers one window row of up to 8 pixels per MFMA");
-    static constexpr int PH = DC_TH + KH - 1;
-    static constexpr int PW = DC_TW + (CIN == 16 ? KW - 1 : 8);        // Cin = 4: an 8-pixel K step reaches pixel x + 7
+    static_assert(STRIDE == 1 || (STRIDE == 2 && CIN == 16), "stride 2 for the 16-channel form only");
+    static constexpr int NB = STRIDE;                                  // 16-channel output column blocks: 1 (Cout <= 16) or 2 (Cout <= 32)
+    static constexpr int TH = 8 / NB;                                  // output rows per tile: a wave owns two rows and one column block
+    static constexpr int PH = (TH - 1) * STRIDE + KH;
+    static constexpr int PW = (DC_TW - 1) * STRIDE + (CIN == 16 ? KW : 9);   // Cin = 4: an 8-pixel K step reaches pixel x + 7
     // bytes per patch pixel and piece.  Cin = 16: 32 B of data in a 48-byte slot -- 16 lanes reading 16 B at a 48-byte stride
-    // touch every LDS bank once (at 32 bytes two lanes would share each bank)
-    static constexpr int PXB = CIN == 16 ? 48 : 8;
+    // touch every LDS bank once (at 32 bytes two lanes would share each bank); stride 2: 40-byte slots (lanes 80 B apart: every
+    // bank once per 16 lanes), read as two 8-byte halves
+    static constexpr int PXB = CIN == 16 ? (STRIDE == 1 ? 48 : 40) : 8;
     static constexpr int PLANE = PH * PW * PXB;
     static constexpr int STEPS = CIN == 16 ? (KH * KW + 1) / 2 : KH;
     static constexpr int LDS = 3 * PLANE;
@@ -37,9 +44,9 @@ struct DcCfg {
     static constexpr int NI = (ITEMS + 255) / 256;
 };
 
-template <int KH, int KW, int CIN>
-__global__ __launch_bounds__(256, 3) void direct_conv_kernel(const DeftGemmDesc p, int tiles_x, int tiles_y) {
-    using C = DcCfg<KH, KW, CIN>;
+template <int KH, int KW, int CIN, int STRIDE>
+__global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void direct_conv_kernel(const DeftGemmDesc p, int tiles_x, int tiles_y) {
+    using C = DcCfg<KH, KW, CIN, STRIDE>;
     DEFT_DYN_LDS(char, smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -53,17 +60,19 @@ __global__ __launch_bounds__(256, 3) void direct_conv_kernel(const DeftGemmDesc 
     const int txi = bid % tiles_x; bid /= tiles_x;
     const int tyi = bid % tiles_y;
     const int n = bid / tiles_y;
-    const int oy0 = tyi * DC_TH, ox0 = txi * DC_TW;
+    const int oy0 = tyi * C::TH, ox0 = txi * DC_TW;
+    const int cb = C::NB == 1 ? 0 : wave & 1;          // this wave's 16-channel output column block
+    const int wrow = C::NB == 1 ? 2 * wave : 2 * (wave >> 1);   // ... and its first output row of the tile
 
     // ---- weights: this lane's B fragments of every step (L2-resident, lane-linear) ----
-    const bf16x8* const wf = (const bf16x8*)p.w3;
+    const bf16x8* const wf = (const bf16x8*)p.w3 + cb * C::STEPS * 192;
     bf16x8 Bf[C::STEPS][3];
 #pragma unroll
     for (int t = 0; t < C::STEPS; ++t)
 #pragma unroll
         for (int q = 0; q < 3; ++q) Bf[t][q] = wf[(t * 3 + q) * 64 + lane];
 
-    const int co = lane & 15;                      // epilogue constants, fetched ahead of everything that waits
+    const int co = cb * 16 + (lane & 15);          // epilogue constants, fetched ahead of everything that waits
     const float sc = p.scale ? p.scale[co < p.Cout ? co : 0] : 1.f, sh = p.shift ? p.shift[co < p.Cout ? co : 0] : 0.f;
 
     // ---- stage the patch: fp32 NHWC -> three bf16 piece planes in LDS (zero outside the image) ----
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256, 3) void direct_conv_kernel(const DeftGemmDesc 
             const int it = i * 256 + tid;
             const int px = CIN == 16 ? it >> 2 : it, cq = CIN == 16 ? it & 3 : 0;
             const int py = px / C::PW, pxx = px - py * C::PW;
-            const int iy = oy0 - p.pad + py, ix = ox0 - p.pad + pxx;
+            const int iy = oy0 * STRIDE - p.pad + py, ix = ox0 * STRIDE - p.pad + pxx;
             const bool ok = it < C::ITEMS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const unsigned off = ok ? ((unsigned)((n * p.H + iy) * p.W + ix) * (unsigned)p.ldx + (unsigned)cq * 4u) * 4u : DEFT_OOB;
             v[i] = deft_buffer_load_x4(rx, off);
@@ -108,19 +117,19 @@ __global__ __launch_bounds__(256, 3) void direct_conv_kernel(const DeftGemmDesc 
             int tap = 2 * t + (g >> 1);
             tap = tap < KH * KW ? tap : KH * KW - 1;                // the padding tap of the last step: zero weights, any finite data
             const int tr = tap / KW, ts = tap - tr * KW;
-            a0 = ((2 * wave + tr) * C::PW + prow + ts) * C::PXB + (g & 1) * 16;
+            a0 = ((wrow * STRIDE + tr) * C::PW + prow * STRIDE + ts) * C::PXB + (g & 1) * 16;
         } else {
-            a0 = ((2 * wave + t) * C::PW + prow + 2 * g) * C::PXB;
+            a0 = ((wrow + t) * C::PW + prow + 2 * g) * C::PXB;
         }
         bf16x8 Af[4][3];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const char* const ap = smem + a0 + ((mt >> 1) * C::PW + (mt & 1) * 16) * C::PXB;
+            const char* const ap = smem + a0 + ((mt >> 1) * C::PW + (mt & 1) * 16) * STRIDE * C::PXB;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                if (CIN == 16) {
+                if (CIN == 16 && STRIDE == 1) {
                     Af[mt][q] = *(const bf16x8*)(ap + q * C::PLANE);
-                } else {                                // 8-byte aligned only: two pixels as two 8-byte reads
+                } else {                                // 8-byte aligned only: two 8-byte reads (Cin = 4: two pixels)
                     const bf16x4 u0 = *(const bf16x4*)(ap + q * C::PLANE), u1 = *(const bf16x4*)(ap + q * C::PLANE + 8);
                     Af[mt][q] = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256, 3) void direct_conv_kernel(const DeftGemmDesc 
     if (co < p.Cout) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int oy = oy0 + 2 * wave + (mt >> 1);
+            const int oy = oy0 + wrow + (mt >> 1);
             if (oy >= p.OH) continue;
             float* const yr = p.y + (size_t)((n * p.OH + oy) * (size_t)p.OW) * p.ldy + co;
 #pragma unroll
@@ -154,24 +163,33 @@ __global__ __launch_bounds__(256, 3) void direct_conv_kernel(const DeftGemmDesc 
     }
 }
 
-template <int KH, int KW, int CIN>
+template <int KH, int KW, int CIN, int STRIDE>
 int launch_direct(const DeftGemmDesc& d, hipStream_t s) {
-    using C = DcCfg<KH, KW, CIN>;
-    const int tiles_x = deft_cdiv(d.OW, DC_TW), tiles_y = deft_cdiv(d.OH, DC_TH);
+    using C = DcCfg<KH, KW, CIN, STRIDE>;
+    const int tiles_x = deft_cdiv(d.OW, DC_TW), tiles_y = deft_cdiv(d.OH, C::TH);
     const long long grid = (long long)d.N * tiles_x * tiles_y;
     DEFT_CHECK(grid < (1ll << 31), -70, "deft_conv_direct: too many tiles");
-    hipLaunchKernelGGL((direct_conv_kernel<KH, KW, CIN>), dim3((unsigned)grid), dim3(256), C::LDS, s, d, tiles_x, tiles_y);
+    if (C::LDS > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute((const void*)direct_conv_kernel<KH, KW, CIN, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+            DEFT_CHECK(e == hipSuccess, -101, "deft_conv_direct: hipFuncSetAttribute(%d B LDS) failed: %s", C::LDS, hipGetErrorString(e));
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((direct_conv_kernel<KH, KW, CIN, STRIDE>), dim3((unsigned)grid), dim3(256), C::LDS, s, d, tiles_x, tiles_y);
     DEFT_CHECK_LAUNCH("deft_conv_direct");
     return 0;
 }
 
-// one thread per bf16x8 of the fragment image [steps][3][64 lanes]
+// one thread per bf16x8 of the fragment image [Cout/16 column blocks][steps][3][64 lanes]
 __global__ __launch_bounds__(256) void split_weights_direct_kernel(const float* __restrict__ w, __bf16* __restrict__ w3, int Cout, int Kpad, int KH, int KW,
                                                                    int Cin, int steps) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= steps * 3 * 64) return;
-    const int lane = i & 63, q = (i >> 6) % 3, t = i / 192;
-    const int co = lane & 15, g = lane >> 4;
+    const int nb = (Cout + 15) / 16;
+    if (i >= nb * steps * 3 * 64) return;
+    const int lane = i & 63, q = (i >> 6) % 3, t = (i / 192) % steps, cb = i / (192 * steps);
+    const int co = cb * 16 + (lane & 15), g = lane >> 4;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -197,30 +215,33 @@ int direct_steps(int KH, int KW, int Cin) { return Cin == 16 ? (KH * KW + 1) / 2
 
 extern "C" int deft_conv_direct(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d != nullptr && d->x && d->w3 && d->y, -1, "deft_conv_direct: null descriptor / x / w3 / y");
-    DEFT_CHECK(d->stride == 1 && (d->stride_w == 0 || d->stride_w == 1) && d->OH == d->H && d->OW == d->W && d->KH == d->KW && d->pad == d->KH / 2, -72,
-               "deft_conv_direct: stride-1 'same' convs only (KH=%d KW=%d stride=%d pad=%d)", d->KH, d->KW, d->stride, d->pad);
-    DEFT_CHECK(d->Cout >= 1 && d->Cout <= 16 && d->ldy >= d->Cout, -73, "deft_conv_direct: Cout=%d (at most 16 output channels), ldy=%d", d->Cout, d->ldy);
+    DEFT_CHECK((d->stride == 1 || d->stride == 2) && (d->stride_w == 0 || d->stride_w == d->stride) && d->KH == d->KW && d->pad == d->KH / 2 &&
+                   d->OH == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->OW == (d->W + 2 * d->pad - d->KW) / d->stride + 1, -72,
+               "deft_conv_direct: stride 1 or 2, pad = KH / 2 (KH=%d KW=%d stride=%d pad=%d OH=%d OW=%d)", d->KH, d->KW, d->stride, d->pad, d->OH, d->OW);
+    DEFT_CHECK(d->Cout >= 1 && d->Cout <= 16 * d->stride && d->ldy >= d->Cout, -73, "deft_conv_direct: Cout=%d (at most 16 output channels per unit of stride), ldy=%d", d->Cout, d->ldy);
     DEFT_CHECK(d->res == nullptr && d->rowmap == nullptr && d->splitk <= 1 && d->y3 == nullptr && d->x3 == nullptr, -74,
                "deft_conv_direct: no residual / rowmap / split-K / P3 operands");
     DEFT_CHECK((d->ldx & 3) == 0 && d->ldx >= d->Cin && (((size_t)d->x | (size_t)d->w3) & 15) == 0, -75, "deft_conv_direct: ldx %% 4, 16-byte aligned x / w3");
     DEFT_CHECK(d->M == d->N * d->OH * d->OW && (long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -76, "deft_conv_direct: M mismatch or input exceeds 2 GiB");
     hipStream_t s = (hipStream_t)stream;
-    if (d->KH == 3 && d->Cin == 16) return launch_direct<3, 3, 16>(*d, s);
-    if (d->KH == 7 && d->Cin == 4) return launch_direct<7, 7, 4>(*d, s);
-    DEFT_CHECK(false, -77, "deft_conv_direct: built for 3x3 x 16 channels and 7x7 x 4 channels (KH=%d Cin=%d)", d->KH, d->Cin);
+    if (d->KH == 3 && d->Cin == 16 && d->stride == 1) return launch_direct<3, 3, 16, 1>(*d, s);
+    if (d->KH == 3 && d->Cin == 16 && d->stride == 2) return launch_direct<3, 3, 16, 2>(*d, s);
+    if (d->KH == 7 && d->Cin == 4 && d->stride == 1) return launch_direct<7, 7, 4, 1>(*d, s);
+    DEFT_CHECK(false, -77, "deft_conv_direct: built for 3x3 x 16 channels (stride 1, 2) and 7x7 x 4 channels (KH=%d Cin=%d stride=%d)", d->KH, d->Cin, d->stride);
     return -77;
 }
 
-extern "C" long long deft_direct_weight_bytes(int KH, int KW, int Cin) {
-    if (!((Cin == 16 && KH * KW >= 1) || (Cin == 4 && KW <= 8)) || KH < 1 || KW < 1) return -1;
-    return (long long)direct_steps(KH, KW, Cin) * 3 * 64 * 16;
+extern "C" long long deft_direct_weight_bytes(int KH, int KW, int Cin, int Cout) {
+    if (!((Cin == 16 && KH * KW >= 1) || (Cin == 4 && KW <= 8)) || KH < 1 || KW < 1 || Cout < 1 || Cout > 32) return -1;
+    return (long long)((Cout + 15) / 16) * direct_steps(KH, KW, Cin) * 3 * 64 * 16;
 }
 
 extern "C" int deft_split_weights_direct(const float* w, void* w3, int Cout, int Kpad, int KH, int KW, int Cin, void* stream) {
-    DEFT_CHECK(w && w3 && Cout >= 1 && Cout <= 16 && (Cin == 16 || (Cin == 4 && KW <= 8)) && KH >= 1 && KW >= 1 && Kpad >= KH * KW * Cin, -1,
-               "deft_split_weights_direct: need Cout <= 16, Cin 16 (or 4 with KW <= 8), Kpad >= KH*KW*Cin (%d %d %d %d %d)", Cout, Kpad, KH, KW, Cin);
+    DEFT_CHECK(w && w3 && Cout >= 1 && Cout <= 32 && (Cin == 16 || (Cin == 4 && KW <= 8)) && KH >= 1 && KW >= 1 && Kpad >= KH * KW * Cin, -1,
+               "deft_split_weights_direct: need Cout <= 32, Cin 16 (or 4 with KW <= 8), Kpad >= KH*KW*Cin (%d %d %d %d %d)", Cout, Kpad, KH, KW, Cin);
     const int steps = direct_steps(KH, KW, Cin);
-    hipLaunchKernelGGL(split_weights_direct_kernel, dim3(deft_cdiv(steps * 192, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, Cout, Kpad, KH, KW, Cin, steps);
+    hipLaunchKernelGGL(split_weights_direct_kernel, dim3(deft_cdiv(((Cout + 15) / 16) * steps * 192, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, Cout, Kpad, KH,
+                       KW, Cin, steps);
     DEFT_CHECK_LAUNCH("split_weights_direct");
     return 0;
 }

@@ -553,14 +553,15 @@ class _Plan:
         self.gemm("deft_conv2d_nhwc", name, d, 2.0 * x.N * OH * OW * Cout * true_k)
         return out
 
-    def conv_direct(self, name, x, w_packed, K, KH, pad, Cout, scale, shift, relu, true_cin):
-        """Stride-1 'same' conv with <= 16 output channels on the patch-in-LDS kernel (deft_conv_direct): x is fp32 NHWC with 16
+    def conv_direct(self, name, x, w_packed, K, KH, pad, Cout, scale, shift, relu, true_cin, stride=1):
+        """Conv with <= 16 (stride 2: <= 32) output channels on the patch-in-LDS kernel (deft_conv_direct): x is fp32 NHWC with 16
         (or, for the image, 4) channels; `w_packed` the ordinary packed fp32 matrix, re-laid once into B fragments."""
-        assert pad == KH // 2 and x.C in (4, 16) and Cout <= 16
-        out = self.alloc(x.N, x.H, x.W, Cout)
+        assert pad == KH // 2 and x.C in (4, 16) and Cout <= 16 * stride and stride in (1, 2)
+        OH, OW = (x.H + 2 * pad - KH) // stride + 1, (x.W + 2 * pad - KH) // stride + 1
+        out = self.alloc(x.N, OH, OW, Cout)
         key = (w_packed.data_ptr(), "direct")
         if key not in self._w3:
-            nb = self.lib.cdll.deft_direct_weight_bytes(KH, KH, x.C)
+            nb = self.lib.cdll.deft_direct_weight_bytes(KH, KH, x.C, Cout)
             assert nb > 0
             w3 = torch.empty(nb, dtype=torch.uint8, device=self.device)
             self.lib.call("deft_split_weights_direct", ptr(w_packed), ptr(w3), Cout, w_packed.shape[1], KH, KH, x.C, hiplib.stream_ptr(self.device))
@@ -572,10 +573,10 @@ class _Plan:
         d.shift = shift.data_ptr() if shift is not None else None
         d.y = out.addr
         d.N, d.H, d.W, d.Cin, d.ldx = x.N, x.H, x.W, x.C, x.ld
-        d.OH, d.OW, d.Cout, d.ldy, d.ldr = x.H, x.W, Cout, out.ld, 0
-        d.KH, d.KW, d.stride, d.pad = KH, KH, 1, pad
+        d.OH, d.OW, d.Cout, d.ldy, d.ldr = OH, OW, Cout, out.ld, 0
+        d.KH, d.KW, d.stride, d.pad = KH, KH, stride, pad
         d.Ktot, d.Kpad = K, w_packed.shape[1]
-        d.M = x.N * x.H * x.W
+        d.M = x.N * OH * OW
         d.relu = int(relu)
         d.flop_k = KH * KH * true_cin
         d.prec = 1
@@ -628,14 +629,14 @@ class DlaSegPlan(_Plan):
     # ---- weights -----------------------------------------------------------
     def _conv_bn(self, name, x, wkey, bnkey, KH, stride, pad, relu, out=None, res=None, cin_pad=None):
         w = self.sd[wkey + ".weight"]
-        if (DIRECT and PREC == 1 and w.shape[0] <= 16 and stride == 1 and out is None and res is None and pad == KH // 2
-                and ((KH, x.C) in ((3, 16), (7, 4))) and x.N * ((x.H + 7) // 8) * ((x.W + 31) // 32) >= P3_MIN_TILES):
+        if (DIRECT and PREC == 1 and w.shape[0] <= 16 * stride and out is None and res is None and pad == KH // 2
+                and ((KH, x.C, stride) in ((3, 16, 1), (7, 4, 1), (3, 16, 2))) and x.N * ((x.H + 7) // 8) * ((x.W + 31) // 32) >= P3_MIN_TILES * stride * stride):
             if ("d", wkey) not in self._wcache:
                 wp, K = pack_conv_weight(w, cin_pad)
                 alpha, beta = _bn_fold(self.sd, bnkey)
                 self._wcache[("d", wkey)] = (self.dev(wp), K, self.dev(alpha), self.dev(beta))
             wp, K, alpha, beta = self._wcache[("d", wkey)]
-            return self.conv_direct(name, x, wp, K, KH, pad, w.shape[0], alpha, beta, relu, w.shape[1])
+            return self.conv_direct(name, x, wp, K, KH, pad, w.shape[0], alpha, beta, relu, w.shape[1], stride=stride)
         if w.shape[0] <= 16 and stride == 1 and out is None and res is None and x.W % 2 == 0 and KH > 1:
             # 16-channel full-resolution layers (base_layer, level0): pixel-pair GEMM, 32 useful columns
             if wkey not in self._wcache:

@@ -69,7 +69,7 @@ _SIGS = {
     "deft_fold_finish": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.c_int, C.c_int, c_fp, c_fp, C.c_int, c_fp]),
     "deft_conv_direct": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "deft_split_weights_direct": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp]),
-    "deft_direct_weight_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "deft_direct_weight_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)

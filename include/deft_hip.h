@@ -306,10 +306,11 @@ int deft_split_weights_halo(const float* w, void* w3, int CoutPad, int Kpad, voi
  * c < C; parts are added in index order (deterministic). */
 int deft_fold_finish(const float* part, int nparts, long long M, int C, int ldp, const float* bias, float* y, int ldy, void* stream);
 
-/* Direct (input patch in LDS) convolution for the 16-output-channel full-resolution layers: DLA-34's base_layer (7x7, 3 -> 16,
- * dla.py:301-306; the image as 4-channel NHWC) and level0 (3x3, 16 -> 16, dla.py:307-308), + folded BatchNorm + ReLU.
- * Stride 1, pad = KH / 2, Cout <= 16, Cin = 16 (any KH x KW) or Cin = 4 (KW <= 8); built for 3x3x16 and 7x7x4.  A workgroup
- * stages the fp32 patch of an 8 x 32 output tile once, splits it into the three bf16 pieces on the way into LDS (one split
+/* Direct (input patch in LDS) convolution for the layers that read a full-resolution map: DLA-34's base_layer (7x7, 3 -> 16,
+ * dla.py:301-306; the image as 4-channel NHWC), level0 (3x3, 16 -> 16, dla.py:307-308) and level1 (3x3, 16 -> 32, stride 2,
+ * dla.py:309-310), + folded BatchNorm + ReLU.  pad = KH / 2; stride 1 with Cout <= 16, or stride 2 with Cout <= 32 (Cin = 16);
+ * Cin = 16 or Cin = 4 (KW <= 8); built for 3x3x16 (stride 1, 2) and 7x7x4.  A workgroup
+ * stages the fp32 patch of an 8 x 32 (stride 2: 4 x 32) output tile once, splits it into the three bf16 pieces on the way into LDS (one split
  * per input element instead of one per output pixel and tap) and feeds v_mfma_f32_16x16x32_bf16 with shifted fragment reads:
  * six bf16 products per fp32 product, fp32 accumulation (the arithmetic of DeftGemmDesc.prec = 1; another summation order
  * than the implicit-GEMM kernels).  Uses x, w3, scale, shift, y, N, H, W, Cin, ldx, OH, OW, Cout, ldy, KH, KW, stride, pad,
@@ -317,11 +318,11 @@ int deft_fold_finish(const float* part, int nparts, long long M, int C, int ldp,
 int deft_conv_direct(const DeftGemmDesc* d, void* stream);
 
 /* Packed fp32 weights [>= Cout rows][Kpad], k = (r*KW + s)*Cin + c (DeftGemmDesc.w order), -> the B-fragment image of
- * deft_conv_direct: [steps][3 pieces][64 lanes][8 bf16], deft_direct_weight_bytes(KH, KW, Cin) bytes.  Lane l holds output
- * channel l & 15 and the 8 consecutive k of group g = l >> 4 of an MFMA K step:  Cin = 16: step t = taps 2t, 2t+1
+ * deft_conv_direct: [ceil(Cout / 16) column blocks][steps][3 pieces][64 lanes][8 bf16], deft_direct_weight_bytes(KH, KW, Cin,
+ * Cout) bytes.  Lane l holds output channel 16 * block + (l & 15) and the 8 consecutive k of group g = l >> 4 of an MFMA K step:  Cin = 16: step t = taps 2t, 2t+1
  * (tap 2t + (g >> 1), channels 8 (g & 1) ..+7);  Cin = 4: step t = window row t (pixel 2g + (e >> 2), channel e & 3). */
 int deft_split_weights_direct(const float* w, void* w3, int Cout, int Kpad, int KH, int KW, int Cin, void* stream);
-long long deft_direct_weight_bytes(int KH, int KW, int Cin);
+long long deft_direct_weight_bytes(int KH, int KW, int Cin, int Cout);
 
 #ifdef __cplusplus
 }

@@ -88,7 +88,7 @@ def check_conv_pair(lib, device, Ci, k, N=2, H=6, W=10, Co=16, seed=0):
     assert maxabs(out.to_nchw(), plain.to_nchw()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
-def check_conv_direct(lib, device, Ci, k, N=2, H=11, W=37, Co=16, relu=True, seed=0, wide=False):
+def check_conv_direct(lib, device, Ci, k, N=2, H=11, W=37, Co=16, relu=True, seed=0, wide=False, stride=1):
     """The patch-in-LDS kernel of the 16-channel full-resolution layers (deft_conv_direct): equals conv2d to fp32 round-off on maps
     that are not multiples of the 8 x 32 tile (partial tiles, zero halo on every side); `wide`: operands spread over 30 binades,
     which the three-piece split must carry without loss."""
@@ -103,12 +103,12 @@ def check_conv_direct(lib, device, Ci, k, N=2, H=11, W=37, Co=16, relu=True, see
     cp = (Ci + 3) // 4 * 4
     xv = plan.alloc(N, H, W, cp); fill_view(xv, x)
     wp, K = engine.pack_conv_weight(w, cp)
-    out = plan.conv_direct("d", xv, plan.dev(wp), K, k, k // 2, Co, plan.dev(scale), plan.dev(shift), relu, Ci)
+    out = plan.conv_direct("d", xv, plan.dev(wp), K, k, k // 2, Co, plan.dev(scale), plan.dev(shift), relu, Ci, stride=stride)
     plan.run()
-    ref = F.conv2d(x.double(), w.double(), None, 1, k // 2) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), None, stride, k // 2) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
     if relu:
         ref = F.relu(ref)
-    mag = F.conv2d(x.abs().double(), w.abs().double(), None, 1, k // 2) * scale.double().view(1, -1, 1, 1) + shift.abs().double().view(1, -1, 1, 1)
+    mag = F.conv2d(x.abs().double(), w.abs().double(), None, stride, k // 2) * scale.double().view(1, -1, 1, 1) + shift.abs().double().view(1, -1, 1, 1)
     err = float(((out.to_nchw().cpu().double() - ref).abs() / mag).max())
     assert err <= 2e-6, ("direct conv", Ci, k, N, H, W, Co, err)       # an fp32 chain of k*k*Ci terms: ~ sqrt(K) * 2^-24 relative to sum |a||b|
     return err

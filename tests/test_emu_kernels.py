@@ -37,7 +37,7 @@ def test_conv_pixel_pair(emu_lib, Ci, k):
 
 
 @pytest.mark.parametrize("Ci,k,kw", [(3, 7, {}), (16, 3, {}), (16, 3, {"N": 1, "H": 8, "W": 32, "Co": 12, "relu": False}), (3, 7, {"N": 1, "H": 19, "W": 70, "wide": True}),
-                                     (16, 3, {"wide": True, "seed": 3})])
+                                     (16, 3, {"wide": True, "seed": 3}), (16, 3, {"stride": 2, "Co": 32}), (16, 3, {"stride": 2, "Co": 24, "H": 16, "W": 66, "N": 1, "relu": False}), (16, 3, {"stride": 2, "Co": 32, "H": 9, "W": 130, "wide": True})])
 def test_conv_direct(emu_lib, Ci, k, kw):
     pc.check_conv_direct(emu_lib, "cpu", Ci, k, **kw)
 
@@ -117,7 +117,7 @@ def test_forward_every_presplit_kernel_forced(emu_lib):
         sd = O.synth_state_dict("mot")
         plan, rep, _ = pc.check_forward(emu_lib, "cpu", "mot", 32, 128, sd=sd)
         kinds = [op[0] for op in plan.ops]
-        assert kinds.count("deft_conv_direct") == 2 and kinds.count("deft_fold_finish") >= 1
+        assert kinds.count("deft_conv_direct") == 3 and kinds.count("deft_fold_finish") >= 1
         assert any(d.p3_kernel == 1 for _, _, d in plan._gemms) and any(d.x3 and not d.p3_kernel for _, _, d in plan._gemms)
     finally:
         engine.P3_MIN_TILES = saved

@@ -41,7 +41,7 @@ def test_conv_pixel_pair(gpu_lib, Ci, k):
 
 
 @pytest.mark.parametrize("Ci,k,kw", [(3, 7, {}), (16, 3, {}), (16, 3, {"N": 1, "H": 8, "W": 32, "Co": 12, "relu": False}), (3, 7, {"N": 1, "H": 19, "W": 70, "wide": True}),
-                                     (16, 3, {"wide": True, "seed": 3}), (16, 3, {"N": 3, "H": 152, "W": 272}), (3, 7, {"N": 2, "H": 152, "W": 272, "seed": 5})])
+                                     (16, 3, {"wide": True, "seed": 3}), (16, 3, {"stride": 2, "Co": 32}), (16, 3, {"stride": 2, "Co": 24, "H": 16, "W": 66, "N": 1, "relu": False}), (16, 3, {"stride": 2, "Co": 32, "H": 9, "W": 130, "wide": True}), (16, 3, {"N": 3, "H": 152, "W": 272}), (3, 7, {"N": 2, "H": 152, "W": 272, "seed": 5})])
 def test_conv_direct(gpu_lib, Ci, k, kw):
     pc.check_conv_direct(gpu_lib, "cuda", Ci, k, **kw)
 
