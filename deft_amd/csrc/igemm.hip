@@ -262,6 +262,18 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     int bdma_stage = 0;                              // PREC 2: the B stage the next issue_loads() fills
     int dma_stage = 0;                               // DMA form: LDS stage the next issue_loads() fills
     auto issue_loads = [&]() {
+        // Weight DMA FIRST (PREC 2).  LDS-DMA loads and ordinary (VGPR) loads share vmcnt but need not complete in issue order
+        // relative to each other; the compiler's partial waits (s_waitcnt vmcnt(N > 0) in front of finish_store()'s first use of a
+        // staged register) assume in-order return.  With the DMAs OLDER than the register loads those waits stay sufficient (N counts
+        // only younger register loads, and completions within one kind are in order); with the DMAs younger, a DMA that lands early
+        // satisfies the count while the register load is still in flight -- seen on MI355X as wrong row groups in the DCN (below).
+        if (BDMA && NBS == 2) {
+            const unsigned soff = (unsigned)(kload >> 5) * 12288u;
+#pragma unroll
+            for (int i = 0; i < NBP; ++i)
+                deft_buffer_load_lds_x4s(rw3, Bd + bdma_stage * BN * 192 + (wave + i * 4) * 1024, vB3[i], soff);
+            bdma_stage ^= 1;
+        }
         if (MODE == MODE_CONV) {
             int r, s, toff;                                  // tap of this lane's k-slot, byte offset of (tap, channel)
             bool kok;
@@ -311,13 +323,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
             }
         }
         if (BDMA) {
-            if (NBS == 2) {
-                const unsigned soff = (unsigned)(kload >> 5) * 12288u;
-#pragma unroll
-                for (int i = 0; i < NBP; ++i)
-                    deft_buffer_load_lds_x4s(rw3, Bd + bdma_stage * BN * 192 + (wave + i * 4) * 1024, vB3[i], soff);
-                bdma_stage ^= 1;
-            }
+            // (issued at the top of this function)
         } else if (DMA) {
             const unsigned wo = (unsigned)(((n0 + rbase) * p.Kpad + kload + gs * 4) * 4);
 #pragma unroll
@@ -475,6 +481,9 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         issue_loads();
         if (BDMA && NBS == 1) issue_b();
         for (int kt = 0; kt < nk; ++kt) {
+            // PREC 3: the single weight stage is refilled AFTER the register loads of the chunk were issued (the DMAs are younger):
+            // no partial vmcnt wait is safe there (see issue_loads) -- everything this wave has in flight lands first
+            if (BDMA && NBS == 1) DEFT_WAIT_VM(0);
             finish_store(0);
             if (BDMA) DEFT_WAIT_VM(0);           // this wave's pieces of chunk kt's weight image have landed (the barrier publishes everybody's)
             __syncthreads();
