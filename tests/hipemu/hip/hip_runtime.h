@@ -95,6 +95,10 @@ struct State {
     // wave exchange buffers: [parity][slot][lane]
     float xf[2][16][64];
     int parity = 0;
+    // LDS-DMA pieces issued but not yet delivered ("late" mode, see dma_wait): one FIFO per thread of the block
+    struct Pending { void* dst; unsigned char data[16]; };
+    std::vector<std::vector<Pending>> dmaq;
+    int cur_t = 0;
 };
 inline State& S() { static thread_local State s; return s; }
 inline void yield(int code) {
@@ -116,8 +120,27 @@ struct Fiber {
     int state = Y_NONE;
 };
 inline std::function<void()>& body() { static thread_local std::function<void()> f; return f; }
+// "Late DMA" mode: an LDS-DMA piece is delivered only when its wave WAITS for it (DEFT_WAIT_VM / DEFT_PIPE_BARRIER /
+// __syncthreads -- the latest moment the hardware allows), not at issue (the earliest).  A kernel that reads a DMA stage
+// before the issuing wave's vmcnt wait + a barrier then reads stale LDS here too; a piece still pending when its wave exits
+// is reported (on the hardware it would land in LDS that may already belong to another workgroup).
+inline int& late_dma() { static int on = 0; return on; }
+inline void dma_wait(size_t keep) {
+    State& s = S();
+    if (s.dmaq.empty()) return;
+    std::vector<State::Pending>& q = s.dmaq[s.cur_t];
+    if (q.size() <= keep) return;
+    const size_t n = q.size() - keep;
+    for (size_t i = 0; i < n; ++i) memcpy(q[i].dst, q[i].data, 16);
+    q.erase(q.begin(), q.begin() + n);
+}
 inline void trampoline() {
     body()();
+    State& s = S();
+    if (!s.dmaq.empty() && !s.dmaq[s.cur_t].empty()) {
+        fprintf(stderr, "hipemu: thread %d exits with %zu LDS-DMA pieces in flight\n", s.cur_t, s.dmaq[s.cur_t].size());
+        abort();
+    }
     for (;;) yield(Y_DONE);          // a finished fiber is never resumed; never return into the fabricated frame
 }
 
@@ -149,8 +172,10 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
     }
     const int nwave = (nthr + 63) / 64;
     std::vector<int> wparity(nwave, 0);
+    if (late_dma()) { s.dmaq.resize(nthr); for (auto& q : s.dmaq) q.clear(); } else s.dmaq.clear();
     auto resume = [&](int t) {
         Fiber& f = fibers[t];
+        s.cur_t = t;
         s.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
         s.bid = bid; s.bdim = block; s.gdim = grid;
         s.lane = t & 63; s.wave = t >> 6;
@@ -284,7 +309,8 @@ static const int warpSize = 64;
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
 
-static inline void __syncthreads() { hipemu::yield(hipemu::Y_BLOCK); }
+// (hipcc's __syncthreads() is fence + s_barrier: it drains vmcnt when LDS-DMA pieces are outstanding)
+static inline void __syncthreads() { hipemu::dma_wait(0); hipemu::yield(hipemu::Y_BLOCK); }
 
 typedef float __attribute__((ext_vector_type(16))) hipemu_f32x16;
 typedef float __attribute__((ext_vector_type(4))) hipemu_f32x4;
@@ -420,18 +446,26 @@ static inline hipemu_f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off)
     if (byte_off < r.n && byte_off + 16u <= r.n) memcpy(&v, r.base + byte_off, 16);
     return v;
 }
+static inline void hipemu_dma_deposit(void* dst, const hipemu_f32x4& v) {
+    hipemu::State& s = hipemu::S();
+    if (s.dmaq.empty()) { memcpy(dst, &v, 16); return; }          // default: delivered at issue
+    hipemu::State::Pending p; p.dst = dst; memcpy(p.data, &v, 16);
+    s.dmaq[s.cur_t].push_back(p);
+}
 static inline void deft_buffer_load_lds_x4(deft_rsrc_t r, float* lds_wave_base, unsigned byte_off) {
     const hipemu_f32x4 v = deft_buffer_load_x4(r, byte_off);
-    memcpy(lds_wave_base + 4 * hipemu::S().lane, &v, 16);
+    hipemu_dma_deposit(lds_wave_base + 4 * hipemu::S().lane, v);
 }
 static inline void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* lds_wave_base, unsigned voff, unsigned soff) {
     hipemu_f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (voff < r.n && voff + 16u <= r.n) memcpy(&v, r.base + voff + soff, 16);      // range check on voff alone, like the hardware
-    memcpy((char*)lds_wave_base + 16 * hipemu::S().lane, &v, 16);
+    hipemu_dma_deposit((char*)lds_wave_base + 16 * hipemu::S().lane, v);
 }
-#define DEFT_PIPE_BARRIER(N) __syncthreads()      /* the emulator's DMA is synchronous */
-#define DEFT_PIPE_BARRIER_ONLY() __syncthreads()
-#define DEFT_WAIT_VM(N) ((void)0)
+// the raw barrier does not wait for DMA pieces; the vmcnt forms deliver all but the newest N of the calling thread's wave
+#define DEFT_PIPE_BARRIER(N) do { hipemu::dma_wait(N); hipemu::yield(hipemu::Y_BLOCK); } while (0)
+#define DEFT_PIPE_BARRIER_ONLY() hipemu::yield(hipemu::Y_BLOCK)
+#define DEFT_WAIT_VM(N) hipemu::dma_wait(N)
+extern "C" __attribute__((weak, visibility("default"))) void hipemu_set_late_dma(int on) { hipemu::late_dma() = on; }
 #define DEFT_RINT_HOOK 1
 static inline int deft_rint(double v) { return (int)std::nearbyint(v); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}

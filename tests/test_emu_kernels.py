@@ -329,3 +329,50 @@ def test_composed_dropin_replays_reference_trace(emu_lib, tag):
 
 def test_preprocess_u8(emu_lib):
     pc.check_preprocess_u8(emu_lib, "cpu")
+
+
+# ---- the same kernels with LDS-DMA pieces delivered as LATE as the hardware may (tests/hipemu: late_dma): a read of a DMA stage
+# ---- that is not ordered behind the issuing wave's vmcnt wait + a barrier sees stale LDS, a piece in flight at wave exit aborts
+@pytest.fixture
+def late_dma(emu_lib):
+    emu_lib.cdll.hipemu_set_late_dma(1)
+    yield emu_lib
+    emu_lib.cdll.hipemu_set_late_dma(0)
+
+
+@pytest.mark.parametrize("args", [(1, 9, 11, 64, 64, 64, 3, 1, T(128, 128), T(128, 128)), (1, 7, 9, 64, 128, 64, 3, 1, T(64, 128) | (1 << 30), T(128, 64) | (1 << 30)),
+                                  (1, 6, 10, 32, 64, 128, 3, 1, T(128, 64) | (1 << 29), T(128, 128) | (1 << 29))])
+def test_late_dma_presplit_im2col(late_dma, args):
+    pc.check_conv_p3(late_dma, "cpu", *args)
+
+
+@pytest.mark.parametrize("args", [(2, 9, 37, 64, 128, 3, 1, 1, 0), (1, 6, 33, 32, 32, 3, 1, 1, T(4, 32)), (1, 9, 24, 64, 128, 3, 1, 1, T(8, 128) | (1 << 28)),
+                                  (1, 11, 37, 64, 32, 3, 1, 1, T(8, 32) | (1 << 28))])
+def test_late_dma_halo(late_dma, args):
+    pc.check_conv(late_dma, "cpu", *args, res=True, relu=True, p3="halo")
+
+
+def test_late_dma_inloop_weight_dma(late_dma):
+    pc.check_weight_dma_identical(late_dma, "cpu")
+
+
+@pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (1, 6, 6, 64, 160, T(64, 128))])
+def test_late_dma_dcn_weight_dma(late_dma, args):
+    """The DCN with its weights by DMA (engine.BDMA_DCN: shipped off) under late delivery."""
+    from deft_amd import engine
+    saved, engine.BDMA_DCN = engine.BDMA_DCN, True
+    try:
+        pc.check_dcn(late_dma, "cpu", *args)
+    finally:
+        engine.BDMA_DCN = saved
+
+
+def test_late_dma_forward_every_presplit_kernel(late_dma):
+    import deft_oracle as O
+    from deft_amd import engine
+    saved, engine.P3_MIN_TILES = engine.P3_MIN_TILES, 0
+    saved_b, engine.BDMA_DCN = engine.BDMA_DCN, True
+    try:
+        pc.check_forward(late_dma, "cpu", "mot", 32, 128, sd=O.synth_state_dict("mot"))
+    finally:
+        engine.P3_MIN_TILES, engine.BDMA_DCN = saved, saved_b
