@@ -1,5 +1,8 @@
-"""Debug aid: where does a frame's result start to depend on the batch it runs in?  Compares the stage outputs of a 1-frame and a
-2-frame plan (same frame first) with the cross-workgroup split-K off and every tile gate open, and a plan against its own re-run."""
+"""Debug aid (GPU): where does a frame's result start to depend on the batch it runs in?  Compares the stage outputs of a 1-frame
+and a 2-frame plan (same frame first) with the cross-workgroup split-K off and every tile gate open, every plan-owned buffer in
+allocation order (mapped back to the launch that produced it), each plan against its own re-runs, host-serialised launches, and
+which rows of which DCN tiles are off.  This is the tool that pinned the intermittent fault of the DCN's weight-DMA form
+(DESIGN.md 3.4): run it with DEFT_BDMA_DCN=1 to see it, PROBE_SET=NAME=value,... to flip engine switches."""
 import os
 import sys
 
