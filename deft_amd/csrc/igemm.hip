@@ -685,6 +685,15 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
         if constexpr (WK == 1 && NSTAGE == 1 && BN >= 64) {      // BN = 32: the operand split is amortised over too few columns
+            if (MODE == MODE_DCN && d.prec == 1 && d.w3 != nullptr && S == 1 && ((d.tile >> 28) & 1)) {
+                // DCN with TWO weight stages (tile bit 28): the DMA of chunk k+1 is issued with -- and ahead of -- the chunk's gather loads,
+                // like the plain convs, instead of after the second barrier; 12 KB more LDS per workgroup
+                constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 2>() * 4;
+                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 2>>(lds_p > lds_y3 ? lds_p : lds_y3)) return e;
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 2>), dim3(mtiles * ntiles), dim3(256), lds_p > lds_y3 ? lds_p : lds_y3, s, d, mtiles, ntiles);
+                DEFT_CHECK_LAUNCH("igemm");
+                return 0;
+            }
             if (d.prec == 1 && d.w3 != nullptr && S == 1) {      // ... with the weights pre-split: their chunks arrive by DMA
                 constexpr int PB = MODE == MODE_DCN ? 3 : 2;     // DCN: one weight stage (LDS as before: 3 workgroups/CU); else two
                 constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, PB>() * 4;
@@ -813,7 +822,7 @@ static int pick_splitk(long long tiles, int nk, int wgs_per_cu = 2) {
 extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* splitk, long long* ws_floats, int* ws_tiles) {
     DEFT_CHECK(d && tile && splitk && ws_floats && ws_tiles, -1, "deft_gemm_plan: null pointer");
     DEFT_CHECK(entry == 0 || entry == 1, -2, "deft_gemm_plan: entry %d (0 = conv, 1 = dcn)", entry);
-    int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
+    int bm = (d->tile >> 16) & (entry == 1 ? 0xfff : 0x1fff), bn = d->tile & 0xffff;      // (dcn: bit 28 = two weight stages)
     if (bm == 0) {
         if (entry == 0 && d->x3 != nullptr) deft_p3_pick_tile(d, &bm, &bn);
         else if (entry == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);
@@ -829,7 +838,7 @@ extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* 
         tiles = (long long)deft_cdiv(d->M, bm) * deft_cdiv(d->Cout, bn);
         S = pick_splitk(tiles, nk);
     }
-    *tile = (bm << 16) | bn | (d->tile & (3 << 29));
+    *tile = (bm << 16) | bn | (d->tile & (3 << 29)) | (entry == 1 ? d->tile & (1 << 28) : 0);
     *splitk = S;
     *ws_floats = S > 1 ? tiles * S * bm * bn : 0;
     *ws_tiles = S > 1 ? (int)tiles : 0;
@@ -884,7 +893,7 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->y3 == nullptr || ((d->Cout & 31) == 0 && (d->ldy3 & 31) == 0 && d->ldy3 >= d->Cout && (d->ldy & 3) == 0 && (((size_t)d->y3 | (size_t)d->y) & 15) == 0), -26,
                "deft_dcn_v2_nhwc: y3 needs Cout %% 32 == 0, ldy3 %% 32 == 0, ldy %% 4 == 0, 16-byte aligned outputs");
     hipStream_t s = (hipStream_t)stream;
-    int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
+    int bm = (d->tile >> 16) & 0xfff, bn = d->tile & 0xffff;           // (bit 28: two weight stages, launch_igemm)
     const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) {             // BM = 64: 11.5 KB of sampling records, 39 KB of LDS in all -- four 64x64 (three 64x128) workgroups per CU
         bm = 64; bn = d->Cout >= 128 ? 128 : 64;      // tools/bench_igemm.py dcn (r2, weights by DMA: 64x128 wins from Cout = 128)

@@ -157,8 +157,8 @@ BDMA = _os.environ.get("DEFT_BDMA", "1") != "0"             # igemm.hip prec-1 l
 # OFF by default since the 20-byte sampling records: with the weight DMA the DCN kernel produced, in launches with more workgroups than
 # the chip holds at once, now and then a group of wrong output rows on MI355X (tools/probe/batch_invariance.py; never without the DMA, never
 # in the other DMA kernels, not reproduced by the emulator; a full s_waitcnt vmcnt(0) in front of every use of the staged registers did
-# not cure it).  Not understood -- so the DCN splits its weights in the loop again: 898 -> 871 frames/s.
-BDMA_DCN = _os.environ.get("DEFT_BDMA_DCN", "0") == "1"
+# not cure it, nor did two weight stages).  Not understood -- so the DCN splits its weights in the loop again: 898 -> 871 frames/s.
+BDMA_DCN = int(_os.environ.get("DEFT_BDMA_DCN", "0"))        # 1: one weight stage (the form with the fault); 2: two stages (DeftGemmDesc.tile bit 28)
 P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
 P3_MIN_TILES = int(_os.environ.get("DEFT_P3_MIN_TILES", "512"))   # ... and give every CU two workgroups (latency mode: 2.39 ms/frame on igemm.hip
 # with split-K vs 2.88 on the pre-split kernels, profiles/r2_latency_ab.txt); the im2col form (one 8-wave workgroup per CU) needs half as many
@@ -735,6 +735,8 @@ class DlaSegPlan(_Plan):
         d.relu = 1; d.Q = 0; d.ldom = om.ld; d.tile = 0
         if BDMA_DCN and PREC == 1:
             d.w3 = self.weights_p3(wm).data_ptr()
+            if int(BDMA_DCN) == 2:
+                d.tile = 1 << 28
         if cout % 32 == 0 and out.ld % 4 == 0 and _os.environ.get("DEFT_DCN_Y3", "1") != "0":
             h = self.p3_output(out, d)               # pruned by finalize_p3() when no pre-split conv reads it
             if h is not None:

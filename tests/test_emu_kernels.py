@@ -356,11 +356,12 @@ def test_late_dma_inloop_weight_dma(late_dma):
     pc.check_weight_dma_identical(late_dma, "cpu")
 
 
-@pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (1, 6, 6, 64, 160, T(64, 128))])
-def test_late_dma_dcn_weight_dma(late_dma, args):
-    """The DCN with its weights by DMA (engine.BDMA_DCN: shipped off) under late delivery."""
+@pytest.mark.parametrize("stages", [1, 2])
+@pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (1, 6, 6, 64, 160, 0), (2, 5, 6, 128, 64, 0)])
+def test_late_dma_dcn_weight_dma(late_dma, args, stages):
+    """The DCN with its weights by DMA (engine.BDMA_DCN: shipped off), one and two weight stages, under late delivery."""
     from deft_amd import engine
-    saved, engine.BDMA_DCN = engine.BDMA_DCN, True
+    saved, engine.BDMA_DCN = engine.BDMA_DCN, stages
     try:
         pc.check_dcn(late_dma, "cpu", *args)
     finally:
