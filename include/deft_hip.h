@@ -41,7 +41,11 @@ typedef struct DeftGemmDesc {
     int Q;                        /* pair: number of current-frame objects                   */
     int ldom;                     /* dcn: pixel stride of x2                                 */
     int tile;                     /* 0 = auto; else (BM<<16)|BN forces a tile; bit 29 selects the
-                                     2-stage loop (conv: LDS-DMA form) instead of the 1-stage one */
+                                     2-stage loop (conv: LDS-DMA form) instead of the 1-stage one.
+                                     Pre-split kernels (x3): bit 29 = 3 LDS stages, bit 30 = ONE stage;
+                                     halo form: (TH<<16)|BN, bit 28 = tiles are 16 pixels wide (TH x 16),
+                                     bit 29 = one tap per weight stage.  deft_dcn_v2_nhwc with w3: bit 28 =
+                                     two weight stages */
     /* pair, batched form (Tper > 0): rows are (c, t, j) with c = m / (Tper*Q) the current
      * frame, t its history row, j its object; U' row = u0 + c*du + t, V' row = v0 + c*dv + j.
      * Tper == 0: rows are (t, j), U' row = t, V' row = j.                                   */
@@ -96,8 +100,9 @@ typedef struct DeftGemmDesc {
     /* which pre-split kernel: 0 = im2col chunks (any conv the x3 rules admit); 1 = halo tiles, 3x3 / stride 1 / pad 1 only:
      * a workgroup stages a (TH+2) x 34 input patch once per 16 channels and takes all nine taps out of it (1/7 of the
      * im2col form's activation traffic through the CU's load path).  w3 must then be the halo-form image
-     * (deft_split_weights_halo), korder 1, no split-K; `tile` = (TH << 16) | BN, 0 = automatic.  K order (16-channel block,
-     * tap): same pieces and products as the other forms, another fp32 summation order. */
+     * (deft_split_weights_halo), korder 1, no split-K; `tile` = (TH << 16) | BN (| 1 << 28 for TH x 16-pixel tiles: 8x16 x
+     * {128, 64, 32} are built, next to 4x32 x {128, 64, 32} and 8x32 x {128, 64}), 0 = automatic (4 x 32).  K order (16-channel
+     * block, tap): same pieces and products as the other forms, another fp32 summation order. */
     int p3_kernel;
     /* A following 1x1 conv with few outputs folded into the epilogue of the pre-split conv kernels (x3 != NULL) -- the heat-map
      * head's `Conv2d(256, C, 1)` after `Conv2d(64, 256, 3) + ReLU` (base_model.py:37-66): the 256-channel hidden map is neither
