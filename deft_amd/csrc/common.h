@@ -118,6 +118,11 @@ __device__ __forceinline__ int deft_ws_ticket(int* p) { return __hip_atomic_fetc
 __device__ __forceinline__ void deft_ws_reset(int* p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
+// the value may have changed, as far as the optimiser knows (no instruction is emitted)
+#ifndef DEFT_OPAQUE            /* the unit-test SIMT emulator pre-defines this hook */
+#define DEFT_OPAQUE(v) asm volatile("" : "+v"(v))
+#endif
+
 // round-half-even double -> int (cv2's saturate_cast<int>(double) = lrint)
 #ifndef DEFT_RINT_HOOK        /* the unit-test SIMT emulator pre-defines this hook */
 __device__ __forceinline__ int deft_rint(double v) { return __double2int_rn(v); }
@@ -236,3 +241,5 @@ int deft_p3_check(const DeftGemmDesc* d, const char* who);
 void deft_p3_pick_tile(const DeftGemmDesc* d, int* bm, int* bn);
 int deft_p3_dispatch(const DeftGemmDesc* d, hipStream_t s);
 int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s);
+// dcn.hip (patch form of the DCN, DeftGemmDesc.p3_kernel = 2), called from deft_dcn_v2_nhwc
+int deft_dcnp_dispatch(const DeftGemmDesc* d, hipStream_t s);

@@ -1,0 +1,461 @@
+// DCNv2 main contraction for gfx950, "patch" form (DeftGemmDesc.p3_kernel = 2): replaces dcn_v2.DCN.forward's modulated deformable
+// im2col + GEMM (third-party CharlesShang/DCNv2: modulated_deformable_im2col_cuda + dmcn_im2col_bilinear; imported dla.py:25-29,
+// constructed dla.py:652-660, called dla.py:663) together with DeformConv.actf (dla.py:649-651).
+//
+// Why another form next to igemm.hip's MODE_DCN.  There the deformed im2col tile (the A operand) is gathered from global memory -- four
+// corner loads per sample --, blended, split into its three bf16 pieces and staged through LDS, once per 64-row tile and K chunk; measured
+// on MI355X (profiles/r2_*): the matrix pipe 27 % busy, the CU's L1 path carrying 24 B/clk of corner reads, the LDS port as busy with A/B
+// fragment reads as the matrix cores with the MFMAs they feed.  Here
+//   * a workgroup owns an 8 x 16 pixel output tile (128 GEMM rows, one MFMA row per lane) and all BN output channels of it;
+//   * per 16 input channels it stages the fp32 input PATCH that offsets of up to +-R pixels can reach -- (8 + 2 + 2R) x (16 + 2 + 2R)
+//     pixels x 64 B -- ONCE by LDS-DMA and takes all nine taps out of it: the corner reads are ds_read_b128 (256 B/clk/CU) instead of
+//     L1 traffic, 1/15 of the global bytes.  A sample whose corners leave the patch (|offset| >= R) falls back to global loads, per lane;
+//   * the blended A fragment never goes through LDS: lane l of a wave computes exactly the 8 k-values of row l & 31 that
+//     v_mfma_f32_32x32x16_bf16 wants from it (k group l >> 5), blends, splits and feeds them from registers -- no ds_write, no A
+//     fragment read, no duplicate gather between waves;
+//   * the sampling records (four corner weights x sigmoid(mask), patch address) of the lane's row live in 45 VGPRs for the whole K
+//     loop (the nine taps are unrolled), not in LDS;
+//   * the weights arrive pre-split by LDS-DMA (deft_split_weights_dcn image: one 16-wide K chunk of 64 output channels = 6 KB, lane-
+//     linear = conflict-free for the fragment reads), double buffered, one barrier per tap.
+// Arithmetic: the prec = 1 arithmetic of igemm.hip (three bf16 pieces per fp32 operand, six v_mfma_f32_32x32x16_bf16 products, fp32
+// accumulation); K order (16-channel block, tap, channel) -- another fp32 summation order than MODE_DCN, same error level.
+// Sampling rule (upstream dmcn_im2col_bilinear / modulated_deformable_im2col_gpu_kernel, restated in oracle/dcn_scalar.py):
+//   h_im = oy - 1 + r + dy, w_im likewise; zero outside (-1, H) x (-1, W); four-corner bilinear with every corner outside the map
+//   dropped; the value times sigmoid(mask).
+#include "common.h"
+
+typedef deft_f32x16 f32x16;
+
+// Instruction-order request for the pipelined step: one MFMA, then a few VALU instructions of the next chunk's blend + split, repeated
+// (the matrix pipe works 32 cycles per MFMA: the VALU work issues under it).  DCNP_NOSCHED: leave the order to the compiler.
+#if defined(DCNP_NOSCHED) || !defined(__HIP_DEVICE_COMPILE__)
+#define DCNP_SCHED(TN) do {} while (0)
+#else
+#define DCNP_SCHED(TN)                                                        \
+    do {                                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6 * (TN); ++i_) {             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x002, 12 / (TN), 0);        \
+        }                                                                     \
+    } while (0)
+#endif
+
+#define DP_TH 8
+#define DP_TW 16
+#define DP_R 2
+#define DP_PH (DP_TH + 2 + 2 * DP_R)
+#define DP_PW (DP_TW + 2 + 2 * DP_R)
+#define DP_NPIX (DP_PH * DP_PW)
+#define DP_PARTS ((DP_NPIX + 63) / 64)                // 1 KB DMA pieces per plane (64 pixels x 16 B each)
+#define DP_PLANE (DP_PARTS * 1024)                    // one 4-channel plane of the patch: [pixel][16 B]
+#define DP_PBUF (4 * DP_PLANE)                        // one patch buffer: 16 channels = 4 planes
+#define DP_WBLK 6144                                  // one K chunk (16) of 64 output channels: [3 pieces][2 k groups][64 rows][8 bf16]
+
+template <int TN>
+constexpr int dcnp_lds_bytes() {
+    constexpr int loop = 2 * DP_PBUF + 3 * (TN / 2) * DP_WBLK;
+    constexpr int tile = 128 * (TN * 32 + 4) * 4;                 // epilogue tile
+    return loop > tile ? loop : tile;
+}
+
+// Row i (0..31) of a wave's MFMA tile <-> pixel (trow, tx) of the wave's two tile rows.  ds_read_b128 serves a wave in the lane groups
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): this map makes each group one tile row, i.e. 16 consecutive patch pixels = 256
+// consecutive bytes of a plane when the offsets are equal -- no bank conflict.
+__device__ __forceinline__ void dcnp_row_to_pixel(int i, int& trow, int& tx) {
+    const int blk = i >> 2;
+    // row 0: lanes 0-3 -> tx 0-3, 12-15 -> 4-7, 20-27 -> 8-15;  row 1: lanes 4-11 -> tx 0-7, 16-19 -> 8-11, 28-31 -> 12-15
+    trow = (blk == 1 || blk == 2 || blk == 4 || blk == 7) ? 1 : 0;
+    tx = i - (blk == 0 ? 0 : blk <= 2 ? 4 : blk == 3 ? 8 : blk == 4 ? 8 : blk <= 6 ? 12 : 16);
+}
+
+// (bf16(lo), bf16(hi)) packed into one register: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned dcnp_cvt_pk(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, p);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int tiles_x, int tiles_y, int ntiles) {
+    static_assert(TN == 2 || TN == 4, "64 or 128 output channels per workgroup");
+    constexpr int BN = TN * 32, NBLK = BN / 64;
+    constexpr int NBP = NBLK * 6;                     // weight DMA pieces per chunk
+    constexpr int BSTAGE = NBLK * DP_WBLK;
+    constexpr int NPP = 4 * DP_PARTS / 2;             // patch DMA pieces per wave (waves 2 and 3 issue them)
+
+    DEFT_DYN_LDS(char, smem);
+    char* const patch = smem;                          // [2 buffers][4 planes][DP_PARTS * 64 pixels][16 B]
+    char* const Bd = smem + 2 * DP_PBUF;               // [3 stages][BSTAGE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (in an SGPR: LDS-DMA destinations and scalar offsets derive from it)
+    const int g = lane >> 5;
+
+    // XCD-aware, bijective workgroup remap (see igemm.hip): every XCD gets one contiguous run of tiles, the n-tiles of a
+    // pixel tile and neighbouring pixel tiles (shared halo) in the same L2
+    int bid = blockIdx.x;
+    {
+        const int nwg = p.N * tiles_x * tiles_y * ntiles;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = bid % ntiles;
+    int t = bid / ntiles;
+    const int tpi = tiles_x * tiles_y;
+    const int n = t / tpi;
+    t -= n * tpi;
+    const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    const int ty0 = tyi * DP_TH, tx0 = txi * DP_TW, n0 = nt * BN;
+    const int py0 = ty0 - 1 - DP_R, px0 = tx0 - 1 - DP_R;
+    const int img = n * p.H * p.W;
+
+    // ---- this lane's GEMM row ----
+    int trow, tx;
+    dcnp_row_to_pixel(lane & 31, trow, tx);
+    const int oy = ty0 + 2 * wave + trow, ox = tx0 + tx;
+    const bool rowok = oy < p.H && ox < p.W;
+
+    // ---- DMA sources.  Patch (waves 2, 3): piece j = (wave - 2) + 2 i = (plane j / PARTS, part j % PARTS): lane l deposits channel group
+    // `plane` of patch pixel 64 part + l; pixels outside the map (and beyond the patch) arrive as zeros.  Weights (waves 0, 1). ----
+    const deft_rsrc_t rx = deft_make_rsrc(p.x);
+    const deft_rsrc_t rw = deft_make_rsrc(p.w3);
+    unsigned pv[DP_PARTS];
+#pragma unroll
+    for (int i = 0; i < DP_PARTS; ++i) {
+        const int pp = i * 64 + lane;
+        const int py = pp / DP_PW, px = pp - py * DP_PW;
+        const int gy = py0 + py, gx = px0 + px;
+        const bool ok = pp < DP_NPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        pv[i] = ok ? (unsigned)((img + gy * p.W + gx) * p.ldx * 4) : DEFT_OOB;
+    }
+    const int ncb = p.Cin >> 4, nchunks = ncb * 9;
+    const unsigned vB = (unsigned)((n0 >> 6) * nchunks * DP_WBLK + lane * 16);       // (+ piece and chunk terms in the scalar offset)
+    // the first three weight chunks and the first patch are on their way while the records are computed
+    constexpr int NB_A = NBP / 3, NB_B = NBP / 6;              // weight pieces per step: waves 0, 1 / waves 2, 3
+    auto issue_b3 = [&](int kc, int st) {
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < NB_A; ++i) {
+                const int jp = wave + 2 * i;
+                deft_buffer_load_lds_x4s(rw, Bd + st * BSTAGE + jp * 1024, vB, (unsigned)((jp / 6) * nchunks + kc) * (unsigned)DP_WBLK + (unsigned)(jp % 6) * 1024u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB_B; ++i) {
+                const int jp = 2 * NB_A + (wave - 2) + 2 * i;
+                deft_buffer_load_lds_x4s(rw, Bd + st * BSTAGE + jp * 1024, vB, (unsigned)((jp / 6) * nchunks + kc) * (unsigned)DP_WBLK + (unsigned)(jp % 6) * 1024u);
+            }
+        }
+    };
+    // patch piece `idx` (0 .. 2 PARTS - 1) of this wave (waves 2, 3: planes 0, 1 / 2, 3) of block cb into buffer buf
+    auto issue_patch_piece = [&](int cb, int buf, int idx) {
+        const int plane = (wave & 1) * 2 + idx / DP_PARTS, part = idx % DP_PARTS;
+        deft_buffer_load_lds_x4s(rx, patch + buf * DP_PBUF + plane * DP_PLANE + part * 1024, pv[part], (unsigned)(cb * 64 + plane * 16));
+    };
+    auto wait_vm = [&](int n) {          // (n is a compile-time constant wherever this is called)
+        switch (n) {
+            case 0: DEFT_WAIT_VM(0); break;
+            case 1: DEFT_WAIT_VM(1); break;
+            case 2: DEFT_WAIT_VM(2); break;
+            case 3: DEFT_WAIT_VM(3); break;
+            case 4: DEFT_WAIT_VM(4); break;
+            case 5: DEFT_WAIT_VM(5); break;
+            default: DEFT_WAIT_VM(6); break;
+        }
+    };
+    static_assert(NB_B + 2 <= 6 && NB_A <= 6, "wait_vm cases");
+    constexpr int np9[9] = {2, 2, 2, 1, 1, 1, 1, 0, 0};       // patch pieces a wave (2, 3) issues at the end of tap t: 2 PARTS = 10 in all
+    static_assert(2 * DP_PARTS == 10, "patch piece schedule");
+    constexpr int ps9[9] = {0, 2, 4, 6, 7, 8, 9, 10, 10};     // ... starting at piece
+
+    issue_b3(0, 0);
+    if (nchunks > 1) issue_b3(1, 1);
+    if (nchunks > 2) issue_b3(2, 2);
+    if (wave >= 2) {
+#pragma unroll
+        for (int i = 0; i < NPP; ++i) issue_patch_piece(0, 0, i);
+    }
+    // ---- sampling records of the row, all nine taps, in registers.  Near (all four corners inside the patch): rc = LDS byte address,
+    // inside patch buffer 0, of the lane's first 16 bytes (plane 2 g) of the BASE pixel b; the corners are b, b + 1, b + PW, b + PW + 1
+    // with the weights rw0..rw3 (a corner clamped at the map border is folded away: the base moves one pixel / line back and the weight
+    // of the dropped corner -- zero -- takes its place), so every corner read is `rc + immediate`.  Far: rc = bit 31 | global pixel of the
+    // clamped top-left corner << 2 | bit 0: the right-hand corners are one pixel on | bit 1: the lower corners one line on; weights in
+    // corner order. ----
+    float rw0[9], rw1[9], rw2[9], rw3[9];
+    unsigned rc[9];
+    {
+        f32x4 om[7];
+        const float* omp = p.x2 + (size_t)(rowok ? img + oy * p.W + ox : 0) * p.ldom;
+#ifdef DCNP_ABL_NOOM
+        omp = p.x2 + (lane & 31) * p.ldom;
+#endif
+#pragma unroll
+        for (int q = 0; q < 7; ++q) om[q] = *(const f32x4*)(omp + 4 * q);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+            unsigned c = (unsigned)(g * 2 * DP_PLANE);                     // (an unused record reads patch pixels 0, 1, PW, PW + 1 with weight 0)
+            const float dy = om[(2 * tap) >> 2][(2 * tap) & 3], dx = om[(2 * tap + 1) >> 2][(2 * tap + 1) & 3];
+            const float ml = om[(18 + tap) >> 2][(18 + tap) & 3];
+            const int r = tap / 3, s = tap - 3 * r;
+            const float h_im = (float)(oy - 1 + r) + dy;
+            const float w_im = (float)(ox - 1 + s) + dx;
+            if (rowok && h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                const float hl = floorf(h_im), wl = floorf(w_im);
+                const float lh = h_im - hl, lw = w_im - wl;
+                const float hh = 1.f - lh, hw_ = 1.f - lw;
+                const int h_low = (int)hl, w_low = (int)wl;
+                const int h_high = h_low + 1, w_high = w_low + 1;
+                const float mask = 1.f / (1.f + expf(-ml));
+                if (h_low >= 0 && w_low >= 0) w1 = hh * hw_ * mask;
+                if (h_low >= 0 && w_high <= p.W - 1) w2 = hh * lw * mask;
+                if (h_high <= p.H - 1 && w_low >= 0) w3 = lh * hw_ * mask;
+                if (h_high <= p.H - 1 && w_high <= p.W - 1) w4 = lh * lw * mask;
+                // h_low in [-1, H-1], w_low in [-1, W-1]: clamp the four corners into the map (a clamped corner has weight 0)
+                const int hl_c = h_low < 0 ? 0 : h_low, wl_c = w_low < 0 ? 0 : w_low;
+                const int hh_c = h_high > p.H - 1 ? p.H - 1 : h_high, wh_c = w_high > p.W - 1 ? p.W - 1 : w_high;
+                const int fr = wh_c - wl_c, fd = hh_c - hl_c;
+                const int bpy = hl_c - (1 - fd) - py0, bpx = wl_c - (1 - fr) - px0;          // base pixel of the near form
+                if (bpy >= 0 && bpy + 1 < DP_PH && bpx >= 0 && bpx + 1 < DP_PW) {
+                    c += (unsigned)((bpy * DP_PW + bpx) * 16);
+                    if (!fr) { w2 += w1; w1 = 0.f; w4 += w3; w3 = 0.f; }                   // (one of each pair is zero)
+                    if (!fd) { w3 += w1; w1 = 0.f; w4 += w2; w2 = 0.f; }
+                } else {
+                    c = 0x80000000u | (unsigned)((img + hl_c * p.W + wl_c) << 2) | (unsigned)(fr | (fd << 1));
+                }
+            }
+            rw0[tap] = w1; rw1[tap] = w2; rw2[tap] = w3; rw3[tap] = w4;
+            rc[tap] = c;
+        }
+    }
+
+    f32x16 acc[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    const unsigned far_x = (unsigned)p.ldx * 4u, far_y = (unsigned)(p.W * p.ldx) * 4u;
+    const int brow = (lane & 31) * 16 + g * 1024;     // this lane's slot inside a (piece, k group) block of the weight image
+
+    // corner values of one (row, tap, 16-channel block): v[corner][half of the lane's 8 channels]
+    auto gather = [&](unsigned c, int bufoff, int cb, f32x4 (&v)[4][2]) {
+        if (!(c & 0x80000000u)) {
+            const char* const a = patch + bufoff + c;
+            v[0][0] = *(const f32x4*)(a); v[0][1] = *(const f32x4*)(a + DP_PLANE);
+            v[1][0] = *(const f32x4*)(a + 16); v[1][1] = *(const f32x4*)(a + 16 + DP_PLANE);
+            v[2][0] = *(const f32x4*)(a + DP_PW * 16); v[2][1] = *(const f32x4*)(a + DP_PW * 16 + DP_PLANE);
+            v[3][0] = *(const f32x4*)(a + DP_PW * 16 + 16); v[3][1] = *(const f32x4*)(a + DP_PW * 16 + 16 + DP_PLANE);
+        } else {
+            const unsigned o1 = ((c & 0x7fffffffu) >> 2) * far_x + (unsigned)(cb * 64 + g * 32);
+            const unsigned o2 = o1 + ((c & 1u) ? far_x : 0u);
+            const unsigned dyb = (c & 2u) ? far_y : 0u;
+            v[0][0] = deft_buffer_load_x4(rx, o1); v[0][1] = deft_buffer_load_x4(rx, o1 + 16u);
+            v[1][0] = deft_buffer_load_x4(rx, o2); v[1][1] = deft_buffer_load_x4(rx, o2 + 16u);
+            v[2][0] = deft_buffer_load_x4(rx, o1 + dyb); v[2][1] = deft_buffer_load_x4(rx, o1 + dyb + 16u);
+            v[3][0] = deft_buffer_load_x4(rx, o2 + dyb); v[3][1] = deft_buffer_load_x4(rx, o2 + dyb + 16u);
+        }
+    };
+    // blend the four corners, split into the three bf16 pieces: the lane's A fragment (8 k of its row)
+    auto blend_split = [&](const f32x4 (&v)[4][2], float w0, float w1, float w2, float w3, bf16x8 (&pa)[3]) {
+        f32x4 b0, b1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b0[e] = fmaf(w3, v[3][0][e], fmaf(w2, v[2][0][e], fmaf(w1, v[1][0][e], w0 * v[0][0][e])));
+            b1[e] = fmaf(w3, v[3][1][e], fmaf(w2, v[2][1][e], fmaf(w1, v[1][1][e], w0 * v[0][1][e])));
+        }
+        // the three bf16 pieces (common.h split3: round-to-nearest-even each, exact), two elements at a time so that every conversion
+        // is one v_cvt_pk_bf16_f32 of a PAIR and the pieces come back as floats by a shift / a mask: 11 VALU per pair
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], x1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
+            const unsigned h = dcnp_cvt_pk(x0, x1);
+            const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+            const unsigned m = dcnp_cvt_pk(r0, r1);
+            const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+            ph[e] = h; pm[e] = m; pl[e] = dcnp_cvt_pk(s0, s1);
+        }
+        pa[0] = __builtin_bit_cast(bf16x8, ph);
+        pa[1] = __builtin_bit_cast(bf16x8, pm);
+        pa[2] = __builtin_bit_cast(bf16x8, pl);
+    };
+
+    // ---- K loop, software-pipelined.  Chunk kc = (16-channel block cb, tap).  Step kc starts with A(kc) AND the B fragments of kc in
+    // registers, so its MFMAs issue right behind the barrier:
+    //   wait + barrier   -- the DMA pieces issued two steps ago have landed (vmcnt(N): the N pieces issued ONE step ago may still fly)
+    //   corner reads of kc + 1 (LDS, patch buffer of its block)
+    //   MFMAs of kc  ||  blend + split of kc + 1 -> A(kc + 1)
+    //   B fragments of kc + 1 (LDS; its weights landed two steps ago, visible since this step's barrier)
+    //   DMA: weights of kc + 3 into the stage whose fragments were read one step ago; patch pieces of the NEXT block (taps 0..6)
+    // Three weight stages, two patch buffers; two blocks per loop iteration, so that buffers and stages are immediates. ----
+    bf16x8 pa[3], pb[TN][3];
+    auto read_b = [&](int st, bf16x8 (&o)[TN][3]) {
+        const char* const bs = Bd + st * BSTAGE + brow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const char* const bj = bs + (j >> 1) * DP_WBLK + (j & 1) * 512;
+            o[j][0] = *(const bf16x8*)(bj); o[j][1] = *(const bf16x8*)(bj + 2048); o[j][2] = *(const bf16x8*)(bj + 4096);
+        }
+    };
+    {
+        DEFT_WAIT_VM(0);
+        DEFT_PIPE_BARRIER_ONLY();
+        f32x4 v[4][2];
+        gather(rc[0], 0, 0, v);
+        blend_split(v, rw0[0], rw1[0], rw2[0], rw3[0], pa);
+        read_b(0, pb);
+    }
+    for (int cb2 = 0; cb2 < ncb; cb2 += 2) {
+        const bool lastpair = cb2 + 2 >= ncb;                        // the odd block of this pair is the last block
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int cb = cb2 + half, kc = cb * 9 + tap;
+                const int st = tap % 3;                                // = kc % 3 (18 steps per iteration)
+                const int ntap = tap == 8 ? 0 : tap + 1;
+                const int nbuf = tap == 8 ? (half ^ 1) : half;
+                const int ncbk = tap == 8 ? cb + 1 : cb;
+                const bool last_blk = half == 1 && lastpair;           // (runtime only in the odd half)
+                const bool more = !(tap == 8 && last_blk);             // is there a chunk kc + 1?
+                // ---- wait + barrier (step 0 too: everybody has read the B fragments of chunk 0 before its stage is refilled) ----
+                {
+#ifndef DCNP_ABL_NOBARRIER
+                    const int pt = tap == 0 ? 8 : tap - 1;             // the previous step's tap; it is in the last block iff this one is and tap > 0
+                    if (tap > 0 && last_blk) wait_vm(pt < 6 ? (wave < 2 ? NB_A : NB_B) : 0);
+                    else wait_vm(wave < 2 ? NB_A : NB_B + np9[pt]);
+                    DEFT_PIPE_BARRIER_ONLY();
+#endif
+                }
+                f32x4 v[4][2];
+#ifndef DCNP_ABL_NOGATHER
+                if (more) gather(rc[ntap], nbuf * DP_PBUF, ncbk, v);
+#else
+                for (int a_ = 0; a_ < 4; ++a_) { v[a_][0] = f32x4{rw0[ntap], 1.f, 2.f, 3.f}; v[a_][1] = f32x4{rw1[ntap], 1.f, 2.f, 3.f}; }
+#endif
+#ifndef DCNP_ABL_NOMFMA
+                // six products per fp32 product, smallest terms first (as igemm.hip); product-major so that consecutive MFMAs go to
+                // DIFFERENT accumulators (a dependent MFMA waits for its predecessor's full latency, more with VALU slotted between them)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    constexpr int qa[6] = {1, 2, 0, 1, 0, 0}, qb[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[qa[q]], pb[j][qb[q]], acc[0][j], 0, 0, 0);
+                }
+#endif
+#ifdef DCNP_ABL_NOVALU
+                if (false) {
+#else
+                if (more) {
+#endif
+                    bf16x8 pn[3];
+                    blend_split(v, rw0[ntap], rw1[ntap], rw2[ntap], rw3[ntap], pn);
+                    pa[0] = pn[0]; pa[1] = pn[1]; pa[2] = pn[2];
+                }
+                DCNP_SCHED(TN);
+                DEFT_OPAQUE(pa[0]); DEFT_OPAQUE(pa[1]); DEFT_OPAQUE(pa[2]);      // A(kc + 1) is finished HERE, under the MFMAs -- not after the next barrier
+                if (more) read_b((tap + 1) % 3, pb);
+#ifndef DCNP_ABL_NODMA
+                if (tap < 6 || !last_blk) issue_b3(kc + 3, st);            // (kc + 3 < nchunks)
+                if (wave >= 2 && !last_blk) {
+#pragma unroll
+                    for (int i = 0; i < np9[tap]; ++i) issue_patch_piece(cb + 1, half ^ 1, ps9[tap] + i);
+                }
+#endif
+            }
+        }
+    }
+    __syncthreads();                                   // nobody reads the stages any more, no DMA in flight (the last chunk issued none)
+
+    // ---- epilogue through LDS (common.h): the whole 128-row tile fits the loop's LDS ----
+    float* const T = (float*)smem;
+#ifdef DCNP_ABL_NOSTORE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+#ifdef DCNP_ABL_NOY3
+    p.y3 = nullptr;
+#endif
+    deft_epilogue_stage<1, TN>(T, BN + 4, acc, wave, 0, lane, p, n0);
+    DEFT_PIPE_BARRIER_ONLY();
+    deft_epilogue_rows<128, BN, 256>(T, p, n0, tid, [&](int R) -> long long {
+        int tr, txx;
+        dcnp_row_to_pixel(R & 31, tr, txx);
+        const int y = ty0 + 2 * (R >> 5) + tr, x = tx0 + txx;
+        return (y < p.H && x < p.W) ? (long long)(img + y * p.W + x) : -1;
+    });
+}
+
+template <int TN>
+static int launch_dcnp(const DeftGemmDesc& d, hipStream_t s) {
+    constexpr int lds = dcnp_lds_bytes<TN>();
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute((const void*)dcn_patch_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            DEFT_CHECK(e == hipSuccess, -101, "dcn_patch: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
+            done = true;
+        }
+    }
+    const int tiles_x = deft_cdiv(d.W, DP_TW), tiles_y = deft_cdiv(d.H, DP_TH), ntiles = deft_cdiv(d.Cout, TN * 32);
+    const long long nwg = (long long)d.N * tiles_x * tiles_y * ntiles;
+    DEFT_CHECK(nwg < (1ll << 31), -71, "deft_dcn_v2_nhwc: too many tiles");
+    hipLaunchKernelGGL((dcn_patch_kernel<TN>), dim3((unsigned)nwg), dim3(256), lds, s, d, tiles_x, tiles_y, ntiles);
+    DEFT_CHECK_LAUNCH("dcn_patch");
+    return 0;
+}
+
+// called from deft_dcn_v2_nhwc (igemm.hip) after the common checks, for p3_kernel == 2
+int deft_dcnp_dispatch(const DeftGemmDesc* d, hipStream_t s) {
+    DEFT_CHECK(d->prec == 1 && d->w3 != nullptr && (((size_t)d->w3 | (size_t)d->x2 | (size_t)d->y | (size_t)d->y3) & 15) == 0, -72,
+               "deft_dcn_v2_nhwc: the patch form is the prec = 1 arithmetic and needs w3 (deft_split_weights_dcn); x2 / y / w3 16-byte aligned");
+    DEFT_CHECK((d->ldom & 3) == 0 && d->ldom >= 28 && (d->ldy & 3) == 0 && (d->Cout & 7) == 0 && d->y != nullptr, -73,
+               "deft_dcn_v2_nhwc: the patch form needs ldom %% 4 == 0, ldom >= 28, ldy %% 4 == 0, Cout %% 8 == 0 (ldom=%d ldy=%d Cout=%d)", d->ldom, d->ldy, d->Cout);
+    DEFT_CHECK(d->splitk <= 1 && d->res == nullptr, -74, "deft_dcn_v2_nhwc: the patch form has no split-K and no residual");
+    int bn = d->tile & 0xffff;
+    if (bn == 0) bn = d->Cout > 64 ? 128 : 64;
+    DEFT_CHECK(bn == 64 || bn == 128, -75, "deft_dcn_v2_nhwc: the patch form has 64- and 128-column tiles (tile & 0xffff = %d)", bn);
+    // (the weight image has ceil(Cout / 128) * 128 rows: no n-tile reaches past it)
+    return bn == 128 ? launch_dcnp<4>(*d, s) : launch_dcnp<2>(*d, s);
+}
+
+// ---- weight image of the patch form -----------------------------------------------------------------------------------------------
+// w [CoutPad][9 * Cin] fp32 in the DCN K order of deft_dcn_v2_nhwc (k = ((c / 32) * 9 + tap) * 32 + c % 32) ->
+// w3 [CoutPad / 64][Cin / 16 * 9 chunks][3 pieces][2 k groups][64 rows][8 bf16]: chunk (cb, tap) = channels 16 cb .. 16 cb + 15 of tap.
+__global__ __launch_bounds__(256) void split_weights_dcn_kernel(const float* __restrict__ w, __bf16* __restrict__ w3, int CoutPad, int Cin) {
+    const int nchunks = (Cin >> 4) * 9;
+    const long long total = (long long)(CoutPad >> 6) * nchunks * 384;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int row = (int)(idx & 63);
+    const int sub = (int)((idx >> 6) % 6);
+    const int kc = (int)((idx / 384) % nchunks);
+    const int blk = (int)(idx / (384ll * nchunks));
+    const int q = sub >> 1, g = sub & 1;
+    const int cb = kc / 9, tap = kc - 9 * cb;
+    const float* wr = w + (size_t)(blk * 64 + row) * (size_t)(9 * Cin);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cb * 16 + g * 8 + e;
+        const float v = wr[((c >> 5) * 9 + tap) * 32 + (c & 31)];
+        const __bf16 hh = (__bf16)v;
+        const float r1 = v - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        const __bf16 ll = (__bf16)(r1 - (float)mm);
+        o[e] = q == 0 ? hh : (q == 1 ? mm : ll);
+    }
+    *(bf16x8*)(w3 + idx * 8) = o;
+}
+
+extern "C" int deft_split_weights_dcn(const float* w, void* w3, int CoutPad, int Cin, void* stream) {
+    DEFT_CHECK(w && w3 && CoutPad > 0 && (CoutPad & 63) == 0 && Cin > 0 && (Cin & 31) == 0 && (((size_t)w3) & 15) == 0, -76,
+               "deft_split_weights_dcn: need CoutPad %% 64 == 0, Cin %% 32 == 0, w3 16-byte aligned (%d, %d)", CoutPad, Cin);
+    const long long total = (long long)(CoutPad >> 6) * (Cin >> 4) * 9 * 384;
+    hipLaunchKernelGGL(split_weights_dcn_kernel, dim3((unsigned)deft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, CoutPad, Cin);
+    DEFT_CHECK_LAUNCH("split_weights_dcn");
+    return 0;
+}

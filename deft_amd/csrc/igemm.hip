@@ -893,6 +893,7 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->y3 == nullptr || ((d->Cout & 31) == 0 && (d->ldy3 & 31) == 0 && d->ldy3 >= d->Cout && (d->ldy & 3) == 0 && (((size_t)d->y3 | (size_t)d->y) & 15) == 0), -26,
                "deft_dcn_v2_nhwc: y3 needs Cout %% 32 == 0, ldy3 %% 32 == 0, ldy %% 4 == 0, 16-byte aligned outputs");
     hipStream_t s = (hipStream_t)stream;
+    if (d->p3_kernel == 2) return deft_dcnp_dispatch(d, s);           // patch form (dcn.hip)
     int bm = (d->tile >> 16) & 0xfff, bn = d->tile & 0xffff;           // (bit 28: two weight stages, launch_igemm)
     const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) {             // BM = 64: 11.5 KB of sampling records, 39 KB of LDS in all -- four 64x64 (three 64x128) workgroups per CU

@@ -159,6 +159,12 @@ BDMA = _os.environ.get("DEFT_BDMA", "1") != "0"             # igemm.hip prec-1 l
 # in the other DMA kernels, not reproduced by the emulator; a full s_waitcnt vmcnt(0) in front of every use of the staged registers did
 # not cure it, nor did two weight stages).  Not understood -- so the DCN splits its weights in the loop again: 898 -> 871 frames/s.
 BDMA_DCN = int(_os.environ.get("DEFT_BDMA_DCN", "0"))        # 1: one weight stage (the form with the fault); 2: two stages (DeftGemmDesc.tile bit 28)
+# DCN main contraction on the patch form (csrc/dcn.hip, DeftGemmDesc.p3_kernel = 2): input patch in LDS, blended operand from registers.  Used where
+# its 8 x 16 pixel tiles cover the map with at most DCN_PATCH_WASTE padding and the launch has at least DCN_PATCH_MIN_TILES workgroups (fewer: one
+# frame per GPU on the small maps, where igemm.hip's cross-workgroup split-K fills the chip).  DEFT_DCN_PATCH=0: off.
+DCN_PATCH = _os.environ.get("DEFT_DCN_PATCH", "1") != "0"
+DCN_PATCH_MIN_TILES = int(_os.environ.get("DEFT_DCN_PATCH_MIN_TILES", "384"))
+DCN_PATCH_WASTE = float(_os.environ.get("DEFT_DCN_PATCH_WASTE", "1.3"))
 P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
 P3_MIN_TILES = int(_os.environ.get("DEFT_P3_MIN_TILES", "512"))   # ... and give every CU two workgroups (latency mode: 2.39 ms/frame on igemm.hip
 # with split-K vs 2.88 on the pre-split kernels, profiles/r2_latency_ab.txt); the im2col form (one 8-wave workgroup per CU) needs half as many
@@ -226,6 +232,14 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
     if -(-M // bm) * -(-Cout // bn) < P3_MIN_TILES:
         return None                     # few tiles (one frame per GPU): igemm.hip's cross-workgroup split-K fills the chip better
     return ("im2col", tile)
+
+
+def dcn_patch_choice(N, H, W, Cin, Cout):
+    """Does a DCN layer run on the patch form (csrc/dcn.hip)?  8 x 16 pixel tiles: the padding they add to the map and the number of
+    workgroups decide (module constants above)."""
+    if not (DCN_PATCH and PREC == 1) or Cin % 32 or Cout % 8:
+        return False
+    return halo_waste(H, W, 8, 16) <= DCN_PATCH_WASTE and N * -(-H // 8) * -(-W // 16) * -(-Cout // (128 if Cout > 64 else 64)) >= DCN_PATCH_MIN_TILES
 
 
 class _Plan:
@@ -334,12 +348,17 @@ class _Plan:
         return addr
 
     def weights_p3(self, w_packed, halo=False):
-        """P3 image of a packed fp32 weight matrix (deft_split_weights / deft_split_weights_halo, once per matrix)."""
+        """P3 image of a packed fp32 weight matrix (deft_split_weights / deft_split_weights_halo / deft_split_weights_dcn, once per matrix).
+        halo = "dcn": the patch form's image of a DCN weight matrix (pack_dcn_weight)."""
         key = (w_packed.data_ptr(), halo)
         if key not in self._w3:
             w3 = torch.empty(w_packed.numel() * 3, dtype=torch.bfloat16, device=self.device)
-            self.lib.call("deft_split_weights_halo" if halo else "deft_split_weights", ptr(w_packed), C.c_void_p(w3.data_ptr()),
-                          w_packed.shape[0], w_packed.shape[1], hiplib.stream_ptr(self.device))
+            if halo == "dcn":
+                self.lib.call("deft_split_weights_dcn", ptr(w_packed), C.c_void_p(w3.data_ptr()), w_packed.shape[0], w_packed.shape[1] // 9,
+                              hiplib.stream_ptr(self.device))
+            else:
+                self.lib.call("deft_split_weights_halo" if halo else "deft_split_weights", ptr(w_packed), C.c_void_p(w3.data_ptr()),
+                              w_packed.shape[0], w_packed.shape[1], hiplib.stream_ptr(self.device))
             self._w3[key] = w3
             self._keep.append(w_packed)
         return self._w3[key]
@@ -415,7 +434,7 @@ class _Plan:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         memo = {}
         for entry, name, d in self._gemms:
-            if d.splitk > 1 or d.x3:       # cross-workgroup split-K launches keep their (tile, split, workspace); so do the x3 kernels
+            if d.splitk > 1 or d.x3 or d.p3_kernel:       # cross-workgroup split-K launches keep their (tile, split, workspace); so do the x3 kernels
                 continue
             key = (entry, d.M, d.Cout, d.Ktot, d.Cin, d.KH, d.KW, d.stride, d.H, d.W, d.ldx, d.ldy, bool(d.res), bool(d.rowmap))
             if key not in memo:
@@ -733,7 +752,10 @@ class DlaSegPlan(_Plan):
         d.cin_log2 = int(math.log2(cin))
         d.M = x.N * x.H * x.W
         d.relu = 1; d.Q = 0; d.ldom = om.ld; d.tile = 0
-        if BDMA_DCN and PREC == 1:
+        if dcn_patch_choice(x.N, x.H, x.W, cin, cout) and out.ld % 4 == 0:
+            d.p3_kernel = 2
+            d.w3 = self.weights_p3(wm, "dcn").data_ptr()
+        elif BDMA_DCN and PREC == 1:
             d.w3 = self.weights_p3(wm).data_ptr()
             if int(BDMA_DCN) == 2:
                 d.tile = 1 << 28

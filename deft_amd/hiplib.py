@@ -66,6 +66,7 @@ _SIGS = {
     "deft_split_planes": (C.c_int, [c_fp, c_fp, C.c_longlong, C.c_int, C.c_int, C.c_int, c_fp]),
     "deft_split_weights": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
     "deft_split_weights_halo": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
+    "deft_split_weights_dcn": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp]),
     "deft_fold_finish": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.c_int, C.c_int, c_fp, c_fp, C.c_int, c_fp]),
     "deft_conv_direct": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "deft_split_weights_direct": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp]),
@@ -73,7 +74,7 @@ _SIGS = {
     "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class DeftHipError(RuntimeError):
@@ -136,7 +137,7 @@ class HipLib:
                     info += " split direct"
                 elif self.split_arithmetic(name, d):
                     ceil = 2500.0 / 6   # ... or six v_mfma_f32_32x32x16_bf16 per fp32 product (bf16 dense peak / 6)
-                    info += " split" + (" halo" if d.p3_kernel else (" x3" if d.x3 else ""))
+                    info += " split" + (" patch" if d.p3_kernel == 2 else " halo" if d.p3_kernel else (" x3" if d.x3 else ""))
             prof.append((name, fl, e0, e1, info, nbytes, ceil))
 
     def split_arithmetic(self, name, d):
@@ -144,7 +145,7 @@ class HipLib:
         only on its 1-stage tiles with BN >= 64 (launch_igemm) -- the tile is the library's own choice when tile == 0."""
         if d.prec != 1:
             return False
-        if d.x3:
+        if d.x3 or d.p3_kernel == 2:
             return True
         tile = d.tile
         if (tile & 0xffff) == 0:

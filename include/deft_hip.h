@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 7
+#define DEFT_ABI_VERSION 8
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -102,7 +102,12 @@ typedef struct DeftGemmDesc {
      * im2col form's activation traffic through the CU's load path).  w3 must then be the halo-form image
      * (deft_split_weights_halo), korder 1, no split-K; `tile` = (TH << 16) | BN (| 1 << 28 for TH x 16-pixel tiles: 8x16 x
      * {128, 64, 32} are built, next to 4x32 x {128, 64, 32} and 8x32 x {128, 64}), 0 = automatic (4 x 32).  K order (16-channel
-     * block, tap): same pieces and products as the other forms, another fp32 summation order. */
+     * block, tap): same pieces and products as the other forms, another fp32 summation order.
+     * deft_dcn_v2_nhwc: 2 = the "patch" form (dcn.hip): a workgroup owns an 8 x 16 pixel tile and stages, per 16 input channels, the
+     * fp32 input patch that offsets of up to +-2 pixels can reach in LDS (corners beyond it are fetched from global memory, per lane);
+     * the blended operand goes from registers straight into the matrix cores.  x is read as fp32 (x3 unused); w3 must be the image of
+     * deft_split_weights_dcn; `tile` & 0xffff = 64 / 128 output channels per workgroup (0 = automatic); no split-K; K order
+     * (16-channel block, tap): another fp32 summation order than the default form. */
     int p3_kernel;
     /* A following 1x1 conv with few outputs folded into the epilogue of the pre-split conv kernels (x3 != NULL) -- the heat-map
      * head's `Conv2d(256, C, 1)` after `Conv2d(64, 256, 3) + ReLU` (base_model.py:37-66): the 256-channel hidden map is neither
@@ -306,6 +311,11 @@ int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpad, void* st
 /* The same for the halo form (DeftGemmDesc.p3_kernel = 1): `w` must be packed with korder 1, Kpad = 9 * Cin;
  * image [CoutPad/64][Cin/16][9 taps][64 rows][6 slots of 8 bf16]. */
 int deft_split_weights_halo(const float* w, void* w3, int CoutPad, int Kpad, void* stream);
+
+/* The same for the patch form of deft_dcn_v2_nhwc (DeftGemmDesc.p3_kernel = 2): `w` [CoutPad][9 * Cin] in the DCN K order
+ * (k = ((c / 32) * 9 + tap) * 32 + c % 32), CoutPad % 64 == 0, Cin % 32 == 0; image [CoutPad / 64][Cin / 16 * 9 chunks]
+ * [3 pieces][2 k groups][64 rows][8 bf16] -- chunk (cb, tap) = channels 16 cb .. 16 cb + 15 of tap -- CoutPad * 9 * Cin * 3 bf16. */
+int deft_split_weights_dcn(const float* w, void* w3, int CoutPad, int Cin, void* stream);
 
 /* y[m][c] = bias[c] + sum over the `nparts` partial maps part[(i * M + m) * ldp + c] of a folded 1x1 conv (DeftGemmDesc.fold_y),
  * c < C; parts are added in index order (deterministic). */

@@ -466,7 +466,9 @@ static inline void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* lds_wave_base, 
 #define DEFT_PIPE_BARRIER_ONLY() hipemu::yield(hipemu::Y_BLOCK)
 #define DEFT_WAIT_VM(N) hipemu::dma_wait(N)
 extern "C" __attribute__((weak, visibility("default"))) void hipemu_set_late_dma(int on) { hipemu::late_dma() = on; }
+#define DEFT_OPAQUE(v) ((void)(v))
 #define DEFT_RINT_HOOK 1
 static inline int deft_rint(double v) { return (int)std::nearbyint(v); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }

@@ -137,7 +137,15 @@ def check_concat_conv(lib, device):
     assert float(dst.buf.view(N, H, W, 80)[..., 64:].abs().max()) == 0.0   # untouched slice
 
 
-def check_dcn(lib, device, N, H, W, Ci, Co, tile=0, seed=0, big_offsets=False):
+def check_dcn(lib, device, N, H, W, Ci, Co, tile=0, seed=0, big_offsets=False, patch=None):
+    """patch: None = the engine's own choice of DCN kernel, True / False = the patch form (csrc/dcn.hip) forced on / off."""
+    if patch is not None:
+        saved = engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE
+        engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = bool(patch), 0, 1e9
+        try:
+            return check_dcn(lib, device, N, H, W, Ci, Co, tile=tile, seed=seed, big_offsets=big_offsets)
+        finally:
+            engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = saved
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Ci, H, W, generator=g)
     w_off = torch.randn(27, Ci, 3, 3, generator=g) * ((2.0 if big_offsets else 0.5) / (Ci * 9) ** 0.5)
@@ -169,9 +177,52 @@ def _deform_tiled(plan, p, xv, tile):
     kind, name, fn, fl = plan.ops[-1]
     d = plan._gemms[-1][2]          # the dcn descriptor
     d.tile, d.splitk = tile, 0
+    if d.p3_kernel == 2:
+        assert (tile >> 16) == 0 and (tile & 0xffff) in (64, 128), "patch form: tile = output channels per workgroup"
+        return out
     if engine.SPLITK:
         plan._plan_splitk("deft_dcn_v2_nhwc", d)     # the split factor and workspace follow the tile
     return out
+
+
+def check_dcn_patch_batch_invariance(lib, device, H, W, Ci, Co, N=4, reps=3, seed=0):
+    """The patch form of the DCN (csrc/dcn.hip) gives a frame the same bits alone and inside a batch, run after run: one summation
+    order whatever the launch size.  On the GPU with N large enough for several generations of workgroups per CU this is the test that
+    shows scheduling-dependent faults (the weight-DMA fault of round 2's DCN form showed only there)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    sd = {"d.conv.weight": torch.randn(Co, Ci, 3, 3, generator=g) * (1.0 / (Ci * 9) ** 0.5), "d.conv.bias": torch.randn(Co, generator=g) * 0.1,
+          "d.conv.conv_offset_mask.weight": torch.randn(27, Ci, 3, 3, generator=g) * (1.0 / (Ci * 9) ** 0.5),
+          "d.conv.conv_offset_mask.bias": torch.randn(27, generator=g) * 0.7, "d.actf.0.weight": torch.rand(Co, generator=g) + 0.5,
+          "d.actf.0.bias": torch.randn(Co, generator=g) * 0.2, "d.actf.0.running_mean": torch.randn(Co, generator=g) * 0.2,
+          "d.actf.0.running_var": torch.rand(Co, generator=g) + 0.5}
+    saved = engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.P3_MIN_TILES
+    engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = True, 0, 1e9
+    engine.P3_MIN_TILES = 0              # (the offset conv on the same kernel whatever the batch: its bits decide the sampling positions)
+    try:
+        outs = []
+        for n in (1, N):
+            plan = engine.DlaSegPlan.__new__(engine.DlaSegPlan)
+            engine._Plan.__init__(plan, device, lib)
+            plan.sd = sd; plan._wcache = {}
+            xv = plan.alloc(n, H, W, Ci)
+            fill_view(xv, x[:n])
+            out = plan._deform("d", xv)
+            assert plan._gemms[-1][2].p3_kernel == 2
+            res = []
+            for _ in range(reps):
+                out.buf.zero_()
+                plan.run()
+                res.append(out.to_nchw()[0].cpu().clone())
+            outs.append((plan, res))
+    finally:
+        engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.P3_MIN_TILES = saved
+    ref = outs[0][1][0]
+    for _, res in outs:
+        for r in res:
+            bad = int((r != ref).sum())
+            assert bad == 0, "patch-form DCN: %d elements of frame 0 depend on the batch / the run (%dx%d %d->%d, N=%d)" % (bad, H, W, Ci, Co, N)
+    return ref
 
 
 def check_pool_upsample(lib, device):

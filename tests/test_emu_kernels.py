@@ -53,6 +53,19 @@ def test_dcn(emu_lib, args):
     pc.check_dcn(emu_lib, "cpu", *args[:5], tile=args[5])
 
 
+@pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (2, 5, 6, 128, 64, 0), (1, 6, 6, 64, 160, 0), (1, 9, 19, 64, 64, 0), (1, 17, 35, 32, 128, 0),
+                                  (2, 3, 2, 64, 8, 0), (1, 8, 16, 64, 128, 64), (1, 11, 20, 32, 40, 128)])
+def test_dcn_patch(emu_lib, args):
+    """The patch form of the DCN main contraction (csrc/dcn.hip): partial tiles on every side, several images, Cout not a tile
+    multiple, both tile widths, small and large offsets (large ones take the per-lane global fallback)."""
+    for big in (False, True):
+        pc.check_dcn(emu_lib, "cpu", *args[:5], tile=args[5], seed=3, big_offsets=big, patch=True)
+
+
+def test_dcn_patch_batch_invariance(emu_lib):
+    pc.check_dcn_patch_batch_invariance(emu_lib, "cpu", 9, 18, 64, 64, N=3, reps=2)
+
+
 def test_dcn_big_offsets(emu_lib):
     # offsets of several pixels: samples leave the image, all four zero-padding branches hit
     pc.check_dcn(emu_lib, "cpu", 1, 6, 8, 64, 64, big_offsets=True, seed=3)
@@ -113,14 +126,18 @@ def test_forward_every_presplit_kernel_forced(emu_lib):
     import deft_oracle as O
     from deft_amd import engine
     saved, engine.P3_MIN_TILES = engine.P3_MIN_TILES, 0
+    saved_d = engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE
+    engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = 0, 1e9            # ... and every DCN on the patch form (csrc/dcn.hip)
     try:
         sd = O.synth_state_dict("mot")
         plan, rep, _ = pc.check_forward(emu_lib, "cpu", "mot", 32, 128, sd=sd)
         kinds = [op[0] for op in plan.ops]
         assert kinds.count("deft_conv_direct") == 3 and kinds.count("deft_fold_finish") >= 1
         assert any(d.p3_kernel == 1 for _, _, d in plan._gemms) and any(d.x3 and not d.p3_kernel for _, _, d in plan._gemms)
+        assert sum(d.p3_kernel == 2 for e, _, d in plan._gemms if e == "deft_dcn_v2_nhwc") == 16
     finally:
         engine.P3_MIN_TILES = saved
+        engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = saved_d
 
 
 def test_seam_dcn_module(emu_lib):
@@ -354,6 +371,13 @@ def test_late_dma_halo(late_dma, args):
 
 def test_late_dma_inloop_weight_dma(late_dma):
     pc.check_weight_dma_identical(late_dma, "cpu")
+
+
+@pytest.mark.parametrize("args", [(1, 7, 9, 64, 64), (1, 9, 19, 64, 160), (2, 5, 6, 128, 64)])
+def test_late_dma_dcn_patch(late_dma, args):
+    """The patch form's LDS-DMA pipeline (patch per 16-channel block, double-buffered weight chunks) under late delivery."""
+    for big in (False, True):
+        pc.check_dcn(late_dma, "cpu", *args, big_offsets=big, patch=True)
 
 
 @pytest.mark.parametrize("stages", [1, 2])

@@ -65,6 +65,21 @@ def test_dcn(gpu_lib, args):
     pc.check_dcn(gpu_lib, "cuda", *args[:5], tile=args[5])
 
 
+@pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (2, 5, 6, 128, 64, 0), (1, 6, 6, 64, 160, 0), (1, 9, 19, 64, 64, 0), (1, 17, 35, 32, 128, 0),
+                                  (2, 3, 2, 64, 8, 0), (1, 8, 16, 64, 128, 64), (1, 11, 20, 32, 40, 128), (2, 38, 68, 256, 128, 0), (1, 19, 34, 512, 256, 0)])
+def test_dcn_patch(gpu_lib, args):
+    for big in (False, True):
+        pc.check_dcn(gpu_lib, "cuda", *args[:5], tile=args[5], seed=3, big_offsets=big, patch=True)
+
+
+@pytest.mark.parametrize("shape", [(152, 272, 64, 64, 16), (76, 136, 128, 128, 32), (76, 136, 128, 64, 32), (38, 68, 256, 128, 64)])
+def test_dcn_patch_batch_invariance(gpu_lib, shape):
+    """Several generations of workgroups per CU (5168 / 2880 / 2880 / 1600 workgroups on 256 CUs): a frame alone, inside the batch, run
+    after run -- the same bits (this is where round 2's weight-DMA form of the DCN failed)."""
+    H, W, Ci, Co, N = shape
+    pc.check_dcn_patch_batch_invariance(gpu_lib, "cuda", H, W, Ci, Co, N=N, reps=5)
+
+
 def test_dcn_big_offsets(gpu_lib):
     pc.check_dcn(gpu_lib, "cuda", 1, 6, 8, 64, 64, big_offsets=True, seed=3)
     pc.check_dcn(gpu_lib, "cuda", 1, 19, 34, 128, 64, big_offsets=True, seed=4)
@@ -170,12 +185,14 @@ def test_full_size_properties(gpu_lib):
     #  engine.p3_choice -- the pre-split kernels only when they fill the chip)
     engine.SPLITK = False
     saved_min, engine.P3_MIN_TILES = engine.P3_MIN_TILES, 0
+    saved_dmin, engine.DCN_PATCH_MIN_TILES = engine.DCN_PATCH_MIN_TILES, 0
     try:
         q1 = engine.DlaSegPlan(sd, 1, H, W, "mot", K=100, device="cuda", lib=gpu_lib)
         q2 = engine.DlaSegPlan(sd, 2, H, W, "mot", K=100, device="cuda", lib=gpu_lib)
     finally:
         engine.SPLITK = True
         engine.P3_MIN_TILES = saved_min
+        engine.DCN_PATCH_MIN_TILES = saved_dmin
     assert not any(d.splitk > 1 for _, _, d in q1._gemms)
     q1.forward(x[:1].cuda()); q2.forward(x.cuda())
     torch.cuda.synchronize()

@@ -72,6 +72,35 @@ def dcn_case(name, H, W, Ci, Co, tiles):
             name, (tile >> 16) & 0x1fff, tile & 0xffff, "2st" if (tile >> 29) & 1 else "1st", ms, dcn_op[3] / ms / 1e9, ms_off, off_op[3] / ms_off / 1e9), flush=True)
 
 
+def dcnp_case(name, H, W, Ci, Co):
+    """The DCN main contraction on igemm.hip (library's tile) and on the patch form (csrc/dcn.hip) with 64 / 128 output channels per workgroup."""
+    g = torch.Generator().manual_seed(0)
+    sd = {"d.conv.weight": torch.randn(Co, Ci, 3, 3, generator=g) * 0.05, "d.conv.bias": torch.zeros(Co),
+          "d.conv.conv_offset_mask.weight": torch.randn(27, Ci, 3, 3, generator=g) * 0.01,
+          "d.conv.conv_offset_mask.bias": torch.randn(27, generator=g) * 0.5,
+          "d.actf.0.weight": torch.ones(Co), "d.actf.0.bias": torch.zeros(Co),
+          "d.actf.0.running_mean": torch.zeros(Co), "d.actf.0.running_var": torch.ones(Co)}
+    res = []
+    for patch, tile in ((False, 0), (True, 64), (True, 128)):
+        if patch and tile == 128 and Co < 128:
+            continue
+        engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = patch, 0, 1e9
+        plan = engine.DlaSegPlan.__new__(engine.DlaSegPlan)
+        engine._Plan.__init__(plan, "cuda", lib)
+        plan.sd = sd; plan._wcache = {}
+        xv = plan.alloc(B, H, W, Ci); xv.buf.normal_()
+        plan._deform("d", xv)
+        d = plan._keep[-1]
+        if patch:
+            d.tile = tile
+        off_op, dcn_op = plan.ops[-2], plan.ops[-1]
+        plan.ops = [off_op]; timeit(plan, 3)
+        plan.ops = [dcn_op]
+        ms = timeit(plan)
+        res.append("%s %7.3f ms %6.1f TF/s" % (("patch x%-3d" % tile) if patch else "igemm     ", ms, dcn_op[3] / ms / 1e9))
+    print("%-24s B=%d | %s" % (name, B, " | ".join(res)), flush=True)
+
+
 ONE = 1 << 29    # here: force the 2-stage loop (default is 1-stage)
 ALL = [T(128, 128), T(128, 64), T(64, 64), T(64, 128), T(128, 128) | ONE, T(128, 64) | ONE, T(64, 64) | ONE]
 if len(sys.argv) > 2 and sys.argv[2] == "asym":     # asymptotic loop efficiency: long K, many tiles, no im2col
@@ -86,6 +115,15 @@ if len(sys.argv) > 2 and sys.argv[2] == "dcn":
     dcn_case("dcn 256->128 @38x68", 38, 68, 256, 128, DT)
     dcn_case("dcn 256->256 @38x68", 38, 68, 256, 256, DT)
     dcn_case("dcn 512->256 @19x34", 19, 34, 512, 256, DT)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "dcnp":
+    dcnp_case("dcn 64->64 @152x272", 152, 272, 64, 64)
+    dcnp_case("dcn 128->64 @76x136", 76, 136, 128, 64)
+    dcnp_case("dcn 128->128 @76x136", 76, 136, 128, 128)
+    dcnp_case("dcn 256->64 @38x68", 38, 68, 256, 64)
+    dcnp_case("dcn 256->128 @38x68", 38, 68, 256, 128)
+    dcnp_case("dcn 256->256 @38x68", 38, 68, 256, 256)
+    dcnp_case("dcn 512->256 @19x34", 19, 34, 512, 256)
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "dcn1":     # the two dominant DCN shapes, default tile only (ablation builds via DEFT_HIP_LIB)
     dcn_case("dcn 64->64 @152x272", 152, 272, 64, 64, [T(64, 64)])
