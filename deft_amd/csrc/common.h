@@ -123,6 +123,11 @@ __device__ __forceinline__ void deft_ws_reset(int* p) { __hip_atomic_store(p, 0,
 #define DEFT_OPAQUE(v) asm volatile("" : "+v"(v))
 #endif
 
+// 1 / x to one ulp (v_rcp_f32) instead of the IEEE division sequence
+#ifndef DEFT_FAST_RCP          /* the unit-test SIMT emulator pre-defines this hook */
+#define DEFT_FAST_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+
 // round-half-even double -> int (cv2's saturate_cast<int>(double) = lrint)
 #ifndef DEFT_RINT_HOOK        /* the unit-test SIMT emulator pre-defines this hook */
 __device__ __forceinline__ int deft_rint(double v) { return __double2int_rn(v); }

@@ -26,6 +26,16 @@
 
 typedef deft_f32x16 f32x16;
 
+#ifndef DCNP_R2
+#define DCNP_R2 3
+#endif
+#ifndef DCNP_R4
+#define DCNP_R4 2
+#endif
+#ifndef DCNP_GA
+#define DCNP_GA 2          // corner reads run this many chunks ahead of the MFMAs (1 or 2): a far sample's global loads have a whole step to land
+#endif
+
 // Instruction-order request for the pipelined step: one MFMA, then a few VALU instructions of the next chunk's blend + split, repeated
 // (the matrix pipe works 32 cycles per MFMA: the VALU work issues under it).  DCNP_NOSCHED: leave the order to the compiler.
 #if defined(DCNP_NOSCHED) || !defined(__HIP_DEVICE_COMPILE__)
@@ -42,18 +52,18 @@ typedef deft_f32x16 f32x16;
 
 #define DP_TH 8
 #define DP_TW 16
-#define DP_R 2
-#define DP_PH (DP_TH + 2 + 2 * DP_R)
-#define DP_PW (DP_TW + 2 + 2 * DP_R)
-#define DP_NPIX (DP_PH * DP_PW)
-#define DP_PARTS ((DP_NPIX + 63) / 64)                // 1 KB DMA pieces per plane (64 pixels x 16 B each)
-#define DP_PLANE (DP_PARTS * 1024)                    // one 4-channel plane of the patch: [pixel][16 B]
-#define DP_PBUF (4 * DP_PLANE)                        // one patch buffer: 16 channels = 4 planes
+// patch geometry for a margin of R pixels (offsets of up to +-R stay inside the patch)
+#define DP_PH_(R) (DP_TH + 2 + 2 * (R))
+#define DP_PW_(R) (DP_TW + 2 + 2 * (R))
+#define DP_NPIX_(R) (DP_PH_(R) * DP_PW_(R))
+#define DP_PARTS_(R) ((DP_NPIX_(R) + 63) / 64)            // 1 KB DMA pieces per plane (64 pixels x 16 B each)
+#define DP_PLANE_(R) (DP_PARTS_(R) * 1024)                // one 4-channel plane of the patch: [pixel][16 B]
+#define DP_PBUF_(R) (4 * DP_PLANE_(R))                    // one patch buffer: 16 channels = 4 planes
 #define DP_WBLK 6144                                  // one K chunk (16) of 64 output channels: [3 pieces][2 k groups][64 rows][8 bf16]
 
-template <int TN>
+template <int TN, int R>
 constexpr int dcnp_lds_bytes() {
-    constexpr int loop = 2 * DP_PBUF + 3 * (TN / 2) * DP_WBLK;
+    constexpr int loop = 2 * DP_PBUF_(R) + 3 * (TN / 2) * DP_WBLK;
     constexpr int tile = 128 * (TN * 32 + 4) * 4;                 // epilogue tile
     return loop > tile ? loop : tile;
 }
@@ -75,14 +85,23 @@ __device__ __forceinline__ unsigned dcnp_cvt_pk(float lo, float hi) {
     return __builtin_bit_cast(unsigned, p);
 }
 
-template <int TN>
+template <int TN, int DP_R>
 __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int tiles_x, int tiles_y, int ntiles) {
     static_assert(TN == 2 || TN == 4, "64 or 128 output channels per workgroup");
+    constexpr int DP_PH = DP_PH_(DP_R), DP_PW = DP_PW_(DP_R), DP_NPIX = DP_NPIX_(DP_R), DP_PARTS = DP_PARTS_(DP_R), DP_PLANE = DP_PLANE_(DP_R),
+                  DP_PBUF = DP_PBUF_(DP_R);
     constexpr int BN = TN * 32, NBLK = BN / 64;
     constexpr int NBP = NBLK * 6;                     // weight DMA pieces per chunk
     constexpr int BSTAGE = NBLK * DP_WBLK;
     constexpr int NPP = 4 * DP_PARTS / 2;             // patch DMA pieces per wave (waves 2 and 3 issue them)
 
+#ifdef DCNP_TIMING
+    long long tstamp[8];
+    tstamp[0] = __builtin_readcyclecounter();
+#define DCNP_T(i) tstamp[i] = __builtin_readcyclecounter()
+#else
+#define DCNP_T(i) do {} while (0)
+#endif
     DEFT_DYN_LDS(char, smem);
     char* const patch = smem;                          // [2 buffers][4 planes][DP_PARTS * 64 pixels][16 B]
     char* const Bd = smem + 2 * DP_PBUF;               // [3 stages][BSTAGE]
@@ -116,6 +135,16 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
     dcnp_row_to_pixel(lane & 31, trow, tx);
     const int oy = ty0 + 2 * wave + trow, ox = tx0 + tx;
     const bool rowok = oy < p.H && ox < p.W;
+    // offsets + mask logits of the row (27 floats), requested first: they fly while the DMA sources are computed and issued
+    f32x4 om[7];
+    {
+        const float* omp = p.x2 + (size_t)(rowok ? img + oy * p.W + ox : 0) * p.ldom;
+#ifdef DCNP_ABL_NOOM
+        omp = p.x2 + (lane & 31) * p.ldom;
+#endif
+#pragma unroll
+        for (int q = 0; q < 7; ++q) om[q] = *(const f32x4*)(omp + 4 * q);
+    }
 
     // ---- DMA sources.  Patch (waves 2, 3): piece j = (wave - 2) + 2 i = (plane j / PARTS, part j % PARTS): lane l deposits channel group
     // `plane` of patch pixel 64 part + l; pixels outside the map (and beyond the patch) arrive as zeros.  Weights (waves 0, 1). ----
@@ -165,10 +194,12 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
             default: DEFT_WAIT_VM(6); break;
         }
     };
-    static_assert(NB_B + 2 <= 6 && NB_A <= 6, "wait_vm cases");
-    constexpr int np9[9] = {2, 2, 2, 1, 1, 1, 1, 0, 0};       // patch pieces a wave (2, 3) issues at the end of tap t: 2 PARTS = 10 in all
-    static_assert(2 * DP_PARTS == 10, "patch piece schedule");
-    constexpr int ps9[9] = {0, 2, 4, 6, 7, 8, 9, 10, 10};     // ... starting at piece
+    // patch pieces a wave (2, 3) issues at the end of tap t of the block BEFORE the patch's block: its NPP pieces spread over taps 0 .. PT - 1
+    // (the corner reads of the next block's tap 0 are issued GA steps ahead, and a piece has two steps to land)
+    constexpr int GA = TN == 2 ? DCNP_GA : 1;                  // how many steps ahead the corner reads run (two: 32 more VGPRs)
+    constexpr int PT = 8 - GA;
+    auto ps_of = [](int t) { return t >= PT ? NPP : NPP * t / PT; };
+    static_assert(NB_B + (NPP + PT - 1) / PT <= 6 && NB_A <= 6, "wait_vm cases");
 
     issue_b3(0, 0);
     if (nchunks > 1) issue_b3(1, 1);
@@ -177,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
 #pragma unroll
         for (int i = 0; i < NPP; ++i) issue_patch_piece(0, 0, i);
     }
+    DCNP_T(1);
     // ---- sampling records of the row, all nine taps, in registers.  Near (all four corners inside the patch): rc = LDS byte address,
     // inside patch buffer 0, of the lane's first 16 bytes (plane 2 g) of the BASE pixel b; the corners are b, b + 1, b + PW, b + PW + 1
     // with the weights rw0..rw3 (a corner clamped at the map border is folded away: the base moves one pixel / line back and the weight
@@ -186,46 +218,40 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
     float rw0[9], rw1[9], rw2[9], rw3[9];
     unsigned rc[9];
     {
-        f32x4 om[7];
-        const float* omp = p.x2 + (size_t)(rowok ? img + oy * p.W + ox : 0) * p.ldom;
-#ifdef DCNP_ABL_NOOM
-        omp = p.x2 + (lane & 31) * p.ldom;
-#endif
-#pragma unroll
-        for (int q = 0; q < 7; ++q) om[q] = *(const f32x4*)(omp + 4 * q);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-            unsigned c = (unsigned)(g * 2 * DP_PLANE);                     // (an unused record reads patch pixels 0, 1, PW, PW + 1 with weight 0)
+            // (branch-free: selects instead of nested ifs -- the nine records are 1/7 of the kernel's time at Cin = 64)
             const float dy = om[(2 * tap) >> 2][(2 * tap) & 3], dx = om[(2 * tap + 1) >> 2][(2 * tap + 1) & 3];
             const float ml = om[(18 + tap) >> 2][(18 + tap) & 3];
             const int r = tap / 3, s = tap - 3 * r;
-            const float h_im = (float)(oy - 1 + r) + dy;
-            const float w_im = (float)(ox - 1 + s) + dx;
-            if (rowok && h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-                const float hl = floorf(h_im), wl = floorf(w_im);
-                const float lh = h_im - hl, lw = w_im - wl;
-                const float hh = 1.f - lh, hw_ = 1.f - lw;
-                const int h_low = (int)hl, w_low = (int)wl;
-                const int h_high = h_low + 1, w_high = w_low + 1;
-                const float mask = 1.f / (1.f + expf(-ml));
-                if (h_low >= 0 && w_low >= 0) w1 = hh * hw_ * mask;
-                if (h_low >= 0 && w_high <= p.W - 1) w2 = hh * lw * mask;
-                if (h_high <= p.H - 1 && w_low >= 0) w3 = lh * hw_ * mask;
-                if (h_high <= p.H - 1 && w_high <= p.W - 1) w4 = lh * lw * mask;
-                // h_low in [-1, H-1], w_low in [-1, W-1]: clamp the four corners into the map (a clamped corner has weight 0)
-                const int hl_c = h_low < 0 ? 0 : h_low, wl_c = w_low < 0 ? 0 : w_low;
-                const int hh_c = h_high > p.H - 1 ? p.H - 1 : h_high, wh_c = w_high > p.W - 1 ? p.W - 1 : w_high;
-                const int fr = wh_c - wl_c, fd = hh_c - hl_c;
-                const int bpy = hl_c - (1 - fd) - py0, bpx = wl_c - (1 - fr) - px0;          // base pixel of the near form
-                if (bpy >= 0 && bpy + 1 < DP_PH && bpx >= 0 && bpx + 1 < DP_PW) {
-                    c += (unsigned)((bpy * DP_PW + bpx) * 16);
-                    if (!fr) { w2 += w1; w1 = 0.f; w4 += w3; w3 = 0.f; }                   // (one of each pair is zero)
-                    if (!fd) { w3 += w1; w1 = 0.f; w4 += w2; w2 = 0.f; }
-                } else {
-                    c = 0x80000000u | (unsigned)((img + hl_c * p.W + wl_c) << 2) | (unsigned)(fr | (fd << 1));
-                }
+            const float h_raw = (float)(oy - 1 + r) + dy, w_raw = (float)(ox - 1 + s) + dx;
+            const bool inside = rowok && h_raw > -1.f && w_raw > -1.f && h_raw < (float)p.H && w_raw < (float)p.W;
+            const float h_im = inside ? h_raw : 0.f, w_im = inside ? w_raw : 0.f;
+            const float hl = floorf(h_im), wl = floorf(w_im);
+            const float lh = h_im - hl, lw = w_im - wl;
+            const float hh = 1.f - lh, hw_ = 1.f - lw;
+            const int h_low = (int)hl, w_low = (int)wl;
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float mask = inside ? DEFT_FAST_RCP(1.f + expf(-ml)) : 0.f;
+            const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
+            float w1 = (t_ok && l_ok) ? hh * hw_ * mask : 0.f;
+            float w2 = (t_ok && r_ok) ? hh * lw * mask : 0.f;
+            float w3 = (b_ok && l_ok) ? lh * hw_ * mask : 0.f;
+            float w4 = (b_ok && r_ok) ? lh * lw * mask : 0.f;
+            // h_low in [-1, H-1], w_low in [-1, W-1]: clamp the four corners into the map (a clamped corner has weight 0)
+            const int hl_c = h_low < 0 ? 0 : h_low, wl_c = w_low < 0 ? 0 : w_low;
+            const int hh_c = h_high > p.H - 1 ? p.H - 1 : h_high, wh_c = w_high > p.W - 1 ? p.W - 1 : w_high;
+            const int fr = wh_c - wl_c, fd = hh_c - hl_c;
+            const int bpy = hl_c - (1 - fd) - py0, bpx = wl_c - (1 - fr) - px0;          // base pixel of the near form
+            const bool near = !inside || (bpy >= 0 && bpy + 1 < DP_PH && bpx >= 0 && bpx + 1 < DP_PW);
+            if (near) {          // (weights only: selects)
+                if (!fr) { w2 += w1; w1 = 0.f; w4 += w3; w3 = 0.f; }                   // (one of each pair is zero)
+                if (!fd) { w3 += w1; w1 = 0.f; w4 += w2; w2 = 0.f; }
             }
+            // (an unused record reads patch pixels 0, 1, PW, PW + 1 with weight 0)
+            const unsigned c_near = (unsigned)(g * 2 * DP_PLANE) + (inside ? (unsigned)((bpy * DP_PW + bpx) * 16) : 0u);
+            const unsigned c_far = 0x80000000u | (unsigned)((img + hl_c * p.W + wl_c) << 2) | (unsigned)(fr | (fd << 1));
+            const unsigned c = near ? c_near : c_far;
             rw0[tap] = w1; rw1[tap] = w2; rw2[tap] = w3; rw3[tap] = w4;
             rc[tap] = c;
         }
@@ -301,6 +327,8 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
             o[j][0] = *(const bf16x8*)(bj); o[j][1] = *(const bf16x8*)(bj + 2048); o[j][2] = *(const bf16x8*)(bj + 4096);
         }
     };
+    DCNP_T(2);
+    f32x4 vq[GA][4][2];                                    // corner values in flight: vq[0] = the next chunk's, vq[1] = the one after (GA = 2)
     {
         DEFT_WAIT_VM(0);
         DEFT_PIPE_BARRIER_ONLY();
@@ -308,7 +336,12 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
         gather(rc[0], 0, 0, v);
         blend_split(v, rw0[0], rw1[0], rw2[0], rw3[0], pa);
         read_b(0, pb);
+        if (GA == 2) gather(rc[1], 0, 0, vq[0]);          // (chunk 1 exists: Cin >= 32 -> at least 18 chunks)
     }
+    DCNP_T(3);
+#ifdef DCNP_TIMING
+    long long tsum[4] = {0, 0, 0, 0}, tprev = tstamp[3];
+#endif
     for (int cb2 = 0; cb2 < ncb; cb2 += 2) {
         const bool lastpair = cb2 + 2 >= ncb;                        // the odd block of this pair is the last block
 #pragma unroll
@@ -317,25 +350,32 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
             for (int tap = 0; tap < 9; ++tap) {
                 const int cb = cb2 + half, kc = cb * 9 + tap;
                 const int st = tap % 3;                                // = kc % 3 (18 steps per iteration)
-                const int ntap = tap == 8 ? 0 : tap + 1;
-                const int nbuf = tap == 8 ? (half ^ 1) : half;
-                const int ncbk = tap == 8 ? cb + 1 : cb;
+                const int ntap = (tap + 1) % 9;                        // chunk kc + 1 (blended in this step)
+                const int gtap = (tap + GA) % 9, gblk = (tap + GA) / 9;        // chunk kc + GA (its corner reads are issued in this step)
                 const bool last_blk = half == 1 && lastpair;           // (runtime only in the odd half)
                 const bool more = !(tap == 8 && last_blk);             // is there a chunk kc + 1?
+                const bool moreg = !(tap + GA >= 9 && last_blk);       // ... a chunk kc + GA?
+#ifdef DCNP_TIMING
+                const long long tA = __builtin_readcyclecounter();
+                tsum[3] += tA - tprev;
+#endif
                 // ---- wait + barrier (step 0 too: everybody has read the B fragments of chunk 0 before its stage is refilled) ----
                 {
 #ifndef DCNP_ABL_NOBARRIER
                     const int pt = tap == 0 ? 8 : tap - 1;             // the previous step's tap; it is in the last block iff this one is and tap > 0
                     if (tap > 0 && last_blk) wait_vm(pt < 6 ? (wave < 2 ? NB_A : NB_B) : 0);
-                    else wait_vm(wave < 2 ? NB_A : NB_B + np9[pt]);
+                    else wait_vm(wave < 2 ? NB_A : NB_B + (ps_of(pt + 1) - ps_of(pt)));
                     DEFT_PIPE_BARRIER_ONLY();
 #endif
                 }
-                f32x4 v[4][2];
+#ifdef DCNP_TIMING
+                const long long tB = __builtin_readcyclecounter();
+                tsum[0] += tB - tA;
+#endif
 #ifndef DCNP_ABL_NOGATHER
-                if (more) gather(rc[ntap], nbuf * DP_PBUF, ncbk, v);
+                if (moreg) gather(rc[gtap], ((half + gblk) & 1) * DP_PBUF, cb + gblk, vq[GA - 1]);
 #else
-                for (int a_ = 0; a_ < 4; ++a_) { v[a_][0] = f32x4{rw0[ntap], 1.f, 2.f, 3.f}; v[a_][1] = f32x4{rw1[ntap], 1.f, 2.f, 3.f}; }
+                for (int a_ = 0; a_ < 4; ++a_) { vq[GA - 1][a_][0] = f32x4{rw0[ntap], 1.f, 2.f, 3.f}; vq[GA - 1][a_][1] = f32x4{rw1[ntap], 1.f, 2.f, 3.f}; }
 #endif
 #ifndef DCNP_ABL_NOMFMA
                 // six products per fp32 product, smallest terms first (as igemm.hip); product-major so that consecutive MFMAs go to
@@ -353,22 +393,35 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
                 if (more) {
 #endif
                     bf16x8 pn[3];
-                    blend_split(v, rw0[ntap], rw1[ntap], rw2[ntap], rw3[ntap], pn);
+                    blend_split(vq[0], rw0[ntap], rw1[ntap], rw2[ntap], rw3[ntap], pn);
                     pa[0] = pn[0]; pa[1] = pn[1]; pa[2] = pn[2];
                 }
                 DCNP_SCHED(TN);
                 DEFT_OPAQUE(pa[0]); DEFT_OPAQUE(pa[1]); DEFT_OPAQUE(pa[2]);      // A(kc + 1) is finished HERE, under the MFMAs -- not after the next barrier
-                if (more) read_b((tap + 1) % 3, pb);
+                if (GA == 2) {
+#pragma unroll
+                    for (int a_ = 0; a_ < 4; ++a_) { vq[0][a_][0] = vq[GA - 1][a_][0]; vq[0][a_][1] = vq[GA - 1][a_][1]; }
+                }
+#ifdef DCNP_TIMING
+                const long long tC = __builtin_readcyclecounter();
+                tsum[1] += tC - tB;
+#endif
 #ifndef DCNP_ABL_NODMA
                 if (tap < 6 || !last_blk) issue_b3(kc + 3, st);            // (kc + 3 < nchunks)
                 if (wave >= 2 && !last_blk) {
 #pragma unroll
-                    for (int i = 0; i < np9[tap]; ++i) issue_patch_piece(cb + 1, half ^ 1, ps9[tap] + i);
+                    for (int i = ps_of(tap); i < ps_of(tap + 1); ++i) issue_patch_piece(cb + 1, half ^ 1, i);
                 }
 #endif
+#ifdef DCNP_TIMING
+                tprev = __builtin_readcyclecounter();
+                tsum[2] += tprev - tC;
+#endif
+                if (more) read_b((tap + 1) % 3, pb);
             }
         }
     }
+    DCNP_T(4);
     __syncthreads();                                   // nobody reads the stages any more, no DMA in flight (the last chunk issued none)
 
     // ---- epilogue through LDS (common.h): the whole 128-row tile fits the loop's LDS ----
@@ -381,21 +434,33 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
 #endif
     deft_epilogue_stage<1, TN>(T, BN + 4, acc, wave, 0, lane, p, n0);
     DEFT_PIPE_BARRIER_ONLY();
+    DCNP_T(5);
     deft_epilogue_rows<128, BN, 256>(T, p, n0, tid, [&](int R) -> long long {
         int tr, txx;
         dcnp_row_to_pixel(R & 31, tr, txx);
         const int y = ty0 + 2 * (R >> 5) + tr, x = tx0 + txx;
         return (y < p.H && x < p.W) ? (long long)(img + y * p.W + x) : -1;
     });
+#ifdef DCNP_TIMING
+    DCNP_T(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DCNP_T(7);
+    if (lane == 0 && p.ws != nullptr) {
+        long long* o = (long long*)p.ws + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = tstamp[i];
+        long long* o2 = (long long*)p.ws + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + wave) * 4;
+        for (int i = 0; i < 4; ++i) o2[i] = tsum[i];
+    }
+#endif
 }
 
-template <int TN>
+template <int TN, int R>
 static int launch_dcnp(const DeftGemmDesc& d, hipStream_t s) {
-    constexpr int lds = dcnp_lds_bytes<TN>();
+    constexpr int lds = dcnp_lds_bytes<TN, R>();
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void*)dcn_patch_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipError_t e = hipFuncSetAttribute((const void*)dcn_patch_kernel<TN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             DEFT_CHECK(e == hipSuccess, -101, "dcn_patch: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
             done = true;
         }
@@ -403,7 +468,7 @@ static int launch_dcnp(const DeftGemmDesc& d, hipStream_t s) {
     const int tiles_x = deft_cdiv(d.W, DP_TW), tiles_y = deft_cdiv(d.H, DP_TH), ntiles = deft_cdiv(d.Cout, TN * 32);
     const long long nwg = (long long)d.N * tiles_x * tiles_y * ntiles;
     DEFT_CHECK(nwg < (1ll << 31), -71, "deft_dcn_v2_nhwc: too many tiles");
-    hipLaunchKernelGGL((dcn_patch_kernel<TN>), dim3((unsigned)nwg), dim3(256), lds, s, d, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL((dcn_patch_kernel<TN, R>), dim3((unsigned)nwg), dim3(256), lds, s, d, tiles_x, tiles_y, ntiles);
     DEFT_CHECK_LAUNCH("dcn_patch");
     return 0;
 }
@@ -419,7 +484,8 @@ int deft_dcnp_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     if (bn == 0) bn = d->Cout > 64 ? 128 : 64;
     DEFT_CHECK(bn == 64 || bn == 128, -75, "deft_dcn_v2_nhwc: the patch form has 64- and 128-column tiles (tile & 0xffff = %d)", bn);
     // (the weight image has ceil(Cout / 128) * 128 rows: no n-tile reaches past it)
-    return bn == 128 ? launch_dcnp<4>(*d, s) : launch_dcnp<2>(*d, s);
+    // margin: 3 pixels where two workgroups per CU still fit (64-column tiles: 66 KB of LDS), else 2 (128-column tiles: 76 KB)
+    return bn == 128 ? launch_dcnp<4, DCNP_R4>(*d, s) : launch_dcnp<2, DCNP_R2>(*d, s);
 }
 
 // ---- weight image of the patch form -----------------------------------------------------------------------------------------------

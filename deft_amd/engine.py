@@ -165,6 +165,7 @@ BDMA_DCN = int(_os.environ.get("DEFT_BDMA_DCN", "0"))        # 1: one weight sta
 DCN_PATCH = _os.environ.get("DEFT_DCN_PATCH", "1") != "0"
 DCN_PATCH_MIN_TILES = int(_os.environ.get("DEFT_DCN_PATCH_MIN_TILES", "384"))
 DCN_PATCH_WASTE = float(_os.environ.get("DEFT_DCN_PATCH_WASTE", "1.3"))
+DCN_PATCH_MIN_HW = int(_os.environ.get("DEFT_DCN_PATCH_MIN_HW", "0"))        # ... and only on maps of at least this many pixels
 P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
 P3_MIN_TILES = int(_os.environ.get("DEFT_P3_MIN_TILES", "512"))   # ... and give every CU two workgroups (latency mode: 2.39 ms/frame on igemm.hip
 # with split-K vs 2.88 on the pre-split kernels, profiles/r2_latency_ab.txt); the im2col form (one 8-wave workgroup per CU) needs half as many
@@ -239,7 +240,7 @@ def dcn_patch_choice(N, H, W, Cin, Cout):
     workgroups decide (module constants above)."""
     if not (DCN_PATCH and PREC == 1) or Cin % 32 or Cout % 8:
         return False
-    return halo_waste(H, W, 8, 16) <= DCN_PATCH_WASTE and N * -(-H // 8) * -(-W // 16) * -(-Cout // (128 if Cout > 64 else 64)) >= DCN_PATCH_MIN_TILES
+    return H * W >= DCN_PATCH_MIN_HW and halo_waste(H, W, 8, 16) <= DCN_PATCH_WASTE and N * -(-H // 8) * -(-W // 16) * -(-Cout // (128 if Cout > 64 else 64)) >= DCN_PATCH_MIN_TILES
 
 
 class _Plan:

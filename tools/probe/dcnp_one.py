@@ -29,6 +29,10 @@ plan._deform("d", xv)
 d = plan._keep[-1]
 if patch:
     d.tile = patch
+if os.environ.get("DCNP_TIMING"):
+    nwg = B * -(-H // 8) * -(-W // 16) * -(-Co // (patch or 64))
+    tbuf = torch.zeros(nwg * 4 * 12, dtype=torch.int64, device="cuda")
+    d.ws = tbuf.data_ptr()
 off_op, dcn_op = plan.ops[-2], plan.ops[-1]
 off_op[2](); torch.cuda.synchronize()
 plan.ops = [dcn_op]
@@ -42,3 +46,20 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 print("dcn %dx%d %d->%d B=%d patch=%d: %.3f ms %.1f TF/s" % (H, W, Ci, Co, B, patch, ms, dcn_op[3] / ms / 1e9))
+
+if os.environ.get("DCNP_TIMING"):
+    nwg_ = tbuf.numel() // 48
+    t = tbuf.cpu()[:nwg_ * 32].view(-1, 4, 8).double()
+    ts = tbuf.cpu()[nwg_ * 32:].view(-1, 4, 4).double()
+    nst = Ci // 16 * 9
+    for wv in range(4):
+        print("   wave %d per-step ticks: wait+barrier %.0f | gather+mfma+blend %.0f | dma issue %.0f | read_b (issue + landed) %.0f" % ((wv,) + tuple(float(ts[:, wv, i].mean()) / nst for i in range(4))))
+    names = ["dma-issue", "records", "first wait+gather", "loop", "sync+stage", "store issue", "store drain"]
+    dt = t[:, :, 1:] - t[:, :, :-1]
+    print("per-wave phase cycles (mean over %d workgroups x 4 waves; s_memtime ticks):" % t.shape[0])
+    for i, n in enumerate(names):
+        print("   %-20s mean %9.0f   p10 %9.0f  p90 %9.0f" % (n, float(dt[:, :, i].mean()), float(dt[:, :, i].flatten().kthvalue(max(1, int(0.1 * dt[:, :, i].numel()))).values), float(dt[:, :, i].flatten().kthvalue(int(0.9 * dt[:, :, i].numel())).values)))
+    life = t[:, :, 7] - t[:, :, 0]
+    print("   %-20s mean %9.0f" % ("total", float(life.mean())))
+    span = float(t[:, :, 7].max() - t[:, :, 0].min())
+    print("   kernel span %.0f ticks; sum of wave lives / span = %.2f waves resident" % (span, float(life.sum()) / span))
