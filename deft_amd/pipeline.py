@@ -40,6 +40,7 @@ class HipCompute:
         if streams > 1:
             self.side = [torch.cuda.Stream(device=self.device) for _ in range(streams)]
             self.ev_main = torch.cuda.Event()
+            self.ev_in = torch.cuda.Event()
             self.ev_side = [torch.cuda.Event() for _ in range(streams)]
 
     def use_u8(self, sh, sw):
@@ -98,8 +99,12 @@ class HipCompute:
         if not self.emb_released:                       # nobody told us when emb was consumed: wait for everything
             self.ev_main.record(main)                   # queued on the main stream so far
         self.emb_released = False
+        # the step's INPUT: whatever the caller ordered on the main stream before this call (e.g. FrameFeeder.take(): the H2D copy of
+        # these frames) must be visible to the side streams too -- a fresh event every step, independent of the emb hand-over above
+        self.ev_in.record(main)
         for s, (p, st) in enumerate(zip(self.plans, self.side)):
             st.wait_event(self.ev_main)                 # the previous step's readers of emb are done
+            st.wait_event(self.ev_in)                   # this step's frames are on the device
             with torch.cuda.stream(st):
                 self._run_plan(s, images)
                 self.ev_side[s].record(st)

@@ -37,9 +37,10 @@ def selector_out(dataset):
 # --------------------------------------------------------------------------
 # deterministic synthetic weights (no reference needed; same on the GPU box)
 # --------------------------------------------------------------------------
-def _param_table(dataset):
+def _param_table(dataset, heads=None):
     """Ordered (name, shape, kind) list with the reference's state_dict names
-    (dla.py DLASeg / base_model.py BaseModel / AFE.py AFE_module)."""
+    (dla.py DLASeg / base_model.py BaseModel / AFE.py AFE_module).  heads: {name: channels} when it differs from the
+    dataset's default table (opts.py:500-520)."""
     T = []
 
     def conv(name, co, ci, k, bias=False, kind="conv"):
@@ -87,7 +88,7 @@ def _param_table(dataset):
             T.append((p + ".up_%d.weight" % i, (o, 1, 2 * f, 2 * f), "up"))
             dcn(p + ".node_%d" % i, o, o)
 
-    heads = HEADS[dataset]
+    heads = HEADS[dataset] if heads is None else heads
     for h, c in heads.items():
         conv(h + ".0", 256, 64, 3, bias=True)
         conv(h + ".2", c, 256, 1, bias=True, kind="hm_out" if h == "hm" else "head_out")

@@ -42,9 +42,8 @@ class Detector(_ref.Detector):
         from deft_amd import integrate, tracker as DT
         from deft_amd.detector import Detector as FusedDetector
         import utils.tracker as RT                                   # the reference's tracker module
-        ck = torch.load(opt.load_model, map_location="cpu")
-        sd = ck["state_dict"] if "state_dict" in ck else ck
-        sd = {(k[7:] if k.startswith("module.") and not k.startswith("module_list") else k): v for k, v in sd.items()}   # model.py:49-53
+        from deft_amd import checkpoint
+        sd = checkpoint.load_model_state(opt.load_model, opt)         # model.py:40-90: module. prefixes, shape mismatches, reset_hm / reuse_hm, missing keys
         dev = "cuda" if opt.gpus[0] >= 0 else "cpu"
         kf = integrate.KalmanFilterLSTM(opt) if getattr(opt, "lstm", False) else None
         self._undo_tracker = DT.accelerate(RT, kf)                    # before the Trackers of __init__ / reset_tracking are built

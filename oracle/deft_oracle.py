@@ -45,8 +45,12 @@ from deft_amd.synth import (HEADS, SELECTOR_IN, FEATURE_STRIDES, selector_out,  
 def dcn_v2_forward(x, w_off, b_off, w, b):
     """Modulated deformable 3x3 conv, stride 1, pad 1, dil 1, 1 deformable group.
     Call sites: dla.py:652-660, 663.  Upstream: DCN.forward -> dcn_v2_conv."""
+    return dcn_v2_from_om(x, F.conv2d(x, w_off, b_off, stride=1, padding=1), w, b)          # 27 channels
+
+
+def dcn_v2_from_om(x, out, w, b):
+    """The sampling + contraction of dcn_v2_forward on a given conv_offset_mask output `out` [N, 27, H, W]."""
     N, C, H, W = x.shape
-    out = F.conv2d(x, w_off, b_off, stride=1, padding=1)          # 27 channels
     o1, o2, mask = torch.chunk(out, 3, dim=1)
     offset = torch.cat((o1, o2), dim=1)                           # [N,18,H,W]: 2k=dy, 2k+1=dx
     mask = torch.sigmoid(mask)                                    # [N,9,H,W]

@@ -185,6 +185,36 @@ def _deform_tiled(plan, p, xv, tile):
     return out
 
 
+def check_dcn_golden(lib, device, name, patch):
+    """The DCN main contraction against tests/golden/dcn_v2_<name>.npz -- vectors written by the scalar, tap-by-tap restatement of
+    upstream DCNv2 (oracle/dcn_scalar.py; offsets through every border case) -- on the given offset map, for either kernel form."""
+    fx = np.load(os.path.join(GOLD, "dcn_v2_%s.npz" % name))
+    x, om, w, b, y = (torch.from_numpy(fx[k]) for k in ("x", "om", "w", "b", "y"))
+    N, Ci, H, W = x.shape
+    Co = w.shape[0]
+    sd = {"d.conv.weight": w, "d.conv.bias": b, "d.conv.conv_offset_mask.weight": torch.zeros(27, Ci, 3, 3),
+          "d.conv.conv_offset_mask.bias": torch.zeros(27), "d.actf.0.weight": torch.ones(Co), "d.actf.0.bias": torch.zeros(Co),
+          "d.actf.0.running_mean": torch.zeros(Co), "d.actf.0.running_var": torch.ones(Co) - O.BN_EPS}      # BatchNorm = identity
+    saved = engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE
+    engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = bool(patch), 0, 1e9
+    try:
+        plan = engine.DlaSegPlan.__new__(engine.DlaSegPlan)
+        engine._Plan.__init__(plan, device, lib)
+        plan.sd = sd; plan._wcache = {}
+        xv = plan.alloc(N, H, W, Ci); fill_view(xv, x)
+        omv = plan.alloc(N, H, W, 32, ld=32); fill_view(omv.sub(0, 27), om)
+        out = plan._deform("d", xv, om=omv)
+        d = plan._gemms[-1][2]
+        assert (d.p3_kernel == 2) == bool(patch)
+        d.relu = 0                                   # (the vectors stop before DeformConv.actf's ReLU)
+        plan.run()
+    finally:
+        engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = saved
+    err = maxabs(out.to_nchw(), y)
+    assert err <= 2e-5 * max(1.0, float(y.abs().max())), ("dcn golden", name, patch, err)
+    return err
+
+
 def check_dcn_patch_batch_invariance(lib, device, H, W, Ci, Co, N=4, reps=3, seed=0):
     """The patch form of the DCN (csrc/dcn.hip) gives a frame the same bits alone and inside a batch, run after run: one summation
     order whatever the launch size.  On the GPU with N large enough for several generations of workgroups per CU this is the test that

@@ -62,6 +62,12 @@ def test_dcn_patch(emu_lib, args):
         pc.check_dcn(emu_lib, "cpu", *args[:5], tile=args[5], seed=3, big_offsets=big, patch=True)
 
 
+@pytest.mark.parametrize("patch", [False, True])
+@pytest.mark.parametrize("name", ["small", "borders", "wide"])
+def test_dcn_golden_vectors(emu_lib, name, patch):
+    pc.check_dcn_golden(emu_lib, "cpu", name, patch)
+
+
 def test_dcn_patch_batch_invariance(emu_lib):
     pc.check_dcn_patch_batch_invariance(emu_lib, "cpu", 9, 18, 64, 64, N=3, reps=2)
 

@@ -72,6 +72,13 @@ def test_dcn_patch(gpu_lib, args):
         pc.check_dcn(gpu_lib, "cuda", *args[:5], tile=args[5], seed=3, big_offsets=big, patch=True)
 
 
+@pytest.mark.parametrize("patch", [False, True])
+@pytest.mark.parametrize("name", ["small", "borders", "wide"])
+def test_dcn_golden_vectors(gpu_lib, name, patch):
+    """Both DCN kernel forms against the vectors of the scalar restatement of upstream DCNv2 (tests/golden/dcn_v2_*.npz)."""
+    pc.check_dcn_golden(gpu_lib, "cuda", name, patch)
+
+
 @pytest.mark.parametrize("shape", [(152, 272, 64, 64, 16), (76, 136, 128, 128, 32), (76, 136, 128, 64, 32), (38, 68, 256, 128, 64)])
 def test_dcn_patch_batch_invariance(gpu_lib, shape):
     """Several generations of workgroups per CU (5168 / 2880 / 2880 / 1600 workgroups on 256 CUs): a frame alone, inside the batch, run
@@ -546,6 +553,36 @@ def test_preprocess_u8(gpu_lib):
     pc.check_preprocess_u8(gpu_lib, "cuda")
     pc.check_preprocess_u8(gpu_lib, "cuda", N=1, sh=1080, sw=1920, H=608, W=1088, seed=1)      # MOT17 frame into config B's input
     torch.cuda.synchronize()
+
+
+def test_frame_feeder_with_side_streams(gpu_lib):
+    """FrameFeeder (pinned double buffer, copy stream) feeding the multi-stream HipCompute: every step's frames are different, and the
+    side streams must see THIS step's H2D copy (the round-2 advisor's race: they waited only on the previous step's event).  Two
+    streams against one stream, frame for frame."""
+    from deft_amd import pipeline, preprocess
+    sd = O.synth_state_dict("mot")
+    H, W, sh, sw, B = 64, 96, 45, 80, 4
+    outs = {}
+    for streams in (1, 2):
+        comp = pipeline.HipCompute(sd, B, H, W, "mot", K=20, device="cuda", lib=gpu_lib, streams=streams)
+        comp.use_u8(sh, sw)
+        feeder = preprocess.FrameFeeder(B, sh, sw, "cuda")
+        g = torch.Generator().manual_seed(5)
+        res = []
+        frames = [torch.randint(0, 256, (B, sh, sw, 3), dtype=torch.uint8, generator=g) for _ in range(5)]
+        k = feeder.push(frames[0])
+        for i in range(5):
+            dev = feeder.take(k)
+            kn = feeder.push(frames[i + 1]) if i + 1 < 5 else None           # next step's copy flies while this one computes
+            emb = comp.detect_embed(dev)
+            res.append(emb.clone())
+            comp.release_emb()
+            feeder.release(k)
+            k = kn
+        torch.cuda.synchronize()
+        outs[streams] = torch.stack(res).cpu()
+    assert torch.equal(outs[1], outs[2])
+    assert not torch.equal(outs[1][0], outs[1][1])              # (the steps really saw different frames)
 
 
 def test_sharded_stream_over_rccl(gpu_lib):

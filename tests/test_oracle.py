@@ -121,6 +121,28 @@ def test_dcn_oracle_vs_grid_sample_formulation(N, C, Co, H, W, offs):
     assert maxabs(a, r) <= 2e-5 * max(1.0, float(r.abs().max()))
 
 
+@pytest.mark.parametrize("name", ["small", "borders", "wide"])
+def test_dcn_oracle_vs_scalar_restatement_vectors(name):
+    """oracle.dcn_v2_forward (vectorised torch) against the vectors of the scalar tap-by-tap restatement of upstream DCNv2
+    (oracle/dcn_scalar.py -> tests/golden/dcn_v2_*.npz): on the stored offset map, and -- where the vector holds the
+    conv_offset_mask weights -- through the whole module."""
+    fx = np.load(os.path.join(GOLD, "dcn_v2_%s.npz" % name))
+    x, om, w, b, y = (torch.from_numpy(fx[k]) for k in ("x", "om", "w", "b", "y"))
+    got = O.dcn_v2_from_om(x, om, w, b)
+    assert maxabs(got, y) <= 1e-5 * max(1.0, float(y.abs().max()))
+    if "w_off" in fx:
+        got = O.dcn_v2_forward(x, torch.from_numpy(fx["w_off"]), torch.from_numpy(fx["b_off"]), w, b)
+        assert maxabs(got, y) <= 5e-5 * max(1.0, float(y.abs().max()))      # (the offset conv's own round-off moves the samples)
+
+
+def test_dcn_scalar_restatement_reproduces_its_vectors():
+    """The committed vectors are what oracle/dcn_scalar.py computes today (the smallest case is recomputed)."""
+    import dcn_scalar as DS
+    fx = np.load(os.path.join(GOLD, "dcn_v2_small.npz"))
+    y, om = DS.dcn_v2_module(fx["x"], fx["w_off"], fx["b_off"], fx["w"], fx["b"])
+    assert np.array_equal(om, fx["om"]) and np.array_equal(y, fx["y"])
+
+
 def test_dcn_zero_offsets_is_masked_conv():
     """Upstream initialises conv_offset_mask to zero: offsets 0, mask sigmoid(0)=0.5 -> y = 0.5*conv(x)+b."""
     g = torch.Generator().manual_seed(12)
