@@ -264,6 +264,32 @@ def main():
                                   "value": round(n1 * world / d1, 3), "unit": "frames/s",
                                   "workload": "one frame per GPU per step" + (", 1 all-gather/step" if world > 1 and gather else "")}
         del comp1, pipe1
+        # ---- BASELINE configs[2] as written: ONE video stream, one frame per GPU per step, BOTH all-gathers of the sharded tracker
+        #      stream (records, then affinity blocks; deft_amd.stream.ShardedStream with the device-side record path), 100 detections
+        #      against the 5 stored frames; the association rank's Tracker.update is host work outside this number ----
+        if args.config == "B" and cfg["dataset"] in ("mot", "kitti_tracking"):
+            from deft_amd import integrate
+            from deft_amd.stream import DeviceDetect, ShardedStream
+            afe = integrate.AfeSeam(sd, 100, dev, lib)
+            afe.host_copy = False
+            dd = DeviceDetect(sd, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, img_h=H, img_w=W, out_thresh=-1.0, first_n=NDET, afe_plan=afe.plan)
+            stc = ShardedStream(dd, afe, afe.plan.D, tracker=None, dataset=cfg["dataset"], kmax=KDET, img_h=H, img_w=W, batch=1, device=dev,
+                                max_record=HIST + 1)
+            for i in range(HIST + 4):
+                stc.step([images[i % B:i % B + 1]])
+            sync()
+            nc = 100
+            t1 = time.perf_counter()
+            for i in range(nc):
+                stc.step([images[i % B:i % B + 1]])
+            sync()
+            d1 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([d1], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); d1 = float(t.item())
+            extras["config_C"] = {"workload": "one stream, 1 frame per GPU per step, records + affinity-block all-gathers, %dx%d affinity" % (NDET, NDET * HIST),
+                                  "steps": nc, "ms_per_step": round(d1 / nc * 1e3, 3), "value": round(nc * world / d1, 3), "unit": "frames/s",
+                                  "collectives_per_step": 2 if stc.collective else 0, "bytes_gathered_per_step": stc.bytes_gathered // (nc + HIST + 4)}
+            del stc, dd, afe
 
     # ---- roofline of the dominant kernel family: one profiled step, HIP events per launch
     #      (torch events on the stream every kernel is launched on) ----
@@ -297,19 +323,32 @@ def main():
         split_ms = sum(r[2] for r in gemm if r[5] > FP32_MFMA_PEAK_TF)
         worst = max((r[1] / (r[2] * 1e-3) / 1e12 / r[5], r[3]) for r in gemm)
         traffic, tsrc = None, None                    # HBM bytes per launch from the committed PMC passes of this build, if any
-        tfile = os.path.join(ROOT, "profiles", "r2_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r3_traffic.json")       # written by tools/prof.sh + tools/summarize_prof.py for THIS build; absent -> null
         if os.path.exists(tfile) and args.config == "B":
             tj = json.load(open(tfile))
-            traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, FETCH x2)"
+            traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, FETCH x2)"
+        # the launch group that takes the most time in the step: one lookup for a recompute
+        grp = {}
+        for r in gemm:
+            q = grp.setdefault((r[0], r[3]), [0, 0.0, 0.0, r[5]]); q[0] += 1; q[1] += r[2]; q[2] += r[1]
+        (dk_entry, dk_info), (dk_n, dk_ms, dk_fl, dk_ceil) = max(grp.items(), key=lambda kv: kv[1][1])
+        busy = None
+        cfile = os.path.join(ROOT, "profiles", "r3_dominant_counters.json")
+        if os.path.exists(cfile):
+            busy = json.load(open(cfile)).get("mfma_busy")
+        dominant = {"name": "%s %s" % (dk_entry, dk_info), "launches": dk_n, "avg_us": round(dk_ms / dk_n * 1e3, 2), "ms_per_step": round(dk_ms, 3),
+                    "gflop": round(dk_fl / 1e9, 2), "tflops": round(dk_fl / (dk_ms * 1e-3) / 1e12, 2), "ceiling_tflops": round(dk_ceil, 1),
+                    "frac": round(dk_fl / (dk_ms * 1e-3) / 1e12 / dk_ceil, 4), "mfma_busy": busy}
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak_w, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
-                "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel (conv, DCNv2, pair loaders; fp32 results)",
+                "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel (conv, DCNv2, pair loaders; fp32 results)",
                 "peak_note": "time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split-bf16 kernels (2500 / 6 = 416.7 TFLOP/s: "
                              "3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product), the rest on v_mfma_f32_32x32x2_f32 (157.3)"
                              % (100.0 * split_ms / max(gemm_ms, 1e-9)),
                 "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4),
                 "max_per_launch_frac": round(worst[0], 4), "max_per_launch_frac_shape": worst[1],
+                "dominant_kernel": dominant,
                 "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
                 "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                 "event_bracket_overhead_us": round(ev_over_ms * 1e3, 2),     # median bracket of the step's ~2 us kernels

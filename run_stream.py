@@ -31,6 +31,11 @@ def main():
     ap.add_argument("--dets", type=int, default=30, help="detections kept per frame (random weights: a score threshold is meaningless)")
     ap.add_argument("--force-dist", action="store_true", help="run the collectives in a 1-rank process group")
     ap.add_argument("--check", action="store_true", help="compare records / blocks with a second, collective-free stream")
+    ap.add_argument("--bench", action="store_true", help="timed run: --warmup frames untimed, then --frames frames; a second pass splits the step into its phases")
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--no-tracker", action="store_true", help="exchange only (records + affinity blocks on every rank)")
+    ap.add_argument("--host-detect", action="store_true", help="the round-2 detect path (NCHW adapter, host decode): for A/B")
+    ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     args = ap.parse_args()
     H, W = [int(v) for v in args.size.split("x")]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -43,12 +48,12 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     from deft_amd import integrate, synth
-    from deft_amd.stream import ShardedStream
+    from deft_amd.stream import DeviceDetect, ShardedStream
     torch.set_grad_enabled(False)
     sd = synth.synth_state_dict("mot")
     model = integrate.DeftModel(sd, "mot", K=100, max_object=100, device=dev)
 
-    def detect(x):
+    def detect_host(x):
         out, fmaps = model(x.to(dev), None, None)
         o = dict(out[-1]); o["hm"] = o["hm"].sigmoid()
         dets = {k: v.detach().cpu() for k, v in integrate.generic_decode(o, K=100).items()}
@@ -56,36 +61,54 @@ def main():
                 "bbox": dets["bboxes"][0, i].numpy().astype(np.float32) * 4.0} for i in range(args.dets)]     # down_ratio 4 (opts.py:138-143)
         return res, fmaps
 
-    tracker = None
-    if rank == 0:
+    # the fused device-side front half: hipGraph replay + on-device post-process / centres / embeddings (deft_amd.stream.DeviceDetect)
+    detect = detect_host if args.host_detect else DeviceDetect(sd, H, W, "mot", K=100, device=dev, img_h=H, img_w=W, out_thresh=-1.0,
+                                                               first_n=args.dets, afe_plan=model.AFE.plan)
+    tracker, why = None, None
+    if rank == 0 and not args.no_tracker:
         try:                                              # the reference's Tracker, when its tree is importable
             argv, sys.argv = sys.argv, ["test.py", "tracking"]
             from opts import opts
             from utils import tracker as RT
             sys.argv = argv
             tracker = RT.Tracker(opts().parse(["tracking", "--dataset", "mot"]), model, h=H, w=W)
-        except Exception:
+        except Exception as e:                            # not importable here (the GPU box has no reference tree): exchange-only run
+            why = "%s: %s" % (type(e).__name__, e)
             sys.argv = sys.argv if sys.argv[0] != "test.py" else [__file__]
-    st = ShardedStream(detect, model.AFE, model.AFE.plan.D, tracker=tracker, dataset="mot", kmax=100, img_h=H, img_w=W, batch=1, device=dev,
-                       force_collective=args.force_dist, snapshot=lambda tg: [(int(t.track_id), [float(v) for v in t.tlwh]) for t in tg])
-    ref = ShardedStream(detect, model.AFE, model.AFE.plan.D, dataset="mot", kmax=100, img_h=H, img_w=W, batch=1, device=dev) if args.check else None
+    mk = lambda trk, coll: ShardedStream(detect, model.AFE, model.AFE.plan.D, tracker=trk, dataset="mot", kmax=100, img_h=H, img_w=W, batch=1, device=dev,
+                                         force_collective=coll, snapshot=lambda tg: [(int(t.track_id), [float(v) for v in t.tlwh]) for t in tg])
+    st = mk(tracker, args.force_dist)
+    ref = mk(None, False) if args.check else None
     if ref is not None:
         ref.collective, ref.world, ref.rank = False, 1, 0
     ok, ntracks = True, 0
     nsteps = args.frames // world
-    frames = [torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(500 + t)) for t in range(nsteps * world)]
+    nwarm = (args.warmup // world) if args.bench else 0
+    frames = [torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(500 + t)).to(dev) for t in range(min(nsteps + nwarm, 24) * world)]
+    fr = lambda s: frames[(s * world + rank) % len(frames)]
+    for s in range(nwarm):
+        st.step([fr(s)])
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(nsteps):
-        out = st.step([frames[s * world + rank]])
-        ntracks += sum(len(tg) for _, tg in out)
-        if ref is not None and world == 1:
-            ref.step([frames[s]])
-            ok &= torch.equal(st.all_rec, ref.rec) and torch.equal(st.all_blk, ref.blk)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     if dist.is_initialized():
         dist.barrier()
+    t0 = time.perf_counter()
+    for s in range(nwarm, nwarm + nsteps):
+        out = st.step([fr(s)])
+        ntracks += sum(len(tg) for _, tg in out)
+        if ref is not None and world == 1:
+            ref.step([fr(s)])
+            ok &= torch.equal(st.all_rec, ref.all_rec) and torch.equal(st.all_blk, ref.all_blk)
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    phases = None
+    if args.bench:                                        # second pass with a device synchronisation after every phase: where the step goes
+        st.timers = {}
+        for s in range(nwarm + nsteps, nwarm + 2 * nsteps):
+            st.step([fr(s)])
+        phases = {k: round(v / nsteps * 1e3, 4) for k, v in st.timers.items()}          # ms per STEP (= per `world` frames)
+        st.timers = None
     try:                                   # RCCL prints its banner through C stdio; flush it BEFORE the JSON line (last line of stdout)
         import ctypes
         ctypes.CDLL(None).fflush(None)
@@ -93,10 +116,19 @@ def main():
         pass
     sys.stdout.flush()
     if rank == 0:
-        print(json.dumps({"frames": nsteps * world, "world": world, "size": "%dx%d" % (W, H), "collectives": bool(st.collective),
-                          "backend": dist.get_backend() if dist.is_initialized() else None, "ms_per_frame": round(dt / (nsteps * world) * 1e3, 3),
-                          "bytes_gathered_per_step": st.bytes_gathered // max(nsteps, 1), "reference_tracker": tracker is not None,
-                          "track_outputs": ntracks, "check": ("ok" if ok else "MISMATCH") if args.check else None}), flush=True)
+        check = None
+        if args.check:
+            check = ("ok" if ok else "MISMATCH") if world == 1 else "skipped (compared only in a one-process run)"
+        line = {"frames": nsteps * world, "world": world, "size": "%dx%d" % (W, H), "collectives": bool(st.collective),
+                "backend": dist.get_backend() if dist.is_initialized() else None, "ms_per_frame": round(dt / (nsteps * world) * 1e3, 4),
+                "frames_per_s": round(nsteps * world / dt, 2), "detect": "host" if args.host_detect else "device",
+                "bytes_gathered_per_step": st.bytes_gathered // max(nsteps + nwarm + (nsteps if args.bench else 0), 1),
+                "reference_tracker": tracker is not None, "reference_tracker_unavailable": why,
+                "track_outputs": ntracks, "check": check, "phase_ms_per_step": phases}
+        print(json.dumps(line), flush=True)
+        if args.out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+            json.dump(line, open(args.out, "w"), indent=1)
     if dist.is_initialized():
         dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -1264,3 +1264,30 @@ def check_preprocess_u8(lib, device, N=2, sh=45, sw=80, H=32, W=64, seed=0):
     p2 = engine.DlaSegPlan(sd, N, H, W, "mot", K=5, device=device, lib=lib)
     p2.forward(torch.cat([O.preprocess_u8(frames[n], M, W, H, PR.MEAN, PR.STD) for n in range(N)]).to(p2.device))
     assert torch.equal(a[1], p2.inds) and torch.equal(a[0], p2.scores) and torch.equal(a[2], p2.bboxes)
+
+
+def check_device_detect(lib, device, dataset="mot", H=64, W=96, K=20, first_n=9, seed=3):
+    """deft_amd.stream.DeviceDetect (the frame's record built on the device: post-process affine, threshold / first-n cut, KITTI
+    class filter, convert_detection, embeddings) against the host forms it replaces: postprocess.generic_post_process on the plan's
+    decoded arrays, stream.select_2d / convert_detection, AfePlan.extract on those centres."""
+    from deft_amd import postprocess as PP, stream as ST
+    sd = O.synth_state_dict(dataset)
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(seed))
+    dd = ST.DeviceDetect(sd, H, W, dataset, K=K, device=device, lib=lib, img_h=H, img_w=W, out_thresh=-1.0, first_n=first_n, hip_graphs=False)
+    fr = dd(x)
+    n_res, n_sel = int(fr.n_res), int(fr.n_sel)
+    assert n_res == first_n
+    dets = {k: v.detach().cpu().numpy() for k, v in dd.plan.dets().items()}
+    post = PP.generic_post_process(dets, np.array([W / 2.0, H / 2.0], np.float32), float(max(H, W)), H // 4, W // 4, -1.0)
+    res = PP.as_result_list(post)[:first_n]
+    rows = fr.rows.cpu().numpy()
+    for i, r in enumerate(res):
+        assert np.allclose(rows[i, 0:4], r["bbox"], rtol=0, atol=1e-3) and rows[i, 4] == np.float32(r["score"]) and int(rows[i, 5]) == int(r["class"])
+    assert float(np.abs(rows[n_res:]).max() if n_res < K else 0.0) == 0.0
+    sel = ST.select_2d(res, dataset)
+    assert sel.shape[0] == n_sel
+    if n_sel:
+        centers = ST.convert_detection(np.copy(sel[:, :4]), H, W).reshape(1, n_sel, 2)
+        emb = dd.afe.extract(dd.plan.fmaps, centers.to(device))[0]
+        assert maxabs(fr.emb[:n_sel], emb) <= 1e-4
+    return n_res, n_sel

@@ -146,6 +146,12 @@ def test_forward_every_presplit_kernel_forced(emu_lib):
         engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = saved_d
 
 
+@pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
+def test_device_detect_record(emu_lib, dataset):
+    n_res, n_sel = pc.check_device_detect(emu_lib, "cpu", dataset)
+    assert n_sel <= n_res and (dataset != "mot" or n_sel == n_res)
+
+
 def test_seam_dcn_module(emu_lib):
     pc.check_seam_dcn(emu_lib, "cpu")
 
