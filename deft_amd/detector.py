@@ -34,6 +34,14 @@ class Detector(object):
         self.img_height = 100          # detector.py:108-109
         self.img_width = 100
         self.pre_images = None
+        self.tracker = None            # set_tracker(): the reference's Tracker (or {class: Tracker} for nuScenes), detector.py:102-107
+        self.times = {}                # stage seconds of the last run(), under the reference's names (detector.py:113-114, 340-344)
+        self._u8 = {}                  # (sh, sw) -> plan switched to uint8 input (deft_preprocess_u8)
+
+    def set_tracker(self, tracker):
+        """The object `run()` hands the frame's detections to: `utils.tracker.Tracker(opt, model, h, w)` of the reference (bind
+        deft_amd.tracker.accelerate first for the device forms), or {class name: Tracker} for nuScenes (detector.py:102-107)."""
+        self.tracker = tracker
 
     def _plan(self, N, H, W):
         key = (N, H, W)
@@ -100,6 +108,116 @@ class Detector(object):
         if not results:
             return {n: {"results": [], "ddd_boxes": [], "depths": [], "ddd_org_boxes": [], "submission": []} for n in PP.NUSCENES_TRACKING_NAMES}
         return PP.nuscenes_frame(post, image_info, nms=nms)
+
+    # ---- frame in -> tracks out: Detector.run (detector.py:112-344) on the fused path ----------------------------------------
+    def _meta_for(self, height, width, inp_h, inp_w, input_meta):
+        """The meta dict of Detector.pre_process in fix_res mode (detector.py:363-367, 395-415), without touching the pixels."""
+        from . import preprocess as PR
+        M, c, s = PR.input_affine(height, width, inp_h, inp_w)
+        calib = np.array(input_meta["calib"], dtype=np.float32) if "calib" in input_meta else \
+            np.array([[1200.0, 0, width / 2, 0], [0, 1200.0, height / 2, 0], [0, 0, 1, 0]], np.float32)      # _get_default_calib, detector.py:424-428
+        meta = {"calib": calib, "c": c, "s": s, "height": height, "width": width, "out_height": inp_h // 4, "out_width": inp_w // 4,
+                "inp_height": inp_h, "inp_width": inp_w, "trans_input": M}
+        for k in ("pre_dets", "cur_dets"):
+            if k in input_meta:
+                meta[k] = input_meta[k]
+        return meta
+
+    def run(self, image_or_path_or_tensor, meta={}, image_info=None, nms=True):
+        """detector.py:112-344 -- same argument forms, same return value (`Tracker.update`'s online targets; the post-processed
+        `results` when no tracker is set), same stage timers (self.times: load / pre / net / dec / post / merge / track / tot):
+          * numpy uint8 HWC frame (cv2 channel order): warp + normalise + layout ON THE DEVICE (deft_preprocess_u8, fix_res mode),
+            straight into the plan's input -- the host never touches the pixels (SURVEY.md 8(f) rank 2);
+          * the prefetch-loader dict of src/test.py:106-112, 213 ({"image", "images": {scale: [tensor]}, "meta": {scale: {...}}});
+          * a path: read with cv2 when that is importable (it is not in this image).
+        Then process() -> post_process() -> merge_outputs() -> nuScenes branch / `self.tracker.update(results, FeatureMaps)`.
+        One test scale, no flip test (asserted like detector.py:578)."""
+        import time
+        opt = self.opt
+        scales = list(getattr(opt, "test_scales", [1.0]))
+        assert len(scales) == 1 and not getattr(opt, "flip_test", False), "the fused run() is the single-scale, no-flip configuration (detector.py:578)"
+        scale = scales[0]
+        t_start = time.time()
+        pre_processed, frame = False, None
+        if isinstance(image_or_path_or_tensor, np.ndarray):
+            frame = image_or_path_or_tensor
+        elif isinstance(image_or_path_or_tensor, str):
+            try:
+                import cv2
+            except ImportError as e:
+                raise RuntimeError("reading %r needs cv2, which this environment does not have; pass the decoded uint8 frame" % image_or_path_or_tensor) from e
+            frame = cv2.imread(image_or_path_or_tensor)
+        else:
+            pre_processed = True
+        t_loaded = time.time()
+        if not pre_processed:
+            assert frame.dtype == np.uint8 and frame.ndim == 3 and frame.shape[2] == 3
+            sh, sw = frame.shape[:2]
+            inp_h, inp_w = int(getattr(opt, "input_h", 0)), int(getattr(opt, "input_w", 0))
+            assert inp_h > 0 and inp_w > 0, "the device pre-processing is the fix_res mode (opt.input_h / input_w)"
+            meta = self._meta_for(sh, sw, inp_h, inp_w, meta)
+            plan = self._plan(1, inp_h, inp_w)
+            if self._u8.get((inp_h, inp_w)) != (sh, sw):
+                plan.use_u8_input(sh, sw)
+                self._u8[(inp_h, inp_w)] = (sh, sw)
+                self._graphs.pop((1, inp_h, inp_w), None)
+            src = torch.from_numpy(np.ascontiguousarray(frame)).unsqueeze(0)
+            t_pre = time.time()
+            output, dets, t_fwd, fmaps = self._process_u8(plan, src)
+        else:
+            d = image_or_path_or_tensor
+            images = d["images"][scale][0]
+            meta = {k: v.numpy()[0] for k, v in d["meta"][scale].items()}
+            for k in ("pre_dets", "cur_dets"):
+                if k in d["meta"]:
+                    meta[k] = d["meta"][k]
+            t_pre = time.time()
+            output, dets, t_fwd, fmaps = self.process(images, None, None, None, return_time=True)
+        t_dec = time.time()
+        result = self.post_process(dets, meta, scale)
+        t_post = time.time()
+        results = self.merge_outputs([result])
+        t_merge = time.time()
+        if getattr(opt, "public_det", False) and pre_processed:
+            results = image_or_path_or_tensor["meta"]["cur_dets"]                     # detector.py:190-196
+        if self.tracker is None:
+            targets = results
+        elif self.dataset == "nuscenes":
+            per_class = self.nuscenes_targets(results, image_info, nms=nms)            # detector.py:198-338
+            targets = []
+            for name, a in per_class.items():
+                targets += self.tracker[name].update(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"],
+                                                     ddd_org_boxes=a["ddd_org_boxes"], submission=a["submission"], classe=name)
+        else:
+            targets = self.tracker.update(results, fmaps)                              # detector.py:340-342
+        t_end = time.time()
+        self.times = {"load": t_loaded - t_start, "pre": t_pre - t_loaded, "net": t_fwd - t_pre, "dec": t_dec - t_fwd, "post": t_post - t_dec,
+                      "merge": t_merge - t_post, "track": t_end - t_merge, "tot": t_end - t_start}
+        self.last_results = results
+        return targets
+
+    def _process_u8(self, plan, frames_u8):
+        """process() for a uint8 frame batch [N, sh, sw, 3] (host or device): the plan's first launch is deft_preprocess_u8."""
+        import time
+        key = (plan.N, plan.H, plan.W)
+        frames_u8 = frames_u8.to(self.device, non_blocking=True)
+        if not self.hip_graphs or key not in self._graphs:
+            plan.forward_u8(frames_u8)
+            self._graphs.setdefault(key, None)
+        else:
+            if self._graphs[key] is None:
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
+                    plan.run()
+                self._graphs[key] = g
+            plan.image_u8.copy_(frames_u8, non_blocking=True)
+            self._graphs[key].replay()
+        d = plan.dets()
+        if "dep" in d:
+            d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
+        dets = {k: v.detach().cpu().numpy() for k, v in d.items()}
+        return {"hm": plan.dense["hm"], "pre_inds": None}, dets, time.time(), plan.fmaps
 
     def reset_tracking(self, opt):
         """detector.py:677-686 (the recorder mirror lives in deft_amd.tracker)."""

@@ -1291,3 +1291,43 @@ def check_device_detect(lib, device, dataset="mot", H=64, W=96, K=20, first_n=9,
         emb = dd.afe.extract(dd.plan.fmaps, centers.to(device))[0]
         assert maxabs(fr.emb[:n_sel], emb) <= 1e-4
     return n_res, n_sel
+
+
+def check_fused_run_u8(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=4):
+    """deft_amd.detector.Detector.run on a raw uint8 frame (device pre-processing -> fused process -> vectorised post-process ->
+    merge -> tracker hand-over) against the same stages fed by the host restatement of Detector.pre_process (oracle.preprocess_u8:
+    the arithmetic deft_preprocess_u8 reproduces bit for bit): identical detections, and the tracker receives them with the
+    frame's FeatureMaps."""
+    from types import SimpleNamespace
+    from deft_amd import hiplib, preprocess as PR
+    from deft_amd.detector import Detector
+    sd = O.synth_state_dict("mot")
+    saved_lib, hiplib._lib = hiplib._lib, lib
+    try:
+        opt = SimpleNamespace(dataset="mot", K=K, max_object=100, gpus=[0 if device != "cpu" else -1], hip_graphs=True, depth_scale=1.0,
+                              input_h=H, input_w=W, out_thresh=-1.0, test_scales=[1.0], flip_test=False, public_det=False)
+        det = Detector(opt, sd)
+        calls = []
+
+        class Trk:
+            def update(self, results, fmaps):
+                calls.append((len(results), len(fmaps)))
+                return ["tracks of %d detections" % len(results)]
+
+        det.set_tracker(Trk())
+        g = torch.Generator().manual_seed(seed)
+        for rep in range(3):                               # frame 2 replays the captured hipGraph on a GPU
+            frame = torch.randint(0, 256, (sh, sw, 3), dtype=torch.uint8, generator=g).numpy()
+            out = det.run(frame)
+            assert out == ["tracks of %d detections" % K] and calls[-1] == (K, 13)
+            got = det.last_results
+            M, c, s = PR.input_affine(sh, sw, H, W)
+            images = O.preprocess_u8(frame, M, W, H, PR.MEAN, PR.STD)                       # [1, 3, H, W] float32, the reference's pre_process
+            det2 = Detector(opt, sd)
+            _, dets, _ = det2.process(images)
+            ref = det2.merge_outputs([det2.post_process(dets, det._meta_for(sh, sw, H, W, {}), 1.0)])
+            assert len(ref) == len(got) == K
+            for a, b in zip(got, ref):
+                assert int(a["class"]) == int(b["class"]) and float(a["score"]) == float(b["score"]) and np.array_equal(a["bbox"], b["bbox"])
+    finally:
+        hiplib._lib = saved_lib

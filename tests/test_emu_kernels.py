@@ -152,6 +152,10 @@ def test_device_detect_record(emu_lib, dataset):
     assert n_sel <= n_res and (dataset != "mot" or n_sel == n_res)
 
 
+def test_fused_detector_run_on_uint8_frames(emu_lib):
+    pc.check_fused_run_u8(emu_lib, "cpu")
+
+
 def test_seam_dcn_module(emu_lib):
     pc.check_seam_dcn(emu_lib, "cpu")
 

@@ -560,6 +560,10 @@ def test_device_detect_record(gpu_lib, dataset):
     pc.check_device_detect(gpu_lib, "cuda", dataset, H=128, W=160, K=100, first_n=30)
 
 
+def test_fused_detector_run_on_uint8_frames(gpu_lib):
+    pc.check_fused_run_u8(gpu_lib, "cuda", sh=270, sw=480, H=128, W=160, K=50)
+
+
 def test_frame_feeder_with_side_streams(gpu_lib):
     """FrameFeeder (pinned double buffer, copy stream) feeding the multi-stream HipCompute: every step's frames are different, and the
     side streams must see THIS step's H2D copy (the round-2 advisor's race: they waited only on the previous step's event).  Two

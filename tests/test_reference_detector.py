@@ -80,13 +80,37 @@ def test_detector_shim_matches_reference_detector(emu_lib, tmp_path, monkeypatch
                     det._undo_tracker()                         # leave the reference's tracker module as found (other tests)
             return log
 
+        def run_fused():
+            """deft_amd.detector.Detector.run -- process, the vectorised post_process / merge_outputs and the tracker hand-over composed
+            in this repository (not inherited from the reference) -- driving the reference's own Tracker with the device forms bound."""
+            from deft_amd import checkpoint, detector as FD, integrate, tracker as DT
+            import utils.tracker as RT
+            BaseTrack._count = 0
+            undo = DT.accelerate(RT, None)
+            try:
+                sdl = checkpoint.load_model_state(ck, opt, log=lambda *_: None)
+                fd = FD.Detector(opt, sdl)
+                model = integrate.create_model(opt, sdl, device="cpu")
+                fd.set_tracker(RT.Tracker(opt, model, h=fd.img_height, w=fd.img_width))      # = reset_tracking BEFORE the sizes are set (100 x 100), as `run` above
+                fd.img_height, fd.img_width = H, W
+                log = []
+                for t in range(3):
+                    targets = fd.run(_frame(10 + t, H, W), image_info={})
+                    log.append(sorted((s.track_id, [float(v) for v in s.tlwh], float(s.score)) for s in targets))
+                assert set(fd.times) == {"load", "pre", "net", "dec", "post", "merge", "track", "tot"}
+            finally:
+                undo()
+            return log
+
         ref = run(RD.Detector)
         got = run(shim.Detector)
+        fused = run_fused()
         assert sum(len(f) for f in ref) >= 8
-        for fa, fb in zip(ref, got):
-            assert [a[0] for a in fa] == [b[0] for b in fb]
-            for a, b in zip(fa, fb):
-                assert np.abs(np.array(a[1]) - np.array(b[1])).max() <= 1e-3 and abs(a[2] - b[2]) <= 1e-4
+        for other in (got, fused):
+            for fa, fb in zip(ref, other):
+                assert [a[0] for a in fa] == [b[0] for b in fb]
+                for a, b in zip(fa, fb):
+                    assert np.abs(np.array(a[1]) - np.array(b[1])).max() <= 1e-3 and abs(a[2] - b[2]) <= 1e-4
     finally:
         torch.set_grad_enabled(True)
         sys.modules.pop("dcn_v2", None)
