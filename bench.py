@@ -33,6 +33,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -290,6 +291,44 @@ def main():
                                   "steps": nc, "ms_per_step": round(d1 / nc * 1e3, 3), "value": round(nc * world / d1, 3), "unit": "frames/s",
                                   "collectives_per_step": 2 if stc.collective else 0, "bytes_gathered_per_step": stc.bytes_gathered // (nc + HIST + 4)}
             del stc, dd, afe
+        # ---- frame in -> tracks out on ONE stream: deft_amd.detector.Detector.run = process (hipGraph) -> vectorised
+        #      post-process -> deft_amd.mot_tracker.Tracker2D.update (embedding extraction, affinity chain against the stored frames,
+        #      device-side similarity medians, batched Kalman gate, assignment, IoU stage), K detections per frame ----
+        if args.config == "B" and world == 1:
+            from types import SimpleNamespace
+            from deft_amd import detector as FD, integrate, mot_tracker as MT
+            sde = dict(sd)                       # random regression heads give boxes with negative extent: bias the amodal l/t/r/b head to ~40 x 64 px boxes
+            sde["ltrb_amodal.2.weight"] = sde["ltrb_amodal.2.weight"] * 0.05
+            sde["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
+            opt = SimpleNamespace(dataset="mot", K=KDET, max_object=100, gpus=[local], hip_graphs=True, depth_scale=1.0, input_h=H, input_w=W,
+                                  out_thresh=-1.0, test_scales=[1.0], flip_test=False, public_det=False, track_buffer=30, lstm=False)
+            fdet = FD.Detector(opt, sde)
+            seam = integrate.AfeSeam(sde, 100, dev, lib)
+            seam.host_copy = False
+            MT.TrackIds.count = 0
+            fdet.set_tracker(MT.Tracker2D(opt, SimpleNamespace(AFE=seam), h=H, w=W))
+            c0 = np.array([W / 2.0, H / 2.0], np.float32)
+            meta = {"c": c0, "s": np.float32(max(H, W)), "height": H, "width": W, "out_height": H // 4, "out_width": W // 4, "inp_height": H,
+                    "inp_width": W, "calib": np.eye(3, 4, dtype=np.float32)}
+            mk = lambda x: {"image": [torch.zeros(1)], "images": {1.0: [x]}, "meta": {1.0: {k: torch.from_numpy(np.asarray(v)[None]) for k, v in meta.items()}}}
+            feed = [mk(images[i:i + 1]) for i in range(min(B, 8))]
+            for i in range(12):
+                fdet.run(feed[i % len(feed)])
+            sync()
+            ne = 100
+            acc = {}
+            t1 = time.perf_counter()
+            for i in range(ne):
+                fdet.run(feed[i % len(feed)])
+                for k_, v_ in fdet.times.items():
+                    acc[k_] = acc.get(k_, 0.0) + v_
+            sync()
+            d1 = time.perf_counter() - t1
+            extras["end_to_end"] = {"workload": "one stream, frame -> Detector.run (fused process + post-process) -> Tracker2D.update, %d detections per frame" % KDET,
+                                    "frames": ne, "ms_per_frame": round(d1 / ne * 1e3, 3), "value": round(ne / d1, 3), "unit": "frames/s",
+                                    "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc.items()},
+                                    "tracks_alive": len(fdet.tracker.tracked_stracks), "stored_frames": len(fdet.tracker.recorder.all_frame_index)}
+            del fdet, seam
 
     # ---- roofline of the dominant kernel family: one profiled step, HIP events per launch
     #      (torch events on the stream every kernel is launched on) ----

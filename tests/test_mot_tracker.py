@@ -1,0 +1,150 @@
+"""-m "not gpu" (build container: needs /root/reference): deft_amd.mot_tracker.Tracker2D -- the 2-D tracking loop as arrays, on the
+device forms -- against the REFERENCE's own `Tracker` frame by frame: same track ids, same boxes, same activation flags, over a
+scene with births, a two-frame occlusion, an empty frame, a crossing pair and tracks that age out.  The embedding / affinity side is
+a cheap deterministic stand-in (so the association logic is what is compared); tests/test_reference_detector.py and the GPU replay
+cover the kernels."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+HAVE_REF = os.path.isdir("/root/reference/src/lib")
+pytestmark = pytest.mark.skipif(not HAVE_REF, reason="/root/reference only exists in the build container")
+
+D, H, W = 12, 120, 200
+
+
+class FakeAFE:
+    """Deterministic stand-in for model.AFE with BOTH interfaces: the reference's pairwise `forward_stacker_features` and the
+    one-chain `affinity_many` + `last_device` the device recorder uses."""
+    host_copy = True
+    last_device = None
+    plan = None
+
+    def forward_feature_extracter(self, FeatureMaps, centers):
+        c = centers.reshape(-1, 2).double()
+        k = torch.arange(1, D // 2 + 1, dtype=torch.float64)
+        e = torch.cat([torch.sin(c[:, :1] * k * 1.7 + c[:, 1:] * 0.3), torch.cos(c[:, 1:] * k * 1.3 - c[:, :1] * 0.2)], 1)
+        return e.float().unsqueeze(0)
+
+    def _block(self, xp, xn):
+        d = torch.cdist(xp.double(), xn.double())
+        s = torch.exp(-4.0 * d)
+        miss = torch.full((xp.shape[0], 1), 0.05, dtype=torch.float64)
+        y = torch.cat([s, miss], 1)
+        return (y / y.sum(1, keepdim=True)).float()
+
+    def affinity_many(self, hist, cur):
+        blocks = [self._block(h, cur) for h in hist]
+        starts = [0]
+        for b in blocks:
+            starts.append(starts[-1] + b.shape[0])
+        self.last_device = (torch.cat(blocks, 0), starts)
+        return [b.numpy() for b in blocks]
+
+    def forward_stacker_features(self, xp, xn, fill_up_column=True):
+        y = self._block(xp[0], xn[0]).numpy()
+        P, Q = xp.shape[1], xn.shape[1]
+        if fill_up_column and P > 1:
+            y = np.concatenate([y, np.repeat(y[:, Q:Q + 1], P - 1, axis=1)], axis=1)
+        return y
+
+
+def _scene(t, dataset):
+    """Detections of frame t: objects drift; #3 is occluded in frames 6-7; #5 is born at frame 9; #1 leaves for good at 14 (its track must
+    age out); frame 4 is empty; #0 and #2 cross around frame 12; KITTI gets a class mix (only class 2 is tracked)."""
+    if t == 4 or t >= 26:                 # the stream ends with empty frames: every track ages out (max_time_lost = 10 frames)
+        return []
+    out = []
+    for i in range(7):
+        if (i == 3 and t in (6, 7)) or (i == 5 and t < 9) or (i == 1 and t >= 14) or (i == 6 and t % 5 == 0):
+            continue
+        vx = [1.8, -0.7, -1.6, 0.5, 1.1, -0.9, 0.3][i]
+        x0 = [20.0, 60.0, 80.0, 110.0, 140.0, 30.0, 165.0][i] + vx * t
+        y0 = 10.0 + 12.0 * i + 0.4 * t * (1 if i % 2 else -1)
+        w, h = 14.0 + 0.5 * i, 26.0 + 0.7 * i + 0.05 * t
+        jit = 0.3 * np.sin(1.3 * t + i)
+        cls = 2 if dataset == "mot" or i % 3 != 2 else 1
+        out.append({"score": float(0.9 - 0.05 * i + 0.01 * np.cos(t + i)), "class": cls if dataset != "mot" else 1,
+                    "bbox": np.array([x0 + jit, y0 - jit, x0 + w + jit, y0 + h], np.float32)})
+    if 2 <= t <= 12:                      # an isolated object that disappears for good: its track ages out (max_time_lost = 10 frames)
+        out.append({"score": 0.5, "class": 2 if dataset != "mot" else 1, "bbox": np.array([180.0, 92.0 + 0.1 * t, 193.0, 116.0], np.float32)})
+    return out
+
+
+def _reference(dataset, model):
+    import make_golden as MG
+    import ref_import
+    import ref_shims
+    ref_shims.install()
+    ref_import.install_stubs(MG.OracleDCN)
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]            # utils/tracker.py:139 parses argv at import
+    try:
+        from opts import opts
+        from utils import tracker as RT
+        from utils.basetrack import BaseTrack
+    finally:
+        sys.argv = argv
+    opt = opts().parse(["tracking", "--dataset", dataset, "--gpus", "-1"])
+    BaseTrack._count = 0
+    return opt, RT.Tracker(opt, model, h=H, w=W)
+
+
+def _log(targets):
+    return [(int(t.track_id), bool(t.is_activated), int(t.tracklet_len), [float(v) for v in t.tlwh], float(t.score)) for t in targets]
+
+
+@pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
+def test_tracker2d_matches_reference_tracker(emu_lib, dataset):
+    from deft_amd import mot_tracker as MT
+    nframes = 40
+    opt, ref = _reference(dataset, types.SimpleNamespace(AFE=FakeAFE()))
+    MT.TrackIds.count = 0
+    afe = FakeAFE()
+    afe.plan = types.SimpleNamespace(lib=emu_lib, _stream=lambda: None)       # the similarity medians run through the C ABI (deft_track_similarity)
+    mine = MT.Tracker2D(opt, types.SimpleNamespace(AFE=afe), h=H, w=W)
+    fm = [torch.zeros(1, 1, 1, 1)]
+    ids = set()
+    for t in range(nframes):
+        res = _scene(t, dataset)
+        a = _log(ref.update([dict(r) for r in res], fm))
+        b = _log(mine.update([dict(r) for r in res], fm))
+        assert [x[:3] for x in a] == [x[:3] for x in b], (t, a, b)
+        for x, y in zip(a, b):
+            assert np.abs(np.array(x[3]) - np.array(y[3])).max() <= 1e-9 and x[4] == y[4], (t, x, y)
+        ids |= {x[0] for x in a}
+        assert sorted(tk.track_id for tk in ref.tracked_stracks) == sorted(tk.track_id for tk in mine.tracked_stracks), t
+    assert len(ids) >= 5
+    # tracks aged out (MOT; on KITTI a track unseen for 6 frames leaves the IoU candidates and with them the only place that removes: tracker.py:982-1010)
+    assert len(mine.removed_stracks) == len(ref.removed_stracks) and (dataset != "mot" or len(mine.removed_stracks) >= 5)
+
+
+def test_kalman_batch_forms_match_reference_filter():
+    """kf_initiate / kf_multi_predict / kf_multi_update against utils/tracking_utils/kalman_filter.py (its per-track Cholesky update)."""
+    _reference("mot", types.SimpleNamespace(AFE=FakeAFE()))
+    from utils.tracking_utils.kalman_filter import KalmanFilter
+    from deft_amd import mot_tracker as MT
+    kf = KalmanFilter()
+    g = np.random.default_rng(0)
+    meas = np.stack([g.uniform(10, 500, 9), g.uniform(10, 300, 9), g.uniform(0.3, 0.6, 9), g.uniform(40, 200, 9)], 1)
+    ms, cs = zip(*[kf.initiate(m) for m in meas])
+    for m, c, z in zip(ms, cs, meas):
+        m2, c2 = MT.kf_initiate(z)
+        assert np.array_equal(m, m2) and np.array_equal(c, c2)
+    mean, cov = np.stack(ms), np.stack(cs)
+    for step in range(5):
+        rm, rc = kf.multi_predict(mean.copy(), cov.copy())
+        mm, mc = MT.kf_multi_predict(mean, cov)
+        assert np.array_equal(rm, mm) and np.allclose(rc, mc, rtol=0, atol=1e-12)
+        z = meas + g.normal(0, 2.0, meas.shape) * [1, 1, 0.01, 1]
+        ru = [kf.update(rm[i], rc[i], z[i]) for i in range(len(z))]
+        um, uc = MT.kf_multi_update(mm, mc, z)
+        assert np.allclose(np.stack([u[0] for u in ru]), um, rtol=0, atol=1e-9) and np.allclose(np.stack([u[1] for u in ru]), uc, rtol=0, atol=1e-9)
+        mean, cov = um, uc

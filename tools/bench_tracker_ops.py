@@ -5,6 +5,11 @@
   track similarity D2H of the frame's affinity blocks + per-track numpy medians (tracker.py:219-252, 663-688)
                    vs `deft_amd.tracker.get_similarity` (deft_track_similarity; only [T, N+1] comes back).
 
+  tracker update   deft_amd.mot_tracker.Tracker2D.update (the 2-D association loop on the device forms) over a synthetic scene of
+                   `tracks` objects with the recorder full (`stored` frames): total per frame, and inside it the embedding extraction,
+                   FeatureRecorder.update (the affinity chain), get_similarity, fuse_motion, lapjv, bbox_overlaps, the batched Kalman
+                   steps, and the remaining per-track Python.
+
     python tools/bench_tracker_ops.py [--tracks 100] [--dets 100] [--stored 49]  -> gpurun_out/tracker_ops.json
 """
 import argparse
@@ -28,6 +33,69 @@ def timeit(fn, reps):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
+
+
+def tracker_update_split(T, R, dev, H=608, W=1088, nframes=40):
+    """Tracker2D.update on T drifting objects (every object detected every frame -> T tracks x T detections), real embedding /
+    affinity kernels on random FeatureMaps of the config-B shapes, recorder filled with R frames before timing."""
+    from deft_amd import association as A, mot_tracker as MT, hiplib
+    from deft_amd.engine import View
+    sd = synth.synth_state_dict("mot")
+    lib = hiplib.get_lib()
+    afe = integrate.AfeSeam(sd, 100, dev, lib)
+    afe.host_copy = False
+    opt = SimpleNamespace(dataset="mot", track_buffer=30, max_object=100, lstm=False)
+    trk = MT.Tracker2D(opt, SimpleNamespace(AFE=afe), h=H, w=W)
+    # the 13 FeatureMaps of a 1088x608 frame (random values: the tracker only samples them)
+    fm = []
+    for c, s_ in zip(synth.SELECTOR_IN, synth.FEATURE_STRIDES):
+        v = afe.plan.alloc(1, H // s_, W // s_, c)
+        v.buf.normal_()
+        fm.append(v)
+    g = np.random.RandomState(1)
+    x0 = g.uniform(40, W - 120, T); y0 = g.uniform(40, H - 200, T)
+    vx = g.uniform(-2, 2, T); vy = g.uniform(-1, 1, T)
+    bw = g.uniform(30, 60, T); bh = g.uniform(80, 160, T)
+
+    def frame(t):
+        return [{"score": float(0.9 - 0.004 * i), "class": 1,
+                 "bbox": np.array([x0[i] + vx[i] * t, y0[i] + vy[i] * t, x0[i] + vx[i] * t + bw[i], y0[i] + vy[i] * t + bh[i]], np.float32)} for i in range(T)]
+
+    acc = {}
+
+    def wrap(obj, name, key):
+        fn = getattr(obj, name)
+
+        def timed(*a, **k):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out = fn(*a, **k)
+            torch.cuda.synchronize(); acc[key] = acc.get(key, 0.0) + time.perf_counter() - t0
+            return out
+        setattr(obj, name, timed)
+        return lambda: setattr(obj, name, fn)
+
+    for t in range(R + 2):                    # fill the recorder (R stored frames), un-timed
+        trk.update(frame(t), fm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(R + 2, R + 2 + nframes):
+        trk.update(frame(t), fm)
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t0) / nframes * 1e3
+    undo = [wrap(afe, "forward_feature_extracter", "embed_extract"), wrap(trk.recorder, "update", "recorder_update (affinity chain)"),
+            wrap(trk, "get_similarity", "get_similarity"), wrap(A, "fuse_motion", "fuse_motion"), wrap(A, "lapjv", "lapjv"),
+            wrap(A, "bbox_overlaps", "bbox_overlaps"), wrap(MT, "kf_multi_predict", "kf_multi_predict"), wrap(MT, "kf_multi_update", "kf_multi_update")]
+    t0 = time.perf_counter()
+    for t in range(R + 2 + nframes, R + 2 + 2 * nframes):
+        trk.update(frame(t), fm)
+    torch.cuda.synchronize()
+    total_instr = (time.perf_counter() - t0) / nframes * 1e3
+    for u in undo:
+        u()
+    split = {k: round(v / nframes * 1e3, 4) for k, v in acc.items()}
+    split["other per-track Python"] = round(total_instr - sum(split.values()), 4)
+    return {"ms_per_frame": round(total, 4), "ms_per_frame_with_sync_per_call": round(total_instr, 4), "split_ms": split,
+            "tracks_alive": len(trk.tracked_stracks), "stored_frames": len(trk.recorder.all_frame_index), "detections": T}
 
 
 def main():
@@ -91,6 +159,7 @@ def main():
     assert np.array_equal(device_form(), host_form())
     res["similarity_host_ms"] = timeit(host_form, a.reps)
     res["similarity_device_ms"] = timeit(device_form, a.reps)
+    res["tracker_update"] = tracker_update_split(T, R, dev)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/tracker_ops.json", "w") as f:
         json.dump(res, f, indent=1)
