@@ -256,11 +256,9 @@ def test_topk_seed_sweep_both_arithmetics(gpu_lib, dataset, H, W, nseeds):
     finally:
         engine.PREC = saved
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 8)))      # ATen's CPU convs thrash far below the box's 256 hardware threads
-    # MOT net: heat-map logits agree to <= 1.1e-4 and every index difference is a <= 1e-4 tie.  The synthetic KITTI / nuScenes nets are an
-    # order of magnitude worse conditioned (logit range [-13, 4.6], DCN-stage maps differ by 6e-5 relative between ANY two fp32 summation
-    # orders -- the fp32-MFMA path shows the same 7e-4 as the split path, tools/probe/fmap_errors.py): there the tie level is twice the
-    # frame's own cross-implementation error
-    logit_tol, tie = (2e-4, 1e-4) if dataset == "mot" else (3e-3, None)
+    # heat-map logits agree to <= 2e-4 and every index difference is a <= 1e-4 tie, for every dataset (round 2 needed 3e-3 for the KITTI /
+    # nuScenes nets: their trunks were a worse-conditioned random draw, see deft_amd.synth.synth_state_dict)
+    logit_tol, tie = 2e-4, 1e-4          # ONE tolerance set for all datasets: the synthetic nets share a trunk now (deft_amd.synth.synth_state_dict)
     diff = {0: [], 1: []}
     worst = {0: 0.0, 1: 0.0}
     for seed in range(1000, 1000 + nseeds):
