@@ -40,8 +40,7 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 template <int BM, int BN, int WK, int NSTAGE, int MODE, int PREC = 0>
 constexpr int igemm_lds_floats() {
     constexpr int ld = (MODE == MODE_CONV && NSTAGE == 2) ? 32 : LDS_STRIDE;      // LDS-DMA image is unpadded
-    // PREC = 3: the same with ONE weight stage, refilled after the chunk's second barrier (no extra LDS: the DCN keeps its 3 workgroups/CU)
-    constexpr int stage = (PREC >= 2 ? (3 * BM * LDB * 2 + (PREC == 2 ? 2 : 1) * BN * 192) / 4 : PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 5 : 0);
+    constexpr int stage = (PREC >= 2 ? (3 * BM * LDB * 2 + 2 * BN * 192) / 4 : PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 5 : 0);
     constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
     return stage > red ? stage : red;
 }
@@ -85,7 +84,8 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     float* const As = smem;
     float* const Bs = smem + NSTAGE * BM * LD;
     constexpr bool BDMA = PREC >= 2;
-    constexpr int NBS = PREC == 3 ? 1 : 2;               // weight stages of the DMA form
+    static_assert(!(BDMA && MODE == MODE_DCN), "the DCN reads pre-split weights on its patch form only (dcn.hip)");
+    constexpr int NBS = 2;                               // weight stages of the DMA form
     float* const prm = BDMA ? smem + (3 * BM * LDB * 2 + NBS * BN * 192) / 4 : PREC ? smem + 3 * (BM + BN) * LDB / 2 : Bs + NSTAGE * BN * LD;   // DCN only
     __bf16* const Ap = (__bf16*)smem;            // PREC >= 1: A planes [3][BM][LDB], then B planes [3][BN][LDB] (PREC 2: two DMA stages [BN][192 B])
     __bf16* const Bp = Ap + 3 * BM * LDB;
@@ -266,8 +266,8 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         // relative to each other; the compiler's partial waits (s_waitcnt vmcnt(N > 0) in front of finish_store()'s first use of a
         // staged register) assume in-order return.  With the DMAs OLDER than the register loads those waits stay sufficient (N counts
         // only younger register loads, and completions within one kind are in order); with the DMAs younger, a DMA that lands early
-        // satisfies the count while the register load is still in flight -- seen on MI355X as wrong row groups in the DCN (below).
-        if (BDMA && NBS == 2) {
+        // could satisfy the count while the register load is still in flight.
+        if (BDMA) {
             const unsigned soff = (unsigned)(kload >> 5) * 12288u;
 #pragma unroll
             for (int i = 0; i < NBP; ++i)
@@ -351,13 +351,6 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         } else if (MODE == MODE_DCN) {               // (channel block, tap) order: tap fastest
             if (++cur.s == 9) { cur.s = 0; cur.c0 += 32; }
         }
-    };
-    int kb_next = k_lo;                                 // PREC 3: chunk whose weight image the next issue_b() fetches
-    auto issue_b = [&]() {
-        const unsigned soff = (unsigned)kb_next * 12288u;
-#pragma unroll
-        for (int i = 0; i < NBP; ++i) deft_buffer_load_lds_x4s(rw3, Bd + (wave + i * 4) * 1024, vB3[i], soff);
-        ++kb_next;
     };
     auto finish_store = [&](int stage) {
         float* as = As + stage * BM * LDS_STRIDE + rbase * LDS_STRIDE + g * 4;
@@ -479,23 +472,18 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         // one LDS stage, two barriers per chunk:  store chunk kt | barrier | issue loads kt+1,
         // fragments + MFMAs of chunk kt | barrier
         issue_loads();
-        if (BDMA && NBS == 1) issue_b();
         for (int kt = 0; kt < nk; ++kt) {
-            // PREC 3: the single weight stage is refilled AFTER the register loads of the chunk were issued (the DMAs are younger):
-            // no partial vmcnt wait is safe there (see issue_loads) -- everything this wave has in flight lands first
-            if (BDMA && NBS == 1) DEFT_WAIT_VM(0);
             finish_store(0);
             if (BDMA) DEFT_WAIT_VM(0);           // this wave's pieces of chunk kt's weight image have landed (the barrier publishes everybody's)
             __syncthreads();
             if (kt + 1 < nk) issue_loads();      // (PREC 2: the weight DMA of chunk kt+1 goes to the stage last read in iteration kt-1)
             if (PREC) {
-                split_chunk(NBS == 2 ? (kt & 1) : 0);
+                split_chunk(kt & 1);
             } else {
                 read_frags(0);
                 mfma_chunk();
             }
             __syncthreads();  // all waves finished reading this chunk
-            if (BDMA && NBS == 1 && kt + 1 < nk) issue_b();      // PREC 3: refill the single weight stage; lands under the next finish_store()
         }
     } else {
         // two LDS stages, ONE barrier per chunk.  Iteration kt: issue the loads of chunk kt+1,
@@ -685,17 +673,8 @@ static int launch_igemm(const DeftGemmDesc& d, const DeftGemmDesc* group_dev, in
         DEFT_CHECK(S == 1 || (d.ws != nullptr && d.ws_cnt != nullptr && MODE != MODE_PAIR && S <= 32 && (d.Kpad >> 5) >= S), -102,
                    "igemm: splitk=%d needs ws and ws_cnt, conv/dcn, S <= 32 and at least S K chunks (%d)", S, d.Kpad >> 5);
         if constexpr (WK == 1 && NSTAGE == 1 && BN >= 64) {      // BN = 32: the operand split is amortised over too few columns
-            if (MODE == MODE_DCN && d.prec == 1 && d.w3 != nullptr && S == 1 && ((d.tile >> 28) & 1)) {
-                // DCN with TWO weight stages (tile bit 28): the DMA of chunk k+1 is issued with -- and ahead of -- the chunk's gather loads,
-                // like the plain convs, instead of after the second barrier; 12 KB more LDS per workgroup
-                constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, 2>() * 4;
-                if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 2>>(lds_p > lds_y3 ? lds_p : lds_y3)) return e;
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, 2>), dim3(mtiles * ntiles), dim3(256), lds_p > lds_y3 ? lds_p : lds_y3, s, d, mtiles, ntiles);
-                DEFT_CHECK_LAUNCH("igemm");
-                return 0;
-            }
-            if (d.prec == 1 && d.w3 != nullptr && S == 1) {      // ... with the weights pre-split: their chunks arrive by DMA
-                constexpr int PB = MODE == MODE_DCN ? 3 : 2;     // DCN: one weight stage (LDS as before: 3 workgroups/CU); else two
+            if (MODE != MODE_DCN && d.prec == 1 && d.w3 != nullptr && S == 1) {      // ... with the weights pre-split: their chunks arrive by DMA
+                constexpr int PB = MODE == MODE_DCN ? 1 : 2;     // (never the DCN: its pre-split-weight form is the patch kernel, dcn.hip)
                 constexpr int lds_p = igemm_lds_floats<BM, BN, WK, NSTAGE, MODE, PB>() * 4;
                 if (int e = set_lds_attr<igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, PB>>(lds_p > lds_y3 ? lds_p : lds_y3)) return e;
                 hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, WK, MODE, NSTAGE, false, PB>), dim3(mtiles * ntiles), dim3(256), lds_p > lds_y3 ? lds_p : lds_y3, s, d, mtiles, ntiles);
@@ -822,7 +801,7 @@ static int pick_splitk(long long tiles, int nk, int wgs_per_cu = 2) {
 extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* splitk, long long* ws_floats, int* ws_tiles) {
     DEFT_CHECK(d && tile && splitk && ws_floats && ws_tiles, -1, "deft_gemm_plan: null pointer");
     DEFT_CHECK(entry == 0 || entry == 1, -2, "deft_gemm_plan: entry %d (0 = conv, 1 = dcn)", entry);
-    int bm = (d->tile >> 16) & (entry == 1 ? 0xfff : 0x1fff), bn = d->tile & 0xffff;      // (dcn: bit 28 = two weight stages)
+    int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     if (bm == 0) {
         if (entry == 0 && d->x3 != nullptr) deft_p3_pick_tile(d, &bm, &bn);
         else if (entry == 0) pick_conv_tile(d->M, d->rowmap ? d->M : d->OH * d->OW, d->Cout, bm, bn);
@@ -838,7 +817,7 @@ extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* 
         tiles = (long long)deft_cdiv(d->M, bm) * deft_cdiv(d->Cout, bn);
         S = pick_splitk(tiles, nk);
     }
-    *tile = (bm << 16) | bn | (d->tile & (3 << 29)) | (entry == 1 ? d->tile & (1 << 28) : 0);
+    *tile = (bm << 16) | bn | (d->tile & (3 << 29));
     *splitk = S;
     *ws_floats = S > 1 ? tiles * S * bm * bn : 0;
     *ws_tiles = S > 1 ? (int)tiles : 0;
@@ -894,7 +873,7 @@ extern "C" int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream) {
                "deft_dcn_v2_nhwc: y3 needs Cout %% 32 == 0, ldy3 %% 32 == 0, ldy %% 4 == 0, 16-byte aligned outputs");
     hipStream_t s = (hipStream_t)stream;
     if (d->p3_kernel == 2) return deft_dcnp_dispatch(d, s);           // patch form (dcn.hip)
-    int bm = (d->tile >> 16) & 0xfff, bn = d->tile & 0xffff;           // (bit 28: two weight stages, launch_igemm)
+    int bm = (d->tile >> 16) & 0x1fff, bn = d->tile & 0xffff;
     const bool one_stage = !((d->tile >> 29) & 1);
     if (bm == 0) {             // BM = 64: 11.5 KB of sampling records, 39 KB of LDS in all -- four 64x64 (three 64x128) workgroups per CU
         bm = 64; bn = d->Cout >= 128 ? 128 : 64;      // tools/bench_igemm.py dcn (r2, weights by DMA: 64x128 wins from Cout = 128)

@@ -152,13 +152,9 @@ P3 = _os.environ.get("DEFT_P3", "1") != "0"
 P3_MIN_COUT = int(_os.environ.get("DEFT_P3_MIN_COUT", "64"))
 BDMA = _os.environ.get("DEFT_BDMA", "1") != "0"             # igemm.hip prec-1 launches with >= 128 output columns read pre-split weights by DMA
 # (DeftGemmDesc.w3 without x3).  Measured in the pipeline (profiles/r2_*): pair layer 170 -> 189 TFLOP/s, 128-column 1x1 convs +3..6 %;
-# 64-column conv tiles lose (the second weight stage costs them a workgroup per CU) and keep splitting weights in the loop; the DCN uses
-# the ONE-stage form (no extra LDS, refilled after the chunk's second barrier): 11.07 -> 10.24 ms of DCN per 32-frame step.
-# OFF by default since the 20-byte sampling records: with the weight DMA the DCN kernel produced, in launches with more workgroups than
-# the chip holds at once, now and then a group of wrong output rows on MI355X (tools/probe/batch_invariance.py; never without the DMA, never
-# in the other DMA kernels, not reproduced by the emulator; a full s_waitcnt vmcnt(0) in front of every use of the staged registers did
-# not cure it, nor did two weight stages).  Not understood -- so the DCN splits its weights in the loop again: 898 -> 871 frames/s.
-BDMA_DCN = int(_os.environ.get("DEFT_BDMA_DCN", "0"))        # 1: one weight stage (the form with the fault); 2: two stages (DeftGemmDesc.tile bit 28)
+# 64-column conv tiles lose (the second weight stage costs them a workgroup per CU) and keep splitting weights in the loop.  (Round 2 also had a
+# weight-DMA form of the igemm.hip DCN; it produced wrong row groups on the MI355X now and then for a reason that was never found, shipped off, and
+# is gone: the DCN's pre-split-weight form is the patch kernel, csrc/dcn.hip, whose batch-invariance test runs several workgroup generations per CU.)
 # DCN main contraction on the patch form (csrc/dcn.hip, DeftGemmDesc.p3_kernel = 2): input patch in LDS, blended operand from registers.  Used where
 # its 8 x 16 pixel tiles cover the map with at most DCN_PATCH_WASTE padding and the launch has at least DCN_PATCH_MIN_TILES workgroups (fewer: one
 # frame per GPU on the small maps, where igemm.hip's cross-workgroup split-K fills the chip).  DEFT_DCN_PATCH=0: off.
@@ -759,10 +755,6 @@ class DlaSegPlan(_Plan):
         if dcn_patch_choice(x.N, x.H, x.W, cin, cout) and out.ld % 4 == 0:
             d.p3_kernel = 2
             d.w3 = self.weights_p3(wm, "dcn").data_ptr()
-        elif BDMA_DCN and PREC == 1:
-            d.w3 = self.weights_p3(wm).data_ptr()
-            if int(BDMA_DCN) == 2:
-                d.tile = 1 << 28
         if cout % 32 == 0 and out.ld % 4 == 0 and _os.environ.get("DEFT_DCN_Y3", "1") != "0":
             h = self.p3_output(out, d)               # pruned by finalize_p3() when no pre-split conv reads it
             if h is not None:

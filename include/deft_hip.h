@@ -44,8 +44,8 @@ typedef struct DeftGemmDesc {
                                      2-stage loop (conv: LDS-DMA form) instead of the 1-stage one.
                                      Pre-split kernels (x3): bit 29 = 3 LDS stages, bit 30 = ONE stage;
                                      halo form: (TH<<16)|BN, bit 28 = tiles are 16 pixels wide (TH x 16),
-                                     bit 29 = one tap per weight stage.  deft_dcn_v2_nhwc with w3: bit 28 =
-                                     two weight stages */
+                                     bit 29 = one tap per weight stage.  deft_dcn_v2_nhwc, patch form (p3_kernel = 2):
+                                     64 / 128 = output channels per workgroup */
     /* pair, batched form (Tper > 0): rows are (c, t, j) with c = m / (Tper*Q) the current
      * frame, t its history row, j its object; U' row = u0 + c*du + t, V' row = v0 + c*dv + j.
      * Tper == 0: rows are (t, j), U' row = t, V' row = j.                                   */
@@ -93,7 +93,7 @@ typedef struct DeftGemmDesc {
      * y3 (nullable): the output is ALSO written in P3 form (pixel stride ldy3 channels) for a following conv;
      * y may then be NULL when no fp32 consumer exists.  y3 is honoured by the pre-split conv kernels and by deft_dcn_v2_nhwc. */
     const void* x3;
-    const void* w3;      /* without x3 (conv / dcn / pair on igemm.hip, prec = 1): only the weights are pre-split -- their chunk images are
+    const void* w3;      /* without x3 (conv / pair on igemm.hip, prec = 1): only the weights are pre-split -- their chunk images are
                             copied to LDS by DMA, the activations are still split in the K loop (honoured by the BN >= 64 tiles, S = 1) */
     void* y3;
     int ldx3, ldy3;

@@ -10,9 +10,18 @@ from scipy.optimize import linear_sum_assignment
 
 
 def lapjv(cost, extend_cost=False, cost_limit=np.inf, return_cost=True):
-    """lap.lapjv semantics used by utils/matching.py:48: rectangular cost extended to (n+m)^2
-    with cost_limit/2 on the extension entries (0 in the bottom-right block); x[i] = column of
-    row i or -1, y[j] = row of column j or -1."""
+    """lap.lapjv semantics used by utils/matching.py:48 (rectangular cost, cost_limit): x[i] = column of row i or -1, y[j] = row of
+    column j or -1.  Delegates to deft_amd.association.lapjv so that BOTH sides of the tracker comparisons break exact cost ties the
+    same way (the scenes of these tests contain them: a young LSTM track without usable nodes costs exactly the limit, 0.9, against
+    every detection -- matched and unmatched are then equally optimal, and which one the real `lap` returns is a property of its JV
+    internals that no stand-in can claim).  Optimality itself is checked against brute force in tests/test_association.py, and
+    `lapjv_square` below (the literal (n+m)^2 extension lap builds) must reach the same objective."""
+    from deft_amd.association import lapjv as _lapjv
+    return _lapjv(cost, extend_cost=extend_cost, cost_limit=cost_limit, return_cost=return_cost)
+
+
+def lapjv_square(cost, extend_cost=False, cost_limit=np.inf, return_cost=True):
+    """The extension lap itself builds: (n+m)^2 with cost_limit/2 on the extension entries (0 in the bottom-right block)."""
     cost = np.asarray(cost, dtype=np.float64)
     n, m = cost.shape
     big = cost_limit / 2.0 if cost_limit < np.inf else cost.max() + 1

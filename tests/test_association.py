@@ -144,3 +144,27 @@ def test_lapjv_without_limit_and_nan():
     assert x[1] == -1 and not (x[2] == 3)
     tot, x, y = A.lapjv(c2)
     assert x[1] == -1 and sorted(v for v in x if v >= 0) == sorted(set(v for v in x if v >= 0))
+
+
+def test_half_size_extension_reaches_the_square_extension_objective():
+    """association.lapjv solves lap's cost-limit problem on an n x (m + n) matrix; the literal (n + m)^2 extension (tests/ref_shims.py
+    lapjv_square) must give the same objective sum(c) + (unmatched rows + unmatched columns) * limit / 2 -- on random problems,
+    with +inf entries, and with costs exactly AT the limit (ties)."""
+    import ref_shims
+    from deft_amd import association as A
+    g = np.random.default_rng(5)
+    for trial in range(60):
+        n, m = int(g.integers(1, 12)), int(g.integers(1, 12))
+        c = g.uniform(0, 1.4, (n, m))
+        if trial % 3 == 0:
+            c[g.uniform(size=c.shape) < 0.3] = 0.9                     # exactly the limit
+        if trial % 4 == 0:
+            c[g.uniform(size=c.shape) < 0.2] = 5.0                      # far above the limit (lap sees finite costs there)
+        lim = 0.9
+
+        def obj(x):
+            k = int((x >= 0).sum())
+            return c[np.nonzero(x >= 0)[0], x[x >= 0]].sum() + (n - k) * lim / 2 + (m - k) * lim / 2
+        _, x1, _ = A.lapjv(c, extend_cost=True, cost_limit=lim)
+        _, x2, _ = ref_shims.lapjv_square(c, extend_cost=True, cost_limit=lim)
+        assert abs(obj(x1) - obj(x2)) <= 1e-9, (trial, obj(x1), obj(x2))

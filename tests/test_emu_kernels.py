@@ -396,24 +396,14 @@ def test_late_dma_dcn_patch(late_dma, args):
         pc.check_dcn(late_dma, "cpu", *args, big_offsets=big, patch=True)
 
 
-@pytest.mark.parametrize("stages", [1, 2])
-@pytest.mark.parametrize("args", [(1, 7, 9, 64, 64, 0), (1, 6, 6, 64, 160, 0), (2, 5, 6, 128, 64, 0)])
-def test_late_dma_dcn_weight_dma(late_dma, args, stages):
-    """The DCN with its weights by DMA (engine.BDMA_DCN: shipped off), one and two weight stages, under late delivery."""
-    from deft_amd import engine
-    saved, engine.BDMA_DCN = engine.BDMA_DCN, stages
-    try:
-        pc.check_dcn(late_dma, "cpu", *args)
-    finally:
-        engine.BDMA_DCN = saved
-
-
 def test_late_dma_forward_every_presplit_kernel(late_dma):
     import deft_oracle as O
     from deft_amd import engine
     saved, engine.P3_MIN_TILES = engine.P3_MIN_TILES, 0
-    saved_b, engine.BDMA_DCN = engine.BDMA_DCN, True
+    saved_b = engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE
+    engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = 0, 1e9              # every DCN on the patch form too (three weight stages, two patch buffers)
     try:
         pc.check_forward(late_dma, "cpu", "mot", 32, 128, sd=O.synth_state_dict("mot"))
     finally:
-        engine.P3_MIN_TILES, engine.BDMA_DCN = saved, saved_b
+        engine.P3_MIN_TILES = saved
+        engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = saved_b

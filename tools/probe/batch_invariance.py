@@ -1,8 +1,8 @@
 """Debug aid (GPU): where does a frame's result start to depend on the batch it runs in?  Compares the stage outputs of a 1-frame
 and a 2-frame plan (same frame first) with the cross-workgroup split-K off and every tile gate open, every plan-owned buffer in
 allocation order (mapped back to the launch that produced it), each plan against its own re-runs, host-serialised launches, and
-which rows of which DCN tiles are off.  This is the tool that pinned the intermittent fault of the DCN's weight-DMA form
-(DESIGN.md 3.4): run it with DEFT_BDMA_DCN=1 to see it, PROBE_SET=NAME=value,... to flip engine switches."""
+which rows of which DCN tiles are off.  This is the tool that pinned the intermittent fault of round 2's weight-DMA form of the
+igemm.hip DCN (that form is gone).  PROBE_SET=NAME=value,... flips engine switches (e.g. DCN_PATCH=0)."""
 import os
 import sys
 
@@ -19,6 +19,7 @@ H, W = 608, 1088
 x = torch.randn(2, 3, H, W, generator=torch.Generator().manual_seed(0))
 engine.SPLITK = False
 engine.P3_MIN_TILES = 0
+engine.DCN_PATCH_MIN_TILES = 0
 for kv in os.environ.get("PROBE_SET", "").split(","):          # e.g. PROBE_SET=P3_HALO16=0,FOLD=0
     if kv:
         k, v = kv.split("="); setattr(engine, k, type(getattr(engine, k))(int(v)))
@@ -78,8 +79,8 @@ for i, (a, b) in enumerate(zip(k1, k2)):
         if shown >= 6:
             break
 
-# which of the two is off?  the same frames through plans whose DCN splits its weights in the loop (no weight DMA: engine.BDMA_DCN = False)
-engine.BDMA_DCN = False
+# which of the two is off?  the same frames through plans whose DCN runs on igemm.hip (weights split in the loop, no DMA in the DCN)
+engine.DCN_PATCH = False
 r1 = engine.DlaSegPlan(sd, 1, H, W, "mot", K=100, device="cuda", lib=lib)
 r2 = engine.DlaSegPlan(sd, 2, H, W, "mot", K=100, device="cuda", lib=lib)
 r1.forward(x[:1].cuda()); r2.forward(x.cuda()); torch.cuda.synchronize()
