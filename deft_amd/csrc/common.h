@@ -248,3 +248,4 @@ int deft_p3_dispatch(const DeftGemmDesc* d, hipStream_t s);
 int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s);
 // dcn.hip (patch form of the DCN, DeftGemmDesc.p3_kernel = 2), called from deft_dcn_v2_nhwc
 int deft_dcnp_dispatch(const DeftGemmDesc* d, hipStream_t s);
+int deft_conv3p_dispatch(const DeftGemmDesc* d, hipStream_t s);      // plain 3x3 conv, <= 32 columns, fp32 input (DeftGemmDesc.p3_kernel = 3)

@@ -45,7 +45,7 @@ typedef deft_f32x16 f32x16;
     do {                                                                      \
         _Pragma("unroll") for (int i_ = 0; i_ < 6 * (TN); ++i_) {             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x002, 12 / (TN), 0);        \
+            __builtin_amdgcn_sched_group_barrier(0x002, (TN) == 1 ? 7 : 12 / (TN), 0); \
         }                                                                     \
     } while (0)
 #endif
@@ -63,7 +63,7 @@ typedef deft_f32x16 f32x16;
 
 template <int TN, int R>
 constexpr int dcnp_lds_bytes() {
-    constexpr int loop = 2 * DP_PBUF_(R) + 3 * (TN / 2) * DP_WBLK;
+    constexpr int loop = 2 * DP_PBUF_(R) + 3 * ((TN + 1) / 2) * DP_WBLK;
     constexpr int tile = 128 * (TN * 32 + 4) * 4;                 // epilogue tile
     return loop > tile ? loop : tile;
 }
@@ -85,12 +85,17 @@ __device__ __forceinline__ unsigned dcnp_cvt_pk(float lo, float hi) {
     return __builtin_bit_cast(unsigned, p);
 }
 
-template <int TN, int DP_R>
-__global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int tiles_x, int tiles_y, int ntiles) {
-    static_assert(TN == 2 || TN == 4, "64 or 128 output channels per workgroup");
+// DEFORM = false: the same structure as a PLAIN 3x3 / stride 1 / pad 1 convolution on an fp32 input (the DCN's own conv_offset_mask layer,
+// 27 -> 32 output columns: TN = 1): the "records" are the nine fixed taps (one corner, weight 1: no blend, no offset map), the patch has no
+// margin (R = 0).  It lets the offset conv read the SAME fp32 map the deformable gather reads -- no bf16-piece copy of the DCN's input has
+// to exist (6 more bytes per element written by the producer: the upsample+add pass, the previous DCN).
+template <int TN, int DP_R, bool DEFORM>
+__global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemmDesc p, int tiles_x, int tiles_y, int ntiles) {
+    static_assert(TN == 1 || TN == 2 || TN == 4, "32 (plain conv), 64 or 128 output channels per workgroup");
+    static_assert(DEFORM || (TN == 1 && DP_R == 0), "the plain form is the 32-column conv without margin");
     constexpr int DP_PH = DP_PH_(DP_R), DP_PW = DP_PW_(DP_R), DP_NPIX = DP_NPIX_(DP_R), DP_PARTS = DP_PARTS_(DP_R), DP_PLANE = DP_PLANE_(DP_R),
                   DP_PBUF = DP_PBUF_(DP_R);
-    constexpr int BN = TN * 32, NBLK = BN / 64;
+    constexpr int BN = TN * 32, NBLK = (BN + 63) / 64;
     constexpr int NBP = NBLK * 6;                     // weight DMA pieces per chunk
     constexpr int BSTAGE = NBLK * DP_WBLK;
     constexpr int NPP = 4 * DP_PARTS / 2;             // patch DMA pieces per wave (waves 2 and 3 issue them)
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
     const bool rowok = oy < p.H && ox < p.W;
     // offsets + mask logits of the row (27 floats), requested first: they fly while the DMA sources are computed and issued
     f32x4 om[7];
-    {
+    if (DEFORM) {
         const float* omp = p.x2 + (size_t)(rowok ? img + oy * p.W + ox : 0) * p.ldom;
 #ifdef DCNP_ABL_NOOM
         omp = p.x2 + (lane & 31) * p.ldom;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
     };
     // patch pieces a wave (2, 3) issues at the end of tap t of the block BEFORE the patch's block: its NPP pieces spread over taps 0 .. PT - 1
     // (the corner reads of the next block's tap 0 are issued GA steps ahead, and a piece has two steps to land)
-    constexpr int GA = TN == 2 ? DCNP_GA : 1;                  // how many steps ahead the corner reads run (two: 32 more VGPRs)
+    constexpr int GA = (TN == 2 && DEFORM) ? DCNP_GA : 1;      // how many steps ahead the corner reads run (two: 32 more VGPRs)
     constexpr int PT = 8 - GA;
     auto ps_of = [](int t) { return t >= PT ? NPP : NPP * t / PT; };
     static_assert(NB_B + (NPP + PT - 1) / PT <= 6 && NB_A <= 6, "wait_vm cases");
@@ -220,6 +225,12 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
     {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+            if (!DEFORM) {          // plain conv: tap (r, s) of the lane's pixel, always inside the margin-less patch (zeros outside the map)
+                const int r = tap / 3, s = tap - 3 * r;
+                rw0[tap] = 1.f; rw1[tap] = rw2[tap] = rw3[tap] = 0.f;
+                rc[tap] = (unsigned)(g * 2 * DP_PLANE) + (unsigned)((((oy - ty0) + r) * DP_PW + (ox - tx0) + s) * 16);
+                continue;
+            }
             // (branch-free: selects instead of nested ifs -- the nine records are 1/7 of the kernel's time at Cin = 64)
             const float dy = om[(2 * tap) >> 2][(2 * tap) & 3], dx = om[(2 * tap + 1) >> 2][(2 * tap + 1) & 3];
             const float ml = om[(18 + tap) >> 2][(18 + tap) & 3];
@@ -268,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
 
     // corner values of one (row, tap, 16-channel block): v[corner][half of the lane's 8 channels]
     auto gather = [&](unsigned c, int bufoff, int cb, f32x4 (&v)[4][2]) {
-        if (!(c & 0x80000000u)) {
+        if (!DEFORM) {
+            const char* const a = patch + bufoff + c;
+            v[0][0] = *(const f32x4*)(a); v[0][1] = *(const f32x4*)(a + DP_PLANE);
+        } else if (!(c & 0x80000000u)) {
             const char* const a = patch + bufoff + c;
             v[0][0] = *(const f32x4*)(a); v[0][1] = *(const f32x4*)(a + DP_PLANE);
             v[1][0] = *(const f32x4*)(a + 16); v[1][1] = *(const f32x4*)(a + 16 + DP_PLANE);
@@ -287,10 +301,13 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
     // blend the four corners, split into the three bf16 pieces: the lane's A fragment (8 k of its row)
     auto blend_split = [&](const f32x4 (&v)[4][2], float w0, float w1, float w2, float w3, bf16x8 (&pa)[3]) {
         f32x4 b0, b1;
+        if (!DEFORM) { b0 = v[0][0]; b1 = v[0][1]; }
+        else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            b0[e] = fmaf(w3, v[3][0][e], fmaf(w2, v[2][0][e], fmaf(w1, v[1][0][e], w0 * v[0][0][e])));
-            b1[e] = fmaf(w3, v[3][1][e], fmaf(w2, v[2][1][e], fmaf(w1, v[1][1][e], w0 * v[0][1][e])));
+            for (int e = 0; e < 4; ++e) {
+                b0[e] = fmaf(w3, v[3][0][e], fmaf(w2, v[2][0][e], fmaf(w1, v[1][0][e], w0 * v[0][0][e])));
+                b1[e] = fmaf(w3, v[3][1][e], fmaf(w2, v[2][1][e], fmaf(w1, v[1][1][e], w0 * v[0][1][e])));
+            }
         }
         // the three bf16 pieces (common.h split3: round-to-nearest-even each, exact), two elements at a time so that every conversion
         // is one v_cvt_pk_bf16_f32 of a PAIR and the pieces come back as floats by a shift / a mask: 11 VALU per pair
@@ -454,13 +471,13 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DeftGemmDesc p, int t
 #endif
 }
 
-template <int TN, int R>
+template <int TN, int R, bool DEFORM = true>
 static int launch_dcnp(const DeftGemmDesc& d, hipStream_t s) {
     constexpr int lds = dcnp_lds_bytes<TN, R>();
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void*)dcn_patch_kernel<TN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipError_t e = hipFuncSetAttribute((const void*)dcn_patch_kernel<TN, R, DEFORM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             DEFT_CHECK(e == hipSuccess, -101, "dcn_patch: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
             done = true;
         }
@@ -468,7 +485,7 @@ static int launch_dcnp(const DeftGemmDesc& d, hipStream_t s) {
     const int tiles_x = deft_cdiv(d.W, DP_TW), tiles_y = deft_cdiv(d.H, DP_TH), ntiles = deft_cdiv(d.Cout, TN * 32);
     const long long nwg = (long long)d.N * tiles_x * tiles_y * ntiles;
     DEFT_CHECK(nwg < (1ll << 31), -71, "deft_dcn_v2_nhwc: too many tiles");
-    hipLaunchKernelGGL((dcn_patch_kernel<TN, R>), dim3((unsigned)nwg), dim3(256), lds, s, d, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL((dcn_patch_kernel<TN, R, DEFORM>), dim3((unsigned)nwg), dim3(256), lds, s, d, tiles_x, tiles_y, ntiles);
     DEFT_CHECK_LAUNCH("dcn_patch");
     return 0;
 }
@@ -486,6 +503,19 @@ int deft_dcnp_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     // (the weight image has ceil(Cout / 128) * 128 rows: no n-tile reaches past it)
     // margin: 3 pixels where two workgroups per CU still fit (64-column tiles: 66 KB of LDS), else 2 (128-column tiles: 76 KB)
     return bn == 128 ? launch_dcnp<4, DCNP_R4>(*d, s) : launch_dcnp<2, DCNP_R2>(*d, s);
+}
+
+// called from deft_conv2d_nhwc (igemm.hip) for p3_kernel == 3: the plain 3x3 / stride 1 / pad 1 conv with <= 32 output channels on an fp32 input
+int deft_conv3p_dispatch(const DeftGemmDesc* d, hipStream_t s) {
+    DEFT_CHECK(d->prec == 1 && d->w3 != nullptr && d->x != nullptr && d->y != nullptr && (((size_t)d->w3 | (size_t)d->x | (size_t)d->y) & 15) == 0, -77,
+               "deft_conv2d_nhwc: the fp32-patch form (p3_kernel = 3) is the prec = 1 arithmetic and needs x, y and w3 (deft_split_weights_dcn), 16-byte aligned");
+    DEFT_CHECK(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->stride_w == 0 && d->rowmap == nullptr && d->OH == d->H && d->OW == d->W, -78,
+               "deft_conv2d_nhwc: the fp32-patch form is 3x3 / stride 1 / pad 1, dense");
+    DEFT_CHECK((d->Cin & 31) == 0 && d->Cout <= 32 && (d->Cout & 7) == 0 && (d->ldy & 3) == 0 && (d->ldx & 3) == 0 && d->splitk <= 1 && d->res == nullptr &&
+               d->y3 == nullptr && d->fold_y == nullptr, -79,
+               "deft_conv2d_nhwc: the fp32-patch form needs Cin %% 32 == 0, Cout <= 32 and %% 8 == 0, no residual / split-K / y3 / fold (Cin=%d Cout=%d)", d->Cin, d->Cout);
+    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -80, "deft_conv2d_nhwc: input exceeds 2 GiB (split the batch)");
+    return launch_dcnp<1, 0, false>(*d, s);
 }
 
 // ---- weight image of the patch form -----------------------------------------------------------------------------------------------

@@ -827,6 +827,7 @@ extern "C" int deft_gemm_plan(const DeftGemmDesc* d, int entry, int* tile, int* 
 extern "C" int deft_conv2d_nhwc(const DeftGemmDesc* d, void* stream) {
     if (int e = check_conv(d, "deft_conv2d_nhwc")) return e;
     hipStream_t s = (hipStream_t)stream;
+    if (d->p3_kernel == 3) return deft_conv3p_dispatch(d, s);       // fp32 patch in LDS, operand split in registers (dcn.hip)
     if (d->x3 != nullptr) {                 // pre-split operands: the LDS-DMA kernel (igemm3.hip)
         if (int e = deft_p3_check(d, "deft_conv2d_nhwc")) return e;
         return d->p3_kernel == 1 ? deft_p3h_dispatch(d, s) : deft_p3_dispatch(d, s);

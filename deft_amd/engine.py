@@ -161,6 +161,10 @@ BDMA = _os.environ.get("DEFT_BDMA", "1") != "0"             # igemm.hip prec-1 l
 DCN_PATCH = _os.environ.get("DEFT_DCN_PATCH", "1") != "0"
 DCN_PATCH_MIN_TILES = int(_os.environ.get("DEFT_DCN_PATCH_MIN_TILES", "384"))
 DCN_PATCH_WASTE = float(_os.environ.get("DEFT_DCN_PATCH_WASTE", "1.3"))
+OFFSET_FP32 = _os.environ.get("DEFT_OFFSET_FP32", "1") != "0"     # the offset / mask conv of a patch-form DCN on the fp32-patch kernel (p3_kernel = 3) ...
+OFFSET_FP32_MIN_HW = int(_os.environ.get("DEFT_OFFSET_FP32_MIN_HW", "10000"))   # ... on maps of at least this many pixels (38x68: the halo form on bf16 pieces is
+# faster, 0.055 vs 0.066 ms per 16 frames, and the piece copy of so small a map costs nothing; 76x136 and 152x272: equal speed, and the upsample+add pass that
+# produces most DCN inputs no longer writes the pieces: 1.80 -> 1.22 ms per step, profiles/r3_layers.md)
 DCN_PATCH_MIN_HW = int(_os.environ.get("DEFT_DCN_PATCH_MIN_HW", "0"))        # ... and only on maps of at least this many pixels
 P3_HALO = _os.environ.get("DEFT_P3_HALO", "1") != "0"       # 3x3 / stride 1 convs on the halo-tile kernel (DeftGemmDesc.p3_kernel = 1) ...
 P3_MIN_TILES = int(_os.environ.get("DEFT_P3_MIN_TILES", "512"))   # ... and give every CU two workgroups (latency mode: 2.39 ms/frame on igemm.hip
@@ -738,7 +742,29 @@ class DlaSegPlan(_Plan):
         wo, Ko, bo, wm, Km, alpha, shift = self._wcache[key]
         # offset/mask conv as a 32-column problem (27 channels + 5 zero columns: zero weight rows, zero bias) so that it can run
         # on the pre-split halo kernel, which writes 8 channels per thread; the DCN reads channels 0..26 (ldom = 32)
-        if om is None:
+        patch = dcn_patch_choice(x.N, x.H, x.W, cin, cout)
+        if om is None and patch and OFFSET_FP32 and x.H * x.W >= OFFSET_FP32_MIN_HW and x.ld % 4 == 0:
+            # the offset / mask conv on the fp32-patch form (csrc/dcn.hip, DeftGemmDesc.p3_kernel = 3): it reads the SAME fp32 map the
+            # deformable gather reads, so no producer has to write a bf16-piece copy of a DCN's input
+            om = self.alloc(x.N, x.H, x.W, 32, ld=32)
+            okey = p + ".conv.offset_patch"
+            if okey not in self._wcache:
+                wod, _ = pack_dcn_weight(sd[p + ".conv.conv_offset_mask.weight"])
+                self._wcache[okey] = self.dev(wod)
+            wod = self._wcache[okey]
+            do = GemmDesc()
+            do.x = x.addr; do.w = wod.data_ptr(); do.w3 = self.weights_p3(wod, "dcn").data_ptr()
+            do.scale = None; do.shift = bo.data_ptr(); do.res = None; do.y = om.addr
+            do.N, do.H, do.W, do.Cin, do.ldx = x.N, x.H, x.W, cin, x.ld
+            do.OH, do.OW, do.Cout, do.ldy, do.ldr = x.H, x.W, 32, om.ld, 0
+            do.KH, do.KW, do.stride, do.pad = 3, 3, 1, 1
+            do.Ktot, do.Kpad = 9 * cin, wod.shape[1]
+            do.cin_log2 = int(math.log2(cin)); do.korder = 1
+            do.M = x.N * x.H * x.W
+            do.relu = 0; do.tile = 0; do.p3_kernel = 3
+            do.flop_k = 9 * cin; do.flop_n = 27
+            self.gemm("deft_conv2d_nhwc", p + ".offset", do, 2.0 * do.M * 27 * 9 * cin)
+        elif om is None:
             om = self.alloc(x.N, x.H, x.W, 32, ld=32)
             self.conv(p + ".offset", x, wo, Ko, 3, 3, 1, 1, 32, None, bo, False, out=om, true_cout=27)
         out = self.alloc(x.N, x.H, x.W, cout)
@@ -752,7 +778,7 @@ class DlaSegPlan(_Plan):
         d.cin_log2 = int(math.log2(cin))
         d.M = x.N * x.H * x.W
         d.relu = 1; d.Q = 0; d.ldom = om.ld; d.tile = 0
-        if dcn_patch_choice(x.N, x.H, x.W, cin, cout) and out.ld % 4 == 0:
+        if patch and out.ld % 4 == 0:
             d.p3_kernel = 2
             d.w3 = self.weights_p3(wm, "dcn").data_ptr()
         if cout % 32 == 0 and out.ld % 4 == 0 and _os.environ.get("DEFT_DCN_Y3", "1") != "0":

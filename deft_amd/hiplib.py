@@ -137,7 +137,7 @@ class HipLib:
                     info += " split direct"
                 elif self.split_arithmetic(name, d):
                     ceil = 2500.0 / 6   # ... or six v_mfma_f32_32x32x16_bf16 per fp32 product (bf16 dense peak / 6)
-                    info += " split" + (" patch" if d.p3_kernel == 2 else " halo" if d.p3_kernel else (" x3" if d.x3 else ""))
+                    info += " split" + (" patch" if d.p3_kernel in (2, 3) else " halo" if d.p3_kernel else (" x3" if d.x3 else ""))
             prof.append((name, fl, e0, e1, info, nbytes, ceil))
 
     def split_arithmetic(self, name, d):
@@ -145,7 +145,7 @@ class HipLib:
         only on its 1-stage tiles with BN >= 64 (launch_igemm) -- the tile is the library's own choice when tile == 0."""
         if d.prec != 1:
             return False
-        if d.x3 or d.p3_kernel == 2:
+        if d.x3 or d.p3_kernel in (2, 3):
             return True
         tile = d.tile
         if (tile & 0xffff) == 0:

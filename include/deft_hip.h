@@ -107,7 +107,10 @@ typedef struct DeftGemmDesc {
      * fp32 input patch that offsets of up to +-2 pixels can reach in LDS (corners beyond it are fetched from global memory, per lane);
      * the blended operand goes from registers straight into the matrix cores.  x is read as fp32 (x3 unused); w3 must be the image of
      * deft_split_weights_dcn; `tile` & 0xffff = 64 / 128 output channels per workgroup (0 = automatic); no split-K; K order
-     * (16-channel block, tap): another fp32 summation order than the default form. */
+     * (16-channel block, tap): another fp32 summation order than the default form.
+     * deft_conv2d_nhwc: 3 = the same kernel as a PLAIN 3x3 / stride 1 / pad 1 convolution with Cout <= 32 on the fp32 input x (the
+     * conv_offset_mask layer of a DCN, dcn_v2.py): w3 = deft_split_weights_dcn of the weights packed in the DCN K order; no x3, y3,
+     * residual or split-K; Cin % 32 == 0. */
     int p3_kernel;
     /* A following 1x1 conv with few outputs folded into the epilogue of the pre-split conv kernels (x3 != NULL) -- the heat-map
      * head's `Conv2d(256, C, 1)` after `Conv2d(64, 256, 3) + ReLU` (base_model.py:37-66): the 256-channel hidden map is neither

@@ -140,12 +140,12 @@ def check_concat_conv(lib, device):
 def check_dcn(lib, device, N, H, W, Ci, Co, tile=0, seed=0, big_offsets=False, patch=None):
     """patch: None = the engine's own choice of DCN kernel, True / False = the patch form (csrc/dcn.hip) forced on / off."""
     if patch is not None:
-        saved = engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE
-        engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = bool(patch), 0, 1e9
+        saved = engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW
+        engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW = bool(patch), 0, 1e9, 0
         try:
             return check_dcn(lib, device, N, H, W, Ci, Co, tile=tile, seed=seed, big_offsets=big_offsets)
         finally:
-            engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = saved
+            engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW = saved
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Ci, H, W, generator=g)
     w_off = torch.randn(27, Ci, 3, 3, generator=g) * ((2.0 if big_offsets else 0.5) / (Ci * 9) ** 0.5)

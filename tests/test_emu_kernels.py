@@ -132,8 +132,8 @@ def test_forward_every_presplit_kernel_forced(emu_lib):
     import deft_oracle as O
     from deft_amd import engine
     saved, engine.P3_MIN_TILES = engine.P3_MIN_TILES, 0
-    saved_d = engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE
-    engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = 0, 1e9            # ... and every DCN on the patch form (csrc/dcn.hip)
+    saved_d = engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW
+    engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW = 0, 1e9, 0            # ... and every DCN on the patch form (csrc/dcn.hip)
     try:
         sd = O.synth_state_dict("mot")
         plan, rep, _ = pc.check_forward(emu_lib, "cpu", "mot", 32, 128, sd=sd)
@@ -141,9 +141,10 @@ def test_forward_every_presplit_kernel_forced(emu_lib):
         assert kinds.count("deft_conv_direct") == 3 and kinds.count("deft_fold_finish") >= 1
         assert any(d.p3_kernel == 1 for _, _, d in plan._gemms) and any(d.x3 and not d.p3_kernel for _, _, d in plan._gemms)
         assert sum(d.p3_kernel == 2 for e, _, d in plan._gemms if e == "deft_dcn_v2_nhwc") == 16
+        assert sum(d.p3_kernel == 3 for e, _, d in plan._gemms if e == "deft_conv2d_nhwc") == 16          # ... and their offset convs on the fp32-patch form
     finally:
         engine.P3_MIN_TILES = saved
-        engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = saved_d
+        engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW = saved_d
 
 
 @pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
