@@ -43,10 +43,10 @@ if os.path.exists(st):
             break
         out.append("| `%s` | %s | %.2f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                     float(r["AverageNs"]) / 1e3, r["Percentage"]))
-    ig = [(int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(st)) if "igemm" in r["Name"] or "conv3h" in r["Name"] or "direct_conv" in r["Name"]]
+    ig = [(int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(st)) if "igemm" in r["Name"] or "conv3h" in r["Name"] or "direct_conv" in r["Name"] or "dcn_patch" in r["Name"]]
     if ig:
         out.append("")
-        out.append("All `igemm*` / `conv3h` / `direct_conv` kernels together: %d launches, average %.1f us (compare `roofline.avg_launch_us` of the bench line; "
+        out.append("All `igemm*` / `conv3h` / `direct_conv` / `dcn_patch` kernels together: %d launches, average %.1f us (compare `roofline.avg_launch_us` of the bench line; "
                    "this pass runs the launches serialised on one stream, like bench.py's per-launch HIP-event measurement)."
                    % (sum(c for c, _ in ig), sum(t for _, t in ig) / sum(c for c, _ in ig) / 1e3))
     out.append("")
@@ -71,6 +71,15 @@ if os.path.exists(sq):
             k, n[k], v.get("SQ_WAVES", 0) / n[k], v.get("SQ_WAIT_ANY", 0) / wc, v.get("SQ_WAIT_INST_ANY", 0) / wc,
             v.get("SQ_ACTIVE_INST_ANY", 0) / wc, v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 1024), clk))
     out.append("")
+    # counters of the kernel with the largest total duration: bench.py's roofline.dominant_kernel.mfma_busy reads this file
+    k0 = max((k for k in per if k), key=lambda k: dur[k])
+    v = per[k0]
+    gui = max(v.get("GRBM_GUI_ACTIVE", 0), 1) / 8.0
+    json.dump({"kernel": k0, "launches": n[k0], "mfma_busy": round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 1024), 4),
+               "wait_any": round(v.get("SQ_WAIT_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 0), 1), 4),
+               "wait_inst": round(v.get("SQ_WAIT_INST_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 0), 1), 4),
+               "source": "rocprofv3 --pmc pass of tools/prof.sh (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))"},
+              open(os.path.join(dst, tag + "_dominant_counters.json"), "w"), indent=1)
 fe = os.path.join(src, "pmc_fetch", "p_counter_collection.csv")
 wr = os.path.join(src, "pmc_write", "p_counter_collection.csv")
 if os.path.exists(fe) and os.path.exists(wr):
@@ -86,11 +95,11 @@ if os.path.exists(fe) and os.path.exists(wr):
     out.append("")
 if os.path.exists(fe) and os.path.exists(wr):
     # dominant kernel family for bench.py's roofline.traffic: HBM bytes per launch, averaged over all igemm launches
-    fk = [k for k in pf if "igemm" in k or "conv3h" in k or "direct_conv" in k]
+    fk = [k for k in pf if "igemm" in k or "conv3h" in k or "direct_conv" in k or "dcn_patch" in k]
     nl = sum(nf[k] for k in fk)
     fetch = sum(pf[k]["FETCH_SIZE"] for k in fk) * 1024.0 * 2.0          # KiB -> B, gfx950 wide-stream correction x2
     write = sum(pw.get(k, {}).get("WRITE_SIZE", 0.0) for k in fk) * 1024.0
-    json.dump({"kernel": "igemm* + conv3h + direct_conv", "launches": nl, "fetch_bytes_per_launch": fetch / max(nl, 1), "write_bytes_per_launch": write / max(nl, 1),
+    json.dump({"kernel": "igemm* + conv3h + direct_conv + dcn_patch", "launches": nl, "fetch_bytes_per_launch": fetch / max(nl, 1), "write_bytes_per_launch": write / max(nl, 1),
                "traffic_bytes_per_launch": (fetch + write) / max(nl, 1),
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof.sh), KiB units, FETCH_SIZE x2 per "
                          "MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated"},
