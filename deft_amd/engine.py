@@ -147,7 +147,9 @@ PREC = int(_os.environ.get("DEFT_PREC", "1"))
 
 # pre-split operands (DeftGemmDesc.x3 / w3 / y3, igemm3.hip): convs whose input has Cin % 32 == 0 read the three bf16
 # pieces of activations and weights straight into LDS; producers write the pieces next to the fp32 map.  DEFT_P3=0: off
-# (the operand split stays in the K loop of igemm.hip).  Results are bit-identical either way.
+# (the operand split stays in the K loop of igemm.hip).  Same operands and products, but NOT bit-identical: the halo and patch kernels
+# sum in (16-channel block, tap) order, and the per-layer choice below depends on the tile count, i.e. on the batch -- the same frame can
+# differ in the last bits between batch sizes (tests/parity_checks.check_dcn_patch_batch_invariance pins what IS invariant).
 P3 = _os.environ.get("DEFT_P3", "1") != "0"
 P3_MIN_COUT = int(_os.environ.get("DEFT_P3_MIN_COUT", "64"))
 BDMA = _os.environ.get("DEFT_BDMA", "1") != "0"             # igemm.hip prec-1 launches with >= 128 output columns read pre-split weights by DMA
@@ -994,11 +996,18 @@ class AfePlan(_Plan):
         key = (tuple(fm.addr for fm in fmaps), Nf, ndet)
         if not hasattr(self, "_egroups"):
             self._egroups = collections.OrderedDict()
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if key in self._egroups:
             self._egroups.move_to_end(key)
+            if capturing:
+                self._egroups[key]["pinned"] = True          # its buffers are baked into a hipGraph now: never evicted
             return self._egroups[key]
-        while len(self._egroups) >= self.EGROUP_CACHE:       # drop-in tracker path: ndet changes from frame to frame -- keep the few most
-            self._egroups.popitem(last=False)                # recent shapes (each entry owns rowmaps, scratch and split-K workspaces: MBs)
+        assert not capturing, "AfePlan.extract: warm the (maps, frames, ndet) shape up before capturing it (allocates)"
+        # drop-in tracker path: ndet changes from frame to frame -- keep the few most recent shapes (each entry owns rowmaps, scratch and
+        # split-K workspaces: MBs); entries a captured graph replays into stay
+        victims = [k for k, g_ in self._egroups.items() if not g_.get("pinned")]
+        while len(victims) >= self.EGROUP_CACHE:
+            del self._egroups[victims.pop(0)]
         dev = self.device
         nm = len(self.sel)
         M = Nf * ndet * 4

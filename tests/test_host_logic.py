@@ -110,3 +110,24 @@ def test_accelerate_binds_and_restores(emu_lib):
     assert RT.KalmanFilterLSTM is dict
     assert Tracker.get_similarity is ref_get and RT.FeatureRecorder is object and matching.linear_assignment == 3
     assert "future_predictions" not in STrack.__dict__ and STrack().update_lstm_features(None) == "ref"
+
+
+def test_embed_group_cache_keeps_captured_entries():
+    """AfePlan._embed_group: an LRU of EGROUP_CACHE shapes, except that entries a hipGraph replays into (marked while capturing) are never
+    dropped -- their buffers are baked into the graph."""
+    import types
+    import torch
+    from deft_amd import engine
+    afe = engine.AfePlan.__new__(engine.AfePlan)
+    afe.device = torch.device("cpu")
+    w = torch.zeros(8, 32 * 9)
+    afe.sel = [(w, 32 * 9, torch.zeros(8), 8, 32, 0)]
+    fm = [types.SimpleNamespace(addr=4096, H=8, W=8, C=32, N=1, ld=32)]
+    first = afe._embed_group(fm, 1, 1)
+    first["pinned"] = True                                   # what a hit during capture sets
+    for nd in range(2, 2 + 3 * engine.AfePlan.EGROUP_CACHE):
+        afe._embed_group(fm, 1, nd)
+    keys = list(afe._egroups)
+    assert keys[0][2] == 1 and afe._egroups[keys[0]] is first
+    assert len(keys) == engine.AfePlan.EGROUP_CACHE + 1
+    assert [k[2] for k in keys[1:]] == list(range(2 + 2 * engine.AfePlan.EGROUP_CACHE, 2 + 3 * engine.AfePlan.EGROUP_CACHE))
