@@ -65,11 +65,7 @@ class Detector(object):
             # one frame per call is launch-bound on the host (~100 launches of 5-50 us): replay the plan's launch
             # list as a hipGraph (buffers are plan-owned and static, so the capture stays valid)
             if self._graphs[key] is None:
-                torch.cuda.synchronize(self.device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
-                    plan.run()
-                self._graphs[key] = g
+                self._graphs[key] = plan.capture_graph()
             plan.image.copy_(images, non_blocking=True)
             self._graphs[key].replay()
         d = plan.dets()
@@ -206,11 +202,7 @@ class Detector(object):
             self._graphs.setdefault(key, None)
         else:
             if self._graphs[key] is None:
-                torch.cuda.synchronize(self.device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
-                    plan.run()
-                self._graphs[key] = g
+                self._graphs[key] = plan.capture_graph()
             plan.image_u8.copy_(frames_u8, non_blocking=True)
             self._graphs[key].replay()
         d = plan.dets()

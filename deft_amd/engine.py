@@ -196,6 +196,10 @@ DIRECT = _os.environ.get("DEFT_DIRECT", "1") != "0"
 Y3_INLOOP = _os.environ.get("DEFT_Y3_INLOOP", "1") != "0"    # piece-form output from the in-loop kernel's epilogue (else deft_split_planes)
 FOLD = _os.environ.get("DEFT_FOLD", "1") != "0"       # heat-map head: the 1x1 conv folded into the epilogue of the 3x3 conv (DeftGemmDesc.fold_w)
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
+# launch lists of at most DATAFLOW_MAX_N frames run over this many HIP streams along their data dependencies (_Plan.build_schedule): one
+# frame per GPU leaves most of the chip idle in most launches, and DLA-34's up path has independent branches.  DEFT_DATAFLOW=1: one stream
+DATAFLOW = int(_os.environ.get("DEFT_DATAFLOW", "2"))
+DATAFLOW_MAX_N = int(_os.environ.get("DEFT_DATAFLOW_MAX_N", "1"))
 
 
 class _P3Out:
@@ -245,6 +249,16 @@ def dcn_patch_choice(N, H, W, Cin, Cout):
     return H * W >= DCN_PATCH_MIN_HW and halo_waste(H, W, 8, 16) <= DCN_PATCH_WASTE and N * -(-H // 8) * -(-W // 16) * -(-Cout // (128 if Cout > 64 else 64)) >= DCN_PATCH_MIN_TILES
 
 
+def _region(v):
+    """(storage address, first channel, end channel) of a View -- channel ranges of one NHWC buffer are what concat buffers are written
+    through (dla.py:176-181 Root) -- or (storage address, 0, inf) of a whole tensor.  The bf16-piece companion of a buffer (_Plan._p3)
+    is written by the producer of the fp32 data and read by its consumers, so it needs no region of its own."""
+    if isinstance(v, View):
+        ch = v.c0 % v.ld
+        return (v.buf.untyped_storage().data_ptr(), ch, ch + v.C)
+    return (v.untyped_storage().data_ptr(), 0, 1 << 30)
+
+
 class _Plan:
     """Common machinery: device buffers + an ordered list of bound C-ABI calls."""
 
@@ -259,7 +273,10 @@ class _Plan:
         self._p3_outs = []     # _P3Out records of every producer that can write a P3 copy of its output
         self._w3 = {}          # packed fp32 weight data_ptr -> P3 weight image
         self.ops = []          # (kind, name, callable, flops)
+        self.io = []           # per op: None (= ordered against everything) or (regions read, regions written), see dependencies()
+        self.sched = None      # set by build_schedule(): the op list spread over several HIP streams along its data dependencies
         self._gemms = []       # (entry, name, descriptor) of every implicit-GEMM launch, for autotune()
+        self._op_desc = {}     # op index -> its descriptor (build_schedule gives split-K launches on a side stream their own workspace)
         self._keep = []        # tensors / descriptors kept alive
         self.profile = None    # when set to a list, run() appends (name, kind, flops, ms)
 
@@ -280,13 +297,183 @@ class _Plan:
         s = self._stream_cache
         return s if s is not None else hiplib.stream_ptr(self.device)
 
-    def add(self, kind, name, fn, flops=0.0):
+    def add(self, kind, name, fn, flops=0.0, reads=None, writes=None):
+        """reads / writes: the Views (or whole tensors) the launch touches.  Ops that do not say are ordered against every other op."""
         self.ops.append((kind, name, fn, flops))
+        self.io.append(None if reads is None or writes is None else
+                       ([_region(v) for v in reads if v is not None], [_region(v) for v in writes if v is not None]))
+
+    # ---- data-flow schedule: the launch list over several HIP streams --------------------------------------------------------------
+    def dependencies(self):
+        """deps[i] = the earlier ops launch i has to wait for: the last writers of what it reads, and the readers and writers since
+        of what it writes (regions = channel ranges of NHWC buffers, _region()).  Ops without I/O information wait for everything
+        before them and everything after them waits for them."""
+        n = len(self.ops)
+        deps = [set() for _ in range(n)]
+        fence = -1
+        writes, reads = {}, {}                         # storage -> [(lo, hi, op)]
+        for i, io in enumerate(self.io):
+            if io is None:
+                deps[i] = set(range(max(fence, 0), i))
+                fence, writes, reads = i, {}, {}
+                continue
+            if fence >= 0:
+                deps[i].add(fence)
+            R, W = io
+            for st, lo, hi in R:
+                deps[i].update(j for a, b, j in writes.get(st, ()) if a < hi and lo < b)
+            for st, lo, hi in W:
+                deps[i].update(j for a, b, j in writes.get(st, ()) if a < hi and lo < b)
+                deps[i].update(j for a, b, j in reads.get(st, ()) if a < hi and lo < b)
+            deps[i].discard(i)
+            for st, lo, hi in R:
+                reads.setdefault(st, []).append((lo, hi, i))
+            for st, lo, hi in W:
+                # entries this write covers completely are ordered before it now: later ops only need to order against this op
+                writes[st] = [e for e in writes.get(st, ()) if not (lo <= e[0] and e[1] <= hi)] + [(lo, hi, i)]
+                reads[st] = [e for e in reads.get(st, ()) if not (lo <= e[0] and e[1] <= hi) or e[2] == i]
+        return deps
+
+    def build_schedule(self, nstreams, dur_ms=None, sync_ms=0.003):
+        """Spread the launch list over `nstreams` HIP streams along its data dependencies (one frame per GPU: most launches fill a
+        fraction of the chip, and the up-path of DLA-34 has independent branches -- dla.py:693-699 projects every level before it
+        merges them, and three of DLAUp's projections read backbone outputs only).  List scheduling in program order: every op goes
+        to the stream where it can start first, given measured (or estimated) durations; a stream runs its ops in program order, an
+        event orders an op after a dependency on another stream.  Results cannot change: the same launches on the same buffers, every
+        read after its write.  Returns the modelled (serial, scheduled) time in ms."""
+        n = len(self.ops)
+        deps = self.dependencies()
+        if dur_ms is None:
+            dur_ms = [0.004 + f / 1.0e11 for _, _, _, f in self.ops]
+        assert len(dur_ms) == n and nstreams >= 1
+        succ = [[] for _ in range(n)]
+        for i in range(n):
+            for j in deps[i]:
+                succ[j].append(i)
+        level = [0.0] * n                                  # longest path from the start of op i to the end of the list
+        for i in range(n - 1, -1, -1):
+            level[i] = dur_ms[i] + max((level[k] for k in succ[i]), default=0.0)
+        where, finish, free, order = [0] * n, [0.0] * n, [0.0] * nstreams, []
+        missing = [len(deps[i]) for i in range(n)]
+        ready = [i for i in range(n) if not missing[i]]
+        while ready:
+            i = max(ready, key=lambda k: (level[k], -k))   # the op with the longest tail first; program order among equals
+            ready.remove(i)
+            late = max(deps[i], key=lambda j: finish[j], default=None)
+            s_, start = None, None
+            for c in range(1 if self.io[i] is None else nstreams):          # ops without I/O information stay on the first stream
+                t = max([free[c]] + [finish[j] + (sync_ms if where[j] != c else 0.0) for j in deps[i]])
+                better = start is None or t < start - 1e-9
+                if not better and abs(t - start) <= 1e-9 and late is not None and where[late] == c and where[late] != s_:
+                    better = True                           # tie: continue the chain of the dependency that finishes last
+                if better:
+                    s_, start = c, t
+            where[i], finish[i] = s_, start + dur_ms[i]
+            free[s_] = finish[i]
+            order.append(i)
+            for k in succ[i]:
+                missing[k] -= 1
+                if not missing[k]:
+                    ready.append(k)
+        assert len(order) == n
+        # events: op i waits for its latest dependency on every OTHER stream, unless an earlier op of i's stream already waited for it
+        pos = {i: k for k, i in enumerate(order)}
+        waits, seen = [[] for _ in range(n)], [[-1] * nstreams for _ in range(nstreams)]
+        for i in order:
+            need = {}
+            for j in deps[i]:
+                if where[j] != where[i] and pos[j] > need.get(where[j], (-1, None))[0]:
+                    need[where[j]] = (pos[j], j)
+            for c, (pj, j) in sorted(need.items()):
+                if pj > seen[where[i]][c]:
+                    waits[i].append(j)
+                    seen[where[i]][c] = pj
+        signals = sorted({j for w in waits for j in w})
+        self.sched = {"n": nstreams, "where": where, "waits": waits, "signals": signals, "order": order, "streams": None, "events": None,
+                      "model_ms": (sum(dur_ms), max(finish) if n else 0.0)}
+        # cross-workgroup split-K launches share one workspace per plan: one per stream now
+        sp = getattr(self, "_split", None)
+        if sp is not None and sp["ws"] is not None and nstreams > 1:
+            extra = {}
+            for i, d in self._op_desc.items():
+                if d.splitk > 1 and d.ws == sp["ws"].data_ptr() and where[i] != 0:
+                    if where[i] not in extra:
+                        extra[where[i]] = (torch.empty_like(sp["ws"]), torch.zeros_like(sp["cnt"]))
+                        self._keep += list(extra[where[i]])
+                    d.ws, d.ws_cnt = extra[where[i]][0].data_ptr(), extra[where[i]][1].data_ptr()
+            sp["extra"] = extra
+        return self.sched["model_ms"]
+
+    def tune_schedule(self, nstreams=None, reps=3):
+        """Measure every launch of the list alone (HIP events, best of `reps`) and build the data-flow schedule from those durations.
+        Returns the modelled (serial, scheduled) ms, or None when the list stays on one stream."""
+        if nstreams is None:
+            nstreams = DATAFLOW if getattr(self, "N", 1) <= DATAFLOW_MAX_N else 1
+        self.sched = None
+        if self.device.type != "cuda" or nstreams <= 1:
+            return None
+        dur = None
+        for _ in range(reps + 1):
+            self.profile = []
+            try:
+                self.run()
+                torch.cuda.synchronize(self.device)
+                ms = [e0.elapsed_time(e1) for (_, _, _, e0, e1) in self.profile]
+            finally:
+                self.profile = None
+            dur = ms if dur is None else [min(a, b) for a, b in zip(dur, ms)]
+        model = self.build_schedule(nstreams, [max(0.002, t - 0.005) for t in dur])       # an event pair around a launch costs ~5 us
+        self.run()                                         # creates the side streams and events (not inside a graph capture)
+        torch.cuda.synchronize(self.device)
+        return model
+
+    def capture_graph(self, then=None):
+        """The launch list (plus whatever `then()` launches behind it) as a hipGraph; small-batch lists are spread over several streams
+        first (tune_schedule), which become parallel branches of the graph.  Buffers are plan-owned and static, so replays are valid."""
+        assert self.device.type == "cuda"
+        if self.sched is None and DATAFLOW > 1:
+            self.tune_schedule()
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
+            self.run()
+            if then is not None:
+                then()
+        return g
+
+    def _run_dataflow(self):
+        sc = self.sched
+        main = torch.cuda.current_stream(self.device)
+        if sc["streams"] is None:
+            sc["streams"] = [None] + [torch.cuda.Stream(device=self.device) for _ in range(sc["n"] - 1)]
+            sc["events"] = {j: torch.cuda.Event() for j in sc["signals"]}
+            sc["fork"], sc["join"] = torch.cuda.Event(), [torch.cuda.Event() for _ in range(sc["n"])]
+        streams = [main] + sc["streams"][1:]
+        sc["fork"].record(main)
+        for st in streams[1:]:
+            st.wait_event(sc["fork"])                    # side streams start behind whatever precedes the plan (and join a graph capture)
+        where, waits, events = sc["where"], sc["waits"], sc["events"]
+        for i in sc["order"]:                            # a topological order: every event is recorded before it is waited for
+            fn = self.ops[i][2]
+            st = streams[where[i]]
+            for j in waits[i]:
+                st.wait_event(events[j])
+            self._stream_cache = C.c_void_p(st.cuda_stream)
+            with torch.cuda.stream(st):
+                fn()
+            if i in events:
+                events[i].record(st)
+        for c in range(1, sc["n"]):
+            sc["join"][c].record(streams[c])
+            main.wait_event(sc["join"][c])
 
     def run(self):
         self._stream_cache = hiplib.stream_ptr(self.device)
         try:
-            self._run_ops()
+            if self.sched is not None and self.sched["n"] > 1 and self.profile is None and self.device.type == "cuda":
+                self._run_dataflow()
+            else:
+                self._run_ops()
         except hiplib.DeftHipError:
             self.reset_splitk()            # a launch list that stopped half way may leave split-K tickets taken: start clean next time
             raise
@@ -299,6 +486,8 @@ class _Plan:
         sp = getattr(self, "_split", None)
         if sp is not None and sp["cnt"] is not None:
             sp["cnt"].zero_()
+            for _, cnt in sp.get("extra", {}).values():
+                cnt.zero_()
 
     def _run_ops(self):
         if self.profile is None:
@@ -346,7 +535,7 @@ class _Plan:
         if need:
             lib = self.lib
             a = (C.c_void_p(v.addr), C.c_void_p(addr), C.c_longlong(v.N * v.H * v.W), v.C, v.ld, v.ld)
-            self.add("deft_split_planes", name + ".p3", lambda: lib.call("deft_split_planes", *a, self._stream()))
+            self.add("deft_split_planes", name + ".p3", lambda: lib.call("deft_split_planes", *a, self._stream()), reads=[v], writes=[v])
             self._p3_cover.setdefault(id(v.buf), []).append((ch, ch + v.C, None))
         return addr
 
@@ -383,11 +572,12 @@ class _Plan:
                 h.desc.y3, h.desc.ldy3 = (h.addr, h.ld) if h.used else (None, 0)
 
     # ---- op builders -------------------------------------------------------
-    def gemm(self, entry, name, desc, flops):
+    def gemm(self, entry, name, desc, flops, reads=None, writes=None):
         desc.prec = PREC
         self._keep.append(desc)
         lib, ref = self.lib, C.byref(desc)
-        self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops)
+        self._op_desc[len(self.ops)] = desc
+        self.add(entry, name, lambda: lib.call(entry, ref, self._stream()), flops, reads, writes)
         self._gemms.append((entry, name, desc))
         if SPLITK and entry in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc") and not desc.splitk and not desc.p3_kernel and not desc.fold_y:
             self._plan_splitk(entry, desc)
@@ -547,12 +737,14 @@ class _Plan:
             d.y = None; d.ldy = Cout
             d.fold_w, d.fold_y, d.fold_n, d.fold_ld = fw.data_ptr(), part.data_ptr(), fn, fn
             self._keep += [part, fw, fb]
-        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * (Cout if true_cout is None else true_cout) * KH * KW * cin)
+        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * d.M * (Cout if true_cout is None else true_cout) * KH * KW * cin,
+                  reads=[x, res], writes=[folded[0] if folded is not None else out])
         if folded is not None:
             y2 = self.alloc(x.N, OH, OW, fn)
             lib = self.lib
             a = (ptr(part), nparts, C.c_longlong(d.M), fn, fn, ptr(fb), C.c_void_p(y2.addr), y2.ld)
-            self.add("deft_fold_finish", name + ".fold", lambda: lib.call("deft_fold_finish", *a, self._stream()), 2.0 * d.M * fn * Cout)
+            self.add("deft_fold_finish", name + ".fold", lambda: lib.call("deft_fold_finish", *a, self._stream()), 2.0 * d.M * fn * Cout,
+                     reads=[part], writes=[y2])
             return y2
         return out
 
@@ -576,7 +768,7 @@ class _Plan:
         d.M = x.N * OH * (OW // 2)
         d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0
         d.flop_k = true_k
-        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * x.N * OH * OW * Cout * true_k)
+        self.gemm("deft_conv2d_nhwc", name, d, 2.0 * x.N * OH * OW * Cout * true_k, reads=[x], writes=[out])
         return out
 
     def conv_direct(self, name, x, w_packed, K, KH, pad, Cout, scale, shift, relu, true_cin, stride=1):
@@ -608,7 +800,8 @@ class _Plan:
         d.prec = 1
         self._keep.append(d)
         lib, ref = self.lib, C.byref(d)
-        self.add("deft_conv_direct", name, lambda: lib.call("deft_conv_direct", ref, self._stream()), 2.0 * d.M * Cout * KH * KH * true_cin)
+        self.add("deft_conv_direct", name, lambda: lib.call("deft_conv_direct", ref, self._stream()), 2.0 * d.M * Cout * KH * KH * true_cin,
+                 reads=[x], writes=[out])
         return out
 
     def maxpool(self, name, x, out=None):
@@ -616,7 +809,7 @@ class _Plan:
             out = self.alloc(x.N, x.H // 2, x.W // 2, x.C)
         lib = self.lib
         a = (C.c_void_p(x.addr), C.c_void_p(out.addr), x.N, x.H, x.W, x.C, x.ld, out.ld)
-        self.add("deft_maxpool2x2", name, lambda: lib.call("deft_maxpool2x2", *a, self._stream()))
+        self.add("deft_maxpool2x2", name, lambda: lib.call("deft_maxpool2x2", *a, self._stream()), reads=[x], writes=[out])
         return out
 
     def upsample_add(self, name, x, wup, skip, f):
@@ -627,7 +820,7 @@ class _Plan:
              x.N, x.H, x.W, x.C, f, x.ld, skip.ld, out.ld)
         h = self.p3_output(out)                       # written in P3 form too if a pre-split conv reads it (decided by run time)
         self.add("deft_upsample_add", name, lambda: lib.call("deft_upsample_add", *a, C.c_void_p(h.addr) if h is not None and h.used else None,
-                                                             h.ld if h is not None else 0, self._stream()))
+                                                             h.ld if h is not None else 0, self._stream()), reads=[x, skip], writes=[out])
         return out
 
 
@@ -646,7 +839,7 @@ class DlaSegPlan(_Plan):
         self._x4 = x4
         lib = self.lib
         a = (ptr(self.image), C.c_void_p(x4.addr), N, 3, H, W, 4)
-        self.add("deft_nchw_to_nhwc", "image", lambda: lib.call("deft_nchw_to_nhwc", *a, self._stream()))
+        self.add("deft_nchw_to_nhwc", "image", lambda: lib.call("deft_nchw_to_nhwc", *a, self._stream()), reads=[self.image], writes=[x4])
         self._build_base(x4)
         self._build_neck()
         self._build_heads(dense_heads)
@@ -765,7 +958,7 @@ class DlaSegPlan(_Plan):
             do.M = x.N * x.H * x.W
             do.relu = 0; do.tile = 0; do.p3_kernel = 3
             do.flop_k = 9 * cin; do.flop_n = 27
-            self.gemm("deft_conv2d_nhwc", p + ".offset", do, 2.0 * do.M * 27 * 9 * cin)
+            self.gemm("deft_conv2d_nhwc", p + ".offset", do, 2.0 * do.M * 27 * 9 * cin, reads=[x], writes=[om])
         elif om is None:
             om = self.alloc(x.N, x.H, x.W, 32, ld=32)
             self.conv(p + ".offset", x, wo, Ko, 3, 3, 1, 1, 32, None, bo, False, out=om, true_cout=27)
@@ -787,7 +980,7 @@ class DlaSegPlan(_Plan):
             h = self.p3_output(out, d)               # pruned by finalize_p3() when no pre-split conv reads it
             if h is not None:
                 d.y3, d.ldy3 = h.addr, h.ld
-        self.gemm("deft_dcn_v2_nhwc", p + ".dcn", d, 2.0 * d.M * cout * 9 * cin)
+        self.gemm("deft_dcn_v2_nhwc", p + ".dcn", d, 2.0 * d.M * cout * 9 * cin, reads=[x, om], writes=[out])
         return out
 
     def _ida_up(self, layers, p, startp, endp):
@@ -909,6 +1102,7 @@ class DlaSegPlan(_Plan):
         lib, x4 = self.lib, self._x4
         a = (ptr(self.image_u8), self.N, sh, sw, ptr(self._minv), ptr(self._lut), C.c_void_p(x4.addr), self.H, self.W, x4.ld)
         self.ops[0] = ("deft_preprocess_u8", "image", lambda: lib.call("deft_preprocess_u8", *a, self._stream()), 0.0)
+        self.io[0] = ([_region(self.image_u8)], [_region(x4)])
 
     def forward_u8(self, frames_u8):
         """frames_u8 [N, sh, sw, 3] uint8 on the device (after use_u8_input)."""

@@ -320,11 +320,7 @@ class DeftModel(object):
             self._graphs.setdefault(key, None)
         else:                                       # then replay the launch list (one-frame calls are launch-bound on the host)
             if self._graphs[key] is None:
-                torch.cuda.synchronize(self.device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
-                    plan.run()
-                self._graphs[key] = g
+                self._graphs[key] = plan.capture_graph()
             plan.image.copy_(images, non_blocking=True)
             self._graphs[key].replay()
         s = hiplib.stream_ptr(self.device)

@@ -71,6 +71,8 @@ class HipCompute:
             sl = slice(s_ * self.sub, (s_ + 1) * self.sub)
             p.forward(images[sl]); self.afe.extract(p.fmaps, p.centers if self.ndet == self.K else p.centers[:, :self.ndet], out=self.emb[sl])      # warm-up: attributes, caches
             torch.cuda.synchronize(self.device)
+            if engine.DATAFLOW > 1 and p.sched is None:
+                p.tune_schedule()                  # one frame per GPU: independent branches of the launch list become parallel graph branches
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side[s_ % len(side)]):
                 p.run()

@@ -70,11 +70,7 @@ class DeviceDetect:
         if not self._warm:
             p.forward(frame); self._warm = True; return          # first frame eager: kernel attributes, caches
         if self.graph is None:
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
-                p.run()
-            self.graph = g
+            self.graph = p.capture_graph()
         p.image.copy_(frame, non_blocking=True)
         self.graph.replay()
 

@@ -408,3 +408,70 @@ def test_late_dma_forward_every_presplit_kernel(late_dma):
     finally:
         engine.P3_MIN_TILES = saved
         engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE = saved_b
+
+
+def test_dataflow_schedule_is_order_independent(emu_lib):
+    """_Plan.dependencies / build_schedule: executing the launch list in any order the dependencies allow gives the same bits.  The
+    emulator runs launches synchronously, so the multi-stream schedule is replayed as two adversarial topological orders (always the
+    LAST ready op in program order; the scheduler's own issue order) against program order."""
+    import torch
+    from deft_amd import engine, synth
+    sd = synth.synth_state_dict("mot")
+    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(5))
+    plan = engine.DlaSegPlan(sd, 1, 64, 96, "mot", K=20, device="cpu", lib=emu_lib)
+    outs = lambda: [t.clone() for t in (plan.scores, plan.inds, plan.bboxes, plan.head_vals)] + [fm.buf.clone() for fm in plan.fmaps]
+    plan.forward(x)
+    ref = outs()
+    deps = plan.dependencies()
+    n = len(plan.ops)
+    assert all(j < i for i in range(n) for j in deps[i])
+    # the structure the schedule exploits: a level's project branch is independent of its first conv, DLAUp's projections of backbone maps
+    # do not wait for the previous IDA stage
+    name = {o[1]: i for i, o in enumerate(plan.ops)}
+    reach = [set(d) for d in deps]
+    for i in range(n):
+        for j in list(reach[i]):
+            reach[i] |= reach[j]
+    assert name["base.level3.tree1.project"] not in reach[name["base.level3.tree1.tree1.conv1"]]
+    assert name["base.level3.tree1.tree1.conv1"] not in reach[name["base.level3.tree1.project"]]
+    assert name["dla_up.ida_0.node_1.dcn"] not in reach[name["dla_up.ida_1.proj_1.dcn"]]
+    assert name["dla_up.ida_1.proj_1.offset"] in reach[name["dla_up.ida_1.proj_1.dcn"]]
+    assert name["dla_up.ida_0.node_1.dcn"] in reach[name["dla_up.ida_1.proj_2.offset"]]
+    serial, par = plan.build_schedule(3)
+    sc = plan.sched
+    assert par < serial and sorted(sc["order"]) == list(range(n)) and any(sc["where"])
+    pos = {i: k for k, i in enumerate(sc["order"])}
+    assert all(pos[j] < pos[i] for i in range(n) for j in deps[i])
+    for i in range(n):            # every cross-stream dependency is covered by an event wait of this op or of an earlier op on its stream
+        for j in deps[i]:
+            if sc["where"][j] != sc["where"][i]:
+                cover = [w for k in sc["order"][:pos[i] + 1] if sc["where"][k] == sc["where"][i] for w in sc["waits"][k]
+                         if sc["where"][w] == sc["where"][j] and pos[w] >= pos[j]]
+                assert cover, (plan.ops[i][1], plan.ops[j][1])
+    last_first, done, left = [], set(), set(range(n))
+    while left:
+        i = max(k for k in left if deps[k] <= done)
+        last_first.append(i); done.add(i); left.remove(i)
+    assert last_first != list(range(n))
+    x2 = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(6))
+    for order in (last_first, sc["order"]):
+        plan.forward(x2)                   # every buffer now holds ANOTHER frame's values: an op that ran too early would read those
+        assert not torch.equal(outs()[-1], ref[-1])
+        plan.image.copy_(x)
+        for i in order:
+            plan.ops[i][2]()
+        for a, b in zip(ref, outs()):
+            assert torch.equal(a, b)
+    # the check has teeth: drop one dependency and the reordered run reads stale data
+    broken = [set(d) for d in deps]
+    victim = name["dla_up.ida_1.proj_2.offset"]
+    broken[victim] = set()
+    order, done, left = [], set(), set(range(n))
+    while left:
+        i = max(k for k in left if broken[k] <= done)
+        order.append(i); done.add(i); left.remove(i)
+    plan.forward(x2)
+    plan.image.copy_(x)
+    for i in order:
+        plan.ops[i][2]()
+    assert not all(torch.equal(a, b) for a, b in zip(ref, outs()))

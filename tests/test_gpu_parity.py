@@ -653,3 +653,31 @@ def test_split_is_exact_identity_conv(gpu_lib):
     plan.run()
     torch.cuda.synchronize()
     assert torch.equal(out.to_nchw().cpu(), x)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 608, 1088), (2, 96, 160)])
+def test_dataflow_schedule_bit_identical(gpu_lib, N, H, W):
+    """The launch list spread over several HIP streams along its data dependencies (engine._Plan.build_schedule), eagerly and as a
+    hipGraph with parallel branches, against the same list on one stream: identical bits, replay after replay."""
+    from deft_amd import engine, synth
+    sd = synth.synth_state_dict("mot")
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(N, 3, H, W, generator=g).cuda() for _ in range(3)]
+    plan = engine.DlaSegPlan(sd, N, H, W, "mot", K=100, device="cuda", lib=gpu_lib)
+    outs = lambda: [t.clone() for t in (plan.scores, plan.inds, plan.bboxes, plan.head_vals)] + [fm.buf.clone() for fm in plan.fmaps]
+    ref = []
+    for x in xs:
+        plan.forward(x); torch.cuda.synchronize()
+        ref.append(outs())
+    model = plan.tune_schedule(3)
+    assert model is not None and plan.sched["n"] == 3 and any(plan.sched["where"]) and model[1] < model[0]
+    for _ in range(2):
+        for x, r in zip(xs, ref):
+            plan.forward(x); torch.cuda.synchronize()          # eager, three streams
+            assert all(torch.equal(a, b) for a, b in zip(r, outs()))
+    graph = plan.capture_graph()
+    for _ in range(3):
+        for x, r in zip(xs, ref):
+            plan.image.copy_(x)
+            graph.replay(); torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(r, outs()))
