@@ -167,6 +167,8 @@ def main():
 
     if args.autotune:                                    # plan-build time, outside the timed region
         comp.autotune(images, verbose=args.verbose and rank == 0)
+    if engine.DATAFLOW > 1 and comp.sub <= engine.DATAFLOW_MAX_N and not args.graphs:
+        comp.tune_dataflow(images)                       # (capture() does it itself)
     if args.graphs:
         comp.capture(images)
 

@@ -25,8 +25,11 @@ class HipCompute:
     embedding exchange, so the hardware overlaps one sub-batch's kernel tails (partially
     filled last wave of workgroups) and barrier stalls with the other's workgroups."""
 
-    def __init__(self, sd, batch, H, W, dataset="mot", K=100, max_object=100, device="cuda", lib=None, streams=1, ndet=None):
-        """ndet: embeddings are extracted for the first `ndet` (<= K) decoded detections of every frame (default K)."""
+    def __init__(self, sd, batch, H, W, dataset="mot", K=100, max_object=100, device="cuda", lib=None, streams=1, ndet=None, overlap=False):
+        """ndet: embeddings are extracted for the first `ndet` (<= K) decoded detections of every frame (default K).
+        overlap: with ONE sub-batch, still run detection on a side stream, so that step k+1's detection overlaps step k's affinity
+        chain on the caller's stream.  Off by default: measured SLOWER at one frame per step (2.07 -> 2.11 ms: the cross-stream
+        hand-overs cost more than the chain's idle compute units give back, tools/probe/dataflow_ab.sh)."""
         assert batch % streams == 0
         ndet = K if ndet is None else ndet
         self.device = torch.device(device)
@@ -37,7 +40,8 @@ class HipCompute:
         self.D = self.afe.D
         self.K, self.ndet = K, ndet
         self.emb = torch.zeros(batch, ndet, self.D, dtype=torch.float32, device=self.device)
-        if streams > 1:
+        self.overlap = streams > 1 or (bool(overlap) and self.device.type == "cuda")
+        if self.overlap:
             self.side = [torch.cuda.Stream(device=self.device) for _ in range(streams)]
             self.ev_main = torch.cuda.Event()
             self.ev_in = torch.cuda.Event()
@@ -57,6 +61,15 @@ class HipCompute:
             torch.cuda.synchronize(self.device)
             p.autotune(verbose=verbose and s_ == 0)
 
+    def tune_dataflow(self, images, nstreams=None):
+        """Spread every sub-batch plan's launch list over several HIP streams along its data dependencies (engine._Plan.tune_schedule;
+        decided by engine.DATAFLOW / DATAFLOW_MAX_N unless `nstreams` is given).  Returns the modelled (serial, scheduled) ms per plan."""
+        out = []
+        for s_, p in enumerate(self.plans):
+            (p.image_u8 if images.dtype == torch.uint8 else p.image).copy_(images[s_ * self.sub:(s_ + 1) * self.sub])
+            out.append(p.tune_schedule(nstreams))
+        return out
+
     graphs = None          # per sub-batch hipGraph of (plan launches + embedding extraction), see capture()
 
     def capture(self, images):
@@ -65,7 +78,7 @@ class HipCompute:
         hipLaunchKernel, ~10-20 us each) disappears from the critical path, which matters when the
         sub-batch is small (latency mode).  Buffers are static (plan-owned), so replays are valid."""
         assert self.device.type == "cuda"
-        side = self.side if self.nstream > 1 else [torch.cuda.Stream(device=self.device)]
+        side = self.side if self.overlap else [torch.cuda.Stream(device=self.device)]
         self.graphs = []
         for s_, p in enumerate(self.plans):
             sl = slice(s_ * self.sub, (s_ + 1) * self.sub)
@@ -93,7 +106,7 @@ class HipCompute:
     serialize = False      # profiling aid: run the sub-batch plans one after the other on the current stream
 
     def detect_embed(self, images):
-        if (self.serialize and self.nstream > 1) or self.nstream == 1:
+        if self.serialize or not self.overlap:
             for s in range(len(self.plans)):
                 self._run_plan(s, images)
             return self.emb                                                     # [batch, K, D]
@@ -120,7 +133,7 @@ class HipCompute:
         """Called by the pipeline once the step's embeddings have been copied out of `emb` (into the
         history ring): the NEXT step's detection may start on the side streams while this step's
         affinity chain is still running on the main stream (cross-step overlap)."""
-        if self.nstream > 1:
+        if self.overlap:
             self.ev_main.record(torch.cuda.current_stream(self.device))
             self.emb_released = True
 

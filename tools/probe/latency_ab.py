@@ -12,14 +12,17 @@ sys.path.insert(0, ROOT)
 from deft_amd import engine, hiplib, synth  # noqa: E402
 from deft_amd.pipeline import FramePipeline, HipCompute  # noqa: E402
 
+overlap = False
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
+    if k == "OVERLAP":                       # HipCompute(overlap=...): detection of step k+1 on a side stream next to step k's affinity chain
+        overlap = bool(int(v)); continue
     setattr(engine, k, type(getattr(engine, k))(float(v)) if not isinstance(getattr(engine, k), bool) else bool(int(v)))
 lib = hiplib.get_lib()
 sd = synth.synth_state_dict("mot")
 H, W = 608, 1088
 dev = torch.device("cuda")
-comp = HipCompute(sd, 1, H, W, "mot", K=100, device=dev, lib=lib, streams=1, ndet=100)
+comp = HipCompute(sd, 1, H, W, "mot", K=100, device=dev, lib=lib, streams=1, ndet=100, overlap=overlap)
 pipe = FramePipeline(comp, 1, 100, comp.D, history=5, device=dev, exchange=False)
 x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0)).to(dev)
 comp.capture(x)
