@@ -129,16 +129,22 @@ def fuse_motion(kf, cost_matrix, tracks, detections, frame_id, use_lstm=True, on
 
 def fuse_motion_ddd(kf, cost_matrix, tracks, detections, frame_id, use_lstm=True, only_position=False, lambda_=0.9,
                     use_prediction=False, classe_name=None):
-    """matching.py:374-415 for all tracks at once: distance between the 3-D centres (components 3..5 of the
-    (h,w,l,x,y,z,rot) boxes), gate at max(0.2 * depth, 5 m pedestrians / 10 m others), add 0.001 of it."""
+    """matching.py:374-415 for all tracks at once: the filter's "gaussian" distance between track box and detection box -- with the LSTM
+    motion model the distance between the 3-D centres (components 3..5 of the (h,w,l,x,y,z,rot) boxes, kalman_filter_lstm.py:92-95);
+    with the plain KalmanFilter (opt.lstm off: tracker.py:652) the SQUARED distance over all seven components (kalman_filter.py:271-273)
+    -- gate at max(0.2 * depth, 5 pedestrians / 10 others), add 0.001 of it."""
     if cost_matrix.size == 0:
         return cost_matrix
     if only_position:
         raise NotImplementedError("fuse_motion_ddd: only_position=True is not on the tracker's path")
     meas = np.asarray([det.ddd_bbox for det in detections], dtype=np.float64)
     boxes = np.asarray([(t.ddd_prediction_at_frame(frame_id) if use_prediction else t.ddd_bbox) for t in tracks], dtype=np.float64)
-    d = meas[None, :, 3:-1] - boxes[:, None, 3:-1]
-    g = np.sqrt(np.sum(d * d, axis=2))
+    if type(kf).__name__ == "KalmanFilter":                  # the reference's constant-velocity filter class, used when opt.lstm is off
+        d = meas[None, :, :] - boxes[:, None, :]
+        g = np.sum(d * d, axis=2)
+    else:
+        d = meas[None, :, 3:-1] - boxes[:, None, 3:-1]
+        g = np.sqrt(np.sum(d * d, axis=2))
     floor = 5 if classe_name == "pedestrian" else 10
     thr = np.maximum(0.2 * np.asarray([t.depth for t in tracks], dtype=np.float64), floor)
     cost_matrix[g > thr[:, None]] = np.inf

@@ -348,6 +348,14 @@ def run_association():
     for cls in ("pedestrian", "car"):
         fix["ddd_out_" + cls] = matching.fuse_motion_ddd(kfl, cost.copy(), tracks3, dets3, frame_id=5, classe_name=cls)
         assert np.isinf(fix["ddd_out_" + cls]).any()
+    # opt.lstm off: Tracker.kalman_filter is the plain KalmanFilter (tracker.py:652), whose "gaussian" distance is another formula
+    # (kalman_filter.py:271-273: squared, all seven components); tracks close enough for its 5 / 10 gates
+    trk_near = det_ddd[g.permutation(N)[:T]] + g.randn(T, 7) * np.array([0.3, 0.3, 0.3, 1.2, 0.4, 1.2, 0.2])
+    tracks3n = [SimpleNamespace(ddd_bbox=trk_near[t], depth=depth[t], covariance=np.eye(7)) for t in range(T)]
+    fix["ddd_trk_near"] = trk_near
+    for cls in ("pedestrian", "car"):
+        fix["ddd_out_kf_" + cls] = matching.fuse_motion_ddd(RT.KalmanFilter(), cost.copy(), tracks3n, dets3, frame_id=5, classe_name=cls)
+        assert np.isinf(fix["ddd_out_kf_" + cls]).any() and np.isfinite(fix["ddd_out_kf_" + cls]).any()
     np.savez_compressed(os.path.join(GOLD, "association.npz"), **fix)
     print("  association fixtures written (reference fuse_motion / fuse_motion_ddd)")
 

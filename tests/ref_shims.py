@@ -89,10 +89,80 @@ def get_affine_transform_3pt(src, dst):
     return np.linalg.solve(A, dst).T
 
 
+class Quaternion:
+    """Functional stand-in for `pyquaternion.Quaternion` (absent from this image: PARITY UNPINNED), covering what detector.py:236-276
+    uses: the (axis=, angle=) and 4-sequence constructors, w / x / y / z, the Hamilton product, `rotation_matrix`, and `angle` / `axis`
+    as pyquaternion defines them (angle = 2 atan2(|v|, w) wrapped to (-pi, pi]; axis = v / |v|, zeros when |v| < 1e-17).  Written from
+    pyquaternion's documented behaviour; the rotation matrix goes through scipy, independent of deft_amd.postprocess' quaternion code."""
+
+    def __init__(self, *args, axis=None, angle=None, **kw):
+        if axis is not None:
+            a = np.asarray(axis, np.float64)
+            a = a / np.linalg.norm(a)
+            self.q = np.r_[np.cos(angle / 2.0), a * np.sin(angle / 2.0)].astype(np.float64)
+        elif len(args) == 1 and isinstance(args[0], Quaternion):
+            self.q = args[0].q.copy()
+        elif len(args) == 1:
+            self.q = np.asarray(args[0], np.float64).reshape(4).copy()
+        elif len(args) == 4:
+            self.q = np.asarray(args, np.float64)
+        else:
+            raise TypeError("Quaternion stub: unsupported constructor %r %r" % (args, kw))
+
+    w = property(lambda self: self.q[0]); x = property(lambda self: self.q[1])
+    y = property(lambda self: self.q[2]); z = property(lambda self: self.q[3])
+
+    def __mul__(self, o):
+        a1, b1, c1, d1 = self.q
+        a2, b2, c2, d2 = o.q
+        return Quaternion([a1 * a2 - b1 * b2 - c1 * c2 - d1 * d2, a1 * b2 + b1 * a2 + c1 * d2 - d1 * c2,
+                           a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2, a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2])
+
+    def _unit(self):
+        n = np.linalg.norm(self.q)
+        return self.q / n if n > 0 else self.q
+
+    @property
+    def rotation_matrix(self):
+        from scipy.spatial.transform import Rotation
+        u = self._unit()
+        return Rotation.from_quat([u[1], u[2], u[3], u[0]]).as_matrix()
+
+    @property
+    def angle(self):
+        u = self._unit()
+        th = 2.0 * np.arctan2(np.linalg.norm(u[1:]), u[0])
+        r = ((th + np.pi) % (2 * np.pi)) - np.pi
+        return np.pi if r == -np.pi else r
+
+    @property
+    def axis(self):
+        u = self._unit()
+        n = np.linalg.norm(u[1:])
+        return np.zeros(3) if n < 1e-17 else u[1:] / n
+
+
+class Box:
+    """Functional stand-in for `nuscenes.utils.data_classes.Box` (absent: PARITY UNPINNED): center / wlh / orientation, translate()
+    and rotate() as the devkit defines them (center kept in the dtype it was given, so the first translate of detector.py:258 is
+    float32 arithmetic; rotate() multiplies on the left)."""
+
+    def __init__(self, center, size, orientation, label=np.nan, score=np.nan, velocity=(np.nan, np.nan, np.nan), name=None, token=None):
+        self.center, self.wlh, self.orientation = np.array(center), np.array(size), orientation
+        self.name, self.token = name, token
+
+    def translate(self, x):
+        self.center += x
+
+    def rotate(self, quaternion):
+        self.center = np.dot(quaternion.rotation_matrix, self.center)
+        self.orientation = quaternion * self.orientation
+
+
 def install_detector_stubs():
     """What `src/lib/detector.py` imports at module level beyond the tracker's needs: progress,
-    pyquaternion, nuscenes.*, pycocotools (via dataset_factory) as names only, and a functional
-    cv2.getAffineTransform (utils/image.py:get_affine_transform; post-processing of the 2-D datasets)."""
+    nuscenes.eval.*, pycocotools (via dataset_factory) as names only; functional `pyquaternion.Quaternion` and nuscenes `Box` (the
+    classes above: the nuScenes branch of Detector.run calls them), and a functional cv2.getAffineTransform (utils/image.py:get_affine_transform; post-processing of the 2-D datasets)."""
     def mod(name, **kw):
         m = sys.modules.get(name) or types.ModuleType(name)
         for k, v in kw.items():
@@ -100,9 +170,9 @@ def install_detector_stubs():
         sys.modules[name] = m
         return m
     mod("progress"); mod("progress.bar", Bar=_Anything)
-    mod("pyquaternion", Quaternion=_Anything)
+    mod("pyquaternion", Quaternion=Quaternion)
     mod("nuscenes", NuScenes=_Anything)
-    for n, attrs in (("nuscenes.utils", {}), ("nuscenes.utils.data_classes", {"Box": _Anything}), ("nuscenes.eval", {}),
+    for n, attrs in (("nuscenes.utils", {}), ("nuscenes.utils.data_classes", {"Box": Box}), ("nuscenes.eval", {}),
                      ("nuscenes.eval.common", {}), ("nuscenes.eval.common.data_classes", {"EvalBoxes": _Anything}),
                      ("nuscenes.eval.common.config", {}), ("nuscenes.eval.tracking", {}),
                      ("nuscenes.eval.tracking.data_classes", {"TrackingBox": _Anything}), ("nuscenes.eval.tracking.evaluate", {}),

@@ -51,6 +51,12 @@ def test_fuse_motion_ddd_vs_reference_fixture():
     tracks = [SimpleNamespace(ddd_bbox=fx["ddd_trk"][t], depth=fx["ddd_depth"][t]) for t in range(fx["ddd_trk"].shape[0])]
     for cls in ("pedestrian", "car"):
         _same(A.fuse_motion_ddd(None, fx["ddd_cost"].copy(), tracks, dets, frame_id=5, classe_name=cls), fx["ddd_out_" + cls])
+    # opt.lstm off: the tracker hands over the reference's plain `KalmanFilter`, whose "gaussian" distance is squared and over all seven
+    # components (kalman_filter.py:271-273) -- recognised by its class name
+    KalmanFilter = type("KalmanFilter", (), {})
+    near = [SimpleNamespace(ddd_bbox=fx["ddd_trk_near"][t], depth=fx["ddd_depth"][t]) for t in range(fx["ddd_trk_near"].shape[0])]
+    for cls in ("pedestrian", "car"):
+        _same(A.fuse_motion_ddd(KalmanFilter(), fx["ddd_cost"].copy(), near, dets, frame_id=5, classe_name=cls), fx["ddd_out_kf_" + cls])
 
 
 def test_not_positive_definite_raises_like_cholesky():
