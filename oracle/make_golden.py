@@ -523,6 +523,141 @@ def run_detector_trace(lstm):
     print("  detector trace [%s]: %d frames, %d track rows, %d seam records" % (tag, T, ntr, len(fix)))
 
 
+NUSC_INFO_SEED = 3
+
+
+def nuscenes_image_info():
+    """Synthetic calibrated-sensor / ego-pose records of one nuScenes sample (what src/test.py passes as image_info)."""
+    from scipy.spatial.transform import Rotation as R
+    g = np.random.RandomState(NUSC_INFO_SEED)
+    q1, q2 = g.randn(4), g.randn(4)
+    return {"trans_matrix": np.concatenate([R.from_rotvec(g.randn(3)).as_matrix(), g.randn(3, 1) * 10], 1).tolist(),
+            "cs_record_rot": (q1 / np.linalg.norm(q1)).tolist(), "cs_record_trans": [1.7, 0.0, 1.5],
+            "pose_record_rot": (q2 / np.linalg.norm(q2)).tolist(), "pose_record_trans": [411.3, 1180.9, 0.0]}
+
+
+def nuscenes_trace_state_dict():
+    """Synthetic nuScenes net whose detections survive the 0.3 / 0.35 class thresholds of detector.py:222-225 and have positive sizes."""
+    sd = dict(O.synth_state_dict("nuscenes"))
+    sd["hm.2.weight"] = sd["hm.2.weight"] * 3.0
+    sd["hm.2.bias"] = torch.tensor([-1.0, -0.8, -1.2, -0.9, -1.0, -1.1, -0.7, -1.0, -1.0, -1.0])
+    sd["dim.2.weight"] = sd["dim.2.weight"] * 0.05
+    sd["dim.2.bias"] = torch.tensor([1.6, 1.7, 4.0])
+    sd["wh.2.weight"] = sd["wh.2.weight"] * 0.05
+    sd["wh.2.bias"] = torch.tensor([6.0, 5.0])
+    return sd
+
+
+def run_detector_trace_nuscenes():
+    """BASELINE configs[4]: the reference's OWN nuScenes `Detector.run` (detector.py:112-338: process, post-processing, class thresholds,
+    the pyquaternion / nuscenes `Box` chain, per-class NMS, seven per-class Trackers with the LSTM motion model) over 5 synthetic frames,
+    with a TRACE of what crosses the seams: process() outputs, the arguments of every `self.tracker[class].update(...)` call
+    (detector.py:328-336), the embedding calls, every `update_lstm_features_ddd` and the targets it returns.  pyquaternion and the
+    nuScenes devkit are absent here: the reference runs on tests/ref_shims.{Quaternion, Box} -- that part PARITY UNPINNED."""
+    sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+    import importlib
+    import ref_shims
+    ref_shims.install()
+    ref_import.install_stubs(OracleDCN)
+    ref_shims.install_detector_stubs()
+    argv, sys.argv = sys.argv, ["test.py", "tracking,ddd"]
+    try:
+        from opts import opts
+        from dataset.dataset_factory import dataset_factory
+        from utils import tracker as RT
+        from utils.basetrack import BaseTrack
+        RD = importlib.import_module("detector")
+    finally:
+        sys.argv = argv
+    assert RD.Quaternion is ref_shims.Quaternion and RD.Box is ref_shims.Box
+    ck = os.path.join(GOLD, "_trace_ck.pth")
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in nuscenes_trace_state_dict().items()}}, ck)
+    H, W, K, T = 64, 96, 12, 5
+    opt = opts().parse(["tracking,ddd", "--dataset", "nuscenes", "--gpus", "-1", "--load_model", ck, "--K", str(K),
+                        "--input_h", str(H), "--input_w", str(W)])
+    opt = opts().update_dataset_info_and_set_heads(opt, dataset_factory[opt.test_dataset])
+    opt.lstm = True
+    info = nuscenes_image_info()
+    names = list(RD.NUSCENES_TRACKING_NAMES)
+    calib = np.array([[60.0, 0, W / 2, 0], [0, 60.0, H / 2, 0], [0, 0, 1, 0]], np.float32)
+    fix = {"H": H, "W": W, "K": K, "T": T, "seeds": np.arange(10, 10 + T), "calib": calib, "out_thresh": np.array(opt.out_thresh),
+           "names": np.array(names)}
+    for k, v in info.items():
+        fix["info_" + k] = np.asarray(v, np.float64)
+    real_sync, torch.cuda.synchronize = torch.cuda.synchronize, (lambda *a, **k: None)
+    lsd = O.synth_lstm_state_dict("nuscenes")
+    saved = (RD.Detector.process, RT.Tracker.update, RT.STrack.update_lstm_features_ddd, RT.KalmanFilterLSTM, RT.STrack.shared_kalman_lstm)
+    cur = {"t": 0, "mo": 0, "emb": 0}
+    try:
+        class KF(saved[3]):
+            def __init__(self, o):
+                super().__init__(o)
+                self.model.load_state_dict(lsd, strict=True); self.model.eval()
+        RT.KalmanFilterLSTM = KF
+        RT.STrack.shared_kalman_lstm = KF(opt)
+
+        def process(self, images, *a, **k):
+            r = saved[0](self, images, *a, **k)
+            for key, v in r[1].items():
+                fix["t%d_det_%s" % (cur["t"], key)] = np.asarray(v.detach().cpu() if torch.is_tensor(v) else v)
+            return r
+
+        def update(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None, ddd_org_boxes=None, submission=None, classe=None):
+            p = "t%d_cls_%s_" % (cur["t"], classe)
+            fix[p + "results"] = np.asarray(results, np.float64).reshape(-1, 5)
+            fix[p + "ddd_boxes"] = np.asarray(ddd_boxes, np.float64).reshape(-1, 7)
+            fix[p + "depths"] = np.asarray(depths_by_class, np.float64).reshape(-1, 1)
+            fix[p + "ddd_org_boxes"] = np.asarray(ddd_org_boxes, np.float64).reshape(-1, 7)
+            fix[p + "submission"] = np.asarray(submission, np.float64).reshape(-1, 10)
+            return saved[1](self, results, FeatureMaps, ddd_boxes=ddd_boxes, depths_by_class=depths_by_class, ddd_org_boxes=ddd_org_boxes,
+                            submission=submission, classe=classe)
+
+        def update_lstm_features_ddd(self, ddd_box):
+            box = np.asarray(ddd_box, np.float64).copy()
+            saved[2](self, ddd_box)
+            k = "t%d_mo%d" % (cur["t"], cur["mo"]); cur["mo"] += 1
+            fix[k + "_in"] = np.r_[float(self.track_id), float(self.frame_id), float(names.index(self.classe)), box]
+            fix[k + "_fut"] = np.stack([np.asarray(self.future_predictions[q]) for q in sorted(self.future_predictions)])
+        RD.Detector.process, RT.Tracker.update, RT.STrack.update_lstm_features_ddd = process, update, update_lstm_features_ddd
+        BaseTrack._count = 0
+        det = RD.Detector(opt)
+        det.reset_tracking(opt)
+        det.img_height, det.img_width = H, W
+        afe = det.model.AFE                                     # one model behind all seven trackers
+        real_ffe = afe.forward_feature_extracter
+
+        def ffe(fm, centers):
+            e = real_ffe(fm, centers)
+            k = "t%d_emb%d" % (cur["t"], cur["emb"]); cur["emb"] += 1
+            fix[k + "_centers"] = centers.detach().cpu().numpy(); fix[k + "_out"] = e.detach().cpu().numpy()
+            return e
+        afe.forward_feature_extracter = ffe
+        ntr = 0
+        with torch.no_grad():
+            for t in range(T):
+                cur.update(t=t, mo=0, emb=0)
+                x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(10 + t))
+                c = np.array([W / 2.0, H / 2.0], dtype=np.float32)
+                meta = {"c": c, "s": np.float32(max(H, W)), "height": H, "width": W, "out_height": H // 4, "out_width": W // 4,
+                        "inp_height": H, "inp_width": W, "calib": calib}
+                batch = lambda v: torch.from_numpy(np.asarray(v)[None])
+                targets = det.run({"image": [torch.zeros(H, W, 3)], "images": {1.0: [x]}, "meta": {1.0: {k: batch(v) for k, v in meta.items()}}},
+                                  image_info=info)
+                rows = sorted([float(s.track_id), float(names.index(s.classe))] + [float(v) for v in s.tlwh] + [float(s.score)]
+                              + [float(v) for v in s.ddd_bbox] + [float(v) for v in s.ddd_submission] for s in targets)
+                fix["t%d_targets" % t] = np.array(rows, np.float64).reshape(-1, 24)
+                fix["t%d_nmo" % t] = np.array(cur["mo"]); fix["t%d_nemb" % t] = np.array(cur["emb"])
+                ntr += len(rows)
+        assert ntr >= 15 and len({int(r[1]) for t in range(T) for r in fix["t%d_targets" % t]}) >= 2, "the synthetic stream must produce tracks of several classes"
+        assert sum(int(fix["t%d_nmo" % t]) for t in range(T)) >= 10
+    finally:
+        RD.Detector.process, RT.Tracker.update, RT.STrack.update_lstm_features_ddd, RT.KalmanFilterLSTM, RT.STrack.shared_kalman_lstm = saved
+        torch.cuda.synchronize = real_sync
+        os.remove(ck)
+    np.savez_compressed(os.path.join(GOLD, "detector_trace_nuscenes.npz"), **fix)
+    print("  detector trace [nuscenes]: %d frames, %d target rows, %d seam records" % (T, ntr, len(fix)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -541,4 +676,5 @@ if __name__ == "__main__":
     run_postprocess()
     run_detector_trace(lstm=False)
     run_detector_trace(lstm=True)
+    run_detector_trace_nuscenes()
     print("golden fixtures written to", os.path.abspath(GOLD))

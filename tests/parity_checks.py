@@ -1229,6 +1229,107 @@ def check_detector_trace(lib, device, tag):
         hiplib._lib = saved_lib
 
 
+def nuscenes_trace_state_dict():
+    """oracle/make_golden.py::nuscenes_trace_state_dict (the GPU box has no /root/reference, and make_golden imports it)."""
+    sd = dict(O.synth_state_dict("nuscenes"))
+    sd["hm.2.weight"] = sd["hm.2.weight"] * 3.0
+    sd["hm.2.bias"] = torch.tensor([-1.0, -0.8, -1.2, -0.9, -1.0, -1.1, -0.7, -1.0, -1.0, -1.0])
+    sd["dim.2.weight"] = sd["dim.2.weight"] * 0.05
+    sd["dim.2.bias"] = torch.tensor([1.6, 1.7, 4.0])
+    sd["wh.2.weight"] = sd["wh.2.weight"] * 0.05
+    sd["wh.2.bias"] = torch.tensor([6.0, 5.0])
+    return sd
+
+
+def check_detector_trace_nuscenes(lib, device):
+    """BASELINE configs[4] replayed up to the trackers' doors: tests/golden/detector_trace_nuscenes.npz is a trace of the reference's own
+    nuScenes `Detector.run` (oracle/make_golden.py::run_detector_trace_nuscenes; pyquaternion / nuscenes `Box` are functional stand-ins
+    there: that part unpinned).  Per frame, through the C ABI on `device`: fused process() against the reference's decoded detections;
+    the vectorised post_process / merge_outputs / nuscenes_targets against the ARGUMENTS of every `self.tracker[class].update(...)` call
+    the reference made (detector.py:328-336: 2-D boxes + scores after the class thresholds and per-class NMS, 3-D boxes in the global
+    frame, depths, camera-frame boxes, submission boxes with their quaternions); the embeddings of every tracker's
+    forward_feature_extracter call; and the batched 3-D LSTM motion update against every update_lstm_features_ddd."""
+    from types import SimpleNamespace
+    from deft_amd import hiplib, integrate, tracker as DT
+    from deft_amd.detector import Detector
+    f = np.load(os.path.join(GOLD, "detector_trace_nuscenes.npz"))
+    H, W, K, T = int(f["H"]), int(f["W"]), int(f["K"]), int(f["T"])
+    names = [str(n) for n in f["names"]]
+    info = {k[5:]: f[k].tolist() for k in f.files if k.startswith("info_")}
+    sd = nuscenes_trace_state_dict()
+    saved_lib, hiplib._lib = hiplib._lib, lib
+    try:
+        opt = SimpleNamespace(dataset="nuscenes", K=K, max_object=100, gpus=[0 if device != "cpu" else -1], hip_graphs=True, depth_scale=1.0,
+                              out_thresh=float(f["out_thresh"]), num_classes=10, test_scales=[1.0], flip_test=False)
+        det = Detector(opt, sd)
+        seam = integrate.AfeSeam(sd, 100, device, lib)
+        bank = DT.MotionBank(engine.LstmPlan(O.synth_lstm_state_dict("nuscenes"), device, lib))
+        slots = {}
+        worst = {"det": 0.0, "args": 0.0, "quat": 0.0, "emb": 0.0, "motion": 0.0}
+        nrows = 0
+        for t in range(T):
+            x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(int(f["seeds"][t])))
+            _, dets, fmaps = det.process(x)
+            real = f["t%d_det_scores" % t][0] > 0
+            assert real.sum() >= K - 2
+            assert np.array_equal(dets["clses"][0][real].astype(np.int64), f["t%d_det_clses" % t][0][real].astype(np.int64))
+            for key, tol in (("scores", 1e-5), ("bboxes", TOL), ("cts", TOL), ("tracking", TOL), ("dep", TOL), ("dim", TOL), ("rot", TOL),
+                             ("amodel_offset", TOL)):
+                ref = f["t%d_det_%s" % (t, key)][0][real].astype(np.float64)
+                e = float(np.abs(dets[key][0][real].astype(np.float64) - ref).max() / max(1.0, np.abs(ref).max()))
+                assert e <= tol, (t, key, e)
+                worst["det"] = max(worst["det"], e)
+            c = np.array([W / 2.0, H / 2.0], dtype=np.float32)
+            meta = {"c": c, "s": np.float32(max(H, W)), "height": H, "width": W, "out_height": H // 4, "out_width": W // 4,
+                    "inp_height": H, "inp_width": W, "calib": f["calib"]}
+            results = det.merge_outputs([det.post_process(dets, meta, 1.0)])
+            per_class = det.nuscenes_targets(results, info)
+            for name in names:
+                p = "t%d_cls_%s_" % (t, name)
+                got = per_class[name]
+                for key, fk, wd in (("results", "results", 5), ("ddd_boxes", "ddd_boxes", 7), ("depths", "depths", 1), ("ddd_org_boxes", "ddd_org_boxes", 7)):
+                    a, b = np.asarray(got[key], np.float64).reshape(-1, wd), f[p + fk]
+                    assert a.shape == b.shape, (t, name, key, a.shape, b.shape)
+                    if b.size:
+                        e = float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+                        assert e <= 1e-3, (t, name, key, e)
+                        worst["args"] = max(worst["args"], e)
+                a, b = np.asarray(got["submission"], np.float64).reshape(-1, 10), f[p + "submission"]
+                assert a.shape == b.shape
+                if b.size:
+                    e = float(np.abs(a[:, :6] - b[:, :6]).max() / max(1.0, np.abs(b[:, :6]).max()))
+                    sign = np.sign(np.sum(a[:, 6:] * b[:, 6:], axis=1, keepdims=True))           # q and -q are one rotation
+                    eq = float(np.abs(a[:, 6:] - sign * b[:, 6:]).max())
+                    assert e <= 1e-3 and eq <= 1e-4, (t, name, "submission", e, eq)
+                    worst["args"], worst["quat"] = max(worst["args"], e), max(worst["quat"], eq)
+                nrows += b.shape[0]
+            for k in range(int(f["t%d_nemb" % t])):
+                key = "t%d_emb%d" % (t, k)
+                emb = seam.forward_feature_extracter(fmaps, torch.from_numpy(f[key + "_centers"]))
+                ref = f[key + "_out"]
+                e = float(np.abs(emb.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()))
+                assert e <= 1e-4, (t, "emb", k, e)
+                worst["emb"] = max(worst["emb"], e)
+            nmo = int(f["t%d_nmo" % t])
+            if nmo:
+                ins = np.stack([f["t%d_mo%d_in" % (t, k)] for k in range(nmo)])
+                assert len(set(ins[:, 0])) == nmo and len(set(ins[:, 1])) == 1            # one update per track; the seven trackers count frames alike
+                for tid in ins[:, 0]:
+                    if tid not in slots:
+                        slots[tid] = bank.alloc()
+                _, pred = bank.step([slots[tid] for tid in ins[:, 0]], ins[:, 3:10], int(ins[0, 1]))
+                for k in range(nmo):
+                    ref = f["t%d_mo%d_fut" % (t, k)]
+                    e = float(np.abs(pred[k] - ref).max() / max(1.0, np.abs(ref).max()))
+                    assert e <= 1e-4, (t, "motion", k, e)
+                    worst["motion"] = max(worst["motion"], e)
+        assert nrows >= 20 and worst["motion"] > 0 and worst["emb"] > 0
+        assert bank.launches == sum(1 for t in range(T) if int(f["t%d_nmo" % t]))          # ONE motion launch per frame for all classes' tracks
+        return worst
+    finally:
+        hiplib._lib = saved_lib
+
+
 def check_preprocess_u8(lib, device, N=2, sh=45, sw=80, H=32, W=64, seed=0):
     """deft_preprocess_u8 (uint8 HWC frame -> warped, normalised NHWC input of the plan) against the numpy restatement of
     detector.py:377-395 with cv2's fixed-point warp (oracle.preprocess_u8): EXACT; and that restatement against a float bilinear

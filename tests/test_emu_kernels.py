@@ -361,6 +361,12 @@ def test_composed_dropin_replays_reference_trace(emu_lib, tag):
     print(pc.check_detector_trace(emu_lib, "cpu", tag))
 
 
+@pytest.mark.slow
+def test_nuscenes_run_replays_reference_trace(emu_lib):
+    """BASELINE configs[4]: the reference's nuScenes Detector.run, traced, replayed up to the per-class tracker calls."""
+    print(pc.check_detector_trace_nuscenes(emu_lib, "cpu"))
+
+
 def test_preprocess_u8(emu_lib):
     pc.check_preprocess_u8(emu_lib, "cpu")
 

@@ -546,6 +546,15 @@ def test_composed_dropin_replays_reference_trace(gpu_lib, tag):
     print(worst)
 
 
+def test_nuscenes_run_replays_reference_trace(gpu_lib):
+    """BASELINE configs[4] on the hardware: tests/golden/detector_trace_nuscenes.npz (the reference's own nuScenes `Detector.run`, traced)
+    replayed on cuda:0 -- process(), the vectorised post-processing + class thresholds + quaternion / Box chain + per-class NMS against the
+    arguments of every per-class `Tracker.update` call, every embedding call, and the batched 3-D LSTM motion update."""
+    worst = pc.check_detector_trace_nuscenes(gpu_lib, "cuda")
+    torch.cuda.synchronize()
+    print(worst)
+
+
 def test_preprocess_u8(gpu_lib):
     """uint8 frame -> warp + normalise + NHWC on the device, exact against the numpy restatement."""
     pc.check_preprocess_u8(gpu_lib, "cuda")
