@@ -122,6 +122,10 @@ __device__ __forceinline__ void deft_ws_reset(int* p) { __hip_atomic_store(p, 0,
 #ifndef DEFT_OPAQUE            /* the unit-test SIMT emulator pre-defines this hook */
 #define DEFT_OPAQUE(v) asm volatile("" : "+v"(v))
 #endif
+// the same without pinning the statement's place among the other asm statements (the scheduler may still move it)
+#ifndef DEFT_OPAQUE_NV
+#define DEFT_OPAQUE_NV(v) asm("" : "+v"(v))
+#endif
 
 // 1 / x to one ulp (v_rcp_f32) instead of the IEEE division sequence
 #ifndef DEFT_FAST_RCP          /* the unit-test SIMT emulator pre-defines this hook */

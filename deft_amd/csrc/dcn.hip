@@ -316,9 +316,11 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], x1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
-            const unsigned h = dcnp_cvt_pk(x0, x1);
+            unsigned h = dcnp_cvt_pk(x0, x1);
+            DEFT_OPAQUE_NV(h);                   // (otherwise the compiler converts the low element a second time instead of shifting the pair)
             const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-            const unsigned m = dcnp_cvt_pk(r0, r1);
+            unsigned m = dcnp_cvt_pk(r0, r1);
+            DEFT_OPAQUE_NV(m);
             const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
             ph[e] = h; pm[e] = m; pl[e] = dcnp_cvt_pk(s0, s1);
         }

@@ -467,6 +467,7 @@ static inline void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* lds_wave_base, 
 #define DEFT_WAIT_VM(N) hipemu::dma_wait(N)
 extern "C" __attribute__((weak, visibility("default"))) void hipemu_set_late_dma(int on) { hipemu::late_dma() = on; }
 #define DEFT_OPAQUE(v) ((void)(v))
+#define DEFT_OPAQUE_NV(v) ((void)(v))
 #define DEFT_FAST_RCP(x) (1.0f / (x))
 #define DEFT_RINT_HOOK 1
 static inline int deft_rint(double v) { return (int)std::nearbyint(v); }
