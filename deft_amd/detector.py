@@ -13,6 +13,14 @@ import torch
 from . import engine, hiplib
 
 
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class Detector(object):
     def __init__(self, opt, state_dict=None):
         """opt: the reference's argparse namespace (opts.py); fields used: dataset, K,
@@ -37,6 +45,8 @@ class Detector(object):
         self.tracker = None            # set_tracker(): the reference's Tracker (or {class: Tracker} for nuScenes), detector.py:102-107
         self.times = {}                # stage seconds of the last run(), under the reference's names (detector.py:113-114, 340-344)
         self._u8 = {}                  # (sh, sw) -> plan switched to uint8 input (deft_preprocess_u8)
+        self._ahead = {}               # (inp_h, inp_w, sh, sw) -> the two _Slot objects of run(..., prefetch=): frame k+1's network beside frame k's tracker
+        self._ahead_turn = 0
 
     def set_tracker(self, tracker):
         """The object `run()` hands the frame's detections to: `utils.tracker.Tracker(opt, model, h, w)` of the reference (bind
@@ -119,7 +129,7 @@ class Detector(object):
                 meta[k] = input_meta[k]
         return meta
 
-    def run(self, image_or_path_or_tensor, meta={}, image_info=None, nms=True):
+    def run(self, image_or_path_or_tensor, meta={}, image_info=None, nms=True, prefetch=None):
         """detector.py:112-344 -- same argument forms, same return value (`Tracker.update`'s online targets; the post-processed
         `results` when no tracker is set), same stage timers (self.times: load / pre / net / dec / post / merge / track / tot):
           * numpy uint8 HWC frame (cv2 channel order): warp + normalise + layout ON THE DEVICE (deft_preprocess_u8, fix_res mode),
@@ -127,7 +137,11 @@ class Detector(object):
           * the prefetch-loader dict of src/test.py:106-112, 213 ({"image", "images": {scale: [tensor]}, "meta": {scale: {...}}});
           * a path: read with cv2 when that is importable (it is not in this image).
         Then process() -> post_process() -> merge_outputs() -> nuScenes branch / `self.tracker.update(results, FeatureMaps)`.
-        One test scale, no flip test (asserted like detector.py:578)."""
+        One test scale, no flip test (asserted like detector.py:578).
+        prefetch: the NEXT uint8 frame of the stream (same size), if the caller has it already: its network pass is queued on a second
+        set of plan buffers BEFORE this frame's post-processing and tracker run, so the GPU works on frame k+1 while the host associates
+        frame k (the reference's loop is strictly serial: detector.py:112-344).  The next run() call must pass that same array; results
+        are identical to the serial order (tests/parity_checks.check_fused_run_prefetch)."""
         import time
         opt = self.opt
         scales = list(getattr(opt, "test_scales", [1.0]))
@@ -152,14 +166,19 @@ class Detector(object):
             inp_h, inp_w = int(getattr(opt, "input_h", 0)), int(getattr(opt, "input_w", 0))
             assert inp_h > 0 and inp_w > 0, "the device pre-processing is the fix_res mode (opt.input_h / input_w)"
             meta = self._meta_for(sh, sw, inp_h, inp_w, meta)
-            plan = self._plan(1, inp_h, inp_w)
-            if self._u8.get((inp_h, inp_w)) != (sh, sw):
-                plan.use_u8_input(sh, sw)
-                self._u8[(inp_h, inp_w)] = (sh, sw)
-                self._graphs.pop((1, inp_h, inp_w), None)
-            src = torch.from_numpy(np.ascontiguousarray(frame)).unsqueeze(0)
-            t_pre = time.time()
-            output, dets, t_fwd, fmaps = self._process_u8(plan, src)
+            akey = (inp_h, inp_w, sh, sw)
+            if prefetch is not None or any(sl.frame is frame for sl in self._ahead.get(akey, ())):
+                t_pre = time.time()
+                output, dets, t_fwd, fmaps = self._process_ahead(akey, frame, prefetch)
+            else:
+                plan = self._plan(1, inp_h, inp_w)
+                if self._u8.get((inp_h, inp_w)) != (sh, sw):
+                    plan.use_u8_input(sh, sw)
+                    self._u8[(inp_h, inp_w)] = (sh, sw)
+                    self._graphs.pop((1, inp_h, inp_w), None)
+                src = torch.from_numpy(np.ascontiguousarray(frame)).unsqueeze(0)
+                t_pre = time.time()
+                output, dets, t_fwd, fmaps = self._process_u8(plan, src)
         else:
             d = image_or_path_or_tensor
             images = d["images"][scale][0]
@@ -210,6 +229,72 @@ class Detector(object):
             d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
         dets = {k: v.detach().cpu().numpy() for k, v in d.items()}
         return {"hm": plan.dense["hm"], "pre_inds": None}, dets, time.time(), plan.fmaps
+
+    # ---- one frame of lookahead: two sets of plan buffers, frame k+1's network pass beside frame k's host work ---------------------------
+    class _Slot:
+        def __init__(self, det, inp_h, inp_w, sh, sw):
+            self.plan = engine.DlaSegPlan(det.sd, 1, inp_h, inp_w, det.dataset, K=det.K, device=det.device, lib=det.lib)
+            self.plan.use_u8_input(sh, sw)
+            cuda = det.device.type == "cuda"
+            self.stage = torch.empty(1, sh, sw, 3, dtype=torch.uint8, pin_memory=cuda)
+            self.graph, self.warm, self.frame, self.host = None, False, None, None
+            self.done = torch.cuda.Event() if cuda else None
+
+    def _launch_ahead(self, sl, frame):
+        """Queue frame -> detections on slot `sl` (its own stream): staging copy, H2D, the plan (hipGraph from the second use), one D2H
+        of every decoded field into pinned memory, an event.  Returns without waiting."""
+        p = sl.plan
+        sl.stage[0].copy_(torch.from_numpy(np.ascontiguousarray(frame)))
+        cuda = self.device.type == "cuda"
+        if cuda:
+            if not hasattr(self, "_net_stream"):
+                self._net_stream = torch.cuda.Stream(device=self.device)
+                self._trk_done = torch.cuda.Event()
+            main = torch.cuda.current_stream(self.device)
+            self._trk_done.record(main)
+            self._net_stream.wait_event(self._trk_done)            # whatever read this slot's feature maps (two frames ago) is finished
+            if self.hip_graphs and sl.warm and sl.graph is None:
+                sl.graph = p.capture_graph()
+        ctx = torch.cuda.stream(self._net_stream) if cuda else _null()
+        with ctx:
+            if sl.graph is not None:
+                p.image_u8.copy_(sl.stage, non_blocking=True)
+                sl.graph.replay()
+            else:
+                p.forward_u8(sl.stage.to(self.device, non_blocking=True))
+                sl.warm = True
+            d = p.dets()
+            if "dep" in d:
+                d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
+            if sl.host is None:
+                sl.host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=cuda) for k, v in d.items()}
+            for k, v in d.items():
+                sl.host[k].copy_(v.detach(), non_blocking=True)
+            if cuda:
+                sl.done.record(self._net_stream)
+        sl.frame = frame
+
+    def _process_ahead(self, akey, frame, prefetch):
+        import time
+        if akey not in self._ahead:
+            self._ahead[akey] = [Detector._Slot(self, *akey), Detector._Slot(self, *akey)]
+        slots = self._ahead[akey]
+        cur = next((sl for sl in slots if sl.frame is frame), None)
+        if cur is None:                                                # not announced by the previous call: launch it now
+            cur = slots[self._ahead_turn]
+            self._launch_ahead(cur, frame)
+        self._ahead_turn = 1 - slots.index(cur)
+        if cur.done is not None:
+            cur.done.synchronize()
+        dets = {k: v.numpy().copy() for k, v in cur.host.items()}      # (the pinned buffers are rewritten two frames on)
+        cur.frame = None
+        if cur.done is not None:
+            torch.cuda.current_stream(self.device).wait_event(cur.done)    # the tracker's launches read this slot's feature maps
+        t_fwd = time.time()
+        if prefetch is not None:
+            assert prefetch.dtype == np.uint8 and prefetch.shape == frame.shape, "prefetch: the next frame of the same stream"
+            self._launch_ahead(slots[self._ahead_turn], prefetch)
+        return {"hm": cur.plan.dense["hm"], "pre_inds": None}, dets, t_fwd, cur.plan.fmaps
 
     def reset_tracking(self, opt):
         """detector.py:677-686 (the recorder mirror lives in deft_amd.tracker)."""

@@ -1395,6 +1395,55 @@ def check_device_detect(lib, device, dataset="mot", H=64, W=96, K=20, first_n=9,
     return n_res, n_sel
 
 
+def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9, T=6):
+    """Detector.run(frame, prefetch=next frame): frame k+1's network pass is queued on a second set of plan buffers before frame k's
+    post-processing and tracker run.  Same detections as the serial order, and the tracker sees the FeatureMaps of ITS frame (checksums
+    taken inside update(), i.e. while the next frame's pass may already be running); a caller that announces one frame and then passes
+    another gets the frame it passed."""
+    from types import SimpleNamespace
+    from deft_amd import hiplib
+    from deft_amd.detector import Detector
+    sd = O.synth_state_dict("mot")
+    saved_lib, hiplib._lib = hiplib._lib, lib
+    try:
+        opt = SimpleNamespace(dataset="mot", K=K, max_object=100, gpus=[0 if device != "cpu" else -1], hip_graphs=True, depth_scale=1.0,
+                              input_h=H, input_w=W, out_thresh=-1.0, test_scales=[1.0], flip_test=False, public_det=False)
+        g = torch.Generator().manual_seed(seed)
+        frames = [torch.randint(0, 256, (sh, sw, 3), dtype=torch.uint8, generator=g).numpy() for _ in range(T)]
+
+        det = Detector(opt, sd)                         # one detector: the serial calls use its plan, the lookahead calls its two slots
+        log = []
+
+        class Trk:
+            def update(self, results, fmaps):
+                sums = [float(fm.buf.double().sum().item()) for fm in (fmaps[0], fmaps[6], fmaps[-1])]
+                log.append(([(int(r["class"]), float(r["score"]), tuple(float(v) for v in r["bbox"])) for r in results], sums))
+                return []
+        det.set_tracker(Trk())
+
+        def stream(lookahead, order):
+            del log[:]
+            for i, k in enumerate(order):
+                nxt = frames[order[i + 1]] if lookahead and i + 1 < len(order) else None
+                det.run(frames[k], prefetch=nxt)
+            return list(log)
+
+        order = list(range(T))
+        serial = stream(False, order)
+        ahead = stream(True, order)
+        assert len(serial) == len(ahead) == len(order)
+        for a, b in zip(serial, ahead):
+            assert a == b
+        assert len({tuple(x[1]) for x in serial[:T]}) == T               # the frames really differ
+        # announce frame 1, then pass frame 3: the announced pass is dropped, frame 3 is what gets processed
+        del log[:]
+        det.run(frames[0], prefetch=frames[1])
+        det.run(frames[T - 1], prefetch=None)
+        assert len(log) == 2 and log[0] == serial[0] and log[1] == serial[T - 1]
+    finally:
+        hiplib._lib = saved_lib
+
+
 def check_fused_run_u8(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=4):
     """deft_amd.detector.Detector.run on a raw uint8 frame (device pre-processing -> fused process -> vectorised post-process ->
     merge -> tracker hand-over) against the same stages fed by the host restatement of Detector.pre_process (oracle.preprocess_u8:

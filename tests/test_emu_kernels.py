@@ -367,6 +367,10 @@ def test_nuscenes_run_replays_reference_trace(emu_lib):
     print(pc.check_detector_trace_nuscenes(emu_lib, "cpu"))
 
 
+def test_fused_run_with_lookahead(emu_lib):
+    pc.check_fused_run_prefetch(emu_lib, "cpu", sh=30, sw=50, H=32, W=64, K=8, T=3)
+
+
 def test_preprocess_u8(emu_lib):
     pc.check_preprocess_u8(emu_lib, "cpu")
 

@@ -571,6 +571,12 @@ def test_fused_detector_run_on_uint8_frames(gpu_lib):
     pc.check_fused_run_u8(gpu_lib, "cuda", sh=270, sw=480, H=128, W=160, K=50)
 
 
+def test_fused_run_with_lookahead(gpu_lib):
+    """Detector.run(frame, prefetch=next): two plan buffer sets, frame k+1's hipGraph beside frame k's tracker -- identical to the serial order."""
+    pc.check_fused_run_prefetch(gpu_lib, "cuda")
+    pc.check_fused_run_prefetch(gpu_lib, "cuda", sh=270, sw=480, H=160, W=288, K=50, T=8)
+
+
 def test_frame_feeder_with_side_streams(gpu_lib):
     """FrameFeeder (pinned double buffer, copy stream) feeding the multi-stream HipCompute: every step's frames are different, and the
     side streams must see THIS step's H2D copy (the round-2 advisor's race: they waited only on the previous step's event).  Two
