@@ -13,6 +13,10 @@ import torch
 from . import engine, hiplib
 
 
+import os as _os
+PRIORITY_TRACKER = _os.environ.get("DEFT_TRACKER_PRIORITY", "1") != "0"      # run(prefetch=): the tracker's launches on a high-priority stream
+
+
 class _null:
     def __enter__(self):
         return self
@@ -195,14 +199,35 @@ class Detector(object):
         t_merge = time.time()
         if getattr(opt, "public_det", False) and pre_processed:
             results = image_or_path_or_tensor["meta"]["cur_dets"]                     # detector.py:190-196
+        # the lookahead pass of the NEXT frame (prefetch=): a tracker that says when its device work is over (mot_tracker.Tracker2D:
+        # after the similarity medians, ~40 % into update()) gets it queued at that point, so the pass overlaps the host-only rest of the
+        # association instead of competing with the tracker's own launches; any other tracker gets it queued up front
+        nxt, self._launch_next = getattr(self, "_launch_next", None), None
+        hook = nxt is not None and self.tracker is not None and self.dataset != "nuscenes" and hasattr(self.tracker, "after_device_work")
+        if nxt is not None and not hook:
+            nxt()
         if self.tracker is None:
             targets = results
+        elif hook:
+            self.tracker.after_device_work = nxt
+            targets = self.tracker.update(results, fmaps)
+            if self.tracker.after_device_work is not None:             # (update() returned early)
+                self.tracker.after_device_work = None
+                nxt()
         elif self.dataset == "nuscenes":
             per_class = self.nuscenes_targets(results, image_info, nms=nms)            # detector.py:198-338
             targets = []
             for name, a in per_class.items():
                 targets += self.tracker[name].update(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"],
                                                      ddd_org_boxes=a["ddd_org_boxes"], submission=a["submission"], classe=name)
+        elif getattr(self, "_trk_stream", None) is not None and self._ahead_busy():
+            # the next frame's network pass is running beside us: the tracker's many small launches go to a HIGH-priority stream, so that
+            # they are dispatched ahead of the pass's workgroups instead of queueing behind them
+            main = torch.cuda.current_stream(self.device)
+            self._trk_stream.wait_stream(main)
+            with torch.cuda.stream(self._trk_stream):
+                targets = self.tracker.update(results, fmaps)
+            main.wait_stream(self._trk_stream)
         else:
             targets = self.tracker.update(results, fmaps)                              # detector.py:340-342
         t_end = time.time()
@@ -237,6 +262,8 @@ class Detector(object):
             self.plan.use_u8_input(sh, sw)
             cuda = det.device.type == "cuda"
             self.stage = torch.empty(1, sh, sw, 3, dtype=torch.uint8, pin_memory=cuda)
+            self.stage_np = self.stage[0].numpy()
+            self.fields = None
             self.graph, self.warm, self.frame, self.host = None, False, None, None
             self.done = torch.cuda.Event() if cuda else None
 
@@ -244,12 +271,13 @@ class Detector(object):
         """Queue frame -> detections on slot `sl` (its own stream): staging copy, H2D, the plan (hipGraph from the second use), one D2H
         of every decoded field into pinned memory, an event.  Returns without waiting."""
         p = sl.plan
-        sl.stage[0].copy_(torch.from_numpy(np.ascontiguousarray(frame)))
+        np.copyto(sl.stage_np, frame)                  # (a plain memcpy: torch's multi-threaded CPU copy_ stalls for milliseconds next to the tracker's BLAS threads)
         cuda = self.device.type == "cuda"
         if cuda:
             if not hasattr(self, "_net_stream"):
                 self._net_stream = torch.cuda.Stream(device=self.device)
                 self._trk_done = torch.cuda.Event()
+                self._trk_stream = torch.cuda.Stream(device=self.device, priority=-1) if PRIORITY_TRACKER else None
             main = torch.cuda.current_stream(self.device)
             self._trk_done.record(main)
             self._net_stream.wait_event(self._trk_done)            # whatever read this slot's feature maps (two frames ago) is finished
@@ -266,13 +294,18 @@ class Detector(object):
             d = p.dets()
             if "dep" in d:
                 d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
+            # every decoded field in ONE contiguous record (float64 holds the int64 indices exactly), ONE D2H into pinned memory
+            flat = torch.cat([v.detach().reshape(-1).double() for v in d.values()])
             if sl.host is None:
-                sl.host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=cuda) for k, v in d.items()}
-            for k, v in d.items():
-                sl.host[k].copy_(v.detach(), non_blocking=True)
+                sl.host = torch.empty(flat.shape, dtype=torch.float64, pin_memory=cuda)
+                sl.fields = [(k, tuple(v.shape), v.numel(), v.detach().cpu().numpy().dtype) for k, v in d.items()]
+            sl.host.copy_(flat, non_blocking=True)
             if cuda:
                 sl.done.record(self._net_stream)
         sl.frame = frame
+
+    def _ahead_busy(self):
+        return any(sl.frame is not None for slots in self._ahead.values() for sl in slots)
 
     def _process_ahead(self, akey, frame, prefetch):
         import time
@@ -286,14 +319,19 @@ class Detector(object):
         self._ahead_turn = 1 - slots.index(cur)
         if cur.done is not None:
             cur.done.synchronize()
-        dets = {k: v.numpy().copy() for k, v in cur.host.items()}      # (the pinned buffers are rewritten two frames on)
+        rec, dets, o = cur.host.numpy(), {}, 0                         # (the pinned record is rewritten two frames on: copies)
+        for k, shape, n, dt in cur.fields:
+            dets[k] = rec[o:o + n].astype(dt).reshape(shape)
+            o += n
         cur.frame = None
         if cur.done is not None:
             torch.cuda.current_stream(self.device).wait_event(cur.done)    # the tracker's launches read this slot's feature maps
         t_fwd = time.time()
+        self._launch_next = None
         if prefetch is not None:
             assert prefetch.dtype == np.uint8 and prefetch.shape == frame.shape, "prefetch: the next frame of the same stream"
-            self._launch_ahead(slots[self._ahead_turn], prefetch)
+            nxt = slots[self._ahead_turn]
+            self._launch_next = lambda: self._launch_ahead(nxt, prefetch)     # run() decides when: see there
         return {"hm": cur.plan.dense["hm"], "pre_inds": None}, dets, t_fwd, cur.plan.fmaps
 
     def reset_tracking(self, opt):

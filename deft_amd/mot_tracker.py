@@ -198,6 +198,14 @@ class Tracker2D:
                 matched_out.append(t)
         return u_t, u_d
 
+    after_device_work = None       # set by a caller (Detector.run's lookahead): called ONCE per update(), as soon as the frame's last
+    #                                device-dependent step has returned -- what follows is host work, and the GPU is free for the next frame
+
+    def _device_done(self):
+        cb, self.after_device_work = self.after_device_work, None
+        if cb is not None:
+            cb()
+
     def update(self, results, FeatureMaps):
         """tracker.py:726-1056 (2-D branch, Kalman).  results: the frame's post-processed detections ({"bbox" tlbr, "score", "class"});
         FeatureMaps: the 13 maps of the frame.  Returns the tracks matched or started in this frame."""
@@ -233,6 +241,8 @@ class Tracker2D:
         dists = np.zeros((len(pool), nd0), dtype=float)
         if dists.size:
             dists = 1 - self.get_similarity(fid, pool, nd0)[:, :-1]
+        if self.dataset != "kitti_tracking":
+            self._device_done()
         dists = A.fuse_motion(None, dists, pool, detections, frame_id=fid, use_lstm=False)
         u_track, u_det2 = self._match(dists, 0.9, pool, detections, fid, output, activated)
         r_tracked = [pool[i] for i in u_track]
@@ -244,6 +254,7 @@ class Tracker2D:
                 u_track, u_det = self._match(dists, 0.9, r_tracked, detections, fid, output, activated)
                 detections = [detections[i] for i in u_det]
                 pool = r_tracked
+        self._device_done()
         if self.dataset == "kitti_tracking":
             r_tracked = [pool[i] for i in u_track if abs(fid - pool[i].frame_id) < 6]            # tracker.py:982-990
         else:

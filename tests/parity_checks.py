@@ -1395,7 +1395,7 @@ def check_device_detect(lib, device, dataset="mot", H=64, W=96, K=20, first_n=9,
     return n_res, n_sel
 
 
-def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9, T=6):
+def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9, T=6, hook=False):
     """Detector.run(frame, prefetch=next frame): frame k+1's network pass is queued on a second set of plan buffers before frame k's
     post-processing and tracker run.  Same detections as the serial order, and the tracker sees the FeatureMaps of ITS frame (checksums
     taken inside update(), i.e. while the next frame's pass may already be running); a caller that announces one frame and then passes
@@ -1417,8 +1417,15 @@ def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9
         class Trk:
             def update(self, results, fmaps):
                 sums = [float(fm.buf.double().sum().item()) for fm in (fmaps[0], fmaps[6], fmaps[-1])]
+                if hook:                       # a tracker that announces the end of its device work (mot_tracker.Tracker2D): the next frame's
+                    cb, self.after_device_work = self.after_device_work, None      # pass is queued HERE -- this frame's maps stay what they are
+                    if cb is not None:
+                        cb()
+                    assert sums == [float(fm.buf.double().sum().item()) for fm in (fmaps[0], fmaps[6], fmaps[-1])]
                 log.append(([(int(r["class"]), float(r["score"]), tuple(float(v) for v in r["bbox"])) for r in results], sums))
                 return []
+        if hook:
+            Trk.after_device_work = None
         det.set_tracker(Trk())
 
         def stream(lookahead, order):

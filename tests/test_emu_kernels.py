@@ -368,7 +368,7 @@ def test_nuscenes_run_replays_reference_trace(emu_lib):
 
 
 def test_fused_run_with_lookahead(emu_lib):
-    pc.check_fused_run_prefetch(emu_lib, "cpu", sh=30, sw=50, H=32, W=64, K=8, T=3)
+    pc.check_fused_run_prefetch(emu_lib, "cpu", sh=30, sw=50, H=32, W=64, K=8, T=3, hook=True)
 
 
 def test_preprocess_u8(emu_lib):

@@ -575,6 +575,7 @@ def test_fused_run_with_lookahead(gpu_lib):
     """Detector.run(frame, prefetch=next): two plan buffer sets, frame k+1's hipGraph beside frame k's tracker -- identical to the serial order."""
     pc.check_fused_run_prefetch(gpu_lib, "cuda")
     pc.check_fused_run_prefetch(gpu_lib, "cuda", sh=270, sw=480, H=160, W=288, K=50, T=8)
+    pc.check_fused_run_prefetch(gpu_lib, "cuda", sh=270, sw=480, H=160, W=288, K=50, T=8, hook=True)
 
 
 def test_frame_feeder_with_side_streams(gpu_lib):
