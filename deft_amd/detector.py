@@ -17,6 +17,26 @@ import os as _os
 PRIORITY_TRACKER = _os.environ.get("DEFT_TRACKER_PRIORITY", "1") != "0"      # run(prefetch=): the tracker's launches on a high-priority stream
 
 
+def _fetch(d):
+    """{name: device tensor} -> {name: numpy array} with ONE device->host copy (the fields of a decoded frame are ten small tensors: ten
+    copies are ten stream synchronisations).  float64 holds every field exactly (float32 values, int64 indices < 2^53)."""
+    if not d:
+        return {}
+    ref = next(iter(d.values()))
+    if ref.device.type == "cpu":
+        return {k: v.detach().numpy() for k, v in d.items()}
+    flat = torch.cat([v.detach().reshape(-1).double() for v in d.values()]).cpu().numpy()
+    out, o = {}, 0
+    for k, v in d.items():
+        n = v.numel()
+        out[k] = flat[o:o + n].astype(_NP[v.dtype]).reshape(tuple(v.shape))
+        o += n
+    return out
+
+
+_NP = {torch.float32: np.float32, torch.float64: np.float64, torch.int64: np.int64, torch.int32: np.int32}
+
+
 class _null:
     def __enter__(self):
         return self
@@ -85,7 +105,7 @@ class Detector(object):
         d = plan.dets()
         if "dep" in d:      # _sigmoid_output, detector.py:491-493, applied at the K peaks
             d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
-        dets = {k: v.detach().cpu().numpy() for k, v in d.items()}
+        dets = _fetch(d)
         output = {"hm": plan.dense["hm"], "pre_inds": pre_inds}
         if return_time:
             import time
@@ -252,7 +272,7 @@ class Detector(object):
         d = plan.dets()
         if "dep" in d:
             d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
-        dets = {k: v.detach().cpu().numpy() for k, v in d.items()}
+        dets = _fetch(d)
         return {"hm": plan.dense["hm"], "pre_inds": None}, dets, time.time(), plan.fmaps
 
     # ---- one frame of lookahead: two sets of plan buffers, frame k+1's network pass beside frame k's host work ---------------------------
@@ -298,7 +318,7 @@ class Detector(object):
             flat = torch.cat([v.detach().reshape(-1).double() for v in d.values()])
             if sl.host is None:
                 sl.host = torch.empty(flat.shape, dtype=torch.float64, pin_memory=cuda)
-                sl.fields = [(k, tuple(v.shape), v.numel(), v.detach().cpu().numpy().dtype) for k, v in d.items()]
+                sl.fields = [(k, tuple(v.shape), v.numel(), _NP[v.dtype]) for k, v in d.items()]
             sl.host.copy_(flat, non_blocking=True)
             if cuda:
                 sl.done.record(self._net_stream)
