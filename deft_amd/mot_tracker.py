@@ -113,11 +113,14 @@ def tlwh_to_xyah(tlwh):
 class Track:
     """STrack (tracker.py:140-306) for the Kalman configuration: the fields `Tracker.update`, the result writers (src/test.py:226-258)
     and deft_amd.association read."""
-    __slots__ = ("_tlwh", "mean", "covariance", "is_activated", "score", "tracklet_len", "nodes", "track_id", "state", "frame_id",
-                 "start_frame")
+    __slots__ = ("_tlwh", "_xyah", "_tlbr", "mean", "covariance", "is_activated", "score", "tracklet_len", "nodes", "track_id", "state",
+                 "frame_id", "start_frame")
 
-    def __init__(self, tlwh, score, node):
+    def __init__(self, tlwh, score, node, xyah=None, tlbr=None):
+        """xyah / tlbr: the detection's (x, y, a, h) and corner forms when the caller has computed them for the whole frame at once (the
+        same float64 expressions as to_xyah() / .tlbr below, row by row); they describe the detection, i.e. hold until a filter state exists."""
         self._tlwh = np.asarray(tlwh, dtype=float)
+        self._xyah, self._tlbr = xyah, tlbr
         self.mean = self.covariance = None
         self.is_activated = False
         self.score = score
@@ -138,11 +141,15 @@ class Track:
 
     @property
     def tlbr(self):
+        if self.mean is None and self._tlbr is not None:
+            return self._tlbr.copy()
         r = self.tlwh
         r[2:] += r[:2]
         return r
 
     def to_xyah(self):
+        if self.mean is None and self._xyah is not None:
+            return self._xyah.copy()
         return tlwh_to_xyah(self.tlwh)
 
     def __repr__(self):
@@ -214,7 +221,15 @@ class Tracker2D:
         activated, removed, output = [], [], []
         dets = self._rows(results)
         if len(dets) > 0:
-            detections = [Track(tlbr_to_tlwh(r[:4]), r[4], Node(fid, i)) for i, r in enumerate(dets[:, :5])]
+            tlwh32 = dets[:, :4].copy()                                   # STrack.tlbr_to_tlwh: float32 differences, widened afterwards
+            tlwh32[:, 2:] -= tlwh32[:, :2]
+            tlwh = tlwh32.astype(float)
+            xyah = tlwh.copy()                                            # to_xyah / tlbr of every detection at once (same float64 expressions)
+            xyah[:, :2] += xyah[:, 2:] / 2
+            xyah[:, 2] /= xyah[:, 3]
+            tlbr = tlwh.copy()
+            tlbr[:, 2:] += tlbr[:, :2]
+            detections = [Track(tlwh[i], dets[i, 4], Node(fid, i), xyah[i], tlbr[i]) for i in range(len(dets))]
             org = np.copy(dets[:, :4])
             d = np.array(org, dtype=np.float64)                           # convert_detection, image.py:391-412
             d[:, 2] -= d[:, 0]; d[:, 3] -= d[:, 1]

@@ -105,8 +105,12 @@ max_track_node = 50        # tracker.py:26
 def select_nodes(nodes, frame_index, dataset):
     """The rows STrack.get_similarity medians over (tracker.py:221-248): nodes younger than max_track_node
     frames; all of them while there are at most mm+1, else the last mm (mm = 2 nuScenes, 4 otherwise)."""
-    sel = [n for n in nodes if frame_index - n.frame_index < max_track_node]
     mm = 2 if dataset == "nuscenes" else 4
+    if len(nodes) > mm + 2 and all(frame_index - n.frame_index < max_track_node for n in nodes[-(mm + 2):]):
+        # the last mm + 2 nodes are all young enough: more than mm + 1 qualify, so the answer is the last mm of the qualifying ones = the
+        # last mm nodes -- without walking a list that holds the whole life of the track
+        return nodes[-mm:]
+    sel = [n for n in nodes if frame_index - n.frame_index < max_track_node]
     return sel if len(sel) <= mm + 1 else sel[len(sel) - mm:]
 
 
