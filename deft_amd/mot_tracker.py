@@ -205,6 +205,7 @@ class Tracker2D:
                 matched_out.append(t)
         return u_t, u_d
 
+    lazy_blocks = True             # score the new frame only against the stored frames the pool's selected nodes live in (FeatureRecorder.update)
     after_device_work = None       # set by a caller (Detector.run's lookahead): called ONCE per update(), as soon as the frame's last
     #                                device-dependent step has returned -- what follows is host work, and the GPU is free for the next frame
 
@@ -220,6 +221,7 @@ class Tracker2D:
         fid = self.frame_id
         activated, removed, output = [], [], []
         dets = self._rows(results)
+        pool = list(self.tracked_stracks) + [t for t in self.lost_stracks if t.track_id not in {x.track_id for x in self.tracked_stracks}]
         if len(dets) > 0:
             tlwh32 = dets[:, :4].copy()                                   # STrack.tlbr_to_tlwh: float32 differences, widened afterwards
             tlwh32[:, 2:] -= tlwh32[:, :2]
@@ -237,10 +239,11 @@ class Tracker2D:
             import torch
             centers = torch.from_numpy(((2 * d[:, 0:2] + d[:, 2:4]) - 1.0).astype(float)).float().view(1, -1, 1, 1, 2)
             feats = self.model.AFE.forward_feature_extracter(FeatureMaps, centers)
-            self.recorder.update(self.model, fid, feats.data, org)
+            # only the stored frames the association below can read: those holding one of the last few nodes of a pooled track
+            needed = {n.frame_index for t in pool for n in DT.select_nodes(t.nodes, fid, self.dataset)} if self.lazy_blocks else None
+            self.recorder.update(self.model, fid, feats.data, org, needed=needed)
         else:
             detections = []
-        pool = list(self.tracked_stracks) + [t for t in self.lost_stracks if t.track_id not in {x.track_id for x in self.tracked_stracks}]
         if pool:                                                           # STrack.multi_predict, tracker.py:193-207
             mean = np.stack([t.mean for t in pool]); cov = np.stack([t.covariance for t in pool])
             if any(t.state != TRACKED for t in pool):

@@ -40,8 +40,11 @@ class FeatureRecorder:
     def _m_frame(self):
         return {"kitti_tracking": 5, "nuscenes": 3}.get(self.dataset, 10)      # tracker.py:77-82
 
-    def update(self, model, frame_index, features, boxes):
-        """tracker.py:59-90.  features [1,N,D] (device tensor from forward_feature_extracter)."""
+    def update(self, model, frame_index, features, boxes, needed=None):
+        """tracker.py:59-90.  features [1,N,D] (device tensor from forward_feature_extracter).
+        needed: the stored frames whose blocks this frame's association will read (a caller that knows its track pool: the frames of
+        the pool's selected nodes) -- the reference scores the new frame against ALL (up to 49) stored frames, but `get_similarity` only
+        ever reads the blocks of frames in which a live track has one of its last few nodes; the others are skipped, result-identical."""
         if frame_index in self.all_frame_index:
             return
         if len(self.all_frame_index) == self.max_record_frame:
@@ -55,7 +58,10 @@ class FeatureRecorder:
         self.all_boxes[frame_index] = boxes
         self.all_similarity[frame_index] = {}
         prev = [int(p) for p in self.all_frame_index[:-1]]
+        if needed is not None:
+            prev = [p for p in prev if p in needed]
         if not prev:
+            self._dev = None
             return
         if not hasattr(model.AFE, "affinity_many"):
             raise TypeError("deft_amd.tracker.FeatureRecorder needs deft_amd.integrate.AfeSeam as model.AFE")
