@@ -164,7 +164,8 @@ class Detector(object):
         One test scale, no flip test (asserted like detector.py:578).
         prefetch: the NEXT uint8 frame of the stream (same size), if the caller has it already: its network pass is queued on a second
         set of plan buffers BEFORE this frame's post-processing and tracker run, so the GPU works on frame k+1 while the host associates
-        frame k (the reference's loop is strictly serial: detector.py:112-344).  The next run() call must pass that same array; results
+        frame k (the reference's loop is strictly serial: detector.py:112-344).  The next run() call must pass that same array object,
+        unmodified (its pixels are copied when the pass is queued; a different array simply drops the queued pass); results
         are identical to the serial order (tests/parity_checks.check_fused_run_prefetch)."""
         import time
         opt = self.opt
