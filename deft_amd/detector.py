@@ -288,6 +288,13 @@ class Detector(object):
             self.graph, self.warm, self.frame, self.host = None, False, None, None
             self.done = torch.cuda.Event() if cuda else None
 
+        def __del__(self):                       # a queued pass (announced, never consumed) must not outlive its graph and buffers
+            try:
+                if self.done is not None and self.frame is not None:
+                    self.done.synchronize()
+            except Exception:
+                pass
+
     def _launch_ahead(self, sl, frame):
         """Queue frame -> detections on slot `sl` (its own stream): staging copy, H2D, the plan (hipGraph from the second use), one D2H
         of every decoded field into pinned memory, an event.  Returns without waiting."""

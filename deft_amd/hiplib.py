@@ -177,6 +177,9 @@ def get_lib():
             # explicitly (hiplib.load / the `lib=` arguments), an environment variable alone must not select it
             raise DeftHipError("%s is the host-memory test build of the kernels, not libdeft_hip.so (deft_amd has no CPU path)" % lib.path)
         _lib = lib
+        if not lib.host_pointers:
+            import atexit
+            atexit.register(_idle_at_exit)
     return _lib
 
 
@@ -186,6 +189,16 @@ def ptr(t):
         return None
     assert t.dtype in (torch.float32, torch.int32, torch.float64, torch.uint8), t.dtype
     return C.c_void_p(t.data_ptr())
+
+
+def _idle_at_exit():
+    """Interpreter shutdown with launches, graph replays or copies still in flight tears down streams, graphs and pinned buffers under
+    them: wait for the device first (registered when the library is first loaded on a GPU)."""
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
 
 
 def stream_ptr(device):

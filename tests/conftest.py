@@ -9,6 +9,20 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """Leave nothing of the GPU tests for interpreter shutdown: plans, hipGraphs, side streams and pinned buffers are released, and the
+    device is idle, while the HIP runtime is still fully alive (graph / stream destructors running during runtime teardown are not a
+    thing to depend on)."""
+    import gc
+    if "torch" in sys.modules:
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU emulation test")
