@@ -449,9 +449,10 @@ class _Plan:
             sc["events"] = {j: torch.cuda.Event() for j in sc["signals"]}
             sc["fork"], sc["join"] = torch.cuda.Event(), [torch.cuda.Event() for _ in range(sc["n"])]
         streams = [main] + sc["streams"][1:]
-        sc["fork"].record(main)
-        for st in streams[1:]:
-            st.wait_event(sc["fork"])                    # side streams start behind whatever precedes the plan (and join a graph capture)
+        used = sorted(set(sc["where"]) - {0})            # only side streams that carry launches fork and join: an EMPTY branch (fork event
+        sc["fork"].record(main)                          # wait + join record, nothing between) is what hipStreamEndCapture was seen to
+        for c in used:                                   # segfault on now and then (three streams on a small plan, 2 of 20 test runs)
+            streams[c].wait_event(sc["fork"])            # side streams start behind whatever precedes the plan (and join a graph capture)
         where, waits, events = sc["where"], sc["waits"], sc["events"]
         for i in sc["order"]:                            # a topological order: every event is recorded before it is waited for
             fn = self.ops[i][2]
@@ -463,7 +464,7 @@ class _Plan:
                 fn()
             if i in events:
                 events[i].record(st)
-        for c in range(1, sc["n"]):
+        for c in used:
             sc["join"][c].record(streams[c])
             main.wait_event(sc["join"][c])
 

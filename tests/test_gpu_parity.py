@@ -687,6 +687,7 @@ def test_dataflow_schedule_bit_identical(gpu_lib, N, H, W):
         ref.append(outs())
     model = plan.tune_schedule(3)
     assert model is not None and plan.sched["n"] == 3 and any(plan.sched["where"]) and model[1] < model[0]
+    print("ops per stream:", [plan.sched["where"].count(c) for c in range(3)])
     for _ in range(2):
         for x, r in zip(xs, ref):
             plan.forward(x); torch.cuda.synchronize()          # eager, three streams
