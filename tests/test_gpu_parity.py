@@ -685,12 +685,13 @@ def test_dataflow_schedule_bit_identical(gpu_lib, N, H, W):
     for x in xs:
         plan.forward(x); torch.cuda.synchronize()
         ref.append(outs())
-    model = plan.tune_schedule(3)
-    assert model is not None and plan.sched["n"] == 3 and any(plan.sched["where"]) and model[1] < model[0]
-    print("ops per stream:", [plan.sched["where"].count(c) for c in range(3)])
+    S = int(os.environ.get("DEFT_TEST_DF_STREAMS", "2"))          # 2 = what the product captures (engine.DATAFLOW)
+    model = plan.tune_schedule(S)
+    assert model is not None and plan.sched["n"] == S and any(plan.sched["where"]) and model[1] < model[0]
+    print("ops per stream:", [plan.sched["where"].count(c) for c in range(S)], "cross-stream waits:", sum(len(w) for w in plan.sched["waits"]))
     for _ in range(2):
         for x, r in zip(xs, ref):
-            plan.forward(x); torch.cuda.synchronize()          # eager, three streams
+            plan.forward(x); torch.cuda.synchronize()          # eager, several streams
             assert all(torch.equal(a, b) for a, b in zip(r, outs()))
     graph = plan.capture_graph()
     for _ in range(3):
