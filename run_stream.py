@@ -72,9 +72,12 @@ def main():
             from utils import tracker as RT
             sys.argv = argv
             tracker = RT.Tracker(opts().parse(["tracking", "--dataset", "mot"]), model, h=H, w=W)
-        except Exception as e:                            # not importable here (the GPU box has no reference tree): exchange-only run
-            why = "%s: %s" % (type(e).__name__, e)
+        except Exception as e:                            # not importable here (the GPU box has no reference tree): this repository's own
+            why = "%s: %s" % (type(e).__name__, e)        # 2-D tracker (identical tracks to the reference's, tests/test_mot_tracker.py)
             sys.argv = sys.argv if sys.argv[0] != "test.py" else [__file__]
+            from types import SimpleNamespace
+            from deft_amd.mot_tracker import Tracker2D
+            tracker = Tracker2D(SimpleNamespace(dataset="mot", track_buffer=30, max_object=100, lstm=False), SimpleNamespace(AFE=model.AFE), h=H, w=W)
     mk = lambda trk, coll: ShardedStream(detect, model.AFE, model.AFE.plan.D, tracker=trk, dataset="mot", kmax=100, img_h=H, img_w=W, batch=1, device=dev,
                                          force_collective=coll, snapshot=lambda tg: [(int(t.track_id), [float(v) for v in t.tlwh]) for t in tg])
     st = mk(tracker, args.force_dist)
@@ -123,7 +126,8 @@ def main():
                 "backend": dist.get_backend() if dist.is_initialized() else None, "ms_per_frame": round(dt / (nsteps * world) * 1e3, 4),
                 "frames_per_s": round(nsteps * world / dt, 2), "detect": "host" if args.host_detect else "device",
                 "bytes_gathered_per_step": st.bytes_gathered // max(nsteps + nwarm + (nsteps if args.bench else 0), 1),
-                "reference_tracker": tracker is not None, "reference_tracker_unavailable": why,
+                "reference_tracker": tracker is not None and why is None, "reference_tracker_unavailable": why,
+                "tracker": None if tracker is None else (type(tracker).__module__ + "." + type(tracker).__name__),
                 "track_outputs": ntracks, "check": check, "phase_ms_per_step": phases}
         print(json.dumps(line), flush=True)
         if args.out:

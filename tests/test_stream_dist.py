@@ -198,11 +198,24 @@ def test_stream_with_real_kernels_matches_level0_loop(emu_lib):
             level0.append((t, _log(trk.update(res, fmaps))))
         BaseTrack._count = 0
         trk2 = RT.Tracker(opt, model, h=Hh, w=Ww)
+        afe0 = model.AFE                                   # (ShardedStream swaps the tracker's model.AFE -- here the shared model's -- for its replay)
         st = ShardedStream(detect, model.AFE, model.AFE.plan.D, tracker=trk2, dataset="mot", kmax=20, img_h=Hh, img_w=Ww, batch=1, device="cpu", snapshot=_log)
         got = []
         for x in frames:
             got += st.step([x])
         assert got == level0 and sum(len(f) for _, f in level0) > 0
+        # the repository's own 2-D tracker on the association rank (what run_stream.py uses where the reference tree is absent): same tracks
+        from deft_amd import mot_tracker as MT
+        model.AFE = afe0
+        MT.TrackIds.count = 0
+        trk3 = MT.Tracker2D(types.SimpleNamespace(dataset="mot", track_buffer=30, max_object=100, lstm=False), types.SimpleNamespace(AFE=model.AFE),
+                            h=Hh, w=Ww)
+        st3 = ShardedStream(detect, model.AFE, model.AFE.plan.D, tracker=trk3, dataset="mot", kmax=20, img_h=Hh, img_w=Ww, batch=1, device="cpu", snapshot=_log)
+        assert trk3.lazy_blocks is False
+        got3 = []
+        for x in frames:
+            got3 += st3.step([x])
+        assert got3 == level0
     finally:
         if undo:
             undo()
