@@ -261,7 +261,14 @@ class Tracker2D:
             dists = 1 - self.get_similarity(fid, pool, nd0)[:, :-1]
         if self.dataset != "kitti_tracking":
             self._device_done()
-        dists = A.fuse_motion(None, dists, pool, detections, frame_id=fid, use_lstm=False)
+        if dists.size:
+            # matching.fuse_motion (matching.py:311-371; Kalman branch, position only) on the arrays at hand -- the predicted means / covariances
+            # stacked above and the frame's (x, y, a, h) rows -- instead of collecting them again track by track: the same expressions as
+            # association.fuse_motion (gate at 5 * chi2inv95[2] on the squared Mahalanobis distance, then 0.9 * cost + 0.05 * 0.1 * distance)
+            lam = 0.9
+            g = A._maha2(mean[:, :2], cov[:, :2, :2], xyah[:, :2])
+            dists[g > 5.0 * A.chi2inv95[2]] = np.inf
+            dists = lam * dists + 0.05 * (1 - lam) * g
         u_track, u_det2 = self._match(dists, 0.9, pool, detections, fid, output, activated)
         r_tracked = [pool[i] for i in u_track]
         detections = [detections[i] for i in u_det2]

@@ -148,3 +148,26 @@ def test_kalman_batch_forms_match_reference_filter():
         um, uc = MT.kf_multi_update(mm, mc, z)
         assert np.allclose(np.stack([u[0] for u in ru]), um, rtol=0, atol=1e-9) and np.allclose(np.stack([u[1] for u in ru]), uc, rtol=0, atol=1e-9)
         mean, cov = um, uc
+
+
+def test_inline_kalman_gate_equals_fuse_motion():
+    """Tracker2D.update gates with association._maha2 on its stacked arrays instead of calling association.fuse_motion track by track:
+    the two are the same expressions -- bit for bit, including the gated (inf) entries."""
+    from types import SimpleNamespace
+    from deft_amd import association as A
+    g = np.random.RandomState(2)
+    T, N = 37, 23
+    mean = np.concatenate([g.rand(T, 2) * 300, g.rand(T, 1) * 0.5 + 0.2, g.rand(T, 1) * 80 + 20, g.randn(T, 4)], 1)
+    a = g.randn(T, 8, 8) * 3
+    cov = a @ a.transpose(0, 2, 1) + np.eye(8) * 5
+    xyah = np.concatenate([g.rand(N, 2) * 300, g.rand(N, 1) * 0.5 + 0.2, g.rand(N, 1) * 80 + 20], 1)
+    xyah[:5, :2] = mean[:5, :2] + g.randn(5, 2)                      # some detections inside the gate
+    cost = g.rand(T, N)
+    tracks = [SimpleNamespace(mean=mean[t], covariance=cov[t]) for t in range(T)]
+    dets = [SimpleNamespace(to_xyah=(lambda r=xyah[j]: r.copy())) for j in range(N)]
+    ref = A.fuse_motion(None, cost.copy(), tracks, dets, frame_id=3, use_lstm=False)
+    d = cost.copy()
+    gate = A._maha2(mean[:, :2], cov[:, :2, :2], xyah[:, :2])
+    d[gate > 5.0 * A.chi2inv95[2]] = np.inf
+    d = 0.9 * d + 0.05 * (1 - 0.9) * gate
+    assert np.array_equal(ref, d) and np.isinf(d).any() and np.isfinite(d).any()
