@@ -172,8 +172,8 @@ class Tracker2D:
         self.use_lstm = False
 
     # deft_amd.tracker.get_similarity reads .recorder / .dataset / .model.AFE
-    def get_similarity(self, frame_index, pool, num_detections):
-        return DT.get_similarity(self, frame_index, pool, num_detections)
+    def get_similarity(self, frame_index, pool, num_detections, selected=None):
+        return DT.get_similarity(self, frame_index, pool, num_detections, selected)
 
     def _rows(self, results):
         if self.dataset == "kitti_tracking":
@@ -222,6 +222,7 @@ class Tracker2D:
         activated, removed, output = [], [], []
         dets = self._rows(results)
         pool = list(self.tracked_stracks) + [t for t in self.lost_stracks if t.track_id not in {x.track_id for x in self.tracked_stracks}]
+        sel = {id(t): DT.select_nodes(t.nodes, fid, self.dataset) for t in pool}      # once per track and frame: block selection + both associations
         if len(dets) > 0:
             tlwh32 = dets[:, :4].copy()                                   # STrack.tlbr_to_tlwh: float32 differences, widened afterwards
             tlwh32[:, 2:] -= tlwh32[:, :2]
@@ -240,7 +241,7 @@ class Tracker2D:
             centers = torch.from_numpy(((2 * d[:, 0:2] + d[:, 2:4]) - 1.0).astype(float)).float().view(1, -1, 1, 1, 2)
             feats = self.model.AFE.forward_feature_extracter(FeatureMaps, centers)
             # only the stored frames the association below can read: those holding one of the last few nodes of a pooled track
-            needed = {n.frame_index for t in pool for n in DT.select_nodes(t.nodes, fid, self.dataset)} if self.lazy_blocks else None
+            needed = {n.frame_index for nodes in sel.values() for n in nodes} if self.lazy_blocks else None
             self.recorder.update(self.model, fid, feats.data, org, needed=needed)
         else:
             detections = []
@@ -258,7 +259,7 @@ class Tracker2D:
         # ---- first association: embedding similarity fused with the Kalman gate (tracker.py:879-915) ----
         dists = np.zeros((len(pool), nd0), dtype=float)
         if dists.size:
-            dists = 1 - self.get_similarity(fid, pool, nd0)[:, :-1]
+            dists = 1 - self.get_similarity(fid, pool, nd0, sel)[:, :-1]
         if self.dataset != "kitti_tracking":
             self._device_done()
         if dists.size:
@@ -273,7 +274,7 @@ class Tracker2D:
         r_tracked = [pool[i] for i in u_track]
         detections = [detections[i] for i in u_det2]
         if self.dataset == "kitti_tracking" and detections:                # second, similarity-only association (tracker.py:956-980)
-            dists = self.get_similarity(fid, r_tracked, nd0)
+            dists = self.get_similarity(fid, r_tracked, nd0, sel)
             if dists.size:
                 dists = 1 - dists[:, :-1][:, u_det2]
                 u_track, u_det = self._match(dists, 0.9, r_tracked, detections, fid, output, activated)

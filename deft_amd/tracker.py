@@ -120,7 +120,7 @@ def select_nodes(nodes, frame_index, dataset):
     return sel if len(sel) <= mm + 1 else sel[len(sel) - mm:]
 
 
-def get_similarity(self, frame_index, strack_pool, num_detections):
+def get_similarity(self, frame_index, strack_pool, num_detections, selected=None):
     """Drop-in for `Tracker.get_similarity` (tracker.py:663-688): float64 [T, num_detections+1], row t = the
     column-wise median of track t's selected node rows of the frame's (decayed) affinity blocks, zeros for a
     track without usable nodes.  `self` needs `.recorder` (the FeatureRecorder above), `.dataset`, `.model.AFE`.
@@ -137,8 +137,8 @@ def get_similarity(self, frame_index, strack_pool, num_detections):
     assert sim.shape[1] == num_detections + 1
     L = 5
     rows = np.zeros((T, L), np.int32); scale = np.zeros((T, L), np.float32); cnt = np.zeros(T, np.int32)
-    for t, trk in enumerate(strack_pool):
-        for i, n in enumerate(select_nodes(trk.nodes, frame_index, self.dataset)):
+    for t, trk in enumerate(strack_pool):          # selected: {id(track): its select_nodes(...)} when the caller has them already
+        for i, n in enumerate(selected[id(trk)] if selected is not None else select_nodes(trk.nodes, frame_index, self.dataset)):
             blk, delta = index[n.frame_index]                      # KeyError like the reference for an unknown frame
             if not 0 <= n.id < starts[blk + 1] - starts[blk]:
                 raise IndexError("node id %d outside frame %d" % (n.id, n.frame_index))
