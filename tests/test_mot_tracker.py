@@ -171,3 +171,42 @@ def test_inline_kalman_gate_equals_fuse_motion():
     d[gate > 5.0 * A.chi2inv95[2]] = np.inf
     d = 0.9 * d + 0.05 * (1 - 0.9) * gate
     assert np.array_equal(ref, d) and np.isinf(d).any() and np.isfinite(d).any()
+
+
+def test_lazy_affinity_blocks_change_nothing(emu_lib):
+    """Tracker2D.lazy_blocks: the new frame is scored only against the stored frames that hold one of the pool's selected nodes (the
+    reference scores all of them, tracker.py:76-90, and reads a few).  A crowded random scene with drop-outs and re-finds: identical
+    outputs frame by frame with and without, and the lazy run really asked for fewer blocks."""
+    from deft_amd import mot_tracker as MT
+    opt = types.SimpleNamespace(dataset="mot", track_buffer=30, max_object=100, lstm=False)
+    g = np.random.RandomState(5)
+    base = np.concatenate([g.rand(30, 2) * np.array([170.0, 90.0]), g.rand(30, 2) * 8 + 10], 1)
+    vel = g.randn(30, 2) * 0.6
+    gone = {i: (int(g.randint(5, 40)), int(g.randint(2, 9))) for i in range(0, 30, 3)}        # object -> (first missing frame, length)
+    frames = []
+    for t in range(55):
+        rows = []
+        for i in range(30):
+            if i in gone and gone[i][0] <= t < gone[i][0] + gone[i][1]:
+                continue
+            x, y = base[i, :2] + vel[i] * t
+            w, h = base[i, 2:]
+            rows.append({"score": float(0.6 + 0.01 * i), "class": 1, "bbox": np.array([x, y, x + w, y + h], np.float32)})
+        frames.append(rows)
+
+    def run(lazy):
+        MT.TrackIds.count = 0
+        afe = FakeAFE()
+        afe.plan = types.SimpleNamespace(lib=emu_lib, _stream=lambda: None)
+        asked = []
+        many = afe.affinity_many
+        afe.affinity_many = lambda hist, cur: (asked.append(len(hist)), many(hist, cur))[1]
+        trk = MT.Tracker2D(opt, types.SimpleNamespace(AFE=afe), h=H, w=W)
+        trk.lazy_blocks = lazy
+        return [_log(trk.update([dict(r) for r in rows], [torch.zeros(1)])) for rows in frames], asked, trk
+
+    full, asked_full, _ = run(False)
+    lazy, asked_lazy, trk = run(True)
+    assert full == lazy and sum(len(f) for f in full) > 1000
+    assert max(asked_full) == 49 and sum(asked_lazy) < 0.4 * sum(asked_full)
+    assert len(trk.lost_stracks) + len(trk.removed_stracks) >= 0 and MT.TrackIds.count >= 30
