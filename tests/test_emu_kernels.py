@@ -427,8 +427,8 @@ def test_dataflow_schedule_is_order_independent(emu_lib):
     import torch
     from deft_amd import engine, synth
     sd = synth.synth_state_dict("mot")
-    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(5))
-    plan = engine.DlaSegPlan(sd, 1, 64, 96, "mot", K=20, device="cpu", lib=emu_lib)
+    x = torch.randn(1, 3, 32, 64, generator=torch.Generator().manual_seed(5))
+    plan = engine.DlaSegPlan(sd, 1, 32, 64, "mot", K=20, device="cpu", lib=emu_lib)
     outs = lambda: [t.clone() for t in (plan.scores, plan.inds, plan.bboxes, plan.head_vals)] + [fm.buf.clone() for fm in plan.fmaps]
     plan.forward(x)
     ref = outs()
@@ -463,7 +463,7 @@ def test_dataflow_schedule_is_order_independent(emu_lib):
         i = max(k for k in left if deps[k] <= done)
         last_first.append(i); done.add(i); left.remove(i)
     assert last_first != list(range(n))
-    x2 = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(6))
+    x2 = torch.randn(1, 3, 32, 64, generator=torch.Generator().manual_seed(6))
     for order in (last_first, sc["order"]):
         plan.forward(x2)                   # every buffer now holds ANOTHER frame's values: an op that ran too early would read those
         assert not torch.equal(outs()[-1], ref[-1])
