@@ -3,6 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W [--config A|B|D|E] [--batch B]
 
+`--gpus N` (N > 1) without a launcher re-executes this file under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU over RCCL); under a launcher whose WORLD_SIZE differs from
+--gpus it refuses to run.  `n_gpus` in the JSON line is the size of the process group that ran.
+
 A "step" = one batch of B synthetic frames per GPU through DLA-34 + DCNv2 neck + hm head + decode (K=100) + sparse
 regression heads + embedding head + affinity against the history frames (+ the batched LSTM motion update where the
 config names it).  Inputs are resident in HBM when the timed region starts.  With N>1 (launched by
@@ -14,6 +18,11 @@ A 512x512 + 32x128 affinity; D KITTI 1280x384 + 30x150 affinity + LSTM motion up
 per GPU (replicas: no collective) + 3-D LSTM motion update.
 
 Extra objects in the JSON line:
+  parity          the parity gate, in the same command and outside the timed region (--no-check skips it): frames 0 and 17 of the
+                  timed plan's own step (B frames per GPU on the sub-batch plans and HIP streams that `value` is measured on) against
+                  the oracle (oracle/deft_oracle.py as the CHECKER): ordered top-K (class, index), scores, boxes, embeddings and
+                  the [hist*N, N+1] affinity blocks of FramePipeline.step.
+  configs         BASELINE configs A / D / E on the same GPU, compact (value, ms/step, roofline.frac, parity of frame 0).
   roofline        the implicit-GEMM kernel family (conv / DCNv2 / pair launches of the step): algorithmic FLOPs
                   (2*M*Cout*K per launch, no padding) / launch time (HIP events on the launch stream) against the
                   TIME-WEIGHTED ceiling of the instructions each launch issues (bf16 dense / 6 = 416.7 TFLOP/s for
@@ -98,51 +107,61 @@ def cpu_baseline(cfg, frames=5):
                       % (len(t_all), W, H, nd, hist, nd, nd, " + %d LSTM steps" % nd if lsd is not None else "", torch.get_num_threads())}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
-    ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip sustained / latency_mode / value_incl_pcie (profiling runs)")
-    ap.add_argument("--autotune", action="store_true", help="per-layer tile search at plan-build time (engine._Plan.autotune)")
-    ap.add_argument("--graphs", action="store_true", help="replay each sub-batch's launch list as a captured hipGraph")
-    ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--serialize", action="store_true",
-                    help="profiling aid: same sub-batch plans, launched back to back on one stream (per-kernel durations "
-                         "comparable with the roofline's per-launch HIP events)")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    H, W, NDET, HIST = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"]
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1 or os.environ.get("DEFT_FORCE_DIST") == "1":      # DEFT_FORCE_DIST: 1-rank RCCL group (path check on a 1-GPU box)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
 
-    from deft_amd import engine, hiplib, synth
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: become `torch.distributed.run --nproc-per-node N bench.py <same args>`
+    (one rank per GPU).  A plain one-process run can therefore never report N GPUs."""
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+
+
+class StandInCompute:
+    """CPU stand-in for HipCompute, ONLY for the launch-path test (`--standin`, tests/test_bench_launch.py): lets `bench.py --gpus 2`
+    go through the same self-launch, process group, FramePipeline exchange and JSON assembly on a box without GPUs (gloo).  The line
+    it produces is marked invalid; it measures nothing."""
+
+    def __init__(self, ndet, D):
+        self.ndet, self.D = ndet, D
+        self.plans = []
+
+    def detect_embed(self, images):
+        sig = images.reshape(images.shape[0], -1).mean(1)
+        return (sig.view(-1, 1, 1) + torch.linspace(0, 1, self.ndet * self.D).view(1, self.ndet, self.D)).contiguous()
+
+    def affinity(self, hist, cur):
+        return torch.cat([h @ cur.t() for h in hist], 0)
+
+    def affinity_ring(self, ring, g0, Bc, hist):
+        return torch.stack([torch.cat([ring[t] @ ring[g0 + c].t() for t in range(g0 + c - hist, g0 + c)], 0) for c in range(Bc)])
+
+
+def build_workload(cfg, B, streams, dev, lib, rank, standin=False):
+    """Plans, pipeline, resident frames and the step function of one config."""
+    from deft_amd import engine, synth
     from deft_amd.pipeline import HipCompute, FramePipeline
-    engine_prec = engine.PREC
-    lib = hiplib.get_lib()                      # no fallback: raises if the HIP extension is missing
-    sd = synth.synth_state_dict(cfg["dataset"])
-    B = args.batch
-    comp = HipCompute(sd, B, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=args.streams, ndet=NDET)
-    comp.serialize = args.serialize
+    H, W, NDET, HIST = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"]
     gather = not cfg["replicas"]                # config E: one camera stream per GPU, no cross-GPU state at all
-    pipe = FramePipeline(comp, B, NDET, comp.D, history=HIST, device=dev, exchange=gather)
     g = torch.Generator().manual_seed(1000 + rank)
+    if standin:
+        comp = StandInCompute(NDET, 16)
+        pipe = FramePipeline(comp, B, NDET, 16, history=HIST, device=dev, exchange=gather)
+        images = torch.randn(B, 3, 8, 8, generator=g)
+        return dict(comp=comp, pipe=pipe, images=images, step=pipe.step, sd=None, motion=None, gather=gather)
+    sd = synth.synth_state_dict(cfg["dataset"])
+    comp = HipCompute(sd, B, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=streams, ndet=NDET)
+    pipe = FramePipeline(comp, B, NDET, comp.D, history=HIST, device=dev, exchange=gather)
     images = torch.randn(B, 3, H, W, generator=g).to(dev)      # resident in HBM before timing
-
     motion = None
     if cfg["lstm"]:                             # batched LSTM motion update of the frame's matched tracks (tracker.py:408-580), in the step
         lsd = synth.synth_lstm_state_dict("nuscenes" if cfg["dataset"] == "nuscenes" else "mot")
@@ -164,49 +183,300 @@ def main():
                 box = motion["box3d"]
             motion["out"] = motion["plan"].motion_step(motion["slot"], box, motion["frame"], motion["h"], motion["c"], motion["last"])
         return outs
+    return dict(comp=comp, pipe=pipe, images=images, step=step, sd=sd, motion=motion, gather=gather)
 
-    if args.autotune:                                    # plan-build time, outside the timed region
-        comp.autotune(images, verbose=args.verbose and rank == 0)
-    if engine.DATAFLOW > 1 and comp.sub <= engine.DATAFLOW_MAX_N and not args.graphs:
-        comp.tune_dataflow(images)                       # (capture() does it itself)
-    if args.graphs:
-        comp.capture(images)
 
-    def sync():
-        if dist.is_initialized():
-            dist.barrier()
+def sync():
+    if dist.is_initialized():
+        dist.barrier()
+    if torch.cuda.is_available():
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+
+def max_over_ranks(x, dev):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return x
+
+
+def timed(step, images, steps, warmup, dev):
+    """W untimed steps, then EXACTLY `steps` steps between (barrier + device synchronize) on both sides; MAX over ranks."""
+    for _ in range(warmup):
         step(images)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(images)
     host_dt = time.perf_counter() - t0        # time the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    return max_over_ranks(dt, dev), host_dt
+
+
+def parity_gate(cfg, wl, frames, tol=1e-3, tie=1e-4):
+    """The parity gate of BASELINE.md section 3, on the plans the timed loop runs (same sub-batch size, same kernels, same
+    streams): one more step of the steady-state loop, then, for each frame index f of the step, the device's decode
+    (decode.py:102: ordered top-K classes + indices, scores, boxes), embeddings (AFE.py:88-92) and the frame's affinity block from
+    FramePipeline.step (AFE.py:110-160, hist x [N, N+1]) against the oracle on the same frame.  Bars: ordered (class, index) equality;
+    floats max-abs <= 1e-3.  When the ordered indices differ the report says whether every difference is a round-off tie (the
+    oracle's own heat map puts the index within `tie` of its 3x3 neighbourhood maximum or of the K-th logit) -- it still counts as a
+    FAILED `topk_ordered_equal` for that frame; `pass` is reported both ways.  The oracle is the checker here, never the thing
+    measured (this runs outside the timed region)."""
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import deft_oracle as O
+    comp, pipe, images, sd = wl["comp"], wl["pipe"], wl["images"], wl["sd"]
+    H, W, nd, hist, ds = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"], cfg["dataset"]
+    t0 = time.time()
+    outs = wl["step"](images)
+    torch.cuda.synchronize()
+    B = images.shape[0]
+    emb_dev = comp.emb.detach().cpu()                                   # [B, nd, D] of this step (= of every steady-state step: same frames)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncpu, 32)))
+    rep = {"frames": [], "tolerance": tol, "checker": "oracle/deft_oracle.py (PyTorch-CPU restatement pinned to the reference modules)"}
+    worst = {"score": 0.0, "bbox": 0.0, "embedding": 0.0, "affinity": 0.0, "hm_logit": 0.0}
+    all_equal, all_ties = True, True
+    for f in frames:
+        p, j = comp.plans[f // comp.sub], f % comp.sub
+        with torch.no_grad():
+            out, maps = O.dlaseg_forward(images[f:f + 1].cpu(), sd, ds)
+            od = O.generic_decode(O.sigmoid_output(out), K=KDET)
+        logit = out["hm"][0]
+        hw = logit.shape[1] * logit.shape[2]
+        gk = (p.clses[j].cpu().long() * hw + p.inds[j].cpu().long()).tolist()
+        ok = (od["clses"][0].long() * hw + od["inds"][0].long()).tolist()
+        e_hm = float((p.dense["hm"].to_nchw()[j].cpu() - logit).abs().max())
+        opos = {k: n for n, k in enumerate(ok)}
+        common = [(n, opos[k]) for n, k in enumerate(gk) if k in opos]
+        gi = torch.tensor([n for n, _ in common], dtype=torch.long); oi = torch.tensor([n for _, n in common], dtype=torch.long)
+        e_s = float((p.scores[j].cpu()[gi] - od["scores"][0][oi]).abs().max())
+        e_b = float((p.bboxes[j].cpu()[gi] - od["bboxes"][0][oi]).abs().max())
+        equal = gk == ok
+        ties = True
+        if not equal:
+            nb = F.max_pool2d(logit[None], 3, 1, 1)[0].reshape(-1)
+            flat = logit.reshape(-1)
+            kth = float(torch.logit(od["scores"][0, -1]))
+            for k in set(gk) ^ set(ok):
+                ties = ties and (float(nb[k] - flat[k]) <= tie or abs(float(flat[k]) - kth) <= tie)
+            order = flat[torch.tensor(gk)]
+            ties = ties and bool((order[:-1] >= order[1:] - tie).all())
+        # embeddings at the ORACLE's own detections (centres as convert_detection makes them, image.py:391-412), rows paired by detection
+        b = od["bboxes"][0, :nd]
+        c = torch.stack([(b[:, 0] + b[:, 2]) / (W / 4) - 1, (b[:, 1] + b[:, 3]) / (H / 4) - 1], 1).view(1, nd, 1, 1, 2)
+        with torch.no_grad():
+            emb_o = O.afe_extract(maps, c, sd)[0]                          # [nd, D]
+        pairs = [(n, m) for n, m in common if n < nd and m < nd]
+        gi = torch.tensor([n for n, _ in pairs], dtype=torch.long); oi = torch.tensor([m for _, m in pairs], dtype=torch.long)
+        e_e = float((emb_dev[f][gi] - emb_o[oi]).abs().max())
+        # affinity block of the frame: history = the `hist` frames before it in the stream (the same frames every step)
+        e_a, blk = 0.0, outs[f].detach().cpu()
+        with torch.no_grad():
+            for hrow in range(hist):
+                hf = (f - hist + hrow) % B
+                ref = torch.from_numpy(O.afe_affinity(emb_dev[hf].unsqueeze(0), emb_dev[f].unsqueeze(0), sd, 100))
+                e_a = max(e_a, float((blk[hrow * nd:(hrow + 1) * nd] - ref).abs().max()))
+        rep["frames"].append({"frame": f, "topk_ordered_equal": equal, "common_detections": len(common), "differences_are_ties": ties if not equal else None,
+                              "hm_logit_err": round(e_hm, 7), "score_err": round(e_s, 7), "bbox_err": round(e_b, 6), "embedding_err": round(e_e, 7),
+                              "embedding_rows_compared": len(pairs), "affinity_err": round(e_a, 7), "affinity_block": list(blk.shape)})
+        all_equal, all_ties = all_equal and equal, all_ties and ties
+        for k_, v_ in (("score", e_s), ("bbox", e_b), ("embedding", e_e), ("affinity", e_a), ("hm_logit", e_hm)):
+            worst[k_] = max(worst[k_], v_)
+    floats_ok = max(worst["score"], worst["bbox"], worst["embedding"], worst["affinity"]) <= tol
+    rep.update({"topk_ordered_equal": all_equal, "floats_within_tol": floats_ok, "max_err": {k_: round(v_, 7) for k_, v_ in worst.items()},
+                "pass": bool(all_equal and floats_ok), "pass_up_to_roundoff_ties": bool(all_ties and floats_ok),
+                "plan": "the timed plans: %d frames per step as %d sub-batch plan(s) of %d on %d HIP stream(s)" % (B, len(comp.plans), comp.sub, comp.nstream),
+                "seconds": round(time.time() - t0, 2)})
+    return rep
+
+
+def roofline_of(wl, lib, rank, dt_step, config):
+    """One profiled step, HIP events per launch (torch events on the stream every kernel is launched on)."""
+    comp, step, images = wl["comp"], wl["step"], wl["images"]
+    prof = []
+    gr, comp.graphs = comp.graphs, None          # per-launch events need eager launches
+    ser, comp.serialize = comp.serialize, True   # same sub-batch plans, back to back on one stream: per-launch events
+    step(images)                                 # un-profiled step queued first: the host then runs AHEAD of the GPU, so the
+    if rank == 0:                                # event intervals below hold kernel time, not Python launch latency
+        lib.profile = prof
+    step(images)                                 # EVERY rank runs the step (it contains the all-gather); rank 0 records
+    comp.serialize = ser
+    comp.graphs = gr
+    torch.cuda.synchronize()
+    lib.profile = None
+    if rank != 0:
+        return None, None
+    GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer", "deft_conv_direct")
+    rows = [(k, fl, e0.elapsed_time(e1), info, b, ceil) for (k, fl, e0, e1, info, b, ceil) in prof]
+    gemm = [r for r in rows if r[0] in GEMM]
+    gemm_ms = sum(r[2] for r in gemm)
+    gemm_fl = sum(r[1] for r in gemm)
+    n_launch = len(gemm)
+    all_ms = sum(r[2] for r in rows)
+    # fixed cost of one (event, launch, event) bracket: the smallest kernels of the step (a few us of real work)
+    tiny = sorted(r[2] for r in rows if r[0] in ("deft_peak_rows", "deft_embed_rows", "deft_decode_boxes"))
+    ev_over_ms = tiny[len(tiny) // 2] if tiny else 0.0
+    ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+    ach_corr = gemm_fl / (max(gemm_ms - n_launch * ev_over_ms, 1e-6) * 1e-3) / 1e12
+    # ceiling of the instructions each launch issues: split-bf16 launches 2500/6, fp32-MFMA launches 157.3 (hiplib marks each call)
+    peak_w = sum(r[2] * r[5] for r in gemm) / max(gemm_ms, 1e-9)
+    split_ms = sum(r[2] for r in gemm if r[5] > FP32_MFMA_PEAK_TF)
+    worst = max((r[1] / (r[2] * 1e-3) / 1e12 / r[5], r[3]) for r in gemm)
+    traffic, tsrc, tstep = None, None, None       # HBM bytes per launch from the committed PMC passes of this build, if any
+    tfile = os.path.join(ROOT, "profiles", TRAFFIC_FILE)       # written by tools/prof.sh + tools/summarize_prof.py for THIS build; absent -> null
+    if os.path.exists(tfile) and config == "B":
+        tj = json.load(open(tfile))
+        traffic = round(tj["traffic_bytes_per_launch"])
+        tstep = tj.get("traffic_bytes_per_step")
+        tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, FETCH x2)" % TRAFFIC_FILE
+    # the launch group that takes the most time in the step: one lookup for a recompute
+    grp = {}
+    for r in gemm:
+        q = grp.setdefault((r[0], r[3]), [0, 0.0, 0.0, r[5]]); q[0] += 1; q[1] += r[2]; q[2] += r[1]
+    (dk_entry, dk_info), (dk_n, dk_ms, dk_fl, dk_ceil) = max(grp.items(), key=lambda kv: kv[1][1])
+    busy = None
+    cfile = os.path.join(ROOT, "profiles", COUNTER_FILE)
+    if os.path.exists(cfile) and config == "B":
+        busy = json.load(open(cfile)).get("mfma_busy")
+    dominant = {"name": "%s %s" % (dk_entry, dk_info), "launches": dk_n, "avg_us": round(dk_ms / dk_n * 1e3, 2), "ms_per_step": round(dk_ms, 3),
+                "gflop": round(dk_fl / 1e9, 2), "tflops": round(dk_fl / (dk_ms * 1e-3) / 1e12, 2), "ceiling_tflops": round(dk_ceil, 1),
+                "frac": round(dk_fl / (dk_ms * 1e-3) / 1e12 / dk_ceil, 4), "mfma_busy": busy}
+    roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak_w, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
+            "traffic_bytes_per_step": tstep, "algorithmic_bytes_per_step_lower_bound": ALG_BYTES_PER_STEP.get(config),
+            "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
+            "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel (conv, DCNv2, pair loaders; fp32 results)",
+            "peak_note": "time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split-bf16 kernels (2500 / 6 = 416.7 TFLOP/s of "
+                         "fp32-equivalent work: 3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product), the rest on v_mfma_f32_32x32x2_f32 (157.3)"
+                         % (100.0 * split_ms / max(gemm_ms, 1e-9)),
+            "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4),
+            "max_per_launch_frac": round(worst[0], 4), "max_per_launch_frac_shape": worst[1],
+            "dominant_kernel": dominant,
+            "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
+            "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
+            "event_bracket_overhead_us": round(ev_over_ms * 1e3, 2),     # median bracket of the step's ~2 us kernels
+            "achieved_minus_bracket_overhead": round(ach_corr, 3),
+            "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3),
+            # the same FLOPs over the TIMED steps (sub-batches overlapped on their streams, every other kernel included)
+            "pipeline_achieved": round(gemm_fl / dt_step / 1e12, 3),
+            "pipeline_frac": round(gemm_fl / dt_step / 1e12 / peak_w, 4)}
+    by = {}
+    for r in rows:
+        by.setdefault(r[0], [0.0, 0, 0.0]); by[r[0]][0] += r[2]; by[r[0]][1] += 1; by[r[0]][2] += r[1]
+    ops = {"by_entry_ms_launches_flops": by, "calls": [(r[0], r[1], r[2], r[3], r[5]) for r in rows]}
+    return roof, ops
+
+
+def side_config(name, args, dev, lib, rank):
+    """BASELINE configs A / D / E on the same GPU, compact: throughput of the same step loop (B frames per step, 2 HIP streams), the
+    roofline fraction of its matrix-core launches, and the parity gate on frame 0 of its own timed plans."""
+    cfg = CONFIGS[name]
+    wl = build_workload(cfg, args.batch, args.streams, dev, lib, rank)
+    steps = max(10, min(args.steps, 30))
+    dt, _ = timed(wl["step"], wl["images"], steps, 2, dev)
+    roof, _ = roofline_of(wl, lib, rank, dt / steps, name)
+    par = None
+    if not args.no_check:
+        pr = parity_gate(cfg, wl, (0,))
+        par = {k: pr[k] for k in ("pass", "pass_up_to_roundoff_ties", "topk_ordered_equal", "floats_within_tol", "max_err")}
+    what = "detect+embed+affinity" + ("+LSTM" if cfg["lstm"] else "")
+    return {"metric": "frames/sec (%s) at %dx%d" % (what, cfg["W"], cfg["H"]), "workload": cfg["workload"],
+            "value": round(steps * args.batch / dt, 3), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+            "frames_per_step": args.batch, "roofline_frac": roof["frac"] if roof else None, "roofline_achieved_tflops": roof["achieved"] if roof else None,
+            "parity": par}
+
+
+TRAFFIC_FILE = "r4_traffic.json"
+COUNTER_FILE = "r4_dominant_counters.json"
+# SURVEY 8(d)'s lower bound of the HBM bytes one step has to move: every frame's image read once (4 B x 3 x H x W), the weights once per
+# step (85 MB), detections + embeddings + affinity blocks written once
+ALG_BYTES_PER_STEP = {"B": 32 * (608 * 1088 * 3 * 4 + 100 * 416 * 4 + 500 * 101 * 4) + 85_000_000}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle parity gate (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip sustained / latency_mode / value_incl_pcie / side configs (profiling runs)")
+    ap.add_argument("--autotune", action="store_true", help="per-layer tile search at plan-build time (engine._Plan.autotune)")
+    ap.add_argument("--graphs", action="store_true", help="replay each sub-batch's launch list as a captured hipGraph")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--serialize", action="store_true",
+                    help="profiling aid: same sub-batch plans, launched back to back on one stream (per-kernel durations "
+                         "comparable with the roofline's per-launch HIP events)")
+    ap.add_argument("--standin", action="store_true",
+                    help="TEST ONLY: CPU stand-in compute + gloo, to exercise the --gpus N launch path without GPUs; the line is marked invalid")
+    args = ap.parse_args()
+    self_launch(args)                                   # (does not return when it re-executes under torch.distributed.run)
+    cfg = CONFIGS[args.config]
+    H, W, NDET, HIST = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"]
+
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if env_world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a %d-GPU number. "
+                         "Run `python bench.py --gpus %d` (it launches its own ranks) or torch.distributed.run --nproc-per-node %d.\n"
+                         % (args.gpus, env_world, args.gpus, args.gpus, args.gpus))
+        sys.exit(2)
+    if args.standin:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    if env_world > 1 or os.environ.get("DEFT_FORCE_DIST") == "1":      # DEFT_FORCE_DIST: 1-rank RCCL group (path check on a 1-GPU box)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if args.standin:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    world = dist.get_world_size() if dist.is_initialized() else 1        # what the JSON reports: the ranks RCCL actually connected
+    assert world == args.gpus, (world, args.gpus)
+
+    lib, engine_prec = None, None
+    if not args.standin:
+        from deft_amd import engine, hiplib
+        engine_prec = engine.PREC
+        lib = hiplib.get_lib()                      # no fallback: raises if the HIP extension is missing
+    B = args.batch
+    wl = build_workload(cfg, B, args.streams, dev, lib, rank, standin=args.standin)
+    comp, pipe, images, step, sd, gather = wl["comp"], wl["pipe"], wl["images"], wl["step"], wl["sd"], wl["gather"]
+
+    if not args.standin:
+        from deft_amd.pipeline import HipCompute, FramePipeline
+        comp.serialize = args.serialize
+        if args.autotune:                                    # plan-build time, outside the timed region
+            comp.autotune(images, verbose=args.verbose and rank == 0)
+        if engine.DATAFLOW > 1 and comp.sub <= engine.DATAFLOW_MAX_N and not args.graphs:
+            comp.tune_dataflow(images)                       # (capture() does it itself)
+        if args.graphs:
+            comp.capture(images)
+
+    c0, b0 = pipe.collectives, pipe.bytes_gathered
+    dt, host_dt = timed(step, images, args.steps, args.warmup, dev)
+    n_coll = (pipe.collectives - c0) / float(args.steps + args.warmup)
+    n_bytes = (pipe.bytes_gathered - b0) / float(args.steps + args.warmup)
     frames = args.steps * B * world
     fps = frames / dt
 
     extras = {}
-    if not args.no_extras:
+    if not args.no_extras and not args.standin:
         # ---- sustained: keep stepping until the GPU has been busy for >= 5 s in total (the timed region above is what `value`
         #      reports; an outside sampler needs more than a second of load to see it) ----
         n_more = max(0, int((5.0 - dt) / max(dt / args.steps, 1e-6)) + 1) if dt < 5.0 else 0
         if n_more:
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(n_more):
-                step(images)
-            sync()
-            d1 = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([d1], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); d1 = float(t.item())
+            d1, _ = timed(step, images, n_more, 0, dev)
             extras["sustained"] = {"steps": n_more, "seconds": round(d1, 3), "value": round(n_more * B * world / d1, 3), "unit": "frames/s"}
         # ---- fed from host memory: uint8 camera frames (1920x1080 for MOT17, else the network size) from pinned staging buffers,
         #      double-buffered H2D on a copy stream, warp + normalise ON THE DEVICE (deft_preprocess_u8, detector.py:377-395), and the
@@ -254,17 +524,8 @@ def main():
         comp1 = HipCompute(sd, 1, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=1, ndet=NDET)
         pipe1 = FramePipeline(comp1, 1, NDET, comp1.D, history=HIST, device=dev, exchange=gather)
         comp1.capture(images[:1])
-        for _ in range(HIST + 3):
-            pipe1.step(images[:1])
-        sync()
         n1 = 100
-        t1 = time.perf_counter()
-        for _ in range(n1):
-            pipe1.step(images[:1])
-        sync()
-        d1 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([d1], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); d1 = float(t.item())
+        d1, _ = timed(pipe1.step, images[:1], n1, HIST + 3, dev)
         extras["latency_mode"] = {"frames_per_step_per_gpu": 1, "hip_graphs": True, "steps": n1, "ms_per_step": round(d1 / n1 * 1e3, 3),
                                   "value": round(n1 * world / d1, 3), "unit": "frames/s",
                                   "workload": "one frame per GPU per step" + (", 1 all-gather/step" if world > 1 and gather else "")}
@@ -288,9 +549,7 @@ def main():
             for i in range(nc):
                 stc.step([images[i % B:i % B + 1]])
             sync()
-            d1 = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([d1], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); d1 = float(t.item())
+            d1 = max_over_ranks(time.perf_counter() - t1, dev)
             extras["config_C"] = {"workload": "one stream, 1 frame per GPU per step, records + affinity-block all-gathers, %dx%d affinity" % (NDET, NDET * HIST),
                                   "steps": nc, "ms_per_step": round(d1 / nc * 1e3, 3), "value": round(nc * world / d1, 3), "unit": "frames/s",
                                   "collectives_per_step": 2 if stc.collective else 0, "bytes_gathered_per_step": stc.bytes_gathered // (nc + HIST + 4)}
@@ -299,125 +558,36 @@ def main():
         #      post-process -> deft_amd.mot_tracker.Tracker2D.update (embedding extraction, affinity chain against the stored frames,
         #      device-side similarity medians, batched Kalman gate, assignment, IoU stage), K detections per frame ----
         if args.config == "B" and world == 1:
-            from types import SimpleNamespace
-            from deft_amd import detector as FD, integrate, mot_tracker as MT
-            sde = dict(sd)                       # random regression heads give boxes with negative extent: bias the amodal l/t/r/b head to ~40 x 64 px boxes
-            sde["ltrb_amodal.2.weight"] = sde["ltrb_amodal.2.weight"] * 0.05
-            sde["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
-            opt = SimpleNamespace(dataset="mot", K=KDET, max_object=100, gpus=[local], hip_graphs=True, depth_scale=1.0, input_h=H, input_w=W,
-                                  out_thresh=-1.0, test_scales=[1.0], flip_test=False, public_det=False, track_buffer=30, lstm=False)
-            fdet = FD.Detector(opt, sde)
-            seam = integrate.AfeSeam(sde, 100, dev, lib)
-            seam.host_copy = False
-            MT.TrackIds.count = 0
-            fdet.set_tracker(MT.Tracker2D(opt, SimpleNamespace(AFE=seam), h=H, w=W))
-            # 1920 x 1080 uint8 camera frames in host memory (what a decoder hands over): H2D, warp + normalise on the device, the plan as a
-            # multi-branch hipGraph, one D2H, array post-processing, Tracker2D.  `prefetch` = the next frame of the stream: its network pass
-            # runs on a second set of plan buffers while the host associates this frame (Detector.run's one-frame lookahead).
-            ge = np.random.RandomState(11)
-            feed = [ge.randint(0, 256, (1080, 1920, 3), dtype=np.uint8) for _ in range(6)]
+            extras["end_to_end"] = end_to_end(sd, H, W, dev, lib, local)
 
-            def e2e(lookahead, ne):
-                MT.TrackIds.count = 0
-                fdet.set_tracker(MT.Tracker2D(opt, SimpleNamespace(AFE=seam), h=1080, w=1920))
-                fdet.img_height, fdet.img_width = 1080, 1920
-                for i in range(12):
-                    fdet.run(feed[i % len(feed)], prefetch=feed[(i + 1) % len(feed)] if lookahead else None)
-                sync()
-                acc = {}
-                t1 = time.perf_counter()
-                for i in range(ne):
-                    fdet.run(feed[(12 + i) % len(feed)], prefetch=feed[(13 + i) % len(feed)] if lookahead and i + 1 < ne else None)
-                    for k_, v_ in fdet.times.items():
-                        acc[k_] = acc.get(k_, 0.0) + v_
-                sync()
-                return time.perf_counter() - t1, acc
-            ne = 100
-            d0, acc0 = e2e(False, ne)
-            d1, acc = e2e(True, ne)
-            extras["end_to_end"] = {"workload": "one stream, 1920x1080 uint8 frame in host memory -> Detector.run (H2D, device pre-processing, fused process, "
-                                                "post-process) -> Tracker2D.update, %d detections per frame, one frame of lookahead" % KDET,
-                                    "frames": ne, "ms_per_frame": round(d1 / ne * 1e3, 3), "value": round(ne / d1, 3), "unit": "frames/s",
-                                    "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc.items()},
-                                    "serial": {"ms_per_frame": round(d0 / ne * 1e3, 3), "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc0.items()}},
-                                    "tracks_alive": len(fdet.tracker.tracked_stracks), "stored_frames": len(fdet.tracker.recorder.all_frame_index)}
-            del fdet, seam
-
-    # ---- roofline of the dominant kernel family: one profiled step, HIP events per launch
-    #      (torch events on the stream every kernel is launched on) ----
+    # ---- roofline of the dominant kernel family ----
     roof = None
-    prof = []
-    gr, comp.graphs = comp.graphs, None          # per-launch events need eager launches
-    ser, comp.serialize = comp.serialize, True   # same sub-batch plans, back to back on one stream: per-launch events
-    step(images)                                 # un-profiled step queued first: the host then runs AHEAD of the GPU, so the
-    if rank == 0:                                # event intervals below hold kernel time, not Python launch latency
-        lib.profile = prof
-    step(images)                                 # EVERY rank runs the step (it contains the all-gather); rank 0 records
-    comp.serialize = ser
-    comp.graphs = gr
-    torch.cuda.synchronize()
-    lib.profile = None
-    if rank == 0:
-        GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer", "deft_conv_direct")
-        rows = [(k, fl, e0.elapsed_time(e1), info, b, ceil) for (k, fl, e0, e1, info, b, ceil) in prof]
-        gemm = [r for r in rows if r[0] in GEMM]
-        gemm_ms = sum(r[2] for r in gemm)
-        gemm_fl = sum(r[1] for r in gemm)
-        n_launch = len(gemm)
-        all_ms = sum(r[2] for r in rows)
-        # fixed cost of one (event, launch, event) bracket: the smallest kernels of the step (a few us of real work)
-        tiny = sorted(r[2] for r in rows if r[0] in ("deft_peak_rows", "deft_embed_rows", "deft_decode_boxes"))
-        ev_over_ms = tiny[len(tiny) // 2] if tiny else 0.0
-        ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
-        ach_corr = gemm_fl / (max(gemm_ms - n_launch * ev_over_ms, 1e-6) * 1e-3) / 1e12
-        # ceiling of the instructions each launch issues: split-bf16 launches 2500/6, fp32-MFMA launches 157.3 (hiplib marks each call)
-        peak_w = sum(r[2] * r[5] for r in gemm) / max(gemm_ms, 1e-9)
-        split_ms = sum(r[2] for r in gemm if r[5] > FP32_MFMA_PEAK_TF)
-        worst = max((r[1] / (r[2] * 1e-3) / 1e12 / r[5], r[3]) for r in gemm)
-        traffic, tsrc = None, None                    # HBM bytes per launch from the committed PMC passes of this build, if any
-        tfile = os.path.join(ROOT, "profiles", "r3_traffic.json")       # written by tools/prof.sh + tools/summarize_prof.py for THIS build; absent -> null
-        if os.path.exists(tfile) and args.config == "B":
-            tj = json.load(open(tfile))
-            traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, FETCH x2)"
-        # the launch group that takes the most time in the step: one lookup for a recompute
-        grp = {}
-        for r in gemm:
-            q = grp.setdefault((r[0], r[3]), [0, 0.0, 0.0, r[5]]); q[0] += 1; q[1] += r[2]; q[2] += r[1]
-        (dk_entry, dk_info), (dk_n, dk_ms, dk_fl, dk_ceil) = max(grp.items(), key=lambda kv: kv[1][1])
-        busy = None
-        cfile = os.path.join(ROOT, "profiles", "r3_dominant_counters.json")
-        if os.path.exists(cfile):
-            busy = json.load(open(cfile)).get("mfma_busy")
-        dominant = {"name": "%s %s" % (dk_entry, dk_info), "launches": dk_n, "avg_us": round(dk_ms / dk_n * 1e3, 2), "ms_per_step": round(dk_ms, 3),
-                    "gflop": round(dk_fl / 1e9, 2), "tflops": round(dk_fl / (dk_ms * 1e-3) / 1e12, 2), "ceiling_tflops": round(dk_ceil, 1),
-                    "frac": round(dk_fl / (dk_ms * 1e-3) / 1e12 / dk_ceil, 4), "mfma_busy": busy}
-        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak_w, 1), "unit": "TFLOP/s",
-                "frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
-                "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
-                "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel (conv, DCNv2, pair loaders; fp32 results)",
-                "peak_note": "time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split-bf16 kernels (2500 / 6 = 416.7 TFLOP/s: "
-                             "3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product), the rest on v_mfma_f32_32x32x2_f32 (157.3)"
-                             % (100.0 * split_ms / max(gemm_ms, 1e-9)),
-                "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4),
-                "max_per_launch_frac": round(worst[0], 4), "max_per_launch_frac_shape": worst[1],
-                "dominant_kernel": dominant,
-                "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
-                "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
-                "event_bracket_overhead_us": round(ev_over_ms * 1e3, 2),     # median bracket of the step's ~2 us kernels
-                "achieved_minus_bracket_overhead": round(ach_corr, 3),
-                "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3),
-                # the same FLOPs over the TIMED steps (sub-batches overlapped on their streams, every other kernel included)
-                "pipeline_achieved": round(gemm_fl / (dt / args.steps) / 1e12, 3),
-                "pipeline_frac": round(gemm_fl / (dt / args.steps) / 1e12 / peak_w, 4)}
-        by = {}
-        for r in rows:
-            by.setdefault(r[0], [0.0, 0, 0.0]); by[r[0]][0] += r[2]; by[r[0]][1] += 1; by[r[0]][2] += r[1]
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
-            json.dump({"by_entry_ms_launches_flops": by, "calls": [(r[0], r[1], r[2], r[3], r[5]) for r in rows]}, f)
+    if not args.standin:
+        roof, ops = roofline_of(wl, lib, rank, dt / args.steps, args.config)
+        if rank == 0:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
+                json.dump(ops, f)
+
+    # ---- parity gate on the timed plans (outside the timed region; rank 0's frames) ----
+    parity = None
+    if not args.no_check and not args.standin:
+        if rank == 0:
+            first = 0 if world == 1 or not gather else min(HIST, B - 1)    # (with N ranks frame 0's history lives on the last rank's shard)
+            parity = parity_gate(cfg, wl, (first, 17) if B > 17 else (first, B - 1) if B > 1 + first else (first,))
+        else:
+            step(images)                                  # (the gate runs one more step: it contains the all-gather)
+
+    # ---- BASELINE configs A / D / E next to the headline config (compact) ----
+    sides = None
+    if args.config == "B" and world == 1 and not args.no_extras and not args.standin:
+        sides = {}
+        for name in ("A", "D", "E"):
+            torch.cuda.empty_cache()
+            sides[name] = side_config(name, args, dev, lib, rank)
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.standin:
         cpu = cpu_baseline(cfg)
 
     if rank == 0:
@@ -425,16 +595,23 @@ def main():
         out = {"metric": "frames/sec (%s) at %dx%d" % (what, W, H), "value": round(fps, 3), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "timed_seconds": round(dt, 3), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic" if not args.standin else "INVALID: --standin (CPU stand-in compute, launch-path test only)",
                "config": {"workload": cfg["workload"], "config": args.config,
-                          "contraction": "split-bf16 x6, fp32 accumulate" if engine_prec == 1 else "fp32 MFMA", "frames_per_step_per_gpu": B,
+                          "contraction": None if args.standin else ("split-bf16 x6, fp32 accumulate (fp32-equivalent)" if engine_prec == 1 else "fp32 MFMA"),
+                          "frames_per_step_per_gpu": B,
                           "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": NDET, "history_frames": HIST,
                           "lstm_motion_update_in_step": bool(cfg["lstm"]),
                           "parallelism": ("single GPU (no collective)" if world == 1 else
                                           ("%d independent replicas (one camera stream per GPU, no collective)" % world if cfg["replicas"]
                                            else "frames sharded dp%d, 1 all-gather/step" % world))},
-               "roofline": roof, "cpu_baseline": cpu}
+               "distributed": {"ranks": world, "backend": (dist.get_backend() if dist.is_initialized() else None),
+                               "launcher_world_size": env_world, "collectives_per_step": round(n_coll, 3),
+                               "bytes_gathered_per_step_per_rank": int(n_bytes)},
+               "roofline": roof, "cpu_baseline": cpu, "parity": parity}
         out.update(extras)
+        if sides is not None:
+            out["configs"] = sides
     # RCCL prints its version banner through C stdio on every rank; it would otherwise be flushed at process exit,
     # AFTER the JSON line.  Flush it everywhere first, then rank 0 prints the JSON as the last stdout line.
     try:
@@ -448,6 +625,51 @@ def main():
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def end_to_end(sd, H, W, dev, lib, local):
+    from types import SimpleNamespace
+    from deft_amd import detector as FD, integrate, mot_tracker as MT
+    sde = dict(sd)                       # random regression heads give boxes with negative extent: bias the amodal l/t/r/b head to ~40 x 64 px boxes
+    sde["ltrb_amodal.2.weight"] = sde["ltrb_amodal.2.weight"] * 0.05
+    sde["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
+    opt = SimpleNamespace(dataset="mot", K=KDET, max_object=100, gpus=[local], hip_graphs=True, depth_scale=1.0, input_h=H, input_w=W,
+                          out_thresh=-1.0, test_scales=[1.0], flip_test=False, public_det=False, track_buffer=30, lstm=False)
+    fdet = FD.Detector(opt, sde)
+    seam = integrate.AfeSeam(sde, 100, dev, lib)
+    seam.host_copy = False
+    MT.TrackIds.count = 0
+    fdet.set_tracker(MT.Tracker2D(opt, SimpleNamespace(AFE=seam), h=H, w=W))
+    # 1920 x 1080 uint8 camera frames in host memory (what a decoder hands over): H2D, warp + normalise on the device, the plan as a
+    # multi-branch hipGraph, one D2H, array post-processing, Tracker2D.  `prefetch` = the next frame of the stream: its network pass
+    # runs on a second set of plan buffers while the host associates this frame (Detector.run's one-frame lookahead).
+    ge = np.random.RandomState(11)
+    feed = [ge.randint(0, 256, (1080, 1920, 3), dtype=np.uint8) for _ in range(6)]
+
+    def e2e(lookahead, ne):
+        MT.TrackIds.count = 0
+        fdet.set_tracker(MT.Tracker2D(opt, SimpleNamespace(AFE=seam), h=1080, w=1920))
+        fdet.img_height, fdet.img_width = 1080, 1920
+        for i in range(12):
+            fdet.run(feed[i % len(feed)], prefetch=feed[(i + 1) % len(feed)] if lookahead else None)
+        sync()
+        acc = {}
+        t1 = time.perf_counter()
+        for i in range(ne):
+            fdet.run(feed[(12 + i) % len(feed)], prefetch=feed[(13 + i) % len(feed)] if lookahead and i + 1 < ne else None)
+            for k_, v_ in fdet.times.items():
+                acc[k_] = acc.get(k_, 0.0) + v_
+        sync()
+        return time.perf_counter() - t1, acc
+    ne = 100
+    d0, acc0 = e2e(False, ne)
+    d1, acc = e2e(True, ne)
+    return {"workload": "one stream, 1920x1080 uint8 frame in host memory -> Detector.run (H2D, device pre-processing, fused process, "
+                        "post-process) -> Tracker2D.update, %d detections per frame, one frame of lookahead" % KDET,
+            "frames": ne, "ms_per_frame": round(d1 / ne * 1e3, 3), "value": round(ne / d1, 3), "unit": "frames/s",
+            "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc.items()},
+            "serial": {"ms_per_frame": round(d0 / ne * 1e3, 3), "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc0.items()}},
+            "tracks_alive": len(fdet.tracker.tracked_stracks), "stored_frames": len(fdet.tracker.recorder.all_frame_index)}
 
 
 if __name__ == "__main__":

@@ -127,6 +127,25 @@ def fuse_motion(kf, cost_matrix, tracks, detections, frame_id, use_lstm=True, on
     return cost_matrix
 
 
+def ddd_metric_of(kf):
+    """Which "gaussian" distance the filter object `kf` stands for in fuse_motion_ddd: "centre" (KalmanFilterLSTM.gating_distance,
+    kalman_filter_lstm.py:92-95) or "squared7" (KalmanFilter.gating_distance, kalman_filter.py:271-273).  Decided by an explicit
+    `ddd_metric` attribute when the object has one, else by the class names in its MRO (subclasses and this package's mirrors of the two
+    reference classes resolve like their base); anything else is an error -- a silently wrong metric would change the nuScenes gating."""
+    m = getattr(kf, "ddd_metric", None)
+    if m is not None:
+        if m not in ("centre", "squared7"):
+            raise ValueError("fuse_motion_ddd: unknown ddd_metric %r" % (m,))
+        return m
+    names = [c.__name__ for c in type(kf).__mro__]
+    if "KalmanFilterLSTM" in names:
+        return "centre"
+    if "KalmanFilter" in names:
+        return "squared7"
+    raise TypeError("fuse_motion_ddd: cannot tell the 3-D gating metric of a %s (neither KalmanFilter nor KalmanFilterLSTM, no ddd_metric attribute)"
+                    % type(kf).__name__)
+
+
 def fuse_motion_ddd(kf, cost_matrix, tracks, detections, frame_id, use_lstm=True, only_position=False, lambda_=0.9,
                     use_prediction=False, classe_name=None):
     """matching.py:374-415 for all tracks at once: the filter's "gaussian" distance between track box and detection box -- with the LSTM
@@ -139,7 +158,8 @@ def fuse_motion_ddd(kf, cost_matrix, tracks, detections, frame_id, use_lstm=True
         raise NotImplementedError("fuse_motion_ddd: only_position=True is not on the tracker's path")
     meas = np.asarray([det.ddd_bbox for det in detections], dtype=np.float64)
     boxes = np.asarray([(t.ddd_prediction_at_frame(frame_id) if use_prediction else t.ddd_bbox) for t in tracks], dtype=np.float64)
-    if type(kf).__name__ == "KalmanFilter":                  # the reference's constant-velocity filter class, used when opt.lstm is off
+    metric = ddd_metric_of(kf)
+    if metric == "squared7":                                 # the reference's constant-velocity filter class, used when opt.lstm is off
         d = meas[None, :, :] - boxes[:, None, :]
         g = np.sum(d * d, axis=2)
     else:

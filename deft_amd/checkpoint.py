@@ -32,6 +32,21 @@ def _strip_module(state_dict_):
 def model_template(opt=None, dataset=None, heads=None):
     """name -> freshly initialised tensor of the architecture `create_model(opt.arch = dla_34, opt.heads, opt.head_conv)` builds."""
     dataset = dataset or getattr(opt, "dataset", "mot")
+    # this package builds ONE architecture: dla_34 with 256-wide one-layer head convs (what every DEFT experiment script trains:
+    # experiments/*.sh --arch dla_34, opts.py:225-233 head_conv default for dla = 256).  Anything else must fail here, not load as an
+    # all-initial template with every checkpoint key "dropped".
+    arch = getattr(opt, "arch", "dla_34")
+    if arch not in ("dla_34", "dla34"):
+        raise ValueError("deft_amd builds the dla_34 detector only; opt.arch = %r" % (arch,))
+    hc = getattr(opt, "head_conv", 256)
+    if isinstance(hc, dict):                                           # opts.py:386-389: {head: [widths]}
+        widths = {tuple(v) if isinstance(v, (list, tuple)) else (v,) for v in hc.values()}
+        ok = widths <= {(256,)}
+    else:
+        ok = hc in (256, -1, None) and getattr(opt, "num_head_conv", 1) == 1
+    if not ok:
+        raise ValueError("deft_amd builds heads with one 256-wide 3x3 conv; opt.head_conv = %r, num_head_conv = %r"
+                         % (hc, getattr(opt, "num_head_conv", 1)))
     if heads is None:
         heads = getattr(opt, "heads", None)
     table_ds = dataset if dataset in synth.HEADS else "mot"
@@ -83,8 +98,20 @@ def load_model_state(source, opt=None, template=None, log=print):
                 out[k] = want                                            # model.py:77-85
         else:
             out[k] = v
+    dropped = sum(1 for k in state_dict if k not in model_state_dict)
+    zero_convs = []
     for k, want in model_state_dict.items():
         if k not in out:
             log("No param {}.".format(k))                                # model.py:88-91
             out[k] = want
+            if k.endswith(".weight") and want.dim() == 4 and not bool(want.any()) and "conv_offset_mask" not in k:
+                zero_convs.append(k)
+    # loud, not a log line among hundreds: a checkpoint of another architecture, or one that lacks whole layers
+    if state_dict and dropped > 0.5 * len(state_dict):
+        raise ValueError("load_model_state: %d of %d checkpoint parameters are not parameters of the dla_34 detector this package builds "
+                         "(first: %s) -- wrong architecture or key naming" % (dropped, len(state_dict), next(k for k in state_dict if k not in model_state_dict)))
+    if zero_convs:
+        import warnings
+        warnings.warn("load_model_state: %d convolution weights are missing from the checkpoint and were left at ZERO (the reference would "
+                      "leave them at their random initial value): %s%s" % (len(zero_convs), ", ".join(zero_convs[:4]), " ..." if len(zero_convs) > 4 else ""))
     return out

@@ -68,19 +68,36 @@ class Detector(object):
         self.pre_images = None
         self.tracker = None            # set_tracker(): the reference's Tracker (or {class: Tracker} for nuScenes), detector.py:102-107
         self.times = {}                # stage seconds of the last run(), under the reference's names (detector.py:113-114, 340-344)
-        self._u8 = {}                  # (sh, sw) -> plan switched to uint8 input (deft_preprocess_u8)
         self._ahead = {}               # (inp_h, inp_w, sh, sw) -> the two _Slot objects of run(..., prefetch=): frame k+1's network beside frame k's tracker
         self._ahead_turn = 0
 
-    def set_tracker(self, tracker):
+    def set_tracker(self, tracker, factory=None):
         """The object `run()` hands the frame's detections to: `utils.tracker.Tracker(opt, model, h, w)` of the reference (bind
-        deft_amd.tracker.accelerate first for the device forms), or {class name: Tracker} for nuScenes (detector.py:102-107)."""
+        deft_amd.tracker.accelerate first for the device forms), or {class name: Tracker} for nuScenes (detector.py:102-107).
+        factory(opt, h, w) -> a fresh tracker (or dict): what `reset_tracking` calls per video, like the reference rebuilds its
+        Tracker(s) there (detector.py:677-686).  Without one, reset_tracking re-constructs trackers of the same class with the same
+        model (`type(t)(opt, t.model, h=, w=)`, the reference's constructor signature, tracker.py:632)."""
         self.tracker = tracker
+        self._tracker_factory = factory
 
     def _plan(self, N, H, W):
+        """The plan for fp32 NCHW input (process())."""
         key = (N, H, W)
         if key not in self._plans:
             self._plans[key] = engine.DlaSegPlan(self.sd, N, H, W, self.dataset, K=self.K, device=self.device, lib=self.lib)
+            self._plans[key]._gkey = key
+        return self._plans[key]
+
+    def _plan_u8(self, N, H, W, sh, sw):
+        """The plan for uint8 HWC frames of sh x sw (run() on a camera frame): its OWN plan and graph key -- use_u8_input rewrites the
+        plan's first launch for good, so sharing the fp32 plan of process() would make a later process() call on the same input size
+        run the network on the last uint8 frame."""
+        key = ("u8", N, H, W, sh, sw)
+        if key not in self._plans:
+            p = engine.DlaSegPlan(self.sd, N, H, W, self.dataset, K=self.K, device=self.device, lib=self.lib)
+            p.use_u8_input(sh, sw)
+            p._gkey = key
+            self._plans[key] = p
         return self._plans[key]
 
     def process(self, images, pre_images=None, pre_hms=None, pre_inds=None, return_time=False):
@@ -90,8 +107,9 @@ class Detector(object):
         assert pre_images is None and pre_hms is None, "DEFT inference never passes pre_img/pre_hm (detector.py:153,162)"
         N, _, H, W = images.shape
         plan = self._plan(N, H, W)
+        assert plan.ops[0][0] == "deft_nchw_to_nhwc", "process() needs the fp32-input plan"
         images = images.to(self.device, non_blocking=True)
-        key = (N, H, W)
+        key = plan._gkey
         if not self.hip_graphs or key not in self._graphs:
             plan.forward(images)                    # first frame of a shape: eager (sets kernel attributes, fills caches)
             self._graphs.setdefault(key, None)
@@ -196,11 +214,7 @@ class Detector(object):
                 t_pre = time.time()
                 output, dets, t_fwd, fmaps = self._process_ahead(akey, frame, prefetch)
             else:
-                plan = self._plan(1, inp_h, inp_w)
-                if self._u8.get((inp_h, inp_w)) != (sh, sw):
-                    plan.use_u8_input(sh, sw)
-                    self._u8[(inp_h, inp_w)] = (sh, sw)
-                    self._graphs.pop((1, inp_h, inp_w), None)
+                plan = self._plan_u8(1, inp_h, inp_w, sh, sw)
                 src = torch.from_numpy(np.ascontiguousarray(frame)).unsqueeze(0)
                 t_pre = time.time()
                 output, dets, t_fwd, fmaps = self._process_u8(plan, src)
@@ -260,7 +274,8 @@ class Detector(object):
     def _process_u8(self, plan, frames_u8):
         """process() for a uint8 frame batch [N, sh, sw, 3] (host or device): the plan's first launch is deft_preprocess_u8."""
         import time
-        key = (plan.N, plan.H, plan.W)
+        key = plan._gkey
+        assert plan.ops[0][0] == "deft_preprocess_u8"
         frames_u8 = frames_u8.to(self.device, non_blocking=True)
         if not self.hip_graphs or key not in self._graphs:
             plan.forward_u8(frames_u8)
@@ -363,5 +378,20 @@ class Detector(object):
         return {"hm": cur.plan.dense["hm"], "pre_inds": None}, dets, t_fwd, cur.plan.fmaps
 
     def reset_tracking(self, opt):
-        """detector.py:677-686 (the recorder mirror lives in deft_amd.tracker)."""
+        """detector.py:677-686: a new video -- fresh Tracker(s) built with the current img_height / img_width (tracks, recorder and
+        frame counter must not survive into the next sequence), no previous image, and no lookahead pass left over from the last video."""
+        for slots in self._ahead.values():
+            for sl in slots:
+                if sl.frame is not None and sl.done is not None:
+                    sl.done.synchronize()              # an announced pass that nobody consumed: let it finish, then forget it
+                sl.frame = None
+        self._launch_next = None
+        if self.tracker is not None:
+            fac = getattr(self, "_tracker_factory", None)
+            if fac is not None:
+                self.tracker = fac(opt, self.img_height, self.img_width)
+            elif isinstance(self.tracker, dict):
+                self.tracker = {k: type(t)(opt, t.model, h=self.img_height, w=self.img_width) for k, t in self.tracker.items()}
+            else:
+                self.tracker = type(self.tracker)(opt, self.tracker.model, h=self.img_height, w=self.img_width)
         self.pre_images = None

@@ -391,17 +391,24 @@ class _Plan:
         signals = sorted({j for w in waits for j in w})
         self.sched = {"n": nstreams, "where": where, "waits": waits, "signals": signals, "order": order, "streams": None, "events": None,
                       "model_ms": (sum(dur_ms), max(finish) if n else 0.0)}
-        # cross-workgroup split-K launches share one workspace per plan: one per stream now
+        # cross-workgroup split-K launches share one workspace per plan: one per stream now.  The extra workspaces are keyed by STREAM
+        # INDEX and kept across rebuilds; every split-K descriptor is re-assigned from `where` on every build (a second tune_schedule /
+        # tune_dataflow(nstreams=..) must not leave a descriptor on the workspace of the stream it sat on before), and reset_splitk
+        # zeroes all of them.
         sp = getattr(self, "_split", None)
-        if sp is not None and sp["ws"] is not None and nstreams > 1:
-            extra = {}
+        if sp is not None and sp["ws"] is not None:
+            extra = sp.setdefault("extra", {})
             for i, d in self._op_desc.items():
-                if d.splitk > 1 and d.ws == sp["ws"].data_ptr() and where[i] != 0:
-                    if where[i] not in extra:
-                        extra[where[i]] = (torch.empty_like(sp["ws"]), torch.zeros_like(sp["cnt"]))
-                        self._keep += list(extra[where[i]])
-                    d.ws, d.ws_cnt = extra[where[i]][0].data_ptr(), extra[where[i]][1].data_ptr()
-            sp["extra"] = extra
+                if d.splitk <= 1:
+                    continue
+                c = where[i] if nstreams > 1 else 0
+                if c == 0:
+                    d.ws, d.ws_cnt = sp["ws"].data_ptr(), sp["cnt"].data_ptr()
+                    continue
+                if c not in extra or extra[c][0].numel() < sp["ws"].numel() or extra[c][1].numel() < sp["cnt"].numel():
+                    extra[c] = (torch.empty_like(sp["ws"]), torch.zeros_like(sp["cnt"]))
+                    self._keep += list(extra[c])
+                d.ws, d.ws_cnt = extra[c][0].data_ptr(), extra[c][1].data_ptr()
         return self.sched["model_ms"]
 
     def tune_schedule(self, nstreams=None, reps=3):

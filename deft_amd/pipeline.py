@@ -153,36 +153,45 @@ class FramePipeline:
         self.group = group
         self.world = dist.get_world_size(group) if exchange and dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
-        # ring of the last `history` frames of the GLOBAL stream order, then this step's frames
-        self.tail = torch.zeros(history, K, D, dtype=torch.float32, device=self.device)
+        # ONE flat device buffer holds the stream's recent embeddings in GLOBAL frame order: the up-to-`history` frames before the
+        # step at [pos - tail_valid, pos), the step's world * batch frames at [pos, pos + world * batch) -- the all-gather writes them
+        # there directly (one rank: one copy out of the compute's static buffer).  The window slides by a step per step and is moved
+        # back to the front of the buffer when it reaches the end: no per-step allocation, no torch.cat of the ring.
+        wb = self.world * batch
+        slots = -(-history // wb) * (1 if wb >= history else 4)
+        self.cap = history + wb * slots
+        self.buf = torch.zeros(self.cap, K, D, dtype=torch.float32, device=self.device)
+        self.pos = history
         self.tail_valid = 0
-        self.gathered = torch.zeros(self.world * batch, K, D, dtype=torch.float32, device=self.device)
         # test hook: run the collective even in a 1-rank group (exercises the RCCL path on a 1-GPU box)
         self.force_gather = bool(exchange and dist.is_available() and dist.is_initialized() and self.world == 1)
+        self.collectives = 0
+        self.bytes_gathered = 0
 
     def step(self, images):
         """images [batch,3,H,W]: this rank's frames  (global frame index within the step =
         rank*batch + b).  Returns the list (one per local frame) of affinity blocks
         [sum_f P_f, Q+1] against the up-to-`history` preceding frames of the stream."""
         emb = self.c.detect_embed(images)                                   # [batch,K,D]
+        wb = self.world * self.batch
+        n0 = self.pos
+        dst = self.buf[n0:n0 + wb]
         if self.world > 1 or self.force_gather:
-            dist.all_gather_into_tensor(self.gathered, emb.contiguous(), group=self.group)
-            allf = self.gathered
+            dist.all_gather_into_tensor(dst, emb.contiguous(), group=self.group)
+            self.collectives += 1
+            self.bytes_gathered += dst.numel() * 4
         else:
-            allf = emb
-        if self.tail_valid:
-            ring = torch.cat([self.tail[self.history - self.tail_valid:], allf], 0)      # copies the embeddings out
-            if hasattr(self.c, "release_emb"):
-                self.c.release_emb()
-        else:
-            ring = allf
+            dst.copy_(emb)
+        if hasattr(self.c, "release_emb"):
+            self.c.release_emb()                                            # emb has been read: the next step's detection may start
+        ring = self.buf[n0 - self.tail_valid:n0 + wb]                       # (a view)
         base = self.tail_valid + self.rank * self.batch
         outs = []
         if base >= self.history and hasattr(self.c, "affinity_ring"):
             # steady state: every local frame has `history` predecessors -> one batched chain
             # only the frames this rank scores and their history: the layer-1 products U'/V' are not
             # computed for the other ranks' frames of the step
-            own = ring[base - self.history: base + self.batch].contiguous()
+            own = ring[base - self.history: base + self.batch]              # contiguous slice of the buffer: no copy
             blk = self.c.affinity_ring(own, self.history, self.batch, self.history)
             outs = [blk[b] for b in range(self.batch)]
         for b in range(self.batch if not outs else 0):
@@ -193,8 +202,10 @@ class FramePipeline:
                 continue
             hist = [ring[t] for t in range(lo, g)]
             outs.append(self.c.affinity(hist, ring[g]))
-        n = ring.shape[0]
-        keep = min(self.history, n)
-        self.tail[self.history - keep:] = ring[n - keep:]
-        self.tail_valid = keep
+        self.tail_valid = min(self.history, self.tail_valid + wb)
+        self.pos = n0 + wb
+        if self.pos + wb > self.cap:                                        # window at the end of the buffer: move the history to the front
+            tv = self.tail_valid                                            # (source starts at pos - tv >= history: the ranges are disjoint)
+            self.buf[self.history - tv:self.history].copy_(self.buf[self.pos - tv:self.pos])
+            self.pos = self.history
         return outs

@@ -1487,5 +1487,24 @@ def check_fused_run_u8(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=4):
             assert len(ref) == len(got) == K
             for a, b in zip(got, ref):
                 assert int(a["class"]) == int(b["class"]) and float(a["score"]) == float(b["score"]) and np.array_equal(a["bbox"], b["bbox"])
+            # the SAME detector, fp32 frames of the same input size after a uint8 run (the uint8 form of the first launch must not
+            # leak into process()): other pixels in, the result of those pixels out -- eager first, then the captured graph
+            other = torch.randn(1, 3, H, W, generator=g)
+            _, d_same, _ = det.process(other)
+            _, d_ref, _ = det2.process(other)
+            for k in ("scores", "inds", "bboxes"):
+                assert np.array_equal(d_same[k], d_ref[k]), (rep, k)
+        # reset_tracking (detector.py:677-686): a new video gets a fresh tracker of the same class, built with the current frame size
+        class Trk2:
+            def __init__(self, opt, model, h=100, w=100):
+                self.opt, self.model, self.h, self.w = opt, model, h, w
+        det.set_tracker(Trk2(opt, "the model"))
+        first = det.tracker
+        det.img_height, det.img_width = 1080, 1920
+        det.reset_tracking(opt)
+        assert det.tracker is not first and (det.tracker.model, det.tracker.h, det.tracker.w) == ("the model", 1080, 1920)
+        det.set_tracker(first, factory=lambda o, h, w: ("made", h, w))
+        det.reset_tracking(opt)
+        assert det.tracker == ("made", 1080, 1920)
     finally:
         hiplib._lib = saved_lib

@@ -49,14 +49,24 @@ def test_fuse_motion_ddd_vs_reference_fixture():
     fx = np.load(os.path.join(GOLD, "association.npz"))
     dets = [SimpleNamespace(ddd_bbox=b) for b in fx["ddd_det"]]
     tracks = [SimpleNamespace(ddd_bbox=fx["ddd_trk"][t], depth=fx["ddd_depth"][t]) for t in range(fx["ddd_trk"].shape[0])]
+    KalmanFilterLSTM = type("KalmanFilterLSTM", (), {})
     for cls in ("pedestrian", "car"):
-        _same(A.fuse_motion_ddd(None, fx["ddd_cost"].copy(), tracks, dets, frame_id=5, classe_name=cls), fx["ddd_out_" + cls])
+        _same(A.fuse_motion_ddd(KalmanFilterLSTM(), fx["ddd_cost"].copy(), tracks, dets, frame_id=5, classe_name=cls), fx["ddd_out_" + cls])
     # opt.lstm off: the tracker hands over the reference's plain `KalmanFilter`, whose "gaussian" distance is squared and over all seven
     # components (kalman_filter.py:271-273) -- recognised by its class name
     KalmanFilter = type("KalmanFilter", (), {})
     near = [SimpleNamespace(ddd_bbox=fx["ddd_trk_near"][t], depth=fx["ddd_depth"][t]) for t in range(fx["ddd_trk_near"].shape[0])]
     for cls in ("pedestrian", "car"):
         _same(A.fuse_motion_ddd(KalmanFilter(), fx["ddd_cost"].copy(), near, dets, frame_id=5, classe_name=cls), fx["ddd_out_kf_" + cls])
+    # the metric follows the class hierarchy or an explicit attribute, never a guess: a subclass resolves like its base, a
+    # wrapper names its metric, anything else is an error
+    Sub = type("TunedFilter", (KalmanFilter,), {})
+    _same(A.fuse_motion_ddd(Sub(), fx["ddd_cost"].copy(), near, dets, frame_id=5, classe_name="car"), fx["ddd_out_kf_car"])
+    wrapped = SimpleNamespace(ddd_metric="centre")
+    _same(A.fuse_motion_ddd(wrapped, fx["ddd_cost"].copy(), tracks, dets, frame_id=5, classe_name="car"), fx["ddd_out_car"])
+    for bad in (None, SimpleNamespace(), SimpleNamespace(ddd_metric="euclid")):
+        with pytest.raises((TypeError, ValueError)):
+            A.fuse_motion_ddd(bad, fx["ddd_cost"].copy(), tracks, dets, frame_id=5, classe_name="car")
 
 
 def test_not_positive_definite_raises_like_cholesky():

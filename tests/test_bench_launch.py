@@ -1,0 +1,46 @@
+"""`bench.py --gpus N` launches its own ranks (missing #1): a plain `python bench.py --gpus 2` must come back with a line
+produced by TWO connected ranks, and a launcher whose WORLD_SIZE disagrees with --gpus must be refused -- checked here on CPU through
+the same code path (self-launch under torch.distributed.run, process group, FramePipeline exchange, JSON assembly) with the `--standin`
+compute and gloo.  The stand-in measures nothing (the line says so); the kernels are covered elsewhere."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=e, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_gpus2_self_launches_two_ranks():
+    r = _run(["--gpus", "2", "--standin", "--steps", "3", "--warmup", "1", "--batch", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["distributed"]["ranks"] == 2 and out["distributed"]["launcher_world_size"] == 2
+    assert out["distributed"]["backend"] == "gloo"
+    assert out["distributed"]["collectives_per_step"] == 1.0
+    # one all-gather of every rank's [batch, ndet, D] fp32 embedding record per step
+    assert out["distributed"]["bytes_gathered_per_step_per_rank"] == 2 * 4 * 100 * 16 * 4
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["data"].startswith("INVALID")            # the stand-in can never be mistaken for a measurement
+    assert out["value"] > 0 and abs(out["value"] - 3 * 4 * 2 / (out["ms_per_step"] * 3e-3)) / out["value"] < 0.02
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = _run(["--gpus", "2", "--standin", "--steps", "1", "--warmup", "0"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "refusing" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_one_rank_standin_has_no_collective():
+    r = _run(["--gpus", "1", "--standin", "--steps", "2", "--warmup", "1", "--batch", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["distributed"]["collectives_per_step"] == 0 and out["distributed"]["backend"] is None

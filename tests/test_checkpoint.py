@@ -108,3 +108,27 @@ def test_against_the_reference_load_model(tmp_path):
                 continue
             assert torch.equal(got[k].to(ref[k].dtype), ref[k]), (k, reuse)
         model.load_state_dict(init)
+
+
+def test_wrong_architecture_fails_loudly():
+    """a checkpoint / opt of another architecture must not load as the all-initial dla_34 template with a log line per key."""
+    import warnings
+    from types import SimpleNamespace
+    from deft_amd import checkpoint as CK
+    with pytest.raises(ValueError):
+        CK.model_template(SimpleNamespace(dataset="mot", arch="res_18"))
+    with pytest.raises(ValueError):
+        CK.model_template(SimpleNamespace(dataset="mot", arch="dla_34", head_conv=64))
+    with pytest.raises(ValueError):
+        CK.model_template(SimpleNamespace(dataset="mot", arch="dla_34", head_conv={"hm": [256, 256]}))
+    CK.model_template(SimpleNamespace(dataset="mot", arch="dla_34", head_conv={"hm": [256], "reg": [256]}))
+    foreign = {"layer%d.conv.weight" % i: torch.zeros(4, 4, 3, 3) for i in range(30)}
+    with pytest.raises(ValueError, match="wrong architecture"):
+        CK.load_model_state({"state_dict": foreign}, SimpleNamespace(dataset="mot"), log=lambda *_: None)
+    # a checkpoint that lacks a conv layer: loads (model.py:88-91), but says so as a warning, not only as a log line
+    tpl = CK.model_template(SimpleNamespace(dataset="mot"))
+    part = {k: v for k, v in tpl.items() if k != "base.level2.tree1.conv1.weight"}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        CK.load_model_state(part, SimpleNamespace(dataset="mot"), log=lambda *_: None)
+    assert any("left at ZERO" in str(x.message) for x in w)
