@@ -1508,3 +1508,55 @@ def check_fused_run_u8(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=4):
         assert det.tracker == ("made", 1080, 1920)
     finally:
         hiplib._lib = saved_lib
+
+
+def check_co_residency(lib, H=512, W=512, N=16, reps=4):
+    """Every launch of a sub-batch plan must give the SAME BITS alone and beside another kernel on the same compute units (bench.py runs
+    two sub-batch plans on two HIP streams).  Round 4: igemm.hip's MODE_DCN launches did not -- their sampling records were wrong in
+    lanes 48-63 of a wave whenever a matrix-core launch of another stream was co-resident (compiler-packed v_pk_*_f32 arithmetic;
+    profiles/r4_pkf32_hazard.md) -- while every one-stream test passed.  Plan 0's launches one by one (inputs = the buffers of a clean
+    pass) beside repetitions of a heavy launch of plan 1; outputs compared bit for bit with the clean pass."""
+    from deft_amd import engine, hiplib
+    sd = O.synth_state_dict("mot")
+    x = torch.randn(2 * N, 3, H, W, generator=torch.Generator().manual_seed(1000)).cuda()
+    rec = {}
+    orig = engine._Plan.add
+
+    def add(self, kind, name, fn, flops=0.0, reads=None, writes=None):
+        rec.setdefault(id(self), []).append([v for v in (writes or []) if isinstance(v, engine.View)])
+        return orig(self, kind, name, fn, flops, reads, writes)
+    engine._Plan.add = add
+    try:
+        p0 = engine.DlaSegPlan(sd, N, H, W, "mot", K=100, device="cuda", lib=lib)
+        p1 = engine.DlaSegPlan(sd, N, H, W, "mot", K=100, device="cuda", lib=lib)
+    finally:
+        engine._Plan.add = orig
+    w0 = rec[id(p0)]
+    p0.forward(x[:N]); p1.forward(x[N:]); torch.cuda.synchronize()
+    clean = [[v.buf.clone() for v in vs] for vs in w0]
+    heavy = [i for i, (_, nm, _, _) in enumerate(p1.ops) if nm == "base.level4.tree1.tree1.conv2"][0]
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    checked, kinds = 0, set()
+    for i, (kind, name, fn, _) in enumerate(p0.ops):
+        if not w0[i] or kind in ("zero",):
+            continue
+        for _ in range(reps if kind == "deft_dcn_v2_nhwc" else 1):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s1):
+                p1._stream_cache = hiplib.stream_ptr(p1.device)
+                for _ in range(6):
+                    p1.ops[heavy][2]()
+                p1._stream_cache = None
+            with torch.cuda.stream(s0):
+                p0._stream_cache = hiplib.stream_ptr(p0.device)
+                fn()
+                p0._stream_cache = None
+            torch.cuda.synchronize()
+            for v, c in zip(w0[i], clean[i]):
+                nbad = int((v.buf != c).sum())
+                assert nbad == 0, "launch %d %s %s: %d words differ beside another kernel" % (i, kind, name, nbad)
+        checked += 1
+        kinds.add(kind)
+    assert checked > 60 and "deft_dcn_v2_nhwc" in kinds and "deft_conv2d_nhwc" in kinds
+    assert any(d.p3_kernel == 0 for e, _, d in p0._gemms if e == "deft_dcn_v2_nhwc"), "no igemm.hip MODE_DCN launch in this plan"
+    return checked

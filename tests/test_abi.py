@@ -32,6 +32,33 @@ def test_gfx950_library_exports_every_symbol():
     assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
 
 
+def test_no_packed_fp32_valu_in_any_kernel():
+    """deft_amd/build.py NO_PK_F32: v_pk_add / mul / fma_f32 gave wrong sampling records in lanes 48-63 of a wave whenever another kernel
+    ran on the same compute unit (profiles/r4_pkf32_hazard.md).  The shipped code object must not contain one."""
+    import subprocess
+    from deft_amd import build
+    so = build.build(force=False, verbose=False)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    import glob as _glob
+    import tempfile
+    objs = sorted(_glob.glob(os.path.join(build.OBJ_DIR, "*.hip.o")))
+    assert len(objs) == len(build.SRCS) and os.path.getmtime(so) >= max(os.path.getmtime(o) for o in objs)      # the library is linked from these
+    mfma = 0
+    with tempfile.TemporaryDirectory() as td:
+        for o in objs:                                  # each object embeds its own fat binary (.hip_fatbin): pull it out, take the gfx950 image
+            fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+            subprocess.check_call(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", o, fat])
+            subprocess.check_call([bundler, "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+            dis = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
+            mfma += dis.count("v_mfma_f32_")
+            for op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"):
+                assert op not in dis, (op, os.path.basename(o))
+    assert mfma > 1000                                  # (it WAS the device code)
+
+
 def test_missing_library_fails_loudly():
     from deft_amd import hiplib
     with pytest.raises(hiplib.DeftHipError):

@@ -699,3 +699,30 @@ def test_dataflow_schedule_bit_identical(gpu_lib, N, H, W):
             plan.image.copy_(x)
             graph.replay(); torch.cuda.synchronize()
             assert all(torch.equal(a, b) for a, b in zip(r, outs()))
+
+
+def test_bench_parity_gate_on_the_timed_plans(gpu_lib):
+    """the parity gate of BASELINE.md section 3 runs inside the bench command, on the plans the timed loop runs
+    (32 frames per step as two 16-frame sub-batch plans on two HIP streams -- halo / patch / pre-split kernels, not the one-frame
+    plan of the other full-size tests): frames 0 and 17 of the step against the oracle -- ordered top-K, scores, boxes, embeddings and
+    the [500, 101] affinity blocks of FramePipeline.step."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    par = out["parity"]
+    assert [f["frame"] for f in par["frames"]] == [0, 17] and par["frames"][0]["affinity_block"] == [500, 101]
+    assert par["floats_within_tol"] and par["pass_up_to_roundoff_ties"], par
+    assert par["max_err"]["affinity"] <= 1e-3 and par["max_err"]["embedding"] <= 1e-3 and par["max_err"]["bbox"] <= 1e-3
+    for f in par["frames"]:
+        assert f["common_detections"] >= 97 and f["embedding_rows_compared"] >= 97
+    assert out["n_gpus"] == 1 and out["config"]["frames_per_step_per_gpu"] == 32 and out["config"]["hip_streams"] == 2
+
+
+def test_launches_bit_exact_beside_another_kernel(gpu_lib):
+    """Round 4 finding: a launch must not change its bits when another stream's kernel shares the compute units (the timed plans run on two
+    HIP streams).  See parity_checks.check_co_residency."""
+    pc.check_co_residency(gpu_lib)

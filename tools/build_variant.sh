@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; SRC=$2; shift 2
 python -m deft_amd.build > /dev/null
 EXTRA=""; [ "$SRC" = "dcn.hip" ] && EXTRA="-fno-slp-vectorize"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $EXTRA "$@" -c deft_amd/csrc/$SRC -o /tmp/variant_$NAME.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops $EXTRA "$@" -c deft_amd/csrc/$SRC -o /tmp/variant_$NAME.o
 OBJS=""
 for f in igemm.hip igemm3.hip dcn.hip direct.hip ops.hip; do
     if [ "$f" = "$SRC" ]; then OBJS="$OBJS /tmp/variant_$NAME.o"; else OBJS="$OBJS deft_amd/lib/obj/$f.o"; fi
