@@ -11,7 +11,6 @@ update (`deft_amd.tracker.MotionBank`).
 Drop-in: `bind(matching)` replaces `fuse_motion`, `fuse_motion_ddd`, `linear_assignment` and the `bbox_ious`
 name inside the reference's `utils.matching` module; the track state machine (Tracker.update) is untouched."""
 import numpy as np
-from scipy.optimize import linear_sum_assignment
 
 chi2inv95 = {1: 3.8415, 2: 5.9915, 3: 7.8147, 4: 9.4877, 5: 11.070, 6: 12.592, 7: 14.067, 8: 15.507, 9: 16.919}   # kalman_filter.py:11-21
 
@@ -32,43 +31,52 @@ def bbox_overlaps(boxes, query_boxes):
         return np.where((iw > 0) & (ih > 0), inter / ua, 0.0)
 
 
-def lapjv(cost, extend_cost=False, cost_limit=np.inf, return_cost=True):
-    """`lap.lapjv` (third-party, absent here: parity unpinned).  With a cost_limit -- the only form the reference uses
-    (matching.py:48: extend_cost=True, cost_limit=thresh) -- lap embeds the rectangular matrix in an (n+m) x (n+m) square one
-    with cost_limit/2 in the two off-diagonal blocks and 0 in the bottom-right one, so a pair is only matched while it costs
-    less than leaving both unmatched; the same objective is solved here on an n x (m+n) matrix (see below: 1.77 -> 0.10 ms at
-    100 x 100, profiles/r3_tracker_ops.json).  Without a limit lap pads to a max(n,m) square with ZEROS and matches every row of the
-    smaller side (extend_cost=True), or insists on a square matrix.  NaN costs are treated as +inf (never matched) instead of
-    raising.  Solved exactly (scipy.optimize.linear_sum_assignment).  Returns (total cost of the kept pairs, x, y):
-    x[i] = column of row i or -1, y[j] = row of column j or -1."""
-    cost = np.asarray(cost, dtype=np.float64)
+def _host_lib():
+    """libdeft_hip.so for its host-side helpers (deft_lapjv, deft_iou3d_matrix: plain C++ on host memory, no GPU involved -- the library
+    loads on any box).  No Python re-implementation behind it: one solver, one tie order."""
+    from . import hiplib
+    return hiplib._lib if hiplib._lib is not None else hiplib.get_lib()
+
+
+def lapjv(cost, extend_cost=False, cost_limit=np.inf, return_cost=True, lib=None):
+    """`lap.lapjv` (third-party, absent here: parity unpinned) on this repository's own Jonker-Volgenant solver (csrc/assoc.hip,
+    `deft_lapjv`): lap's dense algorithm on lap's own extension of the rectangular problem -- with a cost_limit (the only form the
+    reference uses, matching.py:48: extend_cost=True, cost_limit=thresh) the (n+m) x (n+m) square with cost_limit/2 in the two
+    off-diagonal blocks and 0 in the bottom-right one, so a pair is only matched while it costs less than leaving both unmatched;
+    without a limit the zero-padded max(n,m) square (extend_cost=True), or a square matrix is required.  NaN / +inf costs are pairs
+    that are never matched.  Ties are broken by the solver's fixed scan order (tests/test_association.py).  Returns (total cost of the
+    kept pairs, x, y): x[i] = column of row i or -1, y[j] = row of column j or -1."""
+    import ctypes as C
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
     n, m = cost.shape
     if n != m and not (extend_cost or cost_limit < np.inf):
         raise ValueError("Square cost array expected. If cost is intentionally non-square, pass extend_cost=True.")
-    x = np.full(n, -1, dtype=int); y = np.full(m, -1, dtype=int)
+    x = np.full(n, -1, dtype=np.int32); y = np.full(m, -1, dtype=np.int32)
+    total = C.c_double(0.0)
     if n and m:
-        cost = np.where(np.isnan(cost), np.inf, cost)
-        finite = cost[np.isfinite(cost)]
-        big = (np.abs(finite).max() if finite.size else 1.0) * (n + m + 1) + 1.0            # stands in for +inf inside the solver
-        if cost_limit < np.inf:
-            # lap's own extension is the (n + m) x (n + m) square with cost_limit / 2 in the off-diagonal blocks: a solution with k pairs
-            # costs sum(c) + (n + m - 2k) * limit / 2 = sum(c - limit) + const.  The same objective on HALF the matrix: one private dummy
-            # column per row at cost `limit` (n x (m + n); unmatched columns are free): sum(c) + (n - k) * limit = sum(c - limit) + const.
-            ext = np.full((n, m + n), max(big, cost_limit + 1.0))
-            ext[:, :m] = np.where(np.isfinite(cost), cost, max(big, cost_limit + 1.0))
-            ext[np.arange(n), m + np.arange(n)] = cost_limit
-            r, c = linear_sum_assignment(ext)
-            keep = c < m
-        else:
-            k = max(n, m)
-            ext = np.zeros((k, k))
-            ext[:n, :m] = np.where(np.isfinite(cost), cost, big)
-            r, c = linear_sum_assignment(ext)
-            keep = (r < n) & (c < m)
-            keep &= np.isfinite(cost[np.minimum(r, n - 1), np.minimum(c, m - 1)])            # a forced +inf pairing is no match
-        x[r[keep]] = c[keep]; y[c[keep]] = r[keep]
-    total = float(cost[np.nonzero(x >= 0)[0], x[x >= 0]].sum())
-    return (total, x, y) if return_cost else (x, y)
+        lib = lib if lib is not None else _host_lib()
+        rc = lib.cdll.deft_lapjv(C.c_void_p(cost.ctypes.data), n, m, C.c_double(float(cost_limit)), C.c_void_p(x.ctypes.data),
+                                 C.c_void_p(y.ctypes.data), C.byref(total))
+        if rc != 0:
+            raise RuntimeError("deft_lapjv failed (%d): %s" % (rc, lib.cdll.deft_last_error().decode()))
+    x, y = x.astype(int), y.astype(int)
+    return (float(total.value), x, y) if return_cost else (x, y)
+
+
+def iou_ddd_distance(a_boxes, b_boxes, lib=None):
+    """matching.iou_ddd_distance (matching.py:107-131) on arrays: a_boxes [T, 7], b_boxes [N, 7] (h, w, l, x, y, z, rot_y) ->
+    float32 [T, N] = 1 - iou3d(b, a) (csrc/assoc.hip `deft_iou3d_matrix`; the reference loops over pairs in Python and builds a
+    scipy ConvexHull per pair)."""
+    import ctypes as C
+    a = np.ascontiguousarray(a_boxes, dtype=np.float64).reshape(-1, 7)
+    b = np.ascontiguousarray(b_boxes, dtype=np.float64).reshape(-1, 7)
+    out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
+    if out.size:
+        lib = lib if lib is not None else _host_lib()
+        rc = lib.cdll.deft_iou3d_matrix(C.c_void_p(a.ctypes.data), a.shape[0], C.c_void_p(b.ctypes.data), b.shape[0], C.c_void_p(out.ctypes.data))
+        if rc != 0:
+            raise RuntimeError("deft_iou3d_matrix failed (%d): %s" % (rc, lib.cdll.deft_last_error().decode()))
+    return out
 
 
 def linear_assignment(cost_matrix, thresh):

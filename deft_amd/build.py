@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("igemm.hip", "igemm3.hip", "dcn.hip", "direct.hip", "ops.hip")]
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("igemm.hip", "igemm3.hip", "dcn.hip", "direct.hip", "ops.hip", "assoc.hip")]
 DEPS = SRCS + [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "..", "include", "deft_hip.h"), os.path.abspath(__file__)]
 OUT = os.path.join(HERE, "lib", "libdeft_hip.so")
 OBJ_DIR = os.path.join(HERE, "lib", "obj")

@@ -72,9 +72,12 @@ _SIGS = {
     "deft_split_weights_direct": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp]),
     "deft_direct_weight_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "deft_track_similarity": (C.c_int, [c_fp] + [C.c_int] * 2 + [c_fp] * 3 + [C.c_int] * 2 + [c_fp, c_fp]),
+    # host-side association helpers (HOST pointers, synchronous)
+    "deft_lapjv": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_double, c_fp, c_fp, c_fp]),
+    "deft_iou3d_matrix": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class DeftHipError(RuntimeError):

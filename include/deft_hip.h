@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 8
+#define DEFT_ABI_VERSION 9
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -341,6 +341,20 @@ int deft_conv_direct(const DeftGemmDesc* d, void* stream);
  * (tap 2t + (g >> 1), channels 8 (g & 1) ..+7);  Cin = 4: step t = window row t (pixel 2g + (e >> 2), channel e & 3). */
 int deft_split_weights_direct(const float* w, void* w3, int Cout, int Kpad, int KH, int KW, int Cin, void* stream);
 long long deft_direct_weight_bytes(int KH, int KW, int Cin, int Cout);
+
+/* ---- host-side association helpers (csrc/assoc.hip): the ONLY entry points that take HOST pointers; synchronous, no stream ---- */
+
+/* matching.linear_assignment's solver (matching.py:40-55: `lap.lapjv(cost_matrix, extend_cost=True, cost_limit=thresh)`; `lap` is a
+ * third-party package the reference does not vendor): Jonker-Volgenant on lap's extension of the n_rows x n_cols problem
+ * ([[cost, L/2], [L/2, 0]] with L = cost_limit; without a finite limit the zero-padded max(n, m) square).  cost [n_rows][n_cols] double,
+ * +inf / NaN = a pair that may not be matched.  x [n_rows]: column of each row or -1; y [n_cols]: row of each column or -1;
+ * total (nullable): cost of the matched pairs. */
+int deft_lapjv(const double* cost, int n_rows, int n_cols, double cost_limit, int* x, int* y, double* total);
+
+/* matching.iou_ddd_distance (matching.py:107-131): out [T][N] float32 = 1 - iou3d(detection box, track box) (:253-276) for boxes
+ * (h, w, l, x, y, z, rot_y) [.][7] double -- convert_3dbox_to_8corner (:207-243), Sutherland-Hodgman clip of the two ground-plane
+ * rectangles (:162-204), intersection area x vertical overlap over the union of the volumes. */
+int deft_iou3d_matrix(const double* trk, int T, const double* det, int N, float* out);
 
 #ifdef __cplusplus
 }

