@@ -1,0 +1,474 @@
+"""DEFT's tracking loop with the track state held in arrays -- `Tracker.update` + `STrack` (utils/tracker.py:140-1056) for every
+configuration the reference runs: MOT17 / KITTI (2-D) and nuScenes (3-D, one tracker per class), Kalman or LSTM motion model.
+
+Why arrays.  The reference keeps one Python object per track and walks the pool several times per frame (multi_predict, get_similarity,
+fuse_motion, iou_distance, update / activate): at 100-200 live tracks that is milliseconds of interpreter time per frame -- more than the
+network pass (profiles/r3_tracker_ops.json: 0.62 ms of 3.5 ms in per-track Python alone).  Here a frame is a fixed
+sequence of array operations over the pool:
+
+  pool state          one row per live track in `self.cols` (ids, flags, counters, last nodes, Kalman mean / covariance or the LSTM side's
+                      last observation + running observation statistics, 3-D box, depth, ...)
+  detections          one array per field, built once from the frame's results
+  embeddings          model.AFE (AfeSeam): centres -> embeddings, new frame scored against the stored frames the pool can read
+                      (deft_amd.tracker.FeatureRecorder, lazy blocks), tracks x detections similarity medians on the device
+                      (deft_track_similarity) -- ONE device round trip per frame, after which `after_device_work` fires
+  gates / costs       association._maha2, the 3-D centre / 7-component gates, bbox_overlaps, deft_iou3d_matrix -- whole matrices
+  assignment          deft_lapjv (own Jonker-Volgenant, fixed tie order)
+  state update        batched Kalman update (mot_tracker.kf_multi_update) or ONE deft_motion_step launch for every track touched
+                      in the frame (features + LSTM + future boxes; fetched lazily, when the next frame first needs a prediction)
+
+Semantics are the reference's, statement by statement (tests/test_mot_tracker.py replays scenes through the reference's own Tracker for
+mot / kitti_tracking / nuscenes x Kalman / LSTM and requires identical ids, flags and boxes frame by frame):
+  * nothing is ever marked Lost: `lost_stracks` stays empty, an unmatched track stays Tracked until `max_time_lost` frames have passed
+    and is then removed in the IoU stage (tracker.py:1006-1010) -- for KITTI / nuScenes only while it is still an IoU candidate (seen
+    within 6 / 3 frames, :982-990), i.e. never: such tracks simply stop matching and stay in the pool (kept as the reference does);
+  * nuScenes, every class but pedestrian: a first association on 3-D IoU between detections and the tracks seen in the last 3 frames
+    (:850-884, thresh 0.999), then the embedding association on the rest with the 3-D motion gate (fuse_motion_ddd), then a
+    similarity-only association (:927-953), then a 2-D IoU stage with threshold 0 (:1001-1004: only identical boxes match);
+  * KITTI: similarity-only second association (:954-980); MOT: straight to IoU;
+  * LSTM: no Kalman predict; fuse_motion uses the "gaussian" distance, which is identically zero on the 2-D position-only path unless
+    the track has >= 300 observations (then Mahalanobis on the predicted box with np.cov of its observations, matching.py:339-366);
+    the IoU stage uses the LSTM's predicted box (prediction_at_frame_tlbr, float32 arithmetic like the reference's arrays);
+  * ids come from the process-wide counter `mot_tracker.TrackIds` (basetrack.py:18, 40-42).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import association as A
+from . import tracker as DT
+from .mot_tracker import TrackIds, kf_multi_predict, kf_multi_update, _SP, _SV
+
+TRACKED, REMOVED = 1, 3                         # basetrack.py:11-15 (New = 0 and Lost = 2 never occur in a pool)
+
+
+class TrackView(object):
+    """What `update()` returns and `tracked_stracks` lists: one track as the reference's STrack shows it to its callers (src/test.py:
+    220-258: tlwh, track_id, score; nuScenes: org_ddd_box, classe, ddd_bbox, ddd_submission), a snapshot taken at the end of the frame."""
+    __slots__ = ("track_id", "is_activated", "tracklet_len", "score", "tlwh", "frame_id", "start_frame", "state", "ddd_bbox", "depth",
+                 "org_ddd_box", "ddd_submission", "classe")
+
+    end_frame = property(lambda self: self.frame_id)
+
+    @property
+    def tlbr(self):
+        r = self.tlwh.copy()
+        r[2:] += r[:2]
+        return r
+
+    def __repr__(self):
+        return "OT_{}_({}-{})".format(self.track_id, self.start_frame, self.frame_id)
+
+
+class _Columns(object):
+    """Structure of arrays with a common first dimension (the pool): append rows, keep a subset, index."""
+
+    def __init__(self, spec):
+        self.spec = spec                         # name -> (trailing shape, dtype)
+        self.a = {k: np.zeros((0,) + shp, dt) for k, (shp, dt) in spec.items()}
+        self.n = 0
+
+    def __getitem__(self, k):
+        return self.a[k]
+
+    def append(self, m, **vals):
+        for k, (shp, dt) in self.spec.items():
+            v = vals.get(k)
+            new = np.zeros((m,) + shp, dt) if v is None else np.asarray(v, dt).reshape((m,) + shp)
+            self.a[k] = np.concatenate([self.a[k], new], 0)
+        self.n += m
+
+    def keep(self, idx):
+        for k in self.a:
+            self.a[k] = self.a[k][idx]
+        self.n = len(self.a["tid"])
+
+
+class ArrayTracker(object):
+    lazy_blocks = True             # score the new frame only against the stored frames the pool's selected nodes live in
+    after_device_work = None       # set by a caller (Detector.run's lookahead): called ONCE per update(), as soon as the frame's last
+    #                                result-bearing device step has been read back; what follows is host work (plus one tiny motion launch)
+
+    def __init__(self, opt, model, h=100, w=100, frame_rate=10):
+        """opt: dataset ("mot" | "kitti_tracking" | "nuscenes"), lstm, track_buffer, max_object (+ load_model_traj for the LSTM).
+        model: carries `.AFE` (deft_amd.integrate.AfeSeam); with opt.lstm optionally `.motion` (a deft_amd.tracker.MotionBank, or any
+        object with alloc / free / step(slots, boxes, frame_id) -> (features, predictions [T, fut, dim])) -- built from
+        deft_amd.integrate.KalmanFilterLSTM(opt) when absent.  h, w: the image size detection centres are normalised with
+        (tracker.py:817-820; 100 until reset_tracking passes the real one)."""
+        assert opt.dataset in ("mot", "kitti_tracking", "nuscenes"), opt.dataset
+        self.opt, self.dataset, self.model = opt, opt.dataset, model
+        self.img_height, self.img_width = h, w
+        self.frame_id = 0
+        self.max_time_lost = int(frame_rate / 30.0 * getattr(opt, "track_buffer", 30))          # tracker.py:648-649
+        self.recorder = DT.FeatureRecorder(opt.dataset)
+        self.det_thresh = 0.0
+        self.use_lstm = bool(getattr(opt, "lstm", False))
+        self.ddd = self.dataset == "nuscenes"
+        self.mm = 2 if self.ddd else 4                                # STrack.get_similarity, tracker.py:233-236
+        self.L = self.mm + 2                                          # nodes kept per track: enough to tell "more than mm + 1 young nodes"
+        self.fut = 4 if self.ddd else 5                               # kalman_filter_lstm.py:60-63
+        self.bank = None
+        if self.use_lstm:
+            self.bank = getattr(model, "motion", None)
+            if self.bank is None:
+                from . import integrate
+                self.bank = DT.MotionBank(integrate.KalmanFilterLSTM(opt))
+        od = 7 if self.ddd else 4
+        spec = {"tid": ((), np.int64), "act": ((), bool), "score": ((), np.float64), "tlen": ((), np.int64), "fid": ((), np.int64),
+                "start": ((), np.int64), "nf": ((self.L,), np.int64), "ni": ((self.L,), np.int64), "nn": ((), np.int64)}
+        if self.use_lstm:
+            spec.update({"tlwh": ((4,), np.float64), "slot": ((), np.int64), "nobs": ((), np.int64), "omean": ((4,), np.float64),
+                         "om2": ((4, 4), np.float64)})
+        else:
+            spec.update({"mean": ((8,), np.float64), "cov": ((8, 8), np.float64)})
+        if self.ddd:
+            spec.update({"ddd": ((7,), np.float64), "depth": ((), np.float64), "org": ((), object), "sub": ((), object)})
+        self.cols = _Columns(spec)
+        self._od = od
+        self.fut_arr = np.zeros((0, self.fut, od))          # LSTM: predictions of the pool rows [T, fut, dim] on the host ...
+        self._pending = None                                  # ... and the motion step whose result has not been read back yet
+        self.removed_ids = []
+        self.lost_stracks = []
+        self.classe = None
+
+    # ---- views ------------------------------------------------------------------------------------------------------------------
+    def _tlwh_rows(self, idx):
+        c = self.cols
+        if self.use_lstm:
+            return c["tlwh"][idx].copy()
+        r = c["mean"][idx][:, :4].copy()
+        r[:, 2] *= r[:, 3]
+        r[:, :2] -= r[:, 2:] / 2
+        return r
+
+    def _views(self, idx, classe=None):
+        c = self.cols
+        idx = np.asarray(idx, dtype=int)
+        tl = self._tlwh_rows(idx) if len(idx) else np.zeros((0, 4))
+        out = []
+        for k, g in enumerate(idx):
+            v = TrackView()
+            v.track_id, v.is_activated, v.tracklet_len = int(c["tid"][g]), bool(c["act"][g]), int(c["tlen"][g])
+            v.score = c["score"][g] if self.ddd else np.float32(c["score"][g])      # (the 2-D datasets' rows are float32, tracker.py:790-803)
+            v.tlwh = tl[k]
+            v.frame_id, v.start_frame, v.state = int(c["fid"][g]), int(c["start"][g]), TRACKED
+            if self.ddd:
+                v.ddd_bbox, v.depth, v.org_ddd_box, v.ddd_submission, v.classe = c["ddd"][g].copy(), c["depth"][g], c["org"][g], c["sub"][g], self.classe
+            else:
+                v.ddd_bbox = v.depth = v.org_ddd_box = v.ddd_submission = v.classe = None
+            out.append(v)
+        return out
+
+    @property
+    def tracked_stracks(self):
+        return self._views(np.arange(self.cols.n))
+
+    @property
+    def removed_stracks(self):
+        return self.removed_ids
+
+    # ---- similarity -------------------------------------------------------------------------------------------------------------
+    def _selected_nodes(self, fid):
+        """For every pool row: (frames [T, L], ids [T, L], valid mask [T, L]) of the nodes STrack.get_similarity medians over
+        (tracker.py:221-248), oldest first."""
+        c = self.cols
+        nf, ni, nn = c["nf"], c["ni"], c["nn"]
+        T, L = nf.shape
+        stored = np.minimum(nn, L)
+        pos = np.arange(L)[None, :]
+        have = pos >= (L - stored)[:, None]                            # nodes are right-aligned: the newest at column L - 1
+        young = have & (fid - nf < DT.max_track_node)
+        q = young.sum(1)                                               # young nodes form a suffix; with all L stored ones young there may be more
+        nsel = np.where(q <= self.mm + 1, q, self.mm)
+        sel = pos >= (L - nsel)[:, None]
+        return nf, ni, sel
+
+    def _similarity(self, fid, rows_idx, nd, sel_all):
+        """deft_amd.tracker.get_similarity on the node arrays: float64 [len(rows_idx), nd + 1]."""
+        T = len(rows_idx)
+        if T == 0:
+            return np.array([])
+        nf, ni, sel = sel_all
+        nf, ni, sel = nf[rows_idx], ni[rows_idx], sel[rows_idx]
+        rec = self.recorder
+        if rec._dev is None or rec._dev[0] != fid:
+            if nd == 0 or not sel.any():
+                return np.zeros((T, nd + 1))
+            raise KeyError("no affinity blocks recorded for frame %r" % (fid,))
+        _, sim, starts, index = rec._dev
+        assert sim.shape[1] == nd + 1
+        L = sel.shape[1]
+        rows = np.zeros((T, L), np.int32); scale = np.zeros((T, L), np.float32)
+        cnt = sel.sum(1).astype(np.int32)
+        if sel.any():
+            frames = np.unique(nf[sel])
+            lut = {}
+            for f in frames.tolist():
+                blk, delta = index[f]                                  # KeyError like the reference for an unknown frame
+                lut[f] = (starts[blk], starts[blk + 1] - starts[blk], delta)
+            st = np.zeros(nf.shape, np.int64); ln = np.ones(nf.shape, np.int64); dl = np.zeros(nf.shape, np.float32)
+            for f, (s0, l0, d0) in lut.items():
+                m = sel & (nf == f)
+                st[m], ln[m], dl[m] = s0, l0, d0
+            if (sel & ((ni < 0) | (ni >= ln))).any():
+                raise IndexError("node id outside its frame")
+            # left-align the selected nodes of every row (the kernel reads node_row[t][0 .. cnt - 1])
+            order = np.argsort(~sel, axis=1, kind="stable")
+            rows = np.take_along_axis(np.where(sel, st + ni, 0), order, 1).astype(np.int32)
+            scale = np.take_along_axis(np.where(sel, dl, 0), order, 1).astype(np.float32)
+        plan = self.model.AFE.plan
+        dev = sim.device
+        pack = torch.from_numpy(np.concatenate([rows.reshape(-1), scale.view(np.int32).reshape(-1), cnt])).to(dev, non_blocking=True)
+        n1 = T * L
+        out = torch.empty(T, nd + 1, dtype=torch.float32, device=dev)
+        base = pack.data_ptr()
+        plan.lib.call("deft_track_similarity", C.c_void_p(sim.data_ptr()), sim.shape[0], nd, C.c_void_p(base), C.c_void_p(base + 4 * n1),
+                      C.c_void_p(base + 8 * n1), T, L, C.c_void_p(out.data_ptr()), plan._stream())
+        return out.cpu().numpy().astype(np.float64)
+
+    # ---- LSTM side --------------------------------------------------------------------------------------------------------------
+    def _resolve(self):
+        """Land the pending motion step (rows it covered, its result or a callable that waits for it) in `fut_arr`."""
+        if self._pending is not None:
+            rows, res = self._pending
+            self._pending = None
+            self.fut_arr[rows] = res() if callable(res) else res
+
+    def _prediction_at(self, idx, fid):
+        """STrack.prediction_at_frame (tracker.py:254-262): the predicted (cx, cy, a, h) / 3-D box of pool rows `idx` for frame `fid`."""
+        self._resolve()
+        delta = fid - self.cols["fid"][idx]
+        k = np.where((delta >= 1) & (delta <= self.fut), delta, self.fut) - 1
+        return self.fut_arr[idx, k]
+
+    def _motion_step(self, rows, boxes, fid):
+        """One deft_motion_step launch for the pool rows touched in this frame; its result is read when somebody asks for a prediction
+        (the next frame's IoU stage), not here."""
+        self._resolve()
+        if self.fut_arr.shape[0] < self.cols.n:
+            self.fut_arr = np.concatenate([self.fut_arr, np.zeros((self.cols.n - self.fut_arr.shape[0], self.fut, self._od))], 0)
+        if len(rows):
+            slots = self.cols["slot"][rows].tolist()
+            step_async = getattr(self.bank, "step_async", None)
+            res = step_async(slots, boxes, fid) if step_async is not None else self.bank.step(slots, boxes, fid)[1]
+            self._pending = (np.asarray(rows), res)
+
+    # ---- one frame --------------------------------------------------------------------------------------------------------------
+    def _device_done(self):
+        cb, self.after_device_work = self.after_device_work, None
+        if cb is not None:
+            cb()
+
+    def update(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None, ddd_org_boxes=None, submission=None, classe=None):
+        """tracker.py:723-1056.  2-D: results = the frame's post-processed detections ({"bbox" tlbr, "score", "class"}).  nuScenes: results =
+        rows (x1, y1, x2, y2, score) of this tracker's class with ddd_boxes (h, w, l, x, y, z, rot_y), depths_by_class, ddd_org_boxes,
+        submission (detector.py:313-338).  Returns the tracks matched or started in this frame (TrackView)."""
+        self.frame_id += 1
+        fid = self.frame_id
+        self.classe = classe if classe is not None else self.classe
+        c = self.cols
+        # ---- detections as arrays ----
+        if self.ddd:
+            dets = np.array(results)
+            det_ddd = np.array(ddd_boxes, dtype=np.float64).reshape(-1, 7) if len(dets) else np.zeros((0, 7))
+            det_depth = np.array([d[0] for d in depths_by_class], dtype=np.float64) if len(dets) else np.zeros(0)
+        elif self.dataset == "kitti_tracking":
+            dets = np.array([np.asarray(d["bbox"]).tolist() + [d["score"]] for d in results if d["class"] == 2], np.float32)     # tracker.py:790-797
+        else:
+            dets = np.array([np.asarray(d["bbox"]).tolist() + [d["score"]] for d in results], np.float32)
+        nd0 = len(dets)
+        sel_all = self._selected_nodes(fid)
+        if nd0 > 0:
+            tl = dets[:, :4].copy()                                   # STrack.tlbr_to_tlwh in the dtype of the rows (float32 for the 2-D datasets)
+            tl[:, 2:] -= tl[:, :2]
+            tlwh = tl.astype(float)
+            xyah = tlwh.copy()
+            xyah[:, :2] += xyah[:, 2:] / 2
+            xyah[:, 2] /= xyah[:, 3]
+            tlbr = tlwh.copy()
+            tlbr[:, 2:] += tlbr[:, :2]
+            dscore = dets[:, 4]
+            org = np.copy(dets[:, :4])
+            d = np.array(org, dtype=np.float64)                           # convert_detection, image.py:391-412
+            d[:, 2] -= d[:, 0]; d[:, 3] -= d[:, 1]
+            d[:, 0] /= self.img_width; d[:, 2] /= self.img_width; d[:, 1] /= self.img_height; d[:, 3] /= self.img_height
+            centers = torch.from_numpy(((2 * d[:, 0:2] + d[:, 2:4]) - 1.0).astype(float)).float().view(1, -1, 1, 1, 2)
+            feats = self.model.AFE.forward_feature_extracter(FeatureMaps, centers)
+            needed = set(np.unique(sel_all[0][sel_all[2]]).tolist()) if self.lazy_blocks else None
+            self.recorder.update(self.model, fid, feats.data, org, needed=needed)
+        else:
+            tlwh = xyah = tlbr = np.zeros((0, 4)); dscore = np.zeros(0, np.float32)
+        T0 = c.n
+        if not self.use_lstm and T0:                                   # STrack.multi_predict, tracker.py:193-207 (every pool track is Tracked)
+            c.a["mean"], c.a["cov"] = kf_multi_predict(c["mean"], c["cov"])
+        matched_t, matched_d = [], []                                  # pool row, detection index -- in the reference's output order
+        pool = np.arange(T0)
+        det_left = np.arange(nd0)
+        # ---- nuScenes (not pedestrian): 3-D IoU association with the recently seen tracks (tracker.py:850-884) ----
+        stage0 = self.ddd and self.classe != "pedestrian"
+        if stage0:
+            recent = np.abs(c["fid"] - fid) < 3
+            new, old = pool[recent], pool[~recent]
+            cost = A.iou_ddd_distance(c["ddd"][new], det_ddd)
+            m, u_t, u_d = A.linear_assignment(cost, 0.999)
+            if len(m):
+                matched_t += new[m[:, 0]].tolist(); matched_d += m[:, 1].tolist()
+            det_left = np.asarray(u_d, dtype=int)
+            pool = np.concatenate([new[np.asarray(u_t, dtype=int)], old]).astype(int)
+        # ---- embedding association fused with the motion gate (tracker.py:886-925) ----
+        sim = self._similarity(fid, pool, nd0, sel_all) if len(pool) and len(det_left) else None
+        self._device_done()
+        dists = np.zeros((len(pool), len(det_left)), dtype=float)
+        if dists.size:
+            dists = 1 - sim[:, :-1][:, det_left]
+        if dists.size:
+            lam = 0.9
+            if self.ddd:                                               # matching.fuse_motion_ddd, :374-415
+                dd = det_ddd[det_left][None, :, :] - c["ddd"][pool][:, None, :]
+                if self.use_lstm:
+                    g = np.sqrt(np.sum(dd[..., 3:-1] * dd[..., 3:-1], axis=2))          # kalman_filter_lstm.py:92-95
+                else:
+                    g = np.sum(dd * dd, axis=2)                                            # kalman_filter.py:271-273
+                thr = np.maximum(0.2 * c["depth"][pool], 5 if self.classe == "pedestrian" else 10)
+                dists[g > thr[:, None]] = np.inf
+                dists = lam * dists + 0.001 * g
+            elif not self.use_lstm:                                    # matching.fuse_motion, Kalman: :330-338
+                g = A._maha2(c["mean"][pool][:, :2], c["cov"][pool][:, :2, :2], xyah[det_left][:, :2])
+                dists[g > 5.0 * A.chi2inv95[2]] = np.inf
+                dists = lam * dists + 0.05 * (1 - lam) * g
+            else:                                                      # LSTM: :339-366
+                old_enough = c["nobs"][pool] >= 300
+                g = np.zeros_like(dists)
+                if old_enough.any():
+                    rows = pool[old_enough]
+                    pm = self._prediction_at(rows, fid).astype(np.float32).astype(np.float64)[:, :2]
+                    cov = c["om2"][rows] / (c["nobs"][rows] - 1)[:, None, None]
+                    gm = A._maha2(pm, cov[:, :2, :2], xyah[det_left][:, :2])
+                    sub = dists[old_enough]
+                    sub[gm > 5.0 * A.chi2inv95[2]] = np.inf
+                    dists[old_enough] = lam * sub + 0.05 * (1 - lam) * gm
+                if (~old_enough).any():
+                    dists[~old_enough] = lam * dists[~old_enough] + 0.0005 * (1 - lam) * g[~old_enough]
+        m, u_t, u_d2 = A.linear_assignment(dists, 0.9)
+        if len(m):
+            matched_t += pool[m[:, 0]].tolist(); matched_d += det_left[m[:, 1]].tolist()
+        u_t = np.asarray(u_t, dtype=int); u_d2 = np.asarray(u_d2, dtype=int)
+        # ---- similarity-only association of the leftovers (KITTI :954-980, nuScenes :927-953) ----
+        cand = pool
+        left2 = det_left[u_d2]
+        if self.dataset in ("kitti_tracking", "nuscenes") and len(left2) > 0:
+            r_tracked = pool[u_t]
+            if len(r_tracked) and sim is not None:
+                d2 = 1 - sim[u_t][:, :-1][:, left2]                    # (the rows of the matrix above: same tracks, same nodes, same frame)
+                m, u_t, u_d = A.linear_assignment(d2, 0.9)
+                if len(m):
+                    matched_t += r_tracked[m[:, 0]].tolist(); matched_d += left2[m[:, 1]].tolist()
+                left2 = left2[np.asarray(u_d, dtype=int)]
+                cand = r_tracked
+                u_t = np.asarray(u_t, dtype=int)
+        # ---- IoU association of what is left (tracker.py:982-1030) ----
+        rest = cand[u_t]
+        if self.dataset in ("kitti_tracking", "nuscenes"):
+            rest = rest[np.abs(fid - c["fid"][rest]) < (3 if self.ddd else 6)]
+        if len(rest) and len(left2):
+            if self.use_lstm and not self.ddd:                          # prediction_at_frame_tlbr (tracker.py:274-280), float32 like the reference's arrays
+                p = self._prediction_at(rest, fid).astype(np.float32)
+                p[:, 2] *= p[:, 3]
+                p[:, :2] -= p[:, 2:] / 2
+                p[:, 2:] += p[:, :2]
+                a_tlbr = p.astype(np.float64)
+            else:
+                a_tlbr = self._tlwh_rows(rest)
+                a_tlbr[:, 2:] += a_tlbr[:, :2]
+            cost = 1 - A.bbox_overlaps(np.ascontiguousarray(a_tlbr), np.ascontiguousarray(tlbr[left2]))
+        else:
+            cost = np.zeros((len(rest), len(left2)), dtype=float)
+        m, u_t, u_d = A.linear_assignment(cost, 0.0 if self.ddd else 0.9)
+        if len(m):
+            matched_t += rest[m[:, 0]].tolist(); matched_d += left2[m[:, 1]].tolist()
+        removed = [int(g) for g in rest[np.asarray(u_t, dtype=int)] if fid - c["fid"][g] > self.max_time_lost]
+        new_d = left2[np.asarray(u_d, dtype=int)]
+        new_d = new_d[dscore[new_d] >= self.det_thresh] if len(new_d) else new_d
+        # ---- state update of the matched tracks: STrack.update (tracker.py:371-400), all at once ----
+        mt = np.asarray(matched_t, dtype=int); md = np.asarray(matched_d, dtype=int)
+        if len(mt):
+            c["fid"][mt] = fid
+            c["tlen"][mt] += 1
+            c["score"][mt] = dscore[md]
+            c["act"][mt] = True
+            c.a["nf"][mt] = np.concatenate([c["nf"][mt][:, 1:], np.full((len(mt), 1), fid)], 1)
+            c.a["ni"][mt] = np.concatenate([c["ni"][mt][:, 1:], md[:, None]], 1)
+            c["nn"][mt] += 1
+            if self.ddd:
+                c["ddd"][mt] = det_ddd[md]; c["depth"][mt] = det_depth[md]
+                for g, j in zip(mt.tolist(), md.tolist()):
+                    c["org"][g] = ddd_org_boxes[j]; c["sub"][g] = submission[j]
+            if self.use_lstm:
+                c["tlwh"][mt] = tlwh[md]
+                if not self.ddd:
+                    self._observe(mt, xyah[md])
+            else:
+                c["mean"][mt], c["cov"][mt] = kf_multi_update(c["mean"][mt], c["cov"][mt], xyah[md])
+        # ---- new tracks: STrack.activate (tracker.py:285-311) ----
+        nnew = len(new_d)
+        if nnew:
+            ids = [TrackIds.next_id() for _ in range(nnew)]
+            vals = {"tid": ids, "act": np.full(nnew, fid == 1), "score": dscore[new_d], "tlen": np.zeros(nnew), "fid": np.full(nnew, fid),
+                    "start": np.full(nnew, fid), "nn": np.ones(nnew),
+                    "nf": np.concatenate([np.zeros((nnew, self.L - 1)), np.full((nnew, 1), fid)], 1),
+                    "ni": np.concatenate([np.zeros((nnew, self.L - 1)), new_d[:, None]], 1)}
+            if self.use_lstm:
+                vals.update({"tlwh": tlwh[new_d], "slot": [self.bank.alloc() for _ in range(nnew)]})
+            else:
+                z = xyah[new_d]
+                hh = z[:, 3]
+                one = np.ones_like(hh)
+                std = np.stack([2 * _SP * hh, 2 * _SP * hh, 1e-2 * one, 2 * _SP * hh, 10 * _SV * hh, 10 * _SV * hh, 1e-5 * one, 10 * _SV * hh], 1)
+                cov = np.zeros((nnew, 8, 8)); ii = np.arange(8)
+                cov[:, ii, ii] = np.square(std)                        # kalman_filter.py:53-88
+                vals.update({"mean": np.concatenate([z, np.zeros((nnew, 4))], 1), "cov": cov})
+            if self.ddd:
+                o = np.empty(nnew, object); s_ = np.empty(nnew, object)
+                for k, j in enumerate(new_d.tolist()):
+                    o[k] = ddd_org_boxes[j]; s_[k] = submission[j]
+                vals.update({"ddd": det_ddd[new_d], "depth": det_depth[new_d], "org": o, "sub": s_})
+            c.append(nnew, **vals)
+            if self.use_lstm and not self.ddd:
+                self._observe(np.arange(T0, T0 + nnew), xyah[new_d])
+        # ---- the LSTM motion update of everything touched in this frame: ONE launch (tracker.py:408-580) ----
+        touched = np.concatenate([mt, np.arange(T0, T0 + nnew)]).astype(int)
+        if self.use_lstm:
+            src = det_ddd if self.ddd else tlwh
+            self._motion_step(touched, np.concatenate([src[md], src[new_d]]).reshape(-1, self._od), fid)
+        output = self._views(touched)
+        # ---- pool for the next frame: tracked minus removed, new tracks at the end (tracker.py:1032-1054) ----
+        if removed:
+            keep = np.ones(c.n, bool); keep[removed] = False
+            self.removed_ids += c["tid"][removed].tolist()
+            if self.use_lstm:
+                for s_ in c["slot"][removed].tolist():
+                    self.bank.free(int(s_))
+                self._resolve()
+                self.fut_arr = self.fut_arr[keep]
+            c.keep(keep)
+        return output
+
+    def _observe(self, rows, x):
+        """np.cov of a 2-D LSTM track's (x, y, a, h) observations (tracker.py:410-412), kept as running mean / scatter (Welford, all
+        touched tracks at once): only read for tracks with >= 300 observations (matching.py:342)."""
+        c = self.cols
+        c["nobs"][rows] += 1
+        n = c["nobs"][rows][:, None]
+        delta = x - c["omean"][rows]
+        mean = c["omean"][rows] + delta / n
+        c["om2"][rows] += delta[:, :, None] * (x - mean)[:, None, :]
+        c["omean"][rows] = mean
+
+
+class Tracker2D(ArrayTracker):
+    """The 2-D datasets (MOT17 / KITTI): `Tracker(opt, model, h, w)` of the reference for BASELINE configs[1] / [2] / [3]."""
+
+    def __init__(self, opt, model, h=100, w=100, frame_rate=10):
+        assert opt.dataset in ("mot", "kitti_tracking"), "Tracker2D: mot / kitti_tracking (nuScenes: ArrayTracker, one per class)"
+        super().__init__(opt, model, h, w, frame_rate)

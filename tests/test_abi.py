@@ -51,7 +51,11 @@ def test_no_packed_fp32_valu_in_any_kernel():
         for o in objs:                                  # each object embeds its own fat binary (.hip_fatbin): pull it out, take the gfx950 image
             fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
             subprocess.check_call(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", o, fat])
-            subprocess.check_call([bundler, "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+            r = subprocess.run([bundler, "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co],
+                               capture_output=True, text=True)
+            if r.returncode != 0:                       # a host-only source (assoc.hip: the association helpers) carries no device image
+                assert os.path.basename(o) == "assoc.hip.o", (o, r.stderr)
+                continue
             dis = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
             mfma += dis.count("v_mfma_f32_")
             for op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"):

@@ -210,3 +210,182 @@ def test_lazy_affinity_blocks_change_nothing(emu_lib):
     assert full == lazy and sum(len(f) for f in full) > 1000
     assert max(asked_full) == 49 and sum(asked_lazy) < 0.4 * sum(asked_full)
     assert len(trk.lost_stracks) + len(trk.removed_stracks) >= 0 and MT.TrackIds.count >= 30
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# round 4: the LSTM configuration (BASELINE configs[3]) and the nuScenes 3-D association (configs[4]) of the array tracker, against the
+# reference's own Tracker with its own KalmanFilterLSTM (synthetic LSTM weights on both sides)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _reference_lstm(dataset, model, lstm, lsd):
+    import make_golden as MG
+    import ref_import
+    import ref_shims
+    ref_shims.install()
+    ref_import.install_stubs(MG.OracleDCN)
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        from opts import opts
+        from utils import tracker as RT
+        from utils.basetrack import BaseTrack
+    finally:
+        sys.argv = argv
+    opt = opts().parse(["tracking", "--dataset", dataset, "--gpus", "-1"])
+    opt.lstm = lstm
+    ref_cls = RT.KalmanFilterLSTM
+
+    def make_ref(o):
+        k = ref_cls(o)
+        k.model.load_state_dict(lsd, strict=True)
+        k.model.eval()
+        return k
+    if lstm:
+        RT.KalmanFilterLSTM = make_ref
+        RT.STrack.shared_kalman_lstm = make_ref(opt)
+    BaseTrack._count = 0
+    trk = RT.Tracker(opt, model, h=H, w=W)
+    assert trk.use_lstm == lstm
+    return opt, trk, (RT, ref_cls)
+
+
+def _mine(opt, emu_lib, lsd):
+    from deft_amd import integrate, mot_tracker as MT, tracker as DT
+    MT.TrackIds.count = 0
+    afe = FakeAFE()
+    afe.plan = types.SimpleNamespace(lib=emu_lib, _stream=lambda: None)
+    model = types.SimpleNamespace(AFE=afe)
+    if opt.lstm:
+        model.motion = DT.MotionBank(integrate.KalmanFilterLSTM(opt, lsd, device="cpu", lib=emu_lib))
+    return MT.ArrayTracker(opt, model, h=H, w=W)
+
+
+@pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
+def test_array_tracker_lstm_matches_reference_tracker(emu_lib, dataset):
+    """`--lstm` on the 2-D datasets (BASELINE configs[3]: KITTI + LSTM motion gating): no Kalman predict, the LSTM's predicted boxes in
+    the IoU stage (matching.py:93-96), one deft_motion_step launch per frame for every track touched."""
+    import deft_oracle as O
+    torch.set_grad_enabled(False)
+    lsd = O.synth_lstm_state_dict("mot")
+    nframes = 40
+    opt, ref, (RT, ref_cls) = _reference_lstm(dataset, types.SimpleNamespace(AFE=FakeAFE()), True, lsd)
+    try:
+        mine = _mine(opt, emu_lib, lsd)
+        fm = [torch.zeros(1, 1, 1, 1)]
+        ids = set()
+        for t in range(nframes):
+            res = _scene(t, dataset)
+            a = _log(ref.update([dict(r) for r in res], fm))
+            b = _log(mine.update([dict(r) for r in res], fm))
+            assert [x[:3] for x in a] == [x[:3] for x in b], (t, a, b)
+            for x, y in zip(a, b):
+                assert np.abs(np.array(x[3]) - np.array(y[3])).max() <= 1e-9 and x[4] == y[4], (t, x, y)
+            ids |= {x[0] for x in a}
+            assert sorted(tk.track_id for tk in ref.tracked_stracks) == sorted(tk.track_id for tk in mine.tracked_stracks), t
+            # the LSTM side: the predictions the next frame's IoU stage will read (float32 on both sides)
+            want = {tk.track_id: tk.future_predictions for tk in ref.tracked_stracks}
+            mine._resolve()
+            for row, tid in enumerate(mine.cols["tid"].tolist()):
+                for k, v in want[tid].items():
+                    assert np.abs(mine.fut_arr[row, k - 1] - np.asarray(v, dtype=np.float64)).max() <= 2e-3 * max(1.0, float(np.abs(v).max())), (t, tid, k)
+        assert len(ids) >= 5 and mine.bank.launches <= nframes
+        assert len(mine.removed_stracks) == len(ref.removed_stracks)
+    finally:
+        RT.KalmanFilterLSTM = ref_cls
+        torch.set_grad_enabled(True)
+        sys.modules.pop("dcn_v2", None)
+
+
+def test_lstm_gate_with_300_observations_matches_fuse_motion(emu_lib):
+    """matching.fuse_motion's branch for LSTM tracks with >= 300 observations (matching.py:342-353: Mahalanobis on the predicted box with
+    np.cov of the observations): the tracker's running scatter against np.cov, and its gate against deft_amd.association.fuse_motion
+    (pinned to the reference by tests/golden/association.npz)."""
+    from deft_amd import association as A, mot_tracker as MT
+    g = np.random.RandomState(4)
+    T, n = 6, 320
+    obs = g.randn(T, n, 4) * np.array([30, 20, 0.05, 10]) + np.array([300, 200, 0.5, 80])
+    opt = types.SimpleNamespace(dataset="mot", track_buffer=30, max_object=100, lstm=True)
+    bank = types.SimpleNamespace(alloc=lambda: 0, free=lambda s: None)
+    trk = MT.ArrayTracker(opt, types.SimpleNamespace(AFE=None, motion=bank), h=H, w=W)
+    trk.cols.append(T, tid=np.arange(1, T + 1))
+    for k in range(n):
+        trk._observe(np.arange(T), obs[:, k])
+    cov = trk.cols["om2"] / (trk.cols["nobs"] - 1)[:, None, None]
+    for t in range(T):
+        assert np.abs(cov[t] - np.cov(obs[t].T)).max() <= 1e-9 * np.abs(np.cov(obs[t].T)).max()
+    pred = (obs.mean(1) + g.randn(T, 4)).astype(np.float32)
+    meas = obs.mean(1)[g.permutation(T)] + g.randn(T, 4) * np.array([40, 40, 0.01, 3])
+    meas[::2, :2] += 400.0                                              # half of the detections far outside every gate
+    cost = g.rand(T, T)
+    tracks = [types.SimpleNamespace(observations=[0] * n, covariance=np.cov(obs[t].T), prediction_at_frame=(lambda f, t=t: pred[t])) for t in range(T)]
+    dets = [types.SimpleNamespace(to_xyah=(lambda r=meas[j]: r.copy())) for j in range(T)]
+    want = A.fuse_motion(None, cost.copy(), tracks, dets, frame_id=9, use_lstm=True)
+    gm = A._maha2(pred.astype(np.float64)[:, :2], cov[:, :2, :2], meas[:, :2])
+    got = cost.copy()
+    got[gm > 5.0 * A.chi2inv95[2]] = np.inf
+    got = 0.9 * got + 0.05 * (1 - 0.9) * gm
+    assert np.isinf(want).any() and np.isfinite(want).any()
+    assert (np.isinf(want) == np.isinf(got)).all() and np.abs(want[np.isfinite(want)] - got[np.isfinite(got)]).max() <= 1e-9
+
+
+def _scene3d(t, classe):
+    """One class's detections of a nuScenes camera frame: objects on the ground plane drifting in x / z with a slow yaw, a fake pinhole
+    projection for the 2-D box; #2 is missed in frames 5-6, #4 appears at frame 8, #1 leaves at 15; frame 3 is empty."""
+    if t == 3 or t >= 24:
+        return [], [], [], [], []
+    rows, ddd, depth, org, sub = [], [], [], [], []
+    for i in range(6):
+        if (i == 2 and t in (5, 6)) or (i == 4 and t < 8) or (i == 1 and t >= 15):
+            continue
+        ped = classe == "pedestrian"
+        h, w, l = (1.7, 0.6, 0.7) if ped else (1.5 + 0.05 * i, 1.8 + 0.03 * i, 4.2 + 0.1 * i)
+        x = -8.0 + 3.5 * i + (0.25 if ped else 0.6) * t * (1 if i % 2 else -1) + 0.02 * np.sin(t * 1.7 + i)
+        z = 12.0 + 4.0 * i + 0.3 * t + 0.03 * np.cos(t * 1.3 + 2 * i)
+        y = 1.0 + 0.01 * np.sin(t + i)
+        rot = 0.2 * i + 0.02 * t + 0.005 * np.sin(3 * t + i)
+        u, v = 100 + 40 * x / z * 6, 60 + 10.0 / z * 20
+        bw, bh = (w + l) * 30 / z, h * 60 / z
+        rows.append([u - bw / 2, v - bh / 2, u + bw / 2, v + bh / 2, 0.8 - 0.05 * i + 0.01 * np.cos(t + i), 1.0])
+        ddd.append([h + 0.01 * np.sin(t + i), w, l + 0.02 * np.cos(t * 0.7 + i), x, y, z, rot])
+        depth.append([z])
+        org.append({"frame": t, "obj": i, "kind": "org"})
+        sub.append({"frame": t, "obj": i, "kind": "submission"})
+    return rows, ddd, depth, org, sub
+
+
+def _log3(targets):
+    return [(int(t.track_id), bool(t.is_activated), int(t.tracklet_len), [float(v) for v in t.tlwh], float(t.score),
+             [float(v) for v in np.asarray(t.ddd_bbox)], float(t.depth), t.org_ddd_box, t.ddd_submission, t.classe) for t in targets]
+
+
+@pytest.mark.parametrize("lstm", [False, True])
+@pytest.mark.parametrize("classe", ["car", "pedestrian"])
+def test_array_tracker_nuscenes_matches_reference_tracker(emu_lib, classe, lstm):
+    """BASELINE configs[4]: the per-class nuScenes tracker -- 3-D IoU first association (all classes but pedestrian; matching.py:107-131
+    through deft_iou3d_matrix), embedding association with the 3-D motion gate (the centre distance with the LSTM, the squared
+    7-component distance with the plain Kalman filter), similarity-only association, 2-D IoU stage at threshold 0 -- against the
+    reference's Tracker.update (tracker.py:738-778, 850-953, 999-1004) on the same arguments, Kalman and LSTM."""
+    import deft_oracle as O
+    torch.set_grad_enabled(False)
+    lsd = O.synth_lstm_state_dict("nuscenes")
+    opt, ref, (RT, ref_cls) = _reference_lstm("nuscenes", types.SimpleNamespace(AFE=FakeAFE()), lstm, lsd)
+    try:
+        mine = _mine(opt, emu_lib, lsd)
+        fm = [torch.zeros(1, 1, 1, 1)]
+        ids, n3d = set(), 0
+        for t in range(30):
+            rows, ddd, depth, org, sub = _scene3d(t, classe)
+            a = _log3(ref.update([list(r) for r in rows], fm, ddd_boxes=[list(d) for d in ddd], depths_by_class=[list(d) for d in depth],
+                                 ddd_org_boxes=list(org), submission=list(sub), classe=classe))
+            b = _log3(mine.update([list(r) for r in rows], fm, ddd_boxes=[list(d) for d in ddd], depths_by_class=[list(d) for d in depth],
+                                  ddd_org_boxes=list(org), submission=list(sub), classe=classe))
+            assert [x[:3] for x in a] == [x[:3] for x in b], (t, [x[:3] for x in a], [x[:3] for x in b])
+            for x, y in zip(a, b):
+                assert np.abs(np.array(x[3]) - np.array(y[3])).max() <= 1e-9 and x[4] == y[4], (t, x, y)
+                assert x[5] == y[5] and x[6] == y[6] and x[7] is y[7] and x[8] is y[8] and x[9] == y[9] == classe
+            ids |= {x[0] for x in a}
+            n3d += sum(1 for x in a if x[2] > 0)
+            assert [tk.track_id for tk in ref.tracked_stracks] == [tk.track_id for tk in mine.tracked_stracks], t
+        assert len(ids) >= 5 and n3d > 40
+    finally:
+        RT.KalmanFilterLSTM = ref_cls
+        torch.set_grad_enabled(True)
+        sys.modules.pop("dcn_v2", None)
