@@ -383,10 +383,16 @@ def side_config(name, args, dev, lib, rank):
         pr = parity_gate(cfg, wl, (0,))
         par = {k: pr[k] for k in ("pass", "pass_up_to_roundoff_ties", "topk_ordered_equal", "floats_within_tol", "max_err")}
     what = "detect+embed+affinity" + ("+LSTM" if cfg["lstm"] else "")
-    return {"metric": "frames/sec (%s) at %dx%d" % (what, cfg["W"], cfg["H"]), "workload": cfg["workload"],
-            "value": round(steps * args.batch / dt, 3), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-            "frames_per_step": args.batch, "roofline_frac": roof["frac"] if roof else None, "roofline_achieved_tflops": roof["achieved"] if roof else None,
-            "parity": par}
+    out = {"metric": "frames/sec (%s) at %dx%d" % (what, cfg["W"], cfg["H"]), "workload": cfg["workload"],
+           "value": round(steps * args.batch / dt, 3), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+           "frames_per_step": args.batch, "roofline_frac": roof["frac"] if roof else None, "roofline_achieved_tflops": roof["achieved"] if roof else None,
+           "parity": par}
+    if name in E2E:
+        del wl
+        torch.cuda.empty_cache()
+        e = end_to_end(name, dev, lib, dev.index or 0, ne=60)
+        out["end_to_end"] = {k: e[k] for k in ("ms_per_frame", "value", "unit", "stage_ms", "serial", "tracks_alive", "workload")}
+    return out
 
 
 TRAFFIC_FILE = "r4_traffic.json"
@@ -558,7 +564,7 @@ def main():
         #      post-process -> deft_amd.mot_tracker.Tracker2D.update (embedding extraction, affinity chain against the stored frames,
         #      device-side similarity medians, batched Kalman gate, assignment, IoU stage), K detections per frame ----
         if args.config == "B" and world == 1:
-            extras["end_to_end"] = end_to_end(sd, H, W, dev, lib, local)
+            extras["end_to_end"] = end_to_end("B", dev, lib, local)
 
     # ---- roofline of the dominant kernel family ----
     roof = None
@@ -627,49 +633,88 @@ def main():
         dist.destroy_process_group()
 
 
-def end_to_end(sd, H, W, dev, lib, local):
+E2E = {"B": dict(frame=(1080, 1920), lstm=False), "D": dict(frame=(375, 1242), lstm=True), "E": dict(frame=(900, 1600), lstm=True)}
+
+
+def end_to_end(name, dev, lib, local, ne=100):
+    """Frame in -> tracks out on ONE stream, configs B / D / E: a uint8 camera frame in host memory ->
+    deft_amd.detector.Detector.run (H2D, warp + normalise on the device, the plan as a multi-branch hipGraph, one D2H, array
+    post-processing [+ the nuScenes 3-D branch]) -> deft_amd.array_tracker.ArrayTracker.update (embedding extraction, affinity chain
+    against the stored frames the pool can read, device-side similarity medians, motion gate, own Jonker-Volgenant assignment, IoU stage;
+    D / E: the LSTM motion model, one deft_motion_step launch per frame; E: seven per-class trackers with the 3-D IoU association).
+    `prefetch` = the next frame of the stream: its network pass runs on a second set of plan buffers while the host associates this
+    frame (Detector.run's one-frame lookahead)."""
     from types import SimpleNamespace
-    from deft_amd import detector as FD, integrate, mot_tracker as MT
-    sde = dict(sd)                       # random regression heads give boxes with negative extent: bias the amodal l/t/r/b head to ~40 x 64 px boxes
-    sde["ltrb_amodal.2.weight"] = sde["ltrb_amodal.2.weight"] * 0.05
-    sde["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
-    opt = SimpleNamespace(dataset="mot", K=KDET, max_object=100, gpus=[local], hip_graphs=True, depth_scale=1.0, input_h=H, input_w=W,
-                          out_thresh=-1.0, test_scales=[1.0], flip_test=False, public_det=False, track_buffer=30, lstm=False)
+    from deft_amd import detector as FD, engine, integrate, mot_tracker as MT, synth, tracker as DT
+    from deft_amd.postprocess import NUSCENES_TRACKING_NAMES
+    cfg, e = CONFIGS[name], E2E[name]
+    H, W, ds = cfg["H"], cfg["W"], cfg["dataset"]
+    sh, sw = e["frame"]
+    sde = dict(synth.synth_state_dict(ds))              # random regression heads give boxes with negative extent: bias them to sensible sizes
+    if "ltrb_amodal.2.weight" in sde:
+        sde["ltrb_amodal.2.weight"] = sde["ltrb_amodal.2.weight"] * 0.05
+        sde["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
+    else:
+        sde["wh.2.weight"] = sde["wh.2.weight"] * 0.05
+        sde["wh.2.bias"] = torch.tensor([10.0, 16.0])
+    if ds == "nuscenes":                                # detections must survive the 0.3 / 0.35 class thresholds (detector.py:222-225)
+        sde["hm.2.weight"] = sde["hm.2.weight"] * 3.0
+        sde["hm.2.bias"] = torch.tensor([-1.0, -0.8, -1.2, -0.9, -1.0, -1.1, -0.7, -1.0, -1.0, -1.0])
+        sde["dim.2.weight"] = sde["dim.2.weight"] * 0.05
+        sde["dim.2.bias"] = torch.tensor([1.6, 1.7, 4.0])
+    opt = SimpleNamespace(dataset=ds, K=KDET, max_object=100, gpus=[local], hip_graphs=True, depth_scale=1.0, input_h=H, input_w=W,
+                          out_thresh=-1.0 if ds != "nuscenes" else 0.1, test_scales=[1.0], flip_test=False, public_det=False, track_buffer=30,
+                          lstm=e["lstm"], num_classes={"mot": 1, "kitti_tracking": 3, "nuscenes": 10}[ds])
     fdet = FD.Detector(opt, sde)
     seam = integrate.AfeSeam(sde, 100, dev, lib)
     seam.host_copy = False
-    MT.TrackIds.count = 0
-    fdet.set_tracker(MT.Tracker2D(opt, SimpleNamespace(AFE=seam), h=H, w=W))
-    # 1920 x 1080 uint8 camera frames in host memory (what a decoder hands over): H2D, warp + normalise on the device, the plan as a
-    # multi-branch hipGraph, one D2H, array post-processing, Tracker2D.  `prefetch` = the next frame of the stream: its network pass
-    # runs on a second set of plan buffers while the host associates this frame (Detector.run's one-frame lookahead).
-    ge = np.random.RandomState(11)
-    feed = [ge.randint(0, 256, (1080, 1920, 3), dtype=np.uint8) for _ in range(6)]
+    model = SimpleNamespace(AFE=seam)
+    if e["lstm"]:
+        model.motion = DT.MotionBank(engine.LstmPlan(synth.synth_lstm_state_dict("nuscenes" if ds == "nuscenes" else "mot"), dev, lib))
+    info = None
+    if ds == "nuscenes":
+        from scipy.spatial.transform import Rotation as R
+        g = np.random.RandomState(5)
+        q1, q2 = g.randn(4), g.randn(4)
+        info = {"trans_matrix": np.concatenate([R.from_rotvec(g.randn(3)).as_matrix(), g.randn(3, 1) * 10], 1).tolist(),
+                "cs_record_rot": (q1 / np.linalg.norm(q1)).tolist(), "cs_record_trans": [1.7, 0.0, 1.5],
+                "pose_record_rot": (q2 / np.linalg.norm(q2)).tolist(), "pose_record_trans": [411.3, 1180.9, 0.0]}
 
-    def e2e(lookahead, ne):
+    def fresh_tracker():
         MT.TrackIds.count = 0
-        fdet.set_tracker(MT.Tracker2D(opt, SimpleNamespace(AFE=seam), h=1080, w=1920))
-        fdet.img_height, fdet.img_width = 1080, 1920
+        if ds == "nuscenes":
+            return {n: MT.ArrayTracker(opt, model, h=sh, w=sw) for n in NUSCENES_TRACKING_NAMES}
+        return MT.ArrayTracker(opt, model, h=sh, w=sw)
+    ge = np.random.RandomState(11)
+    feed = [ge.randint(0, 256, (sh, sw, 3), dtype=np.uint8) for _ in range(6)]
+
+    def e2e(lookahead, n):
+        fdet.set_tracker(fresh_tracker())
+        fdet.img_height, fdet.img_width = sh, sw
         for i in range(12):
-            fdet.run(feed[i % len(feed)], prefetch=feed[(i + 1) % len(feed)] if lookahead else None)
+            fdet.run(feed[i % len(feed)], image_info=info, prefetch=feed[(i + 1) % len(feed)] if lookahead else None)
         sync()
         acc = {}
         t1 = time.perf_counter()
-        for i in range(ne):
-            fdet.run(feed[(12 + i) % len(feed)], prefetch=feed[(13 + i) % len(feed)] if lookahead and i + 1 < ne else None)
+        for i in range(n):
+            fdet.run(feed[(12 + i) % len(feed)], image_info=info, prefetch=feed[(13 + i) % len(feed)] if lookahead and i + 1 < n else None)
             for k_, v_ in fdet.times.items():
                 acc[k_] = acc.get(k_, 0.0) + v_
         sync()
         return time.perf_counter() - t1, acc
-    ne = 100
     d0, acc0 = e2e(False, ne)
     d1, acc = e2e(True, ne)
-    return {"workload": "one stream, 1920x1080 uint8 frame in host memory -> Detector.run (H2D, device pre-processing, fused process, "
-                        "post-process) -> Tracker2D.update, %d detections per frame, one frame of lookahead" % KDET,
+    trk = fdet.tracker
+    alive = sum(t.cols.n for t in trk.values()) if isinstance(trk, dict) else trk.cols.n
+    stored = max(len(t.recorder.all_frame_index) for t in trk.values()) if isinstance(trk, dict) else len(trk.recorder.all_frame_index)
+    return {"workload": "one stream, %dx%d uint8 frame in host memory -> Detector.run (H2D, device pre-processing, fused process, post-process%s) -> "
+                        "ArrayTracker.update (%s%s), one frame of lookahead" % (sw, sh, ", nuScenes 3-D branch" if ds == "nuscenes" else "",
+                                                                                "7 per-class trackers, 3-D IoU association, " if ds == "nuscenes" else "",
+                                                                                "LSTM motion model" if e["lstm"] else "Kalman motion model"),
             "frames": ne, "ms_per_frame": round(d1 / ne * 1e3, 3), "value": round(ne / d1, 3), "unit": "frames/s",
             "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc.items()},
             "serial": {"ms_per_frame": round(d0 / ne * 1e3, 3), "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc0.items()}},
-            "tracks_alive": len(fdet.tracker.tracked_stracks), "stored_frames": len(fdet.tracker.recorder.all_frame_index)}
+            "tracks_alive": int(alive), "stored_frames": int(stored), "detections_tracked_last_frame": len(fdet.last_results)}
 
 
 if __name__ == "__main__":

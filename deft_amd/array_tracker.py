@@ -38,7 +38,7 @@ import torch
 
 from . import association as A
 from . import tracker as DT
-from .mot_tracker import TrackIds, kf_multi_predict, kf_multi_update, _SP, _SV
+from .kalman import TrackIds, kf_multi_predict, kf_multi_update, _SP, _SV
 
 TRACKED, REMOVED = 1, 3                         # basetrack.py:11-15 (New = 0 and Lost = 2 never occur in a pool)
 
@@ -219,13 +219,28 @@ class ArrayTracker(object):
             scale = np.take_along_axis(np.where(sel, dl, 0), order, 1).astype(np.float32)
         plan = self.model.AFE.plan
         dev = sim.device
-        pack = torch.from_numpy(np.concatenate([rows.reshape(-1), scale.view(np.int32).reshape(-1), cnt])).to(dev, non_blocking=True)
         n1 = T * L
+        host = np.concatenate([rows.reshape(-1), scale.view(np.int32).reshape(-1), cnt])
+        if dev.type == "cuda":                                         # pinned staging both ways: no pageable (= blocking) copies in the frame
+            need_in, need_out = 2 * n1 + T, T * (nd + 1)
+            pin = getattr(self, "_pin", None)
+            if pin is None or pin[0].numel() < need_in or pin[1].numel() < need_out:
+                pin = self._pin = (torch.empty(max(2048, 2 * need_in), dtype=torch.int32).pin_memory(),
+                                   torch.empty(max(32768, 2 * need_out), dtype=torch.float32).pin_memory())
+            pin[0][:need_in] = torch.from_numpy(host)
+            pack = pin[0][:need_in].to(dev, non_blocking=True)
+        else:
+            pack = torch.from_numpy(host)
         out = torch.empty(T, nd + 1, dtype=torch.float32, device=dev)
         base = pack.data_ptr()
         plan.lib.call("deft_track_similarity", C.c_void_p(sim.data_ptr()), sim.shape[0], nd, C.c_void_p(base), C.c_void_p(base + 4 * n1),
                       C.c_void_p(base + 8 * n1), T, L, C.c_void_p(out.data_ptr()), plan._stream())
-        return out.cpu().numpy().astype(np.float64)
+        if dev.type == "cuda":
+            land = pin[1][:T * (nd + 1)].view(T, nd + 1)
+            land.copy_(out, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()               # THE device round trip of the frame
+            return land.numpy().astype(np.float64)
+        return out.numpy().astype(np.float64)
 
     # ---- LSTM side --------------------------------------------------------------------------------------------------------------
     def _resolve(self):

@@ -238,23 +238,33 @@ class Detector(object):
         # after the similarity medians, ~40 % into update()) gets it queued at that point, so the pass overlaps the host-only rest of the
         # association instead of competing with the tracker's own launches; any other tracker gets it queued up front
         nxt, self._launch_next = getattr(self, "_launch_next", None), None
-        hook = nxt is not None and self.tracker is not None and self.dataset != "nuscenes" and hasattr(self.tracker, "after_device_work")
-        if nxt is not None and not hook:
+        per_class = self.nuscenes_targets(results, image_info, nms=nms) if self.tracker is not None and self.dataset == "nuscenes" else None
+        hook_on = None                                  # the tracker object whose update() will fire the queued pass
+        if nxt is not None and self.tracker is not None:
+            last = self.tracker[list(per_class)[-1]] if per_class is not None else self.tracker      # nuScenes: the last class's tracker
+            if hasattr(last, "after_device_work"):
+                hook_on = last
+        if nxt is not None and hook_on is None:
             nxt()
         if self.tracker is None:
             targets = results
-        elif hook:
+        elif per_class is not None:                                                    # detector.py:198-338
+            targets = []
+            for name, a in per_class.items():
+                trk = self.tracker[name]
+                if trk is hook_on:
+                    trk.after_device_work = nxt
+                targets += trk.update(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"],
+                                      ddd_org_boxes=a["ddd_org_boxes"], submission=a["submission"], classe=name)
+            if hook_on is not None and hook_on.after_device_work is not None:
+                hook_on.after_device_work = None
+                nxt()
+        elif hook_on is not None:
             self.tracker.after_device_work = nxt
             targets = self.tracker.update(results, fmaps)
             if self.tracker.after_device_work is not None:             # (update() returned early)
                 self.tracker.after_device_work = None
                 nxt()
-        elif self.dataset == "nuscenes":
-            per_class = self.nuscenes_targets(results, image_info, nms=nms)            # detector.py:198-338
-            targets = []
-            for name, a in per_class.items():
-                targets += self.tracker[name].update(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"],
-                                                     ddd_org_boxes=a["ddd_org_boxes"], submission=a["submission"], classe=name)
         elif getattr(self, "_trk_stream", None) is not None and self._ahead_busy():
             # the next frame's network pass is running beside us: the tracker's many small launches go to a HIGH-priority stream, so that
             # they are dispatched ahead of the pass's workgroups instead of queueing behind them

@@ -1308,6 +1308,22 @@ class AfePlan(_Plan):
             d.w3 = self.weights_p3(wp).data_ptr()
         self.lib.call("deft_conv2d_nhwc", C.byref(d), self._stream())
 
+    def _staged_ints(self, values):
+        """A small int32 host list as a device tensor without a blocking copy: written into one of a few pinned staging rows, copied
+        non_blocking on the plan's stream.  Eight rows in rotation: a row is rewritten eight calls later, long after its copy ran (every
+        caller reads results back -- i.e. synchronises -- at least once per frame)."""
+        n = len(values)
+        if self.device.type != "cuda":
+            return torch.tensor(values, dtype=torch.int32, device=self.device)
+        st = getattr(self, "_stage", None)
+        if st is None or st[0].shape[1] < n:
+            st = self._stage = (torch.empty(8, max(64, 2 * n), dtype=torch.int32).pin_memory(), [0])
+        buf, turn = st
+        row = buf[turn[0] % 8]
+        turn[0] += 1
+        row[:n] = torch.as_tensor(values, dtype=torch.int32)
+        return row[:n].to(self.device, non_blocking=True)
+
     def affinity(self, hist, cur):
         """hist: list of [P_f, D] embeddings of F stored frames; cur [Q, D].
         Returns the F matrices [P_f, Q+1] of forward_stacker_features (AFE.py:110-160,
@@ -1347,7 +1363,7 @@ class AfePlan(_Plan):
         h4 = torch.empty(M, c4, dtype=torch.float32, device=dev)
         self._lin(h3, M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, h4, c4)
         out = torch.empty(T, Q + 1, dtype=torch.float32, device=dev)
-        rs = torch.tensor(starts, dtype=torch.int32, device=dev)
+        rs = self._staged_ints(starts)                # (pinned staging: a pageable torch.tensor(..., device=) is a blocking copy behind the whole chain)
         self.lib.call("deft_affinity_finish", ptr(h4), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(rs), len(hist), T, Q,
                       self.max_object, ptr(out), self._stream())
         return out, starts

@@ -128,10 +128,10 @@ class AfeSeam:
         n = l.shape[1]
         centers = l.reshape(1, n, 2).to(self.device, torch.float32).expand(Nf, n, 2).contiguous()
         emb = self.plan.extract(views, centers)
-        if self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()
-        if len(self.plan._keep) > keep:               # NCHW adapter made temporaries: drop them and the
-            del self.plan._keep[keep:]                # descriptors built on their addresses
+        if len(self.plan._keep) > keep:               # NCHW adapter made temporaries: wait for the launches that read them, then drop them
+            if self.device.type == "cuda":            # and the descriptors built on their addresses (NHWC Views -- the plan's own maps -- need
+                torch.cuda.current_stream(self.device).synchronize()          # neither: no host wait in the tracker's per-frame path)
+            del self.plan._keep[keep:]
             self.plan._egroups.clear()
         return emb[0:1]
 

@@ -198,6 +198,38 @@ class MotionBank:
         self.launches += 1
         return feat.cpu().numpy(), pred.cpu().numpy()
 
+    def step_async(self, slots, boxes, frame_id):
+        """`step` without waiting: the launch and a non-blocking copy of the future boxes into pinned memory are queued; the returned
+        callable waits for that copy (an event) and hands back the float64 [T, fut, dim] array -- the array tracker calls it when the
+        NEXT frame first needs a prediction, so the motion update costs the frame that issues it no host time."""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, self.dim)
+        assert len(set(slots)) == len(slots) == boxes.shape[0]
+        dev = self.h.device
+        if dev.type != "cuda":
+            pred = self.step(slots, boxes, frame_id)[1]
+            return lambda: pred
+        T = len(slots)
+        if getattr(self, "_pin", None) is None or self._pin[0].shape[0] < T:
+            cap = max(128, 2 * T)
+            self._pin = (torch.empty(cap, 1 + self.dim, dtype=torch.float64).pin_memory(),
+                         torch.empty(cap, self.fut, self.dim, dtype=torch.float64).pin_memory())
+        hin, hout = self._pin
+        hin[:T, 0] = torch.as_tensor(list(slots), dtype=torch.float64)
+        hin[:T, 1:] = torch.from_numpy(boxes)
+        din = hin[:T].to(dev, non_blocking=True)
+        st = din[:, 0].to(torch.int32).contiguous()
+        bt = din[:, 1:].contiguous()
+        _, pred = self.plan.motion_step(st, bt, frame_id, self.h, self.c, self.last)
+        self.launches += 1
+        hout[:T].copy_(pred, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+
+        def wait():
+            ev.synchronize()
+            return hout[:T].numpy().copy()
+        return wait
+
     # ---- deferred form used by the STrack adapter ----
     def enqueue(self, track, slot, box, frame_id):
         if any(p[1] == slot for p in self.pending):                # the same track twice before a read: keep order

@@ -1560,3 +1560,147 @@ def check_co_residency(lib, H=512, W=512, N=16, reps=4):
     assert checked > 60 and "deft_dcn_v2_nhwc" in kinds and "deft_conv2d_nhwc" in kinds
     assert any(d.p3_kernel == 0 for e, _, d in p0._gemms if e == "deft_dcn_v2_nhwc"), "no igemm.hip MODE_DCN launch in this plan"
     return checked
+
+
+def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64, W=96, K=12, T=4, seed=6):
+    """deft_amd.detector.Detector.run -> deft_amd.array_tracker.ArrayTracker on the configurations round 4 adds (KITTI + LSTM, nuScenes
+    with its seven per-class trackers): frames in, tracks out, serial and with one frame of lookahead -- the SAME tracks both ways (ids,
+    boxes, scores), the motion bank stepped once per frame, the queued pass fired by the tracker's after_device_work hook."""
+    from types import SimpleNamespace
+    from deft_amd import engine, hiplib, integrate, mot_tracker as MT, tracker as DT
+    from deft_amd.detector import Detector
+    from deft_amd.postprocess import NUSCENES_TRACKING_NAMES
+    sd = dict(O.synth_state_dict(dataset))
+    if "ltrb_amodal.2.weight" in sd:
+        sd["ltrb_amodal.2.weight"] = sd["ltrb_amodal.2.weight"] * 0.05
+        sd["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
+    else:
+        sd["wh.2.weight"] = sd["wh.2.weight"] * 0.05
+        sd["wh.2.bias"] = torch.tensor([10.0, 16.0])
+    if dataset == "nuscenes":
+        sd["hm.2.weight"] = sd["hm.2.weight"] * 3.0
+        sd["hm.2.bias"] = torch.tensor([-1.0, -0.8, -1.2, -0.9, -1.0, -1.1, -0.7, -1.0, -1.0, -1.0])
+        sd["dim.2.weight"] = sd["dim.2.weight"] * 0.05
+        sd["dim.2.bias"] = torch.tensor([1.6, 1.7, 4.0])
+    saved_lib, hiplib._lib = hiplib._lib, lib
+    try:
+        opt = SimpleNamespace(dataset=dataset, K=K, max_object=100, gpus=[0 if device != "cpu" else -1], hip_graphs=True, depth_scale=1.0,
+                              input_h=H, input_w=W, out_thresh=-1.0 if dataset != "nuscenes" else 0.1, test_scales=[1.0], flip_test=False,
+                              public_det=False, track_buffer=30, lstm=lstm, num_classes=10)
+        info = None
+        if dataset == "nuscenes":
+            from scipy.spatial.transform import Rotation as R
+            g = np.random.RandomState(5)
+            q1, q2 = g.randn(4), g.randn(4)
+            info = {"trans_matrix": np.concatenate([R.from_rotvec(g.randn(3)).as_matrix(), g.randn(3, 1) * 10], 1).tolist(),
+                    "cs_record_rot": (q1 / np.linalg.norm(q1)).tolist(), "cs_record_trans": [1.7, 0.0, 1.5],
+                    "pose_record_rot": (q2 / np.linalg.norm(q2)).tolist(), "pose_record_trans": [411.3, 1180.9, 0.0]}
+        gen = torch.Generator().manual_seed(seed)
+        base = torch.randint(0, 256, (sh, sw, 3), dtype=torch.uint8, generator=gen).numpy()
+        frames = []
+        for t in range(T):                              # the same scene drifting by a pixel per frame: detections re-associate
+            f = np.roll(base, t, axis=1).copy()
+            frames.append(f)
+
+        def run(lookahead):
+            det = Detector(opt, sd)
+            seam = integrate.AfeSeam(sd, 100, device, lib)
+            model = SimpleNamespace(AFE=seam)
+            if lstm:
+                model.motion = DT.MotionBank(engine.LstmPlan(O.synth_lstm_state_dict("nuscenes" if dataset == "nuscenes" else "mot"), device, lib))
+            MT.TrackIds.count = 0
+            if dataset == "nuscenes":
+                det.set_tracker({n: MT.ArrayTracker(opt, model, h=sh, w=sw) for n in NUSCENES_TRACKING_NAMES})
+            else:
+                det.set_tracker(MT.ArrayTracker(opt, model, h=sh, w=sw))
+            det.img_height, det.img_width = sh, sw
+            log, fired = [], []
+            for t in range(T):
+                nxt = frames[t + 1] if lookahead and t + 1 < T else None
+                targets = det.run(frames[t], image_info=info, prefetch=nxt)
+                log.append(sorted((int(x.track_id), bool(x.is_activated), int(x.tracklet_len), [round(float(v), 9) for v in x.tlwh], float(x.score),
+                                   None if x.ddd_bbox is None else [float(v) for v in x.ddd_bbox]) for x in targets))
+            launches = model.motion.launches if lstm else 0
+            return log, launches
+
+        serial, l0 = run(False)
+        ahead, l1 = run(True)
+        assert serial == ahead
+        assert sum(len(f) for f in serial) >= T and any(x[2] > 0 for f in serial for x in f), "tracks must have been matched across frames"
+        if lstm:
+            assert 0 < l0 <= (7 * T if dataset == "nuscenes" else T) and l1 == l0
+        return serial
+    finally:
+        hiplib._lib = saved_lib
+
+
+def check_tracks_against_reference_trace(lib, device, tag):
+    """frames in -> TRACKS out through the C ABI on `device`, against the tracks the reference's own
+    `Detector.run` + `Tracker.update` returned on the same stream (tests/golden/detector_trace_<tag>.npz `t<k>_tracks` / `t<k>_targets`,
+    written by oracle/make_golden.py from the reference with its real embeddings; mot = Kalman, mot_lstm = LSTM, nuscenes = seven per-class
+    trackers with the LSTM and the 3-D association).  deft_amd.detector.Detector.run (fused process -> post-process -> merge [-> nuScenes
+    branch]) feeds deft_amd.array_tracker.ArrayTracker: same track ids, same boxes / scores / 3-D boxes, frame by frame."""
+    from types import SimpleNamespace
+    from deft_amd import hiplib, integrate, mot_tracker as MT, tracker as DT
+    from deft_amd.detector import Detector
+    from deft_amd.postprocess import NUSCENES_TRACKING_NAMES
+    f = np.load(os.path.join(GOLD, "detector_trace_%s.npz" % tag))
+    H, W, K, T = int(f["H"]), int(f["W"]), int(f["K"]), int(f["T"])
+    nusc = tag == "nuscenes"
+    lstm = True if nusc else bool(int(f["lstm"]))
+    ds = "nuscenes" if nusc else "mot"
+    if nusc:
+        sd = nuscenes_trace_state_dict()
+        info = {k[5:]: f[k].tolist() for k in f.files if k.startswith("info_")}
+        names = [str(n) for n in f["names"]]
+    else:
+        sd = dict(O.synth_state_dict("mot"))
+        sd["ltrb_amodal.2.weight"] = sd["ltrb_amodal.2.weight"] * 0.05
+        sd["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
+        info = {}
+    saved_lib, hiplib._lib = hiplib._lib, lib
+    try:
+        opt = SimpleNamespace(dataset=ds, K=K, max_object=100, gpus=[0 if device != "cpu" else -1], hip_graphs=True, depth_scale=1.0,
+                              out_thresh=float(f["out_thresh"]) if nusc else 0.0, num_classes=10 if nusc else 1, test_scales=[1.0], flip_test=False,
+                              public_det=False, track_buffer=30, lstm=lstm)
+        det = Detector(opt, sd)
+        model = SimpleNamespace(AFE=integrate.AfeSeam(sd, 100, device, lib))
+        if lstm:
+            model.motion = DT.MotionBank(engine.LstmPlan(O.synth_lstm_state_dict(ds), device, lib))
+        MT.TrackIds.count = 0
+        # the trace's trackers were built by `reset_tracking` BEFORE the image size was set (oracle/make_golden.py, like src/test.py:95-164 before
+        # its first reset): they normalise detection centres with the constructor's default h = w = 100 (tracker.py:632; SURVEY App. C #2)
+        det.set_tracker({n: MT.ArrayTracker(opt, model, h=100, w=100) for n in NUSCENES_TRACKING_NAMES} if nusc else MT.ArrayTracker(opt, model, h=100, w=100))
+        det.img_height, det.img_width = H, W
+        worst, nrows = 0.0, 0
+        for t in range(T):
+            x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(int(f["seeds"][t])))
+            c = np.array([W / 2.0, H / 2.0], dtype=np.float32)
+            meta = {"c": c, "s": np.float32(max(H, W)), "height": H, "width": W, "out_height": H // 4, "out_width": W // 4,
+                    "inp_height": H, "inp_width": W, "calib": f["calib"] if nusc else np.eye(3, 4, dtype=np.float32)}
+            batch = lambda v: torch.from_numpy(np.asarray(v)[None])
+            targets = det.run({"image": [torch.zeros(H, W, 3)], "images": {1.0: [x]}, "meta": {1.0: {k: batch(v) for k, v in meta.items()}}}, image_info=info)
+            if nusc:
+                got = np.array(sorted([float(s.track_id), float(names.index(s.classe))] + [float(v) for v in s.tlwh] + [float(s.score)]
+                                      + [float(v) for v in s.ddd_bbox] + [float(v) for v in s.ddd_submission] for s in targets), np.float64).reshape(-1, 24)
+                ref = f["t%d_targets" % t]
+            else:
+                got = np.array(sorted([s.track_id] + [float(v) for v in s.tlwh] + [float(s.score)] for s in targets), np.float64).reshape(-1, 6)
+                ref = f["t%d_tracks" % t]
+            assert got.shape == ref.shape, (t, got.shape, ref.shape)
+            ncol = 2 if nusc else 1
+            assert np.array_equal(got[:, :ncol], ref[:, :ncol]), (t, got[:, :ncol].tolist(), ref[:, :ncol].tolist())       # ids (and classes)
+            if ref.size:
+                body_g, body_r = got[:, ncol:], ref[:, ncol:]
+                if nusc:                              # quaternions of the submission boxes: equal up to sign
+                    qg, qr = body_g[:, -4:], body_r[:, -4:]
+                    sgn = np.sign((qg * qr).sum(1, keepdims=True)); sgn[sgn == 0] = 1
+                    body_g = np.concatenate([body_g[:, :-4], qg * sgn], 1)
+                e = float((np.abs(body_g - body_r) / np.maximum(1.0, np.abs(body_r))).max())
+                assert e <= 1e-3, (t, e)
+                worst = max(worst, e)
+            nrows += len(ref)
+        assert nrows >= 12
+        return worst
+    finally:
+        hiplib._lib = saved_lib

@@ -485,3 +485,13 @@ def test_dataflow_schedule_is_order_independent(emu_lib):
     for i in order:
         plan.ops[i][2]()
     assert not all(torch.equal(a, b) for a, b in zip(ref, outs()))
+
+
+@pytest.mark.parametrize("dataset,lstm", [("kitti_tracking", True), ("nuscenes", True), ("nuscenes", False)])
+def test_fused_run_array_tracker(emu_lib, dataset, lstm):
+    pc.check_fused_run_array_tracker(emu_lib, "cpu", dataset, lstm, T=3)
+
+
+@pytest.mark.parametrize("tag", ["mot", "mot_lstm", "nuscenes"])
+def test_tracks_against_reference_trace(emu_lib, tag):
+    pc.check_tracks_against_reference_trace(emu_lib, "cpu", tag)

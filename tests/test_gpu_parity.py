@@ -726,3 +726,15 @@ def test_launches_bit_exact_beside_another_kernel(gpu_lib):
     """Round 4 finding: a launch must not change its bits when another stream's kernel shares the compute units (the timed plans run on two
     HIP streams).  See parity_checks.check_co_residency."""
     pc.check_co_residency(gpu_lib)
+
+
+@pytest.mark.parametrize("tag", ["mot", "mot_lstm", "nuscenes"])
+def test_tracks_against_reference_trace_on_device(gpu_lib, tag):
+    """Detector.run -> ArrayTracker on the MI355X against the tracks of the reference's own Detector.run + Tracker
+    (ids exact, boxes / scores / 3-D boxes 1e-3)."""
+    pc.check_tracks_against_reference_trace(gpu_lib, "cuda", tag)
+
+
+@pytest.mark.parametrize("dataset,lstm", [("kitti_tracking", True), ("nuscenes", True)])
+def test_fused_run_array_tracker_on_device(gpu_lib, dataset, lstm):
+    pc.check_fused_run_array_tracker(gpu_lib, "cuda", dataset, lstm, sh=270, sw=480, H=128, W=160, K=40, T=5)
