@@ -145,16 +145,21 @@ class ArrayTracker(object):
     def _views(self, idx, classe=None):
         c = self.cols
         idx = np.asarray(idx, dtype=int)
-        tl = self._tlwh_rows(idx) if len(idx) else np.zeros((0, 4))
+        if len(idx) == 0:
+            return []
+        tl = self._tlwh_rows(idx)
+        tid, act, tlen = c["tid"][idx].tolist(), c["act"][idx].tolist(), c["tlen"][idx].tolist()
+        fid, start = c["fid"][idx].tolist(), c["start"][idx].tolist()
+        score = c["score"][idx] if self.ddd else c["score"][idx].astype(np.float32)      # (the 2-D datasets' rows are float32, tracker.py:790-803)
+        if self.ddd:
+            ddd, depth, org, sub = c["ddd"][idx], c["depth"][idx], c["org"][idx], c["sub"][idx]
         out = []
-        for k, g in enumerate(idx):
+        for k in range(len(idx)):
             v = TrackView()
-            v.track_id, v.is_activated, v.tracklet_len = int(c["tid"][g]), bool(c["act"][g]), int(c["tlen"][g])
-            v.score = c["score"][g] if self.ddd else np.float32(c["score"][g])      # (the 2-D datasets' rows are float32, tracker.py:790-803)
-            v.tlwh = tl[k]
-            v.frame_id, v.start_frame, v.state = int(c["fid"][g]), int(c["start"][g]), TRACKED
+            v.track_id, v.is_activated, v.tracklet_len, v.score, v.tlwh = tid[k], act[k], tlen[k], score[k], tl[k]
+            v.frame_id, v.start_frame, v.state = fid[k], start[k], TRACKED
             if self.ddd:
-                v.ddd_bbox, v.depth, v.org_ddd_box, v.ddd_submission, v.classe = c["ddd"][g].copy(), c["depth"][g], c["org"][g], c["sub"][g], self.classe
+                v.ddd_bbox, v.depth, v.org_ddd_box, v.ddd_submission, v.classe = ddd[k].copy(), depth[k], org[k], sub[k], self.classe
             else:
                 v.ddd_bbox = v.depth = v.org_ddd_box = v.ddd_submission = v.classe = None
             out.append(v)

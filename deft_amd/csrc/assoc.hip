@@ -4,13 +4,18 @@
 //
 //  * deft_lapjv: the assignment solver behind matching.linear_assignment (matching.py:40-55).  The reference calls the third-party
 //    package `lap` (`lap.lapjv(cost, extend_cost=True, cost_limit=thresh)`, version unpinned, not in /root/reference, not in this
-//    image): the Jonker-Volgenant dense LAP algorithm (R. Jonker, A. Volgenant, "A shortest augmenting path algorithm for dense and
-//    sparse linear assignment problems", Computing 38, 1987) in the arrangement lap's dense solver uses -- column reduction + reduction
-//    transfer, two passes of augmenting row reduction, then shortest augmenting paths -- on lap's own extension of the rectangular
-//    problem: an (n + m) x (n + m) matrix with cost_limit / 2 in the two off-diagonal blocks and 0 in the lower-right block, so that
-//    a pair is matched only while it is cheaper than leaving both sides unmatched.  Restated here (no code of `lap` is available) so
-//    that the order in which ties are broken is fixed and this repository's own: column scans run in index order, `<` / `<=`
-//    comparisons as published.  tests/test_association.py: optimal against brute force, equal-cost ties resolved reproducibly.
+//    image), which solves the Jonker-Volgenant LAP (R. Jonker, A. Volgenant, "A shortest augmenting path algorithm for dense and sparse
+//    linear assignment problems", Computing 38, 1987) on its extension of the rectangular problem: an (n + m) x (n + m) matrix with
+//    cost_limit / 2 in the two off-diagonal blocks and 0 in the lower-right block, so that a pair is matched only while it is cheaper
+//    than leaving both sides unmatched -- i.e. it minimises  sum(matched costs) + cost_limit * #unmatched rows  (+ a constant).
+//    With a finite limit (the only form the tracker uses) THAT objective is solved here directly: shortest augmenting paths with row /
+//    column potentials over the n x m matrix, every row carrying an implicit private "stay unmatched" column at cost_limit (`Sap`
+//    below; O(m) per scan step instead of the O((n + m)^2) scans of the square extension, whose constant blocks are one big tie:
+//    1.5 ms -> 0.06 ms at 118 x 100).  Without a limit: the published dense algorithm (column reduction + reduction transfer,
+//    augmenting row reduction, augmentation) on the zero-padded square (`Jv` below).  No code of `lap` is available; both are
+//    restated from the literature so that the order in which ties are broken is fixed and this repository's own: rows in index order,
+//    among equally near columns the lowest index, a real column before "unmatched".  tests/test_association.py: optimal against brute
+//    force and scipy, equal-cost ties resolved reproducibly.
 //  * deft_iou3d_matrix: matching.iou_ddd_distance (matching.py:107-131) = 1 - iou3d for every (track box, detection box) pair, with
 //    convert_3dbox_to_8corner (:207-243), polygon_clip (Sutherland-Hodgman, :162-204), poly_area, box3d_vol and iou3d (:253-276)
 //    written out per pair in float64; the intersection polygon's area by the shoelace formula instead of scipy's ConvexHull.volume
@@ -178,6 +183,79 @@ struct Jv {
     }
 };
 
+// ---- shortest augmenting paths with an implicit "unmatched" column per row ------------------------------------------------------
+// minimise  sum_{matched (i,j)} c[i][j] + limit * #unmatched rows.  Potentials u (rows), v (columns); the private column of row i has
+// potential 0 and is reachable from row i only, so it is free whenever row i is in a search tree (a row matched to it can only be
+// reached through it): a path may end at a free real column or at the private column of any row of the tree.
+struct Sap {
+    int n, m;
+    const cost_t* c;          // [n][m] row-major, finite
+    cost_t limit;
+    std::vector<int> col4row, row4col;          // col4row: real column, -1 = not processed yet, -2 = unmatched (its private column)
+
+    void solve() {
+        col4row.assign(n, -1); row4col.assign(m, -1);
+        std::vector<cost_t> u(n, 0.0), v(m, 0.0), shortest(m), rowdist(n);
+        std::vector<int> path(m), remaining(m), SR; std::vector<char> SC(m);
+        SR.reserve(n);
+        for (int cur = 0; cur < n; ++cur) {
+            for (int j = 0; j < m; ++j) { shortest[j] = LARGE; remaining[j] = j; SC[j] = 0; }
+            int nrem = m;
+            SR.clear();
+            cost_t minVal = 0.0;
+            int i = cur, sink = -1, sink_row = -1;          // sink >= 0: a free real column; sink_row >= 0: the private column of that row
+            cost_t best_dummy = LARGE; int dummy_row = -1;
+            rowdist[cur] = 0.0;
+            while (true) {
+                SR.push_back(i);
+                const cost_t di = minVal;                   // distance at which row i entered the tree
+                rowdist[i] = di;
+                const cost_t rd = di + limit - u[i];         // its private column
+                if (rd < best_dummy) { best_dummy = rd; dummy_row = i; }
+                cost_t lowest = LARGE; int idx = -1;
+                for (int k = 0; k < nrem; ++k) {
+                    const int j = remaining[k];
+                    const cost_t r = di + c[(size_t)i * m + j] - u[i] - v[j];
+                    if (r < shortest[j]) { shortest[j] = r; path[j] = i; }
+                    // the nearest column; among equals the lowest column index (remaining[] is permuted by the removals below)
+                    if (shortest[j] < lowest || (idx >= 0 && shortest[j] == lowest && j < remaining[idx])) { lowest = shortest[j]; idx = k; }
+                }
+                if (idx < 0 || best_dummy < lowest) {        // ending unmatched is strictly nearer than every real column
+                    minVal = best_dummy; sink_row = dummy_row;
+                    break;
+                }
+                minVal = lowest;
+                const int j = remaining[idx];
+                SC[j] = 1;
+                remaining[idx] = remaining[--nrem];
+                if (row4col[j] < 0) { sink = j; break; }
+                i = row4col[j];
+            }
+            // dual update (before the assignment changes)
+            u[cur] += minVal;
+            for (size_t k = 1; k < SR.size(); ++k) { const int r = SR[k]; u[r] += minVal - shortest[col4row[r]]; }
+            for (int j = 0; j < m; ++j) if (SC[j]) v[j] -= minVal - shortest[j];
+            // augment
+            int j;
+            if (sink_row >= 0) {
+                j = col4row[sink_row];                      // the real column row `sink_row` gives up (or -1 / none when it is `cur`)
+                col4row[sink_row] = -2;
+                if (sink_row == cur) continue;
+            } else {
+                j = sink;
+            }
+            while (true) {
+                const int r = path[j];
+                row4col[j] = r;
+                const int prev = col4row[r];
+                col4row[r] = j;
+                if (r == cur) break;
+                j = prev;
+            }
+        }
+    }
+};
+
 // ---- 3-D boxes ----------------------------------------------------------------------------------------------------------------
 struct P2 { double x, y; };
 
@@ -277,31 +355,40 @@ extern "C" int deft_lapjv(const double* cost, int n_rows, int n_cols, double cos
         if (std::isfinite(cost[k]) && std::fabs(cost[k]) > big) big = std::fabs(cost[k]);
     big = big * (n_rows + n_cols + 1) + 1.0;
     if (limited && big < cost_limit + 1.0) big = cost_limit + 1.0;
-    Jv jv;
-    if (limited) {                                     // lap's extension: [[cost, L/2], [L/2, 0]]
-        jv.n = n_rows + n_cols;
-    } else {                                           // extend_cost without a limit: zero-padded max(n, m) square
-        jv.n = n_rows > n_cols ? n_rows : n_cols;
-    }
-    const int n = jv.n;
-    std::vector<cost_t> ext((size_t)n * n, limited ? cost_limit / 2 : 0.0);
-    for (int i = 0; i < n_rows; ++i)
-        for (int j = 0; j < n_cols; ++j) {
-            const double c = cost[(size_t)i * n_cols + j];
-            ext[(size_t)i * n + j] = std::isfinite(c) ? c : big;
-        }
-    if (limited)
-        for (int i = n_rows; i < n; ++i)
-            for (int j = n_cols; j < n; ++j) ext[(size_t)i * n + j] = 0.0;
-    jv.c = ext.data();
-    jv.solve();
     double sum = 0.0;
-    for (int i = 0; i < n_rows; ++i) {
-        const int j = jv.x[i];
-        if (j >= 0 && j < n_cols && std::isfinite(cost[(size_t)i * n_cols + j])) {      // (a forced +inf pairing is no match)
-            x[i] = j;
-            y[j] = i;
-            sum += cost[(size_t)i * n_cols + j];
+    if (limited) {
+        std::vector<cost_t> fin((size_t)n_rows * n_cols);
+        for (long long k = 0; k < (long long)n_rows * n_cols; ++k) fin[k] = std::isfinite(cost[k]) ? cost[k] : big;
+        Sap sap;
+        sap.n = n_rows; sap.m = n_cols; sap.c = fin.data(); sap.limit = cost_limit;
+        sap.solve();
+        for (int i = 0; i < n_rows; ++i) {
+            const int j = sap.col4row[i];
+            if (j >= 0 && std::isfinite(cost[(size_t)i * n_cols + j])) {
+                x[i] = j;
+                y[j] = i;
+                sum += cost[(size_t)i * n_cols + j];
+            }
+        }
+    } else {                                           // extend_cost without a limit: zero-padded max(n, m) square
+        Jv jv;
+        jv.n = n_rows > n_cols ? n_rows : n_cols;
+        const int n = jv.n;
+        std::vector<cost_t> ext((size_t)n * n, 0.0);
+        for (int i = 0; i < n_rows; ++i)
+            for (int j = 0; j < n_cols; ++j) {
+                const double cc = cost[(size_t)i * n_cols + j];
+                ext[(size_t)i * n + j] = std::isfinite(cc) ? cc : big;
+            }
+        jv.c = ext.data();
+        jv.solve();
+        for (int i = 0; i < n_rows; ++i) {
+            const int j = jv.x[i];
+            if (j >= 0 && j < n_cols && std::isfinite(cost[(size_t)i * n_cols + j])) {      // (a forced +inf pairing is no match)
+                x[i] = j;
+                y[j] = i;
+                sum += cost[(size_t)i * n_cols + j];
+            }
         }
     }
     if (total) *total = sum;

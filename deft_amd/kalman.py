@@ -67,8 +67,9 @@ def kf_multi_update(mean, cov, meas):
     # K = P H^T S^-1  (the reference solves with a Cholesky factor of S; S is SPD, the solve below gives the same K to round-off)
     gain = np.linalg.solve(pc, cov[:, :4, :]).transpose(0, 2, 1)          # [T, 8, 4]
     innov = meas - pm
-    new_mean = mean + np.einsum("ti,tji->tj", innov, gain)
-    new_cov = cov - np.einsum("tij,tjk,tlk->til", gain, pc, gain)
+    new_mean = mean + np.matmul(gain, innov[:, :, None])[:, :, 0]
+    # K S K^T as two batched products (the reference's multi_dot((K, S, K^T)) in the same association order)
+    new_cov = cov - np.matmul(np.matmul(gain, pc), gain.transpose(0, 2, 1))
     return new_mean, new_cov
 
 

@@ -380,6 +380,41 @@ def run_iou_ddd():
     print("  iou_ddd: %d x %d pairs, %d overlapping (reference iou_ddd_distance)" % (T, N, int((out < 1.0).sum())))
 
 
+def run_result_writers():
+    """src/test.py:322-342 `write_results` (the reference's own function, exec'd out of test.py's source: importing the module would run
+    its argument parser and needs cv2 / the datasets) on synthetic per-frame track lists, MOT and KITTI formats: the text it writes as a
+    fixture for deft_amd.results.write_results."""
+    import ast
+    import tempfile
+    src = open(os.path.join(os.path.dirname(ref_import.REF_LIB), "test.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "write_results"][0]
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "test.py:write_results", "exec"), ns)
+    g = np.random.RandomState(31)
+    results = []
+    for frame in range(1, 7):
+        n = int(g.randint(0, 5))
+        tlwhs = [np.array([g.rand() * 900, g.rand() * 500, 20 + g.rand() * 80, 40 + g.rand() * 160]) for _ in range(n)]
+        if frame == 3 and n:
+            tlwhs[0] = tlwhs[0].astype(np.float32)                   # a float32 row formats with fewer digits
+        ids = [int(v) for v in g.randint(1, 40, n)]
+        if frame == 4 and n:
+            ids[0] = -1                                              # skipped by the writer
+        results.append((frame, tlwhs, ids))
+    fix = {"nframes": len(results)}
+    for k, (frame, tlwhs, ids) in enumerate(results):
+        fix["f%d_frame" % k] = np.array(frame); fix["f%d_ids" % k] = np.array(ids, np.int64)
+        fix["f%d_tlwh" % k] = np.array([np.asarray(t, np.float64) for t in tlwhs]).reshape(-1, 4)
+        fix["f%d_f32" % k] = np.array([t.dtype == np.float32 for t in tlwhs], bool)
+    for data_type in ("mot", "kitti_tracking"):
+        with tempfile.NamedTemporaryFile("r", suffix=".txt") as tmp:
+            ns["write_results"](tmp.name, [(f, list(t), list(i)) for f, t, i in results], data_type)
+            fix["text_" + data_type] = np.array(open(tmp.name).read())
+    np.savez_compressed(os.path.join(GOLD, "result_writers.npz"), **fix)
+    print("  result writers: %d frames, %d + %d characters (reference write_results)" % (len(results), len(str(fix["text_mot"])), len(str(fix["text_kitti_tracking"]))))
+
+
 def run_postprocess():
     """utils.post_process.generic_post_process (post_process.py:29-112) and utils.ddd_utils.nms (ddd_utils.py:178-245) of the
     reference on synthetic decoded detections (MOT heads and the nuScenes 3-D heads): inputs and outputs as fixtures for
@@ -684,6 +719,9 @@ if __name__ == "__main__":
     if "--only-iou-ddd" in sys.argv:
         run_iou_ddd()
         sys.exit(0)
+    if "--only-result-writers" in sys.argv:
+        run_result_writers()
+        sys.exit(0)
     if "--only-tracker" not in sys.argv:                         # the forward fixtures take a few minutes
         run("mot", 128, 160, "mot_128x160")
         run("mot", 224, 384, "mot_224x384")
@@ -697,6 +735,7 @@ if __name__ == "__main__":
     run_track_similarity()
     run_association()
     run_iou_ddd()
+    run_result_writers()
     run_postprocess()
     run_detector_trace(lstm=False)
     run_detector_trace(lstm=True)

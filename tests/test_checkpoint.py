@@ -9,6 +9,7 @@ import torch
 from deft_amd import checkpoint, synth
 
 HAVE_REF = os.path.isdir("/root/reference/src/lib")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _opt(**kw):
@@ -132,3 +133,24 @@ def test_wrong_architecture_fails_loudly():
         warnings.simplefilter("always")
         CK.load_model_state(part, SimpleNamespace(dataset="mot"), log=lambda *_: None)
     assert any("left at ZERO" in str(x.message) for x in w)
+
+
+def test_validate_checkpoint_tool_reports_key_coverage(tmp_path):
+    """tools/validate_checkpoint.py: the one-command check for the day a real DEFT checkpoint exists -- here on a
+    fabricated checkpoint in the reference's format (DataParallel prefixes, an epoch, one key missing, one foreign key)."""
+    import subprocess
+    import sys
+    from deft_amd import synth
+    sd = synth.synth_state_dict("mot")
+    ck = {"epoch": 70, "state_dict": {"module." + k: v for k, v in sd.items() if k != "wh.2.bias"}}
+    ck["state_dict"]["module.some_other.weight"] = torch.zeros(3)
+    p = str(tmp_path / "ck.pth")
+    torch.save(ck, p)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "validate_checkpoint.py"), p], capture_output=True, text=True,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    assert "epoch 70" in r.stdout and "missing: 1" in r.stdout and "No param wh.2.bias." in r.stdout and "Drop parameter some_other.weight." in r.stdout
+    assert "taken from the checkpoint: 461" in r.stdout and r.returncode == 1          # a missing parameter is not OK
+    torch.save({"epoch": 1, "state_dict": dict(sd)}, p)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "validate_checkpoint.py"), p], capture_output=True, text=True,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    assert "missing: 0" in r.stdout and r.returncode == 0, r.stdout + r.stderr
