@@ -98,9 +98,8 @@ def _maha2(mean2, cov2, meas2):
         l11 = np.sqrt(cov2[:, 1, 1] - l10 * l10)
     if not (np.all(np.isfinite(l00)) and np.all(np.isfinite(l11)) and np.all(l00 > 0) and np.all(l11 > 0)):
         raise np.linalg.LinAlgError("Matrix is not positive definite")       # what np.linalg.cholesky raises
-    d = meas2[None, :, :] - mean2[:, None, :]
-    z0 = d[..., 0] / l00[:, None]
-    z1 = (d[..., 1] - l10[:, None] * z0) / l11[:, None]
+    z0 = (meas2[None, :, 0] - mean2[:, None, 0]) / l00[:, None]                  # ([T, N] planes: no [T, N, 2] temporary)
+    z1 = ((meas2[None, :, 1] - mean2[:, None, 1]) - l10[:, None] * z0) / l11[:, None]
     return z0 * z0 + z1 * z1
 
 

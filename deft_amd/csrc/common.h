@@ -62,6 +62,26 @@ __device__ __forceinline__ deft_rsrc_t deft_make_rsrc(const void* base) {
 __device__ __forceinline__ f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+// A register load the COMPILER'S vmcnt SCOREBOARD DOES NOT SEE (inline asm; the inactive lanes of `dst` keep their values: "+v").  For loads
+// issued under a divergent branch inside a software pipeline whose waits are written by hand (DEFT_WAIT_VM): hipcc must give a
+// conditionally issued, tracked load the wait that is right on EVERY path -- the count of the path that skipped the branch -- and so
+// makes the consumer of LAST step's loads wait for THIS step's (dcn.hip: every step of every wave sat out a global round trip).
+// The caller orders the load's completion before its first use (in-order return: everything but the N youngest operations is
+// complete behind DEFT_WAIT_VM(N)).  IMM: immediate byte offset (0 .. 4095).
+typedef int deft_rsrc_words_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ deft_rsrc_words_t deft_make_rsrc_words(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    deft_rsrc_words_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r[2] = 0x7FFFFFFF;
+    r[3] = 0x00020000;
+    return r;
+}
+template <int IMM>
+__device__ __forceinline__ void deft_buffer_load_x4_untracked(f32x4& dst, deft_rsrc_words_t r, unsigned byte_off) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "+v"(dst) : "v"(byte_off), "s"(r), "n"(IMM));
+}
 // LDS-DMA (`buffer_load_dwordx4 ... lds`): lane l of the wave deposits its 16 bytes at
 // lds_wave_base + 16*l (wave-uniform base in M0, lane-linear image); out-of-range lanes deposit
 // zeros (verified on gfx950: tools/probe/lds_dma_oob.hip).  Completion is counted by vmcnt.

@@ -61,9 +61,37 @@ typedef deft_f32x16 f32x16;
 #define DP_PBUF_(R) (4 * DP_PLANE_(R))                    // one patch buffer: 16 channels = 4 planes
 #define DP_WBLK 6144                                  // one K chunk (16) of 64 output channels: [3 pieces][2 k groups][64 rows][8 bf16]
 
+// ---- round-4 experiment switches (all OFF in the product build; each was A/B'd on MI355X against the build without it, same call,
+// 64 -> 64 @152x272 x 16 frames, offsets of sigma 1.5 px: profiles/r4_dcn_experiments.md) -------------------------------------------
+//   DCNP_BREG           weights global -> registers, ONE barrier per 16-channel block instead of one per tap, no weight DMA, no
+//                       fragment reads: 0.507 -> 0.513 ms.  The barriers, the DMA issue cost and the fragment reads are hidden already.
+//   DCNP_FAR_UNTRACKED  the far samples' global loads outside hipcc's vmcnt scoreboard (the tracked form makes the blend of the previous
+//                       step's values wait for this step's loads: the count must be right on the path that skipped the far branch):
+//                       0.491 -> 0.483 ms, but test_dcn_patch fails on the hardware (a hand-counted wait is short somewhere): off.
+//   DCNP_ACC_AGPR       accumulators in AGPRs (hipcc picks the VGPR form of the MFMAs for a kernel under 256 registers): 0.506 -> 0.505 ms.
+// What stays in: corner reads first and far loads second (one if, not if / else: the only wait between them is for LDS), and the
+// two-slot ring of corner values with static slots (no register copies at the end of a step).  Time: unchanged.  The kernel is not
+// limited by waits, barriers, LDS traffic or where the accumulators live; SQ counters of the launch: VALU port 48 %, matrix pipe 31 %,
+// LDS array 26 % busy, 165 instructions per wave and step.
+// Weights of the 32- and 64-column tiles (TN <= 2) go global -> REGISTERS (each lane loads its own B fragments, 16 bytes per piece and
+// n-tile, two steps ahead): no weight stages in LDS, no weight DMA, no fragment reads, and with them no reason for a barrier per tap --
+// one barrier per 16-channel block is left (the patch double buffer).  Round 4, DCNP_TIMING per step of the LDS form: wait + barrier
+// 330, DMA issue 230 (an LDS-DMA piece costs ~100 cycles to issue beside MFMAs), fragment reads 235 of ~1850 cycles.
+#ifndef DCNP_BREG
+#define DCNP_BREG 0
+#endif
+#ifndef DCNP_FAR_UNTRACKED
+#define DCNP_FAR_UNTRACKED 0
+#endif
+#ifndef DCNP_ACC_AGPR
+#define DCNP_ACC_AGPR 0
+#endif
+template <int TN>
+constexpr bool dcnp_breg() { return DCNP_BREG && TN <= 2; }
+
 template <int TN, int R>
 constexpr int dcnp_lds_bytes() {
-    constexpr int loop = 2 * DP_PBUF_(R) + 3 * ((TN + 1) / 2) * DP_WBLK;
+    constexpr int loop = 2 * DP_PBUF_(R) + (dcnp_breg<TN>() ? 0 : 3 * ((TN + 1) / 2) * DP_WBLK);
     constexpr int tile = 128 * (TN * 32 + 4) * 4;                 // epilogue tile
     return loop > tile ? loop : tile;
 }
@@ -95,6 +123,7 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     static_assert(DEFORM || (TN == 1 && DP_R == 0), "the plain form is the 32-column conv without margin");
     constexpr int DP_PH = DP_PH_(DP_R), DP_PW = DP_PW_(DP_R), DP_NPIX = DP_NPIX_(DP_R), DP_PARTS = DP_PARTS_(DP_R), DP_PLANE = DP_PLANE_(DP_R),
                   DP_PBUF = DP_PBUF_(DP_R);
+    constexpr bool BREG = dcnp_breg<TN>();
     constexpr int BN = TN * 32, NBLK = (BN + 63) / 64;
     constexpr int NBP = NBLK * 6;                     // weight DMA pieces per chunk
     constexpr int BSTAGE = NBLK * DP_WBLK;
@@ -155,6 +184,10 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     // `plane` of patch pixel 64 part + l; pixels outside the map (and beyond the patch) arrive as zeros.  Weights (waves 0, 1). ----
     const deft_rsrc_t rx = deft_make_rsrc(p.x);
     const deft_rsrc_t rw = deft_make_rsrc(p.w3);
+    // the far samples' global loads outside the compiler's vmcnt scoreboard (common.h deft_buffer_load_x4_untracked): only in the form
+    // whose corner values are consumed a step after they are requested, behind that step's hand-written wait + barrier
+    constexpr bool FAR_UNTRACKED = DCNP_FAR_UNTRACKED && DEFORM && TN == 2 && DCNP_GA == 2 && !dcnp_breg<TN>();
+    const deft_rsrc_words_t rxw = deft_make_rsrc_words(p.x);
     unsigned pv[DP_PARTS];
 #pragma unroll
     for (int i = 0; i < DP_PARTS; ++i) {
@@ -206,9 +239,11 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     auto ps_of = [](int t) { return t >= PT ? NPP : NPP * t / PT; };
     static_assert(NB_B + (NPP + PT - 1) / PT <= 6 && NB_A <= 6, "wait_vm cases");
 
-    issue_b3(0, 0);
-    if (nchunks > 1) issue_b3(1, 1);
-    if (nchunks > 2) issue_b3(2, 2);
+    if (!BREG) {
+        issue_b3(0, 0);
+        if (nchunks > 1) issue_b3(1, 1);
+        if (nchunks > 2) issue_b3(2, 2);
+    }
     if (wave >= 2) {
 #pragma unroll
         for (int i = 0; i < NPP; ++i) issue_patch_piece(0, 0, i);
@@ -268,6 +303,12 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
         }
     }
 
+#if DCNP_ACC_AGPR && defined(__HIP_DEVICE_COMPILE__)
+    // Accumulators in the ACC half of the register file.  A kernel under 256 registers that has no 'a'-constrained inline asm is compiled
+    // with the VGPR form of every MFMA (accumulators v[..]); this empty statement makes hipcc allocate AGPRs, and the matrix
+    // instructions' C / D traffic stops competing with the blend's VALU operand reads for the VGPR banks.
+    { float agpr_hint = 0.f; asm volatile("; accumulators in AGPRs" :: "a"(agpr_hint)); }
+#endif
     f32x16 acc[1][TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -277,21 +318,38 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     const unsigned far_x = (unsigned)p.ldx * 4u, far_y = (unsigned)(p.W * p.ldx) * 4u;
     const int brow = (lane & 31) * 16 + g * 1024;     // this lane's slot inside a (piece, k group) block of the weight image
 
-    // corner values of one (row, tap, 16-channel block): v[corner][half of the lane's 8 channels]
+    // corner values of one (row, tap, 16-channel block): v[corner][half of the lane's 8 channels].
+    // EVERY lane reads the patch (a far lane some valid address: its values are overwritten); the far lanes then load their corners from
+    // global memory into the SAME registers.  In this order the only wait between the two is for the LDS reads (the global loads
+    // must not be overtaken by them: s_waitcnt lgkmcnt).  Round 3 had the two as the arms of one if / else: the compiler put the global
+    // loads first and -- same destination registers -- a `s_waitcnt vmcnt(0)` in front of the LDS reads, i.e. every step of every wave
+    // waited out a full global-memory round trip of the loads it had just issued (SQ_WAIT_ANY 0.40 of the wave cycles; rocprof round 4).
     auto gather = [&](unsigned c, int bufoff, int cb, f32x4 (&v)[4][2]) {
         if (!DEFORM) {
             const char* const a = patch + bufoff + c;
             v[0][0] = *(const f32x4*)(a); v[0][1] = *(const f32x4*)(a + DP_PLANE);
-        } else if (!(c & 0x80000000u)) {
-            const char* const a = patch + bufoff + c;
+            return;
+        }
+        const bool far = (c & 0x80000000u) != 0u;
+        {
+            const char* const a = patch + bufoff + (far ? (unsigned)(g * 2 * DP_PLANE) : c);
             v[0][0] = *(const f32x4*)(a); v[0][1] = *(const f32x4*)(a + DP_PLANE);
             v[1][0] = *(const f32x4*)(a + 16); v[1][1] = *(const f32x4*)(a + 16 + DP_PLANE);
             v[2][0] = *(const f32x4*)(a + DP_PW * 16); v[2][1] = *(const f32x4*)(a + DP_PW * 16 + DP_PLANE);
             v[3][0] = *(const f32x4*)(a + DP_PW * 16 + 16); v[3][1] = *(const f32x4*)(a + DP_PW * 16 + 16 + DP_PLANE);
-        } else {
+        }
+        if (far) {
             const unsigned o1 = ((c & 0x7fffffffu) >> 2) * far_x + (unsigned)(cb * 64 + g * 32);
             const unsigned o2 = o1 + ((c & 1u) ? far_x : 0u);
             const unsigned dyb = (c & 2u) ? far_y : 0u;
+            if (FAR_UNTRACKED) {
+                // (consumed one step on, behind that step's DEFT_WAIT_VM(<pieces issued after these loads>) + barrier: see the loop)
+                deft_buffer_load_x4_untracked<0>(v[0][0], rxw, o1); deft_buffer_load_x4_untracked<16>(v[0][1], rxw, o1);
+                deft_buffer_load_x4_untracked<0>(v[1][0], rxw, o2); deft_buffer_load_x4_untracked<16>(v[1][1], rxw, o2);
+                deft_buffer_load_x4_untracked<0>(v[2][0], rxw, o1 + dyb); deft_buffer_load_x4_untracked<16>(v[2][1], rxw, o1 + dyb);
+                deft_buffer_load_x4_untracked<0>(v[3][0], rxw, o2 + dyb); deft_buffer_load_x4_untracked<16>(v[3][1], rxw, o2 + dyb);
+                return;
+            }
             v[0][0] = deft_buffer_load_x4(rx, o1); v[0][1] = deft_buffer_load_x4(rx, o1 + 16u);
             v[1][0] = deft_buffer_load_x4(rx, o2); v[1][1] = deft_buffer_load_x4(rx, o2 + 16u);
             v[2][0] = deft_buffer_load_x4(rx, o1 + dyb); v[2][1] = deft_buffer_load_x4(rx, o1 + dyb + 16u);
@@ -346,6 +404,18 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
             o[j][0] = *(const bf16x8*)(bj); o[j][1] = *(const bf16x8*)(bj + 2048); o[j][2] = *(const bf16x8*)(bj + 4096);
         }
     };
+    // BREG: this lane's B fragments of chunk kc straight from the weight image (global / L2 / L1: the four waves of a workgroup and
+    // the workgroups of a pixel row read the same 6 KB chunk) into registers
+    const unsigned vBr = (unsigned)((n0 >> 6) * nchunks * DP_WBLK + brow);
+    auto load_b = [&](int kc, bf16x8 (&o)[TN][3]) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned base = vBr + (unsigned)(((j >> 1) * nchunks + kc) * DP_WBLK + (j & 1) * 512);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) o[j][q] = __builtin_bit_cast(bf16x8, deft_buffer_load_x4(rw, base + (unsigned)(q * 2048)));
+        }
+    };
+    bf16x8 pbr[2][TN][3];                                  // BREG: the fragments of chunk kc in pbr[kc & 1] (loaded at the end of step kc - 2)
     DCNP_T(2);
     f32x4 vq[GA][4][2];                                    // corner values in flight: vq[0] = the next chunk's, vq[1] = the one after (GA = 2)
     {
@@ -353,9 +423,13 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
         DEFT_PIPE_BARRIER_ONLY();
         f32x4 v[4][2];
         gather(rc[0], 0, 0, v);
+        if (FAR_UNTRACKED) DEFT_WAIT_VM(0);               // (chunk 0 is blended at once: its far samples' loads are waited for here, by hand)
         blend_split(v, rw0[0], rw1[0], rw2[0], rw3[0], pa);
-        read_b(0, pb);
-        if (GA == 2) gather(rc[1], 0, 0, vq[0]);          // (chunk 1 exists: Cin >= 32 -> at least 18 chunks)
+        if (BREG) { load_b(0, pbr[0]); load_b(1, pbr[1]); }
+        else read_b(0, pb);
+        if (GA == 2) gather(rc[1], 0, 0, vq[1]);          // (chunk 1 exists: Cin >= 32 -> at least 18 chunks); slot of an ODD chunk, see the loop
+        // chunk 1 is blended in step 0, whose wait counts the DMA pieces a steady-state step issues BEHIND its corner reads -- none here
+        if (FAR_UNTRACKED) DEFT_WAIT_VM(0);
     }
     DCNP_T(3);
 #ifdef DCNP_TIMING
@@ -379,7 +453,15 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 tsum[3] += tA - tprev;
 #endif
                 // ---- wait + barrier (step 0 too: everybody has read the B fragments of chunk 0 before its stage is refilled) ----
-                {
+                if (BREG) {
+                    // ONE barrier per 16-channel block, in front of the first corner read that reaches into the next block's patch: that
+                    // patch has landed (its pieces were issued in taps 0 .. PT - 1: vmcnt(0), then the rendezvous), and every wave has
+                    // finished reading the block before this one -- whose buffer the DMA of the block after next refills from tap 0 on
+                    if (tap == 9 - GA && !last_blk) {
+                        DEFT_WAIT_VM(0);
+                        DEFT_PIPE_BARRIER_ONLY();
+                    }
+                } else {
 #ifndef DCNP_ABL_NOBARRIER
                     const int pt = tap == 0 ? 8 : tap - 1;             // the previous step's tap; it is in the last block iff this one is and tap > 0
                     if (tap > 0 && last_blk) wait_vm(pt < 6 ? (wave < 2 ? NB_A : NB_B) : 0);
@@ -392,9 +474,17 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 tsum[0] += tB - tA;
 #endif
 #ifndef DCNP_ABL_NOGATHER
-                if (moreg) gather(rc[gtap], ((half + gblk) & 1) * DP_PBUF, cb + gblk, vq[GA - 1]);
+                // GA = 2: the corner values live in a two-slot ring with STATIC slots (the 18 steps of an iteration are unrolled, the first chunk
+                // of an iteration is even): the reads issued in step kc (chunk kc + 2) go to slot kc & 1 and are blended in step kc + 1,
+                // which reads slot (kc + 1) & 1 ^ 1.  (Round 3 copied slot 1 to slot 0 at the end of every step: the compiler hoisted those
+                // moves to the top of the step, and with them a wait for the far samples' global loads that had just been issued.)
+                constexpr int GS = GA == 2 ? 2 : 1;
+                const int gslot = GA == 2 ? ((half * 9 + tap) & 1) : 0;
+                if (moreg) gather(rc[gtap], ((half + gblk) & 1) * DP_PBUF, cb + gblk, vq[gslot]);
 #else
-                for (int a_ = 0; a_ < 4; ++a_) { vq[GA - 1][a_][0] = f32x4{rw0[ntap], 1.f, 2.f, 3.f}; vq[GA - 1][a_][1] = f32x4{rw1[ntap], 1.f, 2.f, 3.f}; }
+                constexpr int GS = GA == 2 ? 2 : 1;
+                const int gslot = GA == 2 ? ((half * 9 + tap) & 1) : 0;
+                for (int a_ = 0; a_ < 4; ++a_) { vq[gslot][a_][0] = f32x4{rw0[ntap], 1.f, 2.f, 3.f}; vq[gslot][a_][1] = f32x4{rw1[ntap], 1.f, 2.f, 3.f}; }
 #endif
 #ifndef DCNP_ABL_NOMFMA
                 // six products per fp32 product, smallest terms first (as igemm.hip); product-major so that consecutive MFMAs go to
@@ -403,7 +493,8 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 for (int q = 0; q < 6; ++q) {
                     constexpr int qa[6] = {1, 2, 0, 1, 0, 0}, qb[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[qa[q]], pb[j][qb[q]], acc[0][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[qa[q]], BREG ? pbr[(half * 9 + tap) & 1][j][qb[q]] : pb[j][qb[q]], acc[0][j], 0, 0, 0);
                 }
 #endif
 #ifdef DCNP_ABL_NOVALU
@@ -412,21 +503,17 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 if (more) {
 #endif
                     bf16x8 pn[3];
-                    blend_split(vq[0], rw0[ntap], rw1[ntap], rw2[ntap], rw3[ntap], pn);
+                    blend_split(vq[GS == 2 ? (gslot ^ 1) : 0], rw0[ntap], rw1[ntap], rw2[ntap], rw3[ntap], pn);
                     pa[0] = pn[0]; pa[1] = pn[1]; pa[2] = pn[2];
                 }
                 DCNP_SCHED(TN);
                 DEFT_OPAQUE(pa[0]); DEFT_OPAQUE(pa[1]); DEFT_OPAQUE(pa[2]);      // A(kc + 1) is finished HERE, under the MFMAs -- not after the next barrier
-                if (GA == 2) {
-#pragma unroll
-                    for (int a_ = 0; a_ < 4; ++a_) { vq[0][a_][0] = vq[GA - 1][a_][0]; vq[0][a_][1] = vq[GA - 1][a_][1]; }
-                }
 #ifdef DCNP_TIMING
                 const long long tC = __builtin_readcyclecounter();
                 tsum[1] += tC - tB;
 #endif
 #ifndef DCNP_ABL_NODMA
-                if (tap < 6 || !last_blk) issue_b3(kc + 3, st);            // (kc + 3 < nchunks)
+                if (!BREG && (tap < 6 || !last_blk)) issue_b3(kc + 3, st);            // (kc + 3 < nchunks)
                 if (wave >= 2 && !last_blk) {
 #pragma unroll
                     for (int i = ps_of(tap); i < ps_of(tap + 1); ++i) issue_patch_piece(cb + 1, half ^ 1, i);
@@ -436,7 +523,11 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 tprev = __builtin_readcyclecounter();
                 tsum[2] += tprev - tC;
 #endif
-                if (more) read_b((tap + 1) % 3, pb);
+                if (BREG) {
+                    if (!(tap + 2 >= 9 && last_blk)) load_b(kc + 2, pbr[(half * 9 + tap) & 1]);      // (its registers were read by this step's MFMAs)
+                } else if (more) {
+                    read_b((tap + 1) % 3, pb);
+                }
             }
         }
     }

@@ -15,6 +15,10 @@ from . import engine, hiplib
 
 import os as _os
 PRIORITY_TRACKER = _os.environ.get("DEFT_TRACKER_PRIORITY", "1") != "0"      # run(prefetch=): the tracker's launches on a high-priority stream
+# run(prefetch=): when the next frame's pass is queued -- "hook" = when the tracker announces the end of its device work (the pass then runs
+# beside the host-only rest of the association), "early" = before the tracker starts (the pass runs beside the tracker's own launches,
+# which go to the high-priority stream)
+LOOKAHEAD_AT = _os.environ.get("DEFT_LOOKAHEAD_AT", "hook")
 
 
 def _fetch(d):
@@ -242,7 +246,7 @@ class Detector(object):
         hook_on = None                                  # the tracker object whose update() will fire the queued pass
         if nxt is not None and self.tracker is not None:
             last = self.tracker[list(per_class)[-1]] if per_class is not None else self.tracker      # nuScenes: the last class's tracker
-            if hasattr(last, "after_device_work"):
+            if hasattr(last, "after_device_work") and LOOKAHEAD_AT == "hook":
                 hook_on = last
         if nxt is not None and hook_on is None:
             nxt()
@@ -324,8 +328,13 @@ class Detector(object):
         """Queue frame -> detections on slot `sl` (its own stream): staging copy, H2D, the plan (hipGraph from the second use), one D2H
         of every decoded field into pinned memory, an event.  Returns without waiting."""
         p = sl.plan
-        np.copyto(sl.stage_np, frame)                  # (a plain memcpy: torch's multi-threaded CPU copy_ stalls for milliseconds next to the tracker's BLAS threads)
         cuda = self.device.type == "cuda"
+        src = torch.from_numpy(frame) if frame.flags["C_CONTIGUOUS"] else None
+        if cuda and src is not None and src.is_pinned():
+            stage = src.unsqueeze(0)                   # the frame already lives in pinned host memory (a decoder's output buffer): no staging copy
+        else:
+            np.copyto(sl.stage_np, frame)              # (a plain memcpy: torch's multi-threaded CPU copy_ stalls for milliseconds next to the tracker's BLAS threads)
+            stage = sl.stage
         if cuda:
             if not hasattr(self, "_net_stream"):
                 self._net_stream = torch.cuda.Stream(device=self.device)
@@ -339,10 +348,10 @@ class Detector(object):
         ctx = torch.cuda.stream(self._net_stream) if cuda else _null()
         with ctx:
             if sl.graph is not None:
-                p.image_u8.copy_(sl.stage, non_blocking=True)
+                p.image_u8.copy_(stage, non_blocking=True)
                 sl.graph.replay()
             else:
-                p.forward_u8(sl.stage.to(self.device, non_blocking=True))
+                p.forward_u8(stage.to(self.device, non_blocking=True))
                 sl.warm = True
             d = p.dets()
             if "dep" in d:

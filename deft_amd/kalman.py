@@ -49,8 +49,11 @@ def kf_multi_predict(mean, cov):
     one = np.ones_like(h)
     sqr = np.square(np.stack([_SP * h, _SP * h, 1e-2 * one, _SP * h, _SV * h, _SV * h, 1e-5 * one, _SV * h], 1))
     mean = np.dot(mean, _F.T)
-    left = np.dot(_F, cov).transpose((1, 0, 2))
-    cov = np.dot(left, _F.T)
+    # F P F^T with F = [[I, I], [0, I]] (dt = 1) written out in 4 x 4 blocks: sums only (np.dot(F, P) adds exact products by 1 and 0;
+    # the blocks below add the same terms in the same left-to-right order)
+    cov = np.array(cov, dtype=np.float64, copy=True)
+    cov[:, :4, :] += cov[:, 4:, :]                  # F P
+    cov[:, :, :4] += cov[:, :, 4:]                  # (F P) F^T
     idx = np.arange(8)
     cov[:, idx, idx] += sqr
     return mean, cov

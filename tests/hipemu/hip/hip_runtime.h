@@ -446,6 +446,13 @@ static inline hipemu_f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off)
     if (byte_off < r.n && byte_off + 16u <= r.n) memcpy(&v, r.base + byte_off, 16);
     return v;
 }
+// the "untracked" register load of common.h (inline asm on the hardware: the compiler's vmcnt scoreboard does not see it): here a plain load
+struct deft_rsrc_words_t { const char* base; };
+static inline deft_rsrc_words_t deft_make_rsrc_words(const void* base) { return deft_rsrc_words_t{(const char*)base}; }
+template <int IMM>
+static inline void deft_buffer_load_x4_untracked(hipemu_f32x4& dst, deft_rsrc_words_t r, unsigned byte_off) {
+    dst = deft_buffer_load_x4(deft_rsrc_t{r.base, 0x7FFFFFFFu}, byte_off + (unsigned)IMM);
+}
 static inline void hipemu_dma_deposit(void* dst, const hipemu_f32x4& v) {
     hipemu::State& s = hipemu::S();
     if (s.dmaq.empty()) { memcpy(dst, &v, 16); return; }          // default: delivered at issue

@@ -15,7 +15,8 @@ opt = SimpleNamespace(dataset="mot", K=100, max_object=100, gpus=[0], hip_graphs
 det = FD.Detector(opt, sd)
 seam = integrate.AfeSeam(sd, 100, dev, hiplib.get_lib()); seam.host_copy = False
 g = np.random.RandomState(0)
-frames = [g.randint(0, 256, (1080, 1920, 3), dtype=np.uint8) for _ in range(6)]
+_pinned = [torch.from_numpy(g.randint(0, 256, (1080, 1920, 3), dtype=np.uint8)).pin_memory() for _ in range(6)]
+frames = [t.numpy() for t in _pinned] if os.environ.get("PINNED", "1") == "1" else [t.numpy().copy() for t in _pinned]
 def e2e(look, n=60):
     MT.TrackIds.count = 0
     det.set_tracker(MT.Tracker2D(opt, SimpleNamespace(AFE=seam), h=1080, w=1920)); det.img_height, det.img_width = 1080, 1920
