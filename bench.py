@@ -421,7 +421,11 @@ def main():
                          "comparable with the roofline's per-launch HIP events)")
     ap.add_argument("--standin", action="store_true",
                     help="TEST ONLY: CPU stand-in compute + gloo, to exercise the --gpus N launch path without GPUs; the line is marked invalid")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: print the cpu_baseline object of --config and exit (no GPU)")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(CONFIGS[args.config])), flush=True)
+        return
     self_launch(args)                                   # (does not return when it re-executes under torch.distributed.run)
     cfg = CONFIGS[args.config]
     H, W, NDET, HIST = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"]
@@ -594,7 +598,20 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.standin:
-        cpu = cpu_baseline(cfg)
+        # the CPU side in its own process with the GPU hidden (the reference's modules move tensors to CUDA whenever
+        # one is visible -- AFE.py:104-108, image.py:410-412 -- and this process's HIP runtime threads would share the host cores)
+        import subprocess
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config], capture_output=True, text=True,
+                           env=env, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            cpu = json.loads(line[-1])
+            cpu["process"] = "subprocess, GPU hidden (HIP_VISIBLE_DEVICES empty)"
+        else:
+            sys.stderr.write("cpu baseline subprocess failed (%d): %s\n" % (r.returncode, r.stderr[-500:]))
+            cpu = cpu_baseline(cfg)
+            cpu["process"] = "in-process (the GPU-hidden subprocess failed)"
 
     if rank == 0:
         what = "detect+embed+affinity" + ("+LSTM" if cfg["lstm"] else "")

@@ -1003,7 +1003,7 @@ def check_conv_fold(lib, device, N, H, W, Ci, Cm, fn, p3, tile=0, seed=0):
 
 # ---------------------------------------------------------------------------
 # top-K index parity on arbitrary frames
-def compare_topk_with_oracle(plan, out, K, logit_tol=2e-4, tie=1e-4):
+def compare_topk_with_oracle(plan, out, K, logit_tol=2e-4, tie=1e-4, details=None):
     """Device decode of frame 0 of `plan` against the oracle's head maps `out` of the same frame.  Returns
     (indices_identical, max abs heat-map logit error).  When the ordered indices differ, every difference must be a
     round-off tie: the oracle's OWN heat map puts the index within 1e-4 (logit) of its 3x3 neighbourhood maximum or of
@@ -1037,6 +1037,15 @@ def compare_topk_with_oracle(plan, out, K, logit_tol=2e-4, tie=1e-4):
         near_nms_tie = float(nb[k] - flat[k]) <= tie
         near_kth = abs(float(flat[k]) - kth) <= tie
         assert near_nms_tie or near_kth, (k, float(nb[k] - flat[k]), float(flat[k]) - kth)
+        if details is not None:              # which detection, where in the list, and at what score (does it clear the tracker's thresholds?)
+            side = "device" if k in set(gk) else "oracle"
+            rank = (gk if side == "device" else ok_).index(k)
+            details.append({"key": int(k), "only_in": side, "rank": rank, "kind": "kth_score_boundary" if near_kth and not near_nms_tie else "nms_neighbour_tie",
+                            "score": float(torch.sigmoid(flat[k]))})
+    if details is not None:
+        for n, (a, b) in enumerate(zip(gk, ok_)):
+            if a != b and a in opos and b in set(gk):
+                details.append({"key": int(a), "only_in": "order", "rank": n, "kind": "order_swap_of_tied_scores", "score": float(torch.sigmoid(flat[a]))})
     order = flat[torch.tensor(gk)]                               # the device's order, scored by the oracle's map
     assert bool((order[:-1] >= order[1:] - tie).all())
     return False, err

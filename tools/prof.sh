@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 passes for one tag, run ON THE GPU BOX (through gpurun) from the repo root:
-#     tools/prof.sh <tag> [cmd...]        default cmd: python bench.py --no-cpu-baseline --steps 6 --warmup 2
+#     tools/prof.sh <tag> [cmd...]        default cmd: python bench.py --no-cpu-baseline --no-extras --no-check --steps 6 --warmup 2
 # Writes gpurun_out/<tag>/{bench.log, stats/, pmc_sq/, pmc_fetch/, pmc_write/}; tools/summarize_prof.py <tag>
 # turns them into profiles/<tag>_summary.md.  Counters are collected in their own passes with
 # --kernel-trace only (never together with sys/hip/hsa tracing).
 set -u
 TAG=$1; shift
 ONE=""
-if [ $# -eq 0 ]; then set -- python bench.py --no-cpu-baseline --no-extras --steps 6 --warmup 2; ONE="--serialize"; fi
+if [ $# -eq 0 ]; then set -- python bench.py --no-cpu-baseline --no-extras --no-check --steps 6 --warmup 2; ONE="--serialize"; fi
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

@@ -99,8 +99,12 @@ if os.path.exists(fe) and os.path.exists(wr):
     nl = sum(nf[k] for k in fk)
     fetch = sum(pf[k]["FETCH_SIZE"] for k in fk) * 1024.0 * 2.0          # KiB -> B, gfx950 wide-stream correction x2
     write = sum(pw.get(k, {}).get("WRITE_SIZE", 0.0) for k in fk) * 1024.0
+    # the whole step: every kernel's bytes over the number of steps the run made (two sub-batch plans per step: one layout kernel each)
+    nsteps = max(1, sum(nf[k] for k in pf if "nchw_to_nhwc" in k or "preprocess_u8" in k) // 2)
+    all_bytes = sum(v["FETCH_SIZE"] for v in pf.values()) * 1024.0 * 2.0 + sum(v.get("WRITE_SIZE", 0.0) for v in pw.values()) * 1024.0
     json.dump({"kernel": "igemm* + conv3h + direct_conv + dcn_patch", "launches": nl, "fetch_bytes_per_launch": fetch / max(nl, 1), "write_bytes_per_launch": write / max(nl, 1),
                "traffic_bytes_per_launch": (fetch + write) / max(nl, 1),
+               "steps_in_the_run": nsteps, "traffic_bytes_per_step": all_bytes / nsteps,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof.sh), KiB units, FETCH_SIZE x2 per "
                          "MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated"},
               open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
