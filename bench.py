@@ -339,8 +339,17 @@ def roofline_of(wl, lib, rank, dt_step, config):
     (dk_entry, dk_info), (dk_n, dk_ms, dk_fl, dk_ceil) = max(grp.items(), key=lambda kv: kv[1][1])
     busy = None
     cfile = os.path.join(ROOT, "profiles", COUNTER_FILE)
-    if os.path.exists(cfile) and config == "B":
-        busy = json.load(open(cfile)).get("mfma_busy")
+    if os.path.exists(cfile) and config == "B":                       # the SQ counter pass of this build (tools/prof.sh): the kernel behind the dominant entry
+        pk = json.load(open(cfile)).get("per_kernel", {})
+        want = None
+        if dk_entry == "deft_dcn_v2_nhwc" and "patch" in dk_info:
+            want = "dcn_patch_kernel<2" if " N=64 " in dk_info else "dcn_patch_kernel<4"
+        elif "halo" in dk_info:
+            want = "conv3h_kernel<8, 64" if " N=64 " in dk_info else "conv3h_kernel<8, 128"
+        elif "x3" in dk_info:
+            want = "igemm3_kernel<64, 128"
+        hit = [v for k, v in pk.items() if want and k.startswith(want)]
+        busy = hit[0]["mfma_busy"] if hit else None
     dominant = {"name": "%s %s" % (dk_entry, dk_info), "launches": dk_n, "avg_us": round(dk_ms / dk_n * 1e3, 2), "ms_per_step": round(dk_ms, 3),
                 "gflop": round(dk_fl / 1e9, 2), "tflops": round(dk_fl / (dk_ms * 1e-3) / 1e12, 2), "ceiling_tflops": round(dk_ceil, 1),
                 "frac": round(dk_fl / (dk_ms * 1e-3) / 1e12 / dk_ceil, 4), "mfma_busy": busy}

@@ -276,7 +276,9 @@ def test_topk_seed_sweep_both_arithmetics(gpu_lib, dataset, H, W, nseeds):
             worst[prec] = max(worst[prec], err)
             if not same:
                 diff[prec].append(seed)
-                events[prec].append({"seed": seed, "differences": det, "reaches_the_tracker": any(d["score"] > out_thresh for d in det)})
+                events[prec].append({"seed": seed, "differences": det, "reaches_the_tracker": any(d["score"] > out_thresh for d in det),
+                                     # a detection only ONE side reports, above the threshold: the tracker would see another detection set
+                                     "another_detection_reaches_the_tracker": any(d["score"] > out_thresh and d["only_in"] != "order" for d in det)})
     rep = {"dataset": dataset, "H": H, "W": W, "frames": nseeds, "K": 100,
            "frames_with_tie_level_index_differences": {"prec0_fp32_mfma": len(diff[0]), "prec1_split_bf16": len(diff[1])},
            "seeds": {"prec0": diff[0], "prec1": diff[1]}, "max_abs_logit_error": {"prec0": worst[0], "prec1": worst[1]},
@@ -285,6 +287,8 @@ def test_topk_seed_sweep_both_arithmetics(gpu_lib, dataset, H, W, nseeds):
            "out_thresh": out_thresh, "events": {"prec0": events[0], "prec1": events[1]},
            "frames_whose_difference_reaches_the_tracker": {"prec0": sum(e["reaches_the_tracker"] for e in events[0]),
                                                            "prec1": sum(e["reaches_the_tracker"] for e in events[1])},
+           "frames_where_another_detection_reaches_the_tracker": {"prec0": sum(e["another_detection_reaches_the_tracker"] for e in events[0]),
+                                                                  "prec1": sum(e["another_detection_reaches_the_tracker"] for e in events[1])},
            "max_score_of_a_differing_detection": max([d["score"] for p_ in (0, 1) for e in events[p_] for d in e["differences"]] + [0.0])}
     print(json.dumps(rep))
     try:

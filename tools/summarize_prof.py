@@ -75,7 +75,14 @@ if os.path.exists(sq):
     k0 = max((k for k in per if k), key=lambda k: dur[k])
     v = per[k0]
     gui = max(v.get("GRBM_GUI_ACTIVE", 0), 1) / 8.0
-    json.dump({"kernel": k0, "launches": n[k0], "mfma_busy": round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 1024), 4),
+    allk = {}
+    for k in per:
+        vv = per[k]
+        g_ = max(vv.get("GRBM_GUI_ACTIVE", 0), 1) / 8.0
+        wc_ = max(vv.get("SQ_WAVE_CYCLES", 0), 1)
+        allk[k] = {"launches": n[k], "mfma_busy": round(vv.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g_ * 1024), 4),
+                   "wait_any": round(vv.get("SQ_WAIT_ANY", 0) / wc_, 4), "wait_inst": round(vv.get("SQ_WAIT_INST_ANY", 0) / wc_, 4)}
+    json.dump({"kernel": k0, "launches": n[k0], "per_kernel": allk, "mfma_busy": round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 1024), 4),
                "wait_any": round(v.get("SQ_WAIT_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 0), 1), 4),
                "wait_inst": round(v.get("SQ_WAIT_INST_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 0), 1), 4),
                "source": "rocprofv3 --pmc pass of tools/prof.sh (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))"},
