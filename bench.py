@@ -400,7 +400,7 @@ def side_config(name, args, dev, lib, rank):
         del wl
         torch.cuda.empty_cache()
         e = end_to_end(name, dev, lib, dev.index or 0, ne=60)
-        out["end_to_end"] = {k: e[k] for k in ("ms_per_frame", "value", "unit", "stage_ms", "serial", "tracks_alive", "workload")}
+        out["end_to_end"] = {k: e[k] for k in ("ms_per_frame", "value", "unit", "frames_per_pass", "stage_ms", "one_frame_lookahead", "serial", "tracks_alive", "workload")}
     return out
 
 
@@ -490,17 +490,20 @@ def main():
     fps = frames / dt
 
     extras = {}
+    skip = set(filter(None, os.environ.get("DEFT_BENCH_SKIP", "").split(",")))      # debugging: leave sections of the extras out
     if not args.no_extras and not args.standin:
+        if "e2e_early" in skip and args.config == "B" and world == 1:
+            extras["end_to_end_early"] = end_to_end("B", dev, lib, local)
         # ---- sustained: keep stepping until the GPU has been busy for >= 5 s in total (the timed region above is what `value`
         #      reports; an outside sampler needs more than a second of load to see it) ----
         n_more = max(0, int((5.0 - dt) / max(dt / args.steps, 1e-6)) + 1) if dt < 5.0 else 0
-        if n_more:
+        if n_more and "sustained" not in skip:
             d1, _ = timed(step, images, n_more, 0, dev)
             extras["sustained"] = {"steps": n_more, "seconds": round(d1, 3), "value": round(n_more * B * world / d1, 3), "unit": "frames/s"}
         # ---- fed from host memory: uint8 camera frames (1920x1080 for MOT17, else the network size) from pinned staging buffers,
         #      double-buffered H2D on a copy stream, warp + normalise ON THE DEVICE (deft_preprocess_u8, detector.py:377-395), and the
         #      detections + affinity blocks copied back every step ----
-        if world == 1:
+        if world == 1 and "pcie" not in skip:
             from deft_amd.preprocess import FrameFeeder
             sh, sw = (1080, 1920) if args.config == "B" else (H, W)
             compu = HipCompute(sd, B, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=args.streams, ndet=NDET)
@@ -543,7 +546,7 @@ def main():
         comp1 = HipCompute(sd, 1, H, W, cfg["dataset"], K=KDET, device=dev, lib=lib, streams=1, ndet=NDET)
         pipe1 = FramePipeline(comp1, 1, NDET, comp1.D, history=HIST, device=dev, exchange=gather)
         comp1.capture(images[:1])
-        n1 = 100
+        n1 = 100 if "latency" not in skip else 2
         d1, _ = timed(pipe1.step, images[:1], n1, HIST + 3, dev)
         extras["latency_mode"] = {"frames_per_step_per_gpu": 1, "hip_graphs": True, "steps": n1, "ms_per_step": round(d1 / n1 * 1e3, 3),
                                   "value": round(n1 * world / d1, 3), "unit": "frames/s",
@@ -552,7 +555,7 @@ def main():
         # ---- BASELINE configs[2] as written: ONE video stream, one frame per GPU per step, BOTH all-gathers of the sharded tracker
         #      stream (records, then affinity blocks; deft_amd.stream.ShardedStream with the device-side record path), 100 detections
         #      against the 5 stored frames; the association rank's Tracker.update is host work outside this number ----
-        if args.config == "B" and cfg["dataset"] in ("mot", "kitti_tracking"):
+        if args.config == "B" and cfg["dataset"] in ("mot", "kitti_tracking") and "configC" not in skip:
             from deft_amd import integrate
             from deft_amd.stream import DeviceDetect, ShardedStream
             afe = integrate.AfeSeam(sd, 100, dev, lib)
@@ -602,6 +605,8 @@ def main():
     if args.config == "B" and world == 1 and not args.no_extras and not args.standin:
         sides = {}
         for name in ("A", "D", "E"):
+            if "sides" in skip:
+                break
             torch.cuda.empty_cache()
             sides[name] = side_config(name, args, dev, lib, rank)
 
@@ -662,14 +667,17 @@ def main():
 E2E = {"B": dict(frame=(1080, 1920), lstm=False), "D": dict(frame=(375, 1242), lstm=True), "E": dict(frame=(900, 1600), lstm=True)}
 
 
+E2E_PER_PASS = 4                # frames per lookahead pass of the end-to-end figure (Detector.lookahead_frames)
+
+
 def end_to_end(name, dev, lib, local, ne=100):
     """Frame in -> tracks out on ONE stream, configs B / D / E: a uint8 camera frame in host memory ->
     deft_amd.detector.Detector.run (H2D, warp + normalise on the device, the plan as a multi-branch hipGraph, one D2H, array
     post-processing [+ the nuScenes 3-D branch]) -> deft_amd.array_tracker.ArrayTracker.update (embedding extraction, affinity chain
     against the stored frames the pool can read, device-side similarity medians, motion gate, own Jonker-Volgenant assignment, IoU stage;
     D / E: the LSTM motion model, one deft_motion_step launch per frame; E: seven per-class trackers with the 3-D IoU association).
-    `prefetch` = the next frame of the stream: its network pass runs on a second set of plan buffers while the host associates this
-    frame (Detector.run's one-frame lookahead)."""
+    `prefetch` = the next frames of the stream: their network pass runs on a second set of plan buffers while the host associates this
+    frame (Detector.run's lookahead: one frame per pass, and E2E_PER_PASS frames per pass -- the batch-1 launch list is latency-bound)."""
     from types import SimpleNamespace
     from deft_amd import detector as FD, engine, integrate, mot_tracker as MT, synth, tracker as DT
     from deft_amd.postprocess import NUSCENES_TRACKING_NAMES
@@ -714,35 +722,54 @@ def end_to_end(name, dev, lib, local, ne=100):
     ge = np.random.RandomState(11)
     # frames in PINNED host memory, the way a decoder / capture driver delivers them (numpy views of pinned tensors: the lookahead pass
     # copies them to the device without a staging memcpy)
-    keep_pinned = [torch.from_numpy(ge.randint(0, 256, (sh, sw, 3), dtype=np.uint8)).pin_memory() for _ in range(6)]
+    keep_pinned = [torch.from_numpy(ge.randint(0, 256, (sh, sw, 3), dtype=np.uint8)).pin_memory() for _ in range(12)]
     feed = [t.numpy() for t in keep_pinned]
+    NF = len(feed)
 
-    def e2e(lookahead, n):
+    def e2e(per_pass, n):
+        """per_pass 0: serial; 1: one frame of lookahead; n: Detector.lookahead_frames = n (n frames per lookahead pass)."""
         fdet.set_tracker(fresh_tracker())
         fdet.img_height, fdet.img_width = sh, sw
-        for i in range(12):
-            fdet.run(feed[i % len(feed)], image_info=info, prefetch=feed[(i + 1) % len(feed)] if lookahead else None)
+        fdet.lookahead_frames = max(1, per_pass)
+        warm = 6 * max(2, per_pass)                  # both plan buffer sets of the lookahead have run once and captured their hipGraph (4 passes)
+        total = warm + n
+
+        def upcoming(i):
+            f = [feed[(i + j) % NF] for j in range(1, 2 * max(1, per_pass)) if i + j < total]
+            return None if per_pass == 0 or not f else (f if per_pass > 1 else f[0])
+        for i in range(warm):
+            fdet.run(feed[i % NF], image_info=info, prefetch=upcoming(i))
         sync()
-        acc = {}
+        acc, trace = {}, []
         t1 = time.perf_counter()
-        for i in range(n):
-            fdet.run(feed[(12 + i) % len(feed)], image_info=info, prefetch=feed[(13 + i) % len(feed)] if lookahead and i + 1 < n else None)
+        for i in range(warm, total):
+            fdet.run(feed[i % NF], image_info=info, prefetch=upcoming(i))
             for k_, v_ in fdet.times.items():
                 acc[k_] = acc.get(k_, 0.0) + v_
+            if os.environ.get("DEFT_E2E_TRACE") == "1":
+                trace.append((round(fdet.times["net"] * 1e3, 2), round(fdet.times["track"] * 1e3, 2)))
         sync()
+        if os.environ.get("DEFT_E2E_TRACE") == "1":
+            sys.stderr.write("e2e trace %s per_pass=%d (net, track) ms: %s\n" % (name, per_pass, trace[:48]))
         return time.perf_counter() - t1, acc
-    d0, acc0 = e2e(False, ne)
-    d1, acc = e2e(True, ne)
+    d0, acc0 = e2e(0, ne)
+    d1, acc1 = e2e(1, ne)
+    d4, acc = e2e(E2E_PER_PASS, ne)
     trk = fdet.tracker
     alive = sum(t.cols.n for t in trk.values()) if isinstance(trk, dict) else trk.cols.n
     stored = max(len(t.recorder.all_frame_index) for t in trk.values()) if isinstance(trk, dict) else len(trk.recorder.all_frame_index)
-    return {"workload": "one stream, %dx%d uint8 frame in host memory -> Detector.run (H2D, device pre-processing, fused process, post-process%s) -> "
-                        "ArrayTracker.update (%s%s), one frame of lookahead" % (sw, sh, ", nuScenes 3-D branch" if ds == "nuscenes" else "",
-                                                                                "7 per-class trackers, 3-D IoU association, " if ds == "nuscenes" else "",
-                                                                                "LSTM motion model" if e["lstm"] else "Kalman motion model"),
-            "frames": ne, "ms_per_frame": round(d1 / ne * 1e3, 3), "value": round(ne / d1, 3), "unit": "frames/s",
-            "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc.items()},
-            "serial": {"ms_per_frame": round(d0 / ne * 1e3, 3), "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc0.items()}},
+
+    def stages(a):
+        return {k_: round(v_ / ne * 1e3, 3) for k_, v_ in a.items()}
+    return {"workload": "one recorded stream, %dx%d uint8 frames in host memory -> Detector.run (H2D, device pre-processing, fused process, post-process%s) -> "
+                        "ArrayTracker.update (%s%s); the network runs %d frames per lookahead pass on a second set of plan buffers while the host "
+                        "associates (Detector.lookahead_frames), tracks are handed out frame by frame"
+                        % (sw, sh, ", nuScenes 3-D branch" if ds == "nuscenes" else "", "7 per-class trackers, 3-D IoU association, " if ds == "nuscenes" else "",
+                           "LSTM motion model" if e["lstm"] else "Kalman motion model", E2E_PER_PASS),
+            "frames": ne, "frames_per_pass": E2E_PER_PASS, "ms_per_frame": round(d4 / ne * 1e3, 3), "value": round(ne / d4, 3), "unit": "frames/s",
+            "stage_ms": stages(acc),
+            "one_frame_lookahead": {"ms_per_frame": round(d1 / ne * 1e3, 3), "stage_ms": stages(acc1)},
+            "serial": {"ms_per_frame": round(d0 / ne * 1e3, 3), "stage_ms": stages(acc0)},
             "tracks_alive": int(alive), "stored_frames": int(stored), "detections_tracked_last_frame": len(fdet.last_results)}
 
 

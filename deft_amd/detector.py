@@ -214,7 +214,7 @@ class Detector(object):
             assert inp_h > 0 and inp_w > 0, "the device pre-processing is the fix_res mode (opt.input_h / input_w)"
             meta = self._meta_for(sh, sw, inp_h, inp_w, meta)
             akey = (inp_h, inp_w, sh, sw)
-            if prefetch is not None or any(sl.frame is frame for sl in self._ahead.get(akey, ())):
+            if prefetch is not None or any(sl.frame is frame for slots in self._ahead.values() for sl in slots):
                 t_pre = time.time()
                 output, dets, t_fwd, fmaps = self._process_ahead(akey, frame, prefetch)
             else:
@@ -250,35 +250,44 @@ class Detector(object):
                 hook_on = last
         if nxt is not None and hook_on is None:
             nxt()
-        if self.tracker is None:
-            targets = results
-        elif per_class is not None:                                                    # detector.py:198-338
-            targets = []
-            for name, a in per_class.items():
-                trk = self.tracker[name]
-                if trk is hook_on:
-                    trk.after_device_work = nxt
-                targets += trk.update(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"],
-                                      ddd_org_boxes=a["ddd_org_boxes"], submission=a["submission"], classe=name)
-            if hook_on is not None and hook_on.after_device_work is not None:
-                hook_on.after_device_work = None
-                nxt()
-        elif hook_on is not None:
-            self.tracker.after_device_work = nxt
-            targets = self.tracker.update(results, fmaps)
-            if self.tracker.after_device_work is not None:             # (update() returned early)
-                self.tracker.after_device_work = None
-                nxt()
-        elif getattr(self, "_trk_stream", None) is not None and self._ahead_busy():
-            # the next frame's network pass is running beside us: the tracker's many small launches go to a HIGH-priority stream, so that
-            # they are dispatched ahead of the pass's workgroups instead of queueing behind them
+        # a lookahead pass running (or about to be queued) beside us: the tracker's many small launches go to a HIGH-priority stream, so
+        # that they are dispatched ahead of the pass's workgroups instead of queueing behind them
+        prio = getattr(self, "_trk_stream", None) if (self._ahead_busy() or nxt is not None) else None
+        ready, self._fm_ready = getattr(self, "_fm_ready", None), None
+        if prio is not None:
             main = torch.cuda.current_stream(self.device)
-            self._trk_stream.wait_stream(main)
-            with torch.cuda.stream(self._trk_stream):
+            if ready is not None:
+                # NOT prio.wait_stream(main): the caller's stream is normally the null stream, and HIP multiplexes streams onto a few
+                # hardware queues -- when the null stream shares its queue with the pass's stream (or a branch stream of its graph), an
+                # event recorded on it completes only when the pass does, and the tracker would wait ~a whole pass for nothing
+                # (tools/probe/stall_probe.py, profiles/r4_hw_queue_stall.md).  The feature maps' own event is all the tracker needs.
+                prio.wait_event(ready)
+            else:
+                prio.wait_stream(main)
+        with (torch.cuda.stream(prio) if prio is not None else _null()):
+            if self.tracker is None:
+                targets = results
+            elif per_class is not None:                                                    # detector.py:198-338
+                targets = []
+                for name, a in per_class.items():
+                    trk = self.tracker[name]
+                    if trk is hook_on:
+                        trk.after_device_work = nxt
+                    targets += trk.update(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"],
+                                          ddd_org_boxes=a["ddd_org_boxes"], submission=a["submission"], classe=name)
+                if hook_on is not None and hook_on.after_device_work is not None:
+                    hook_on.after_device_work = None
+                    nxt()
+            elif hook_on is not None:
+                self.tracker.after_device_work = nxt
                 targets = self.tracker.update(results, fmaps)
-            main.wait_stream(self._trk_stream)
-        else:
-            targets = self.tracker.update(results, fmaps)                              # detector.py:340-342
+                if self.tracker.after_device_work is not None:             # (update() returned early)
+                    self.tracker.after_device_work = None
+                    nxt()
+            else:
+                targets = self.tracker.update(results, fmaps)                              # detector.py:340-342
+        if prio is not None:
+            main.wait_stream(prio)
         t_end = time.time()
         self.times = {"load": t_loaded - t_start, "pre": t_pre - t_loaded, "net": t_fwd - t_pre, "dec": t_dec - t_fwd, "post": t_post - t_dec,
                       "merge": t_merge - t_post, "track": t_end - t_merge, "tot": t_end - t_start}
@@ -307,51 +316,67 @@ class Detector(object):
 
     # ---- one frame of lookahead: two sets of plan buffers, frame k+1's network pass beside frame k's host work ---------------------------
     class _Slot:
-        def __init__(self, det, inp_h, inp_w, sh, sw):
-            self.plan = engine.DlaSegPlan(det.sd, 1, inp_h, inp_w, det.dataset, K=det.K, device=det.device, lib=det.lib)
+        """One set of plan buffers of the lookahead: `n` frames per pass (Detector.lookahead_frames)."""
+
+        def __init__(self, det, inp_h, inp_w, sh, sw, n=1):
+            self.n = n
+            self.plan = engine.DlaSegPlan(det.sd, n, inp_h, inp_w, det.dataset, K=det.K, device=det.device, lib=det.lib)
             self.plan.use_u8_input(sh, sw)
             cuda = det.device.type == "cuda"
-            self.stage = torch.empty(1, sh, sw, 3, dtype=torch.uint8, pin_memory=cuda)
-            self.stage_np = self.stage[0].numpy()
+            self.stage = torch.empty(n, sh, sw, 3, dtype=torch.uint8, pin_memory=cuda)
+            self.stage_np = self.stage.numpy()
             self.fields = None
-            self.graph, self.warm, self.frame, self.host = None, False, None, None
+            self.graph, self.warm, self.host = None, False, None
+            self.frames, self.pos = None, 0              # the frame arrays of the pass in flight / being handed out, and how many were consumed
             self.done = torch.cuda.Event() if cuda else None
+
+        @property
+        def frame(self):                                 # the frame the next run() call may claim (None: the slot is free)
+            return self.frames[self.pos] if self.frames is not None else None
 
         def __del__(self):                       # a queued pass (announced, never consumed) must not outlive its graph and buffers
             try:
-                if self.done is not None and self.frame is not None:
+                if self.done is not None and self.frames is not None:
                     self.done.synchronize()
             except Exception:
                 pass
 
-    def _launch_ahead(self, sl, frame):
-        """Queue frame -> detections on slot `sl` (its own stream): staging copy, H2D, the plan (hipGraph from the second use), one D2H
-        of every decoded field into pinned memory, an event.  Returns without waiting."""
+    def _launch_ahead(self, sl, frames):
+        """Queue frames -> detections on slot `sl` (its own stream): staging copy, H2D, the plan (hipGraph from the second use), one D2H
+        of every decoded field into pinned memory, an event.  Returns without waiting.  frames: 1 .. sl.n uint8 arrays (a pass with
+        fewer frames than the plan holds repeats the last one: its results are never handed out)."""
         p = sl.plan
         cuda = self.device.type == "cuda"
-        src = torch.from_numpy(frame) if frame.flags["C_CONTIGUOUS"] else None
-        if cuda and src is not None and src.is_pinned():
-            stage = src.unsqueeze(0)                   # the frame already lives in pinned host memory (a decoder's output buffer): no staging copy
-        else:
-            np.copyto(sl.stage_np, frame)              # (a plain memcpy: torch's multi-threaded CPU copy_ stalls for milliseconds next to the tracker's BLAS threads)
-            stage = sl.stage
+        frames = list(frames)
+        srcs = []
+        for i in range(sl.n):
+            f = frames[min(i, len(frames) - 1)]
+            src = torch.from_numpy(f) if f.flags["C_CONTIGUOUS"] else None
+            if cuda and src is not None and src.is_pinned():
+                srcs.append(src)                           # the frame already lives in pinned host memory (a decoder's output buffer): no staging copy
+            else:
+                np.copyto(sl.stage_np[i], f)               # (a plain memcpy: torch's multi-threaded CPU copy_ stalls for milliseconds next to the tracker's BLAS threads)
+                srcs.append(sl.stage[i])
         if cuda:
             if not hasattr(self, "_net_stream"):
                 self._net_stream = torch.cuda.Stream(device=self.device)
                 self._trk_done = torch.cuda.Event()
-                self._trk_stream = torch.cuda.Stream(device=self.device, priority=-1) if PRIORITY_TRACKER else None
+                # the tracker's stream: never the null stream (see run()); high priority = its own hardware-queue pool, and its many
+                # small launches are dispatched ahead of the pass's workgroups
+                self._trk_stream = torch.cuda.Stream(device=self.device, priority=-1 if PRIORITY_TRACKER else 0)
             main = torch.cuda.current_stream(self.device)
             self._trk_done.record(main)
-            self._net_stream.wait_event(self._trk_done)            # whatever read this slot's feature maps (two frames ago) is finished
+            self._net_stream.wait_event(self._trk_done)            # whatever read this slot's feature maps (two passes ago) is finished
             if self.hip_graphs and sl.warm and sl.graph is None:
                 sl.graph = p.capture_graph()
         ctx = torch.cuda.stream(self._net_stream) if cuda else _null()
         with ctx:
+            for i, src in enumerate(srcs):
+                p.image_u8[i].copy_(src, non_blocking=True)
             if sl.graph is not None:
-                p.image_u8.copy_(stage, non_blocking=True)
                 sl.graph.replay()
             else:
-                p.forward_u8(stage.to(self.device, non_blocking=True))
+                p.run()
                 sl.warm = True
             d = p.dets()
             if "dep" in d:
@@ -364,46 +389,69 @@ class Detector(object):
             sl.host.copy_(flat, non_blocking=True)
             if cuda:
                 sl.done.record(self._net_stream)
-        sl.frame = frame
+        sl.frames, sl.pos = frames, 0
 
     def _ahead_busy(self):
-        return any(sl.frame is not None for slots in self._ahead.values() for sl in slots)
+        return any(sl.frames is not None for slots in self._ahead.values() for sl in slots)
+
+    lookahead_frames = 1           # n > 1: run(prefetch=[the next 2n-1 frames]) runs n frames per lookahead pass (an n-frame plan: the batch-1
+    #                                launch list is latency-bound, n frames cost less than n passes), queued up to 2n-1 frames ahead; the
+    #                                results are handed out one per call.  For recorded streams (test.py reads files); a live camera pays
+    #                                n-1 frame periods of latency for it
 
     def _process_ahead(self, akey, frame, prefetch):
         import time
-        if akey not in self._ahead:
-            self._ahead[akey] = [Detector._Slot(self, *akey), Detector._Slot(self, *akey)]
-        slots = self._ahead[akey]
+        n = int(self.lookahead_frames)
+        upcoming = list(prefetch) if isinstance(prefetch, (list, tuple)) else ([] if prefetch is None else [prefetch])
+        key = akey + (n,)
+        if key not in self._ahead:
+            self._ahead[key] = [Detector._Slot(self, *akey, n=n), Detector._Slot(self, *akey, n=n)]
+        slots = self._ahead[key]
         cur = next((sl for sl in slots if sl.frame is frame), None)
-        if cur is None:                                                # not announced by the previous call: launch it now
+        if cur is None:                                                # not announced by an earlier call: launch it now (with what is known to follow)
+            for sl in slots:                                           # announced passes that were never claimed are dropped
+                if sl.frames is not None and sl.done is not None:
+                    sl.done.synchronize()
+                sl.frames = None
             cur = slots[self._ahead_turn]
-            self._launch_ahead(cur, frame)
-        self._ahead_turn = 1 - slots.index(cur)
+            self._launch_ahead(cur, [frame] + upcoming[:n - 1])
+        other = slots[1 - slots.index(cur)]
+        self._ahead_turn = slots.index(other)
         if cur.done is not None:
             cur.done.synchronize()
-        rec, dets, o = cur.host.numpy(), {}, 0                         # (the pinned record is rewritten two frames on: copies)
-        for k, shape, n, dt in cur.fields:
-            dets[k] = rec[o:o + n].astype(dt).reshape(shape)
-            o += n
-        cur.frame = None
+        j = cur.pos
+        rec, dets, o = cur.host.numpy(), {}, 0                         # (the pinned record is rewritten two passes on: copies)
+        for k, shape, cnt, dt in cur.fields:
+            a = rec[o:o + cnt].astype(dt).reshape(shape)
+            dets[k] = a[j:j + 1] if shape and shape[0] == cur.n else a
+            o += cnt
+        fmaps = cur.plan.fmaps if cur.n == 1 else [fm[j] for fm in cur.plan.fmaps]
+        hm = cur.plan.dense["hm"] if cur.n == 1 else cur.plan.dense["hm"][j]
+        cur.pos += 1
+        left = len(cur.frames) - cur.pos                               # frames of this pass still to be handed out
+        if left == 0:
+            cur.frames = None
         if cur.done is not None:
             torch.cuda.current_stream(self.device).wait_event(cur.done)    # the tracker's launches read this slot's feature maps
+        self._fm_ready = cur.done
         t_fwd = time.time()
         self._launch_next = None
-        if prefetch is not None:
-            assert prefetch.dtype == np.uint8 and prefetch.shape == frame.shape, "prefetch: the next frame of the same stream"
-            nxt = slots[self._ahead_turn]
-            self._launch_next = lambda: self._launch_ahead(nxt, prefetch)     # run() decides when: see there
-        return {"hm": cur.plan.dense["hm"], "pre_inds": None}, dets, t_fwd, cur.plan.fmaps
+        if other.frames is None and len(upcoming) > left:              # the free slot takes the frames behind the ones this slot still holds
+            nxt = upcoming[left:left + n]
+            for f in nxt:
+                assert f.dtype == np.uint8 and f.shape == frame.shape, "prefetch: the next frames of the same stream"
+            if len(nxt) == n or left == 0:                             # (a short pass only when nothing else is in flight: the stream is ending)
+                self._launch_next = lambda: self._launch_ahead(other, nxt)      # run() decides when: see there
+        return {"hm": hm, "pre_inds": None}, dets, t_fwd, fmaps
 
     def reset_tracking(self, opt):
         """detector.py:677-686: a new video -- fresh Tracker(s) built with the current img_height / img_width (tracks, recorder and
         frame counter must not survive into the next sequence), no previous image, and no lookahead pass left over from the last video."""
         for slots in self._ahead.values():
             for sl in slots:
-                if sl.frame is not None and sl.done is not None:
+                if sl.frames is not None and sl.done is not None:
                     sl.done.synchronize()              # an announced pass that nobody consumed: let it finish, then forget it
-                sl.frame = None
+                sl.frames = None
         self._launch_next = None
         if self.tracker is not None:
             fac = getattr(self, "_tracker_factory", None)

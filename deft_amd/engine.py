@@ -64,7 +64,8 @@ class View:
 
     def to_nchw(self):
         """Debug/test view (torch indexing, not on the hot path)."""
-        return self.buf.view(self.N, self.H, self.W, self.ld)[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2).contiguous()
+        return torch.as_strided(self.buf.view(-1), (self.N, self.C, self.H, self.W),
+                                (self.H * self.W * self.ld, 1, self.W * self.ld, self.ld), self.c0).contiguous()
 
 
 class _LazyView(View):
@@ -1324,6 +1325,14 @@ class AfePlan(_Plan):
         row[:n] = torch.as_tensor(values, dtype=torch.int32)
         return row[:n].to(self.device, non_blocking=True)
 
+    def _work(self, name, numel):
+        """Grow-only fp32 device workspace `name` of at least `numel` elements (1.5x headroom on growth)."""
+        ws = self.__dict__.setdefault("_workspaces", {})
+        t = ws.get(name)
+        if t is None or t.numel() < numel:
+            t = ws[name] = torch.empty(max(numel + numel // 2, 1 << 16), dtype=torch.float32, device=self.device)
+        return t[:numel]
+
     def affinity(self, hist, cur):
         """hist: list of [P_f, D] embeddings of F stored frames; cur [Q, D].
         Returns the F matrices [P_f, Q+1] of forward_stacker_features (AFE.py:110-160,
@@ -1336,17 +1345,27 @@ class AfePlan(_Plan):
             starts.append(starts[-1] + hx.shape[0])
         T = starts[-1]
         assert 0 < Q <= self.max_object and T > 0
-        xh = torch.zeros(T, Kd, dtype=torch.float32, device=dev)
-        xh[:, :D] = torch.cat([hx.to(dev, torch.float32) for hx in hist], 0)
-        xc = torch.zeros(Q, Kd, dtype=torch.float32, device=dev)
-        xc[:, :D] = cur.to(dev, torch.float32)
-        U = torch.empty(T, 512, dtype=torch.float32, device=dev)
-        V = torch.empty(Q, 512, dtype=torch.float32, device=dev)
-        self._lin(xh, T, Kd, Kd, self.Ua, Kd, 512, None, None, False, U, 512)
-        self._lin(xc, Q, Kd, Kd, self.Vb, Kd, 512, None, self.cb, False, V, 512)
+        # grow-only workspaces (h2 alone is T*Q rows: up to 0.5 GB for 50 stored frames of 100 objects).  Fresh torch.empty calls of a size
+        # that changes every frame (the lazily-computed block set does) keep missing the caching allocator: each miss is a hipMalloc of
+        # hundreds of MB, and each garbage-collection of the cache a hipFree -- which waits for EVERYTHING the device is running, e.g. a
+        # lookahead pass on another stream (profiles/r4_hw_queue_stall.md).  Safe to reuse: launches of consecutive calls are
+        # ordered on the caller's stream(s), and only `out` outlives the call.
         M = T * Q
         (w2, K2, c2, s2, t2), (w3, K3, c3, s3, t3), (w4, K4, c4, s4, t4) = self.layers
-        h2 = torch.empty(M, c2, dtype=torch.float32, device=dev)
+        xh = self._work("xh", T * Kd).view(T, Kd)
+        xc = self._work("xc", Q * Kd).view(Q, Kd)
+        hd = [hx.to(dev, torch.float32) for hx in hist]
+        if Kd == D:
+            torch.cat(hd, 0, out=xh)                       # one launch, straight into the workspace
+        else:
+            xh[:, D:].zero_(); xc[:, D:].zero_()
+            xh[:, :D] = torch.cat(hd, 0)
+        xc[:, :D].copy_(cur, non_blocking=True)
+        U = self._work("U", T * 512).view(T, 512)
+        V = self._work("V", Q * 512).view(Q, 512)
+        self._lin(xh, T, Kd, Kd, self.Ua, Kd, 512, None, None, False, U, 512)
+        self._lin(xc, Q, Kd, Kd, self.Vb, Kd, 512, None, self.cb, False, V, 512)
+        h2 = self._work("h2", M * c2).view(M, c2)
         d = GemmDesc()
         d.x = U.data_ptr(); d.x2 = V.data_ptr(); d.w = w2.data_ptr()
         d.scale = s2.data_ptr(); d.shift = t2.data_ptr(); d.res = None; d.y = h2.data_ptr()
@@ -1358,9 +1377,9 @@ class AfePlan(_Plan):
         if BDMA and PREC == 1:
             d.w3 = self.weights_p3(w2).data_ptr()
         self.lib.call("deft_pair_layer", C.byref(d), self._stream())
-        h3 = torch.empty(M, c3, dtype=torch.float32, device=dev)
+        h3 = self._work("h3", M * c3).view(M, c3)
         self._lin(h2, M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, h3, c3)
-        h4 = torch.empty(M, c4, dtype=torch.float32, device=dev)
+        h4 = self._work("h4", M * c4).view(M, c4)
         self._lin(h3, M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, h4, c4)
         out = torch.empty(T, Q + 1, dtype=torch.float32, device=dev)
         rs = self._staged_ints(starts)                # (pinned staging: a pageable torch.tensor(..., device=) is a blocking copy behind the whole chain)

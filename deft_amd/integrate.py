@@ -120,13 +120,28 @@ class AfeSeam:
             out.append(v)
         return out
 
+    def _to_device_f32(self, t):
+        """Host -> device through PINNED staging (a ring of 4 buffers; the tracker's per-frame stream sync retires a slot long before it comes
+        round again).  A pageable source makes the copy synchronous, and on this runtime it then also waits for whatever else the device is
+        running -- e.g. a whole lookahead pass on another stream (profiles/r4_hw_queue_stall.md)."""
+        if self.device.type != "cuda" or t.device.type == "cuda":
+            return t.to(self.device, torch.float32)
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None or ring[0].numel() < t.numel():
+            ring = self._pin_ring = [torch.empty(max(1024, 2 * t.numel()), dtype=torch.float32).pin_memory() for _ in range(4)]
+            self._pin_turn = 0
+        self._pin_turn = (self._pin_turn + 1) % len(ring)
+        stage = ring[self._pin_turn][:t.numel()].view(t.shape)
+        stage.copy_(t)
+        return stage.to(self.device, non_blocking=True)
+
     def forward_feature_extracter(self, s, l):
         """AFE.py:88-92.  s: FeatureMaps (13), l: centres [1,N,1,1,2] in [-1,1] -> [1,N,D]."""
         keep = len(self.plan._keep)
         views = self._views(s)
         Nf = views[0].N
         n = l.shape[1]
-        centers = l.reshape(1, n, 2).to(self.device, torch.float32).expand(Nf, n, 2).contiguous()
+        centers = self._to_device_f32(l.reshape(1, n, 2)).expand(Nf, n, 2).contiguous()
         emb = self.plan.extract(views, centers)
         if len(self.plan._keep) > keep:               # NCHW adapter made temporaries: wait for the launches that read them, then drop them
             if self.device.type == "cuda":            # and the descriptors built on their addresses (NHWC Views -- the plan's own maps -- need

@@ -1404,11 +1404,13 @@ def check_device_detect(lib, device, dataset="mot", H=64, W=96, K=20, first_n=9,
     return n_res, n_sel
 
 
-def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9, T=6, hook=False):
+def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9, T=6, hook=False, pairs=False):
     """Detector.run(frame, prefetch=next frame): frame k+1's network pass is queued on a second set of plan buffers before frame k's
     post-processing and tracker run.  Same detections as the serial order, and the tracker sees the FeatureMaps of ITS frame (checksums
     taken inside update(), i.e. while the next frame's pass may already be running); a caller that announces one frame and then passes
-    another gets the frame it passed."""
+    another gets the frame it passed.
+    pairs (True = 2, or n): Detector.lookahead_frames -- prefetch is the list of the next 2n-1 frames, a pass holds n frames (an n-frame plan)
+    and is handed out over n calls; a 2-frame plan may split its reductions differently from the 1-frame plan, so floats agree to 1e-4."""
     from types import SimpleNamespace
     from deft_amd import hiplib
     from deft_amd.detector import Detector
@@ -1421,16 +1423,22 @@ def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9
         frames = [torch.randint(0, 256, (sh, sw, 3), dtype=torch.uint8, generator=g).numpy() for _ in range(T)]
 
         det = Detector(opt, sd)                         # one detector: the serial calls use its plan, the lookahead calls its two slots
+        det.lookahead_frames = int(pairs) + 1 if isinstance(pairs, bool) else pairs
+        npass = det.lookahead_frames
         log = []
+
+        def checksums(fmaps):
+            return [float(fm.to_nchw().double().sum().item()) for fm in (fmaps[0], fmaps[6], fmaps[-1])]
 
         class Trk:
             def update(self, results, fmaps):
-                sums = [float(fm.buf.double().sum().item()) for fm in (fmaps[0], fmaps[6], fmaps[-1])]
+                assert all(fm.N == 1 for fm in fmaps)
+                sums = checksums(fmaps)
                 if hook:                       # a tracker that announces the end of its device work (mot_tracker.Tracker2D): the next frame's
                     cb, self.after_device_work = self.after_device_work, None      # pass is queued HERE -- this frame's maps stay what they are
                     if cb is not None:
                         cb()
-                    assert sums == [float(fm.buf.double().sum().item()) for fm in (fmaps[0], fmaps[6], fmaps[-1])]
+                    assert sums == checksums(fmaps)
                 log.append(([(int(r["class"]), float(r["score"]), tuple(float(v) for v in r["bbox"])) for r in results], sums))
                 return []
         if hook:
@@ -1441,21 +1449,35 @@ def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9
             del log[:]
             for i, k in enumerate(order):
                 nxt = frames[order[i + 1]] if lookahead and i + 1 < len(order) else None
+                if lookahead and pairs:
+                    nxt = [frames[j] for j in order[i + 1:i + 2 * npass]]
                 det.run(frames[k], prefetch=nxt)
             return list(log)
+
+        def same(a, b):
+            if not pairs:
+                return a == b
+            (ra, sa), (rb, sb) = a, b
+            return len(ra) == len(rb) and all(x[0] == y[0] and abs(x[1] - y[1]) < 1e-4 and np.allclose(x[2], y[2], atol=1e-3) for x, y in zip(ra, rb)) \
+                and np.allclose(sa, sb, rtol=1e-5)
 
         order = list(range(T))
         serial = stream(False, order)
         ahead = stream(True, order)
         assert len(serial) == len(ahead) == len(order)
         for a, b in zip(serial, ahead):
-            assert a == b
+            assert same(a, b)
+        if pairs:
+            passes = [sl.n for slots in det._ahead.values() for sl in slots]
+            assert passes == [npass, npass]
+            odd = stream(True, order[:T - 1])                            # an odd number of frames: the last pass holds one frame
+            assert len(odd) == T - 1 and all(same(a, b) for a, b in zip(serial, odd))
         assert len({tuple(x[1]) for x in serial[:T]}) == T               # the frames really differ
         # announce frame 1, then pass frame 3: the announced pass is dropped, frame 3 is what gets processed
         del log[:]
-        det.run(frames[0], prefetch=frames[1])
+        det.run(frames[0], prefetch=frames[1:2 * npass] if pairs else frames[1])
         det.run(frames[T - 1], prefetch=None)
-        assert len(log) == 2 and log[0] == serial[0] and log[1] == serial[T - 1]
+        assert len(log) == 2 and same(log[0], serial[0]) and same(log[1], serial[T - 1])
     finally:
         hiplib._lib = saved_lib
 
@@ -1571,7 +1593,7 @@ def check_co_residency(lib, H=512, W=512, N=16, reps=4):
     return checked
 
 
-def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64, W=96, K=12, T=4, seed=6):
+def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64, W=96, K=12, T=4, seed=6, pairs=False):
     """deft_amd.detector.Detector.run -> deft_amd.array_tracker.ArrayTracker on the configurations round 4 adds (KITTI + LSTM, nuScenes
     with its seven per-class trackers): frames in, tracks out, serial and with one frame of lookahead -- the SAME tracks both ways (ids,
     boxes, scores), the motion bank stepped once per frame, the queued pass fired by the tracker's after_device_work hook."""
@@ -1623,9 +1645,12 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
             else:
                 det.set_tracker(MT.ArrayTracker(opt, model, h=sh, w=sw))
             det.img_height, det.img_width = sh, sw
+            det.lookahead_frames = 2 if lookahead == "pairs" else 1
             log, fired = [], []
             for t in range(T):
                 nxt = frames[t + 1] if lookahead and t + 1 < T else None
+                if lookahead == "pairs":
+                    nxt = frames[t + 1:t + 4]
                 targets = det.run(frames[t], image_info=info, prefetch=nxt)
                 log.append(sorted((int(x.track_id), bool(x.is_activated), int(x.tracklet_len), [round(float(v), 9) for v in x.tlwh], float(x.score),
                                    None if x.ddd_bbox is None else [float(v) for v in x.ddd_bbox]) for x in targets))
@@ -1635,6 +1660,13 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
         serial, l0 = run(False)
         ahead, l1 = run(True)
         assert serial == ahead
+        if pairs:                       # two frames per lookahead pass (a 2-frame plan: floats to round-off of another reduction split)
+            two, l2 = run("pairs")
+            assert l2 == l0 and len(two) == len(serial)
+            for fa, fb in zip(serial, two):
+                assert [x[:3] for x in fa] == [x[:3] for x in fb]
+                for x, y in zip(fa, fb):
+                    assert np.allclose(x[3], y[3], atol=1e-3) and abs(x[4] - y[4]) < 1e-4
         assert sum(len(f) for f in serial) >= T and any(x[2] > 0 for f in serial for x in f), "tracks must have been matched across frames"
         if lstm:
             assert 0 < l0 <= (7 * T if dataset == "nuscenes" else T) and l1 == l0

@@ -371,6 +371,11 @@ def test_fused_run_with_lookahead(emu_lib):
     pc.check_fused_run_prefetch(emu_lib, "cpu", sh=30, sw=50, H=32, W=64, K=8, T=3, hook=True)
 
 
+def test_fused_run_with_pair_lookahead(emu_lib):
+    """Detector.lookahead_frames = 2: two frames per lookahead pass, handed out over two calls."""
+    pc.check_fused_run_prefetch(emu_lib, "cpu", sh=30, sw=50, H=32, W=64, K=8, T=6, hook=True, pairs=True)
+
+
 def test_preprocess_u8(emu_lib):
     pc.check_preprocess_u8(emu_lib, "cpu")
 
@@ -489,7 +494,7 @@ def test_dataflow_schedule_is_order_independent(emu_lib):
 
 @pytest.mark.parametrize("dataset,lstm", [("kitti_tracking", True), ("nuscenes", True), ("nuscenes", False)])
 def test_fused_run_array_tracker(emu_lib, dataset, lstm):
-    pc.check_fused_run_array_tracker(emu_lib, "cpu", dataset, lstm, T=3)
+    pc.check_fused_run_array_tracker(emu_lib, "cpu", dataset, lstm, T=3, pairs=(dataset == "kitti_tracking"))
 
 
 @pytest.mark.parametrize("tag", ["mot", "mot_lstm", "nuscenes"])

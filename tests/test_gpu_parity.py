@@ -591,6 +591,9 @@ def test_fused_run_with_lookahead(gpu_lib):
     pc.check_fused_run_prefetch(gpu_lib, "cuda")
     pc.check_fused_run_prefetch(gpu_lib, "cuda", sh=270, sw=480, H=160, W=288, K=50, T=8)
     pc.check_fused_run_prefetch(gpu_lib, "cuda", sh=270, sw=480, H=160, W=288, K=50, T=8, hook=True)
+    pc.check_fused_run_prefetch(gpu_lib, "cuda", sh=270, sw=480, H=160, W=288, K=50, T=9, hook=True, pairs=True)
+    pc.check_fused_run_prefetch(gpu_lib, "cuda", sh=270, sw=480, H=160, W=288, K=50, T=8, pairs=True)
+    pc.check_fused_run_prefetch(gpu_lib, "cuda", sh=270, sw=480, H=160, W=288, K=50, T=11, hook=True, pairs=4)
 
 
 def test_frame_feeder_with_side_streams(gpu_lib):
@@ -752,4 +755,4 @@ def test_tracks_against_reference_trace_on_device(gpu_lib, tag):
 
 @pytest.mark.parametrize("dataset,lstm", [("kitti_tracking", True), ("nuscenes", True)])
 def test_fused_run_array_tracker_on_device(gpu_lib, dataset, lstm):
-    pc.check_fused_run_array_tracker(gpu_lib, "cuda", dataset, lstm, sh=270, sw=480, H=128, W=160, K=40, T=5)
+    pc.check_fused_run_array_tracker(gpu_lib, "cuda", dataset, lstm, sh=270, sw=480, H=128, W=160, K=40, T=5, pairs=True)
