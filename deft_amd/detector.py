@@ -447,6 +447,30 @@ class Detector(object):
                 self._launch_next = lambda: self._launch_ahead(other, nxt)      # run() decides when: see there
         return {"hm": hm, "pre_inds": None}, dets, t_fwd, fmaps
 
+    def track_stream(self, frames, image_infos=None, frames_per_pass=None, nms=True):
+        """The per-video loop of src/test.py:100-150 (`for ind, (img_id, pre_processed_images) in enumerate(data_loader): ret =
+        detector.run(...)`) over a recorded stream: yields run()'s return value (the tracks / detections of one frame) per frame, in
+        order.  `frames`: any iterable of uint8 HWC arrays (a decoder, a list); it is read at most 2n-1 frames ahead, n =
+        frames_per_pass (default: self.lookahead_frames), and those frames ride in the lookahead passes (n per pass) while the host
+        associates -- the caller does not build prefetch lists.  Every frame must be its own array and stay untouched until its tracks
+        have been yielded (a decoder that recycles ONE buffer needs a copy per frame); pinned host memory skips the staging copy.
+        image_infos: per-frame `image_info` records (nuScenes), same order."""
+        import collections
+        import itertools
+        if frames_per_pass is not None:
+            self.lookahead_frames = int(frames_per_pass)
+        n = int(self.lookahead_frames)
+        it = iter(frames)
+        infos = iter(image_infos) if image_infos is not None else itertools.repeat(None)
+        window = collections.deque(itertools.islice(it, 2 * n))        # the frame of this call + the 2n-1 behind it
+        while window:
+            frame = window.popleft()
+            ahead = list(window)
+            yield self.run(frame, image_info=next(infos), prefetch=(ahead if n > 1 else ahead[0]) if ahead else None, nms=nms)
+            nxt = next(it, None)
+            if nxt is not None:
+                window.append(nxt)
+
     def reset_tracking(self, opt):
         """detector.py:677-686: a new video -- fresh Tracker(s) built with the current img_height / img_width (tracks, recorder and
         frame counter must not survive into the next sequence), no previous image, and no lookahead pass left over from the last video."""

@@ -1645,13 +1645,13 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
             else:
                 det.set_tracker(MT.ArrayTracker(opt, model, h=sh, w=sw))
             det.img_height, det.img_width = sh, sw
-            det.lookahead_frames = 2 if lookahead == "pairs" else 1
+            det.lookahead_frames = 1
             log, fired = [], []
-            for t in range(T):
-                nxt = frames[t + 1] if lookahead and t + 1 < T else None
-                if lookahead == "pairs":
-                    nxt = frames[t + 1:t + 4]
-                targets = det.run(frames[t], image_info=info, prefetch=nxt)
+            if lookahead == "pairs":                    # Detector.track_stream: the per-video loop with two frames per lookahead pass
+                outs = det.track_stream(iter(frames), image_infos=[info] * T, frames_per_pass=2)
+            else:
+                outs = (det.run(frames[t], image_info=info, prefetch=frames[t + 1] if lookahead and t + 1 < T else None) for t in range(T))
+            for targets in outs:
                 log.append(sorted((int(x.track_id), bool(x.is_activated), int(x.tracklet_len), [round(float(v), 9) for v in x.tlwh], float(x.score),
                                    None if x.ddd_bbox is None else [float(v) for v in x.ddd_bbox]) for x in targets))
             launches = model.motion.launches if lstm else 0
