@@ -400,7 +400,7 @@ def side_config(name, args, dev, lib, rank):
         del wl
         torch.cuda.empty_cache()
         e = end_to_end(name, dev, lib, dev.index or 0, ne=60)
-        out["end_to_end"] = {k: e[k] for k in ("ms_per_frame", "value", "unit", "frames_per_pass", "stage_ms", "one_frame_lookahead", "serial", "tracks_alive", "workload")}
+        out["end_to_end"] = {k: e[k] for k in ("ms_per_frame", "value", "unit", "frames_per_pass", "runs_ms_per_frame", "stage_ms", "one_frame_lookahead", "serial", "tracks_alive", "workload")}
     return out
 
 
