@@ -204,7 +204,14 @@ def _idle_at_exit():
         pass
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # one C call instead of building a torch.cuda.Stream object per launch
+
+
 def stream_ptr(device):
+    """The current HIP stream of `device` as the void* every entry point takes (None on the host test build)."""
     if device.type == "cuda":
+        if _raw_stream is not None:
+            idx = device.index
+            return C.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
         return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     return None
