@@ -220,6 +220,8 @@ class Detector(object):
                 t_pre = time.time()
                 output, dets, t_fwd, fmaps = self._process_ahead(akey, frame, prefetch)
             else:
+                if self._ahead_busy():
+                    self._drop_ahead()                 # a frame nobody announced, and no announcement with it: the stream left the lookahead
                 plan = self._plan_u8(1, inp_h, inp_w, sh, sw)
                 src = torch.from_numpy(np.ascontiguousarray(frame)).unsqueeze(0)
                 t_pre = time.time()
@@ -394,6 +396,16 @@ class Detector(object):
                 sl.done.record(self._net_stream)
         sl.frames, sl.pos = frames, 0
 
+    def _drop_ahead(self):
+        """Forget every lookahead pass that was announced and never claimed (the caller moved on to another frame, another video or the
+        serial form of run()): let it finish -- its graph writes into the slot's buffers -- then release the slot and its frames."""
+        for slots in self._ahead.values():
+            for sl in slots:
+                if sl.frames is not None and sl.done is not None:
+                    sl.done.synchronize()
+                sl.frames = None
+        self._launch_next = None
+
     def _ahead_busy(self):
         return any(sl.frames is not None for slots in self._ahead.values() for sl in slots)
 
@@ -406,18 +418,19 @@ class Detector(object):
         import time
         n = int(self.lookahead_frames)
         upcoming = list(prefetch) if isinstance(prefetch, (list, tuple)) else ([] if prefetch is None else [prefetch])
-        key = akey + (n,)
-        if key not in self._ahead:
-            self._ahead[key] = [Detector._Slot(self, *akey, n=n), Detector._Slot(self, *akey, n=n)]
-        slots = self._ahead[key]
-        cur = next((sl for sl in slots if sl.frame is frame), None)
+        # the pass that already holds this frame -- in whichever slot pair (the caller may have changed the frame size or
+        # lookahead_frames since it was announced) -- else a fresh one
+        slots = next((sl_ for sl_ in self._ahead.values() if any(sl.frame is frame for sl in sl_)), None)
+        cur = None if slots is None else next(sl for sl in slots if sl.frame is frame)
         if cur is None:                                                # not announced by an earlier call: launch it now (with what is known to follow)
-            for sl in slots:                                           # announced passes that were never claimed are dropped
-                if sl.frames is not None and sl.done is not None:
-                    sl.done.synchronize()
-                sl.frames = None
+            self._drop_ahead()                                         # announced passes that were never claimed are dropped, everywhere
+            key = akey + (n,)
+            if key not in self._ahead:
+                self._ahead[key] = [Detector._Slot(self, *akey, n=n), Detector._Slot(self, *akey, n=n)]
+            slots = self._ahead[key]
             cur = slots[self._ahead_turn]
             self._launch_ahead(cur, [frame] + upcoming[:n - 1])
+        n = cur.n
         other = slots[1 - slots.index(cur)]
         self._ahead_turn = slots.index(other)
         if cur.done is not None:
@@ -474,12 +487,7 @@ class Detector(object):
     def reset_tracking(self, opt):
         """detector.py:677-686: a new video -- fresh Tracker(s) built with the current img_height / img_width (tracks, recorder and
         frame counter must not survive into the next sequence), no previous image, and no lookahead pass left over from the last video."""
-        for slots in self._ahead.values():
-            for sl in slots:
-                if sl.frames is not None and sl.done is not None:
-                    sl.done.synchronize()              # an announced pass that nobody consumed: let it finish, then forget it
-                sl.frames = None
-        self._launch_next = None
+        self._drop_ahead()
         if self.tracker is not None:
             fac = getattr(self, "_tracker_factory", None)
             if fac is not None:

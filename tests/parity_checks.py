@@ -1472,6 +1472,15 @@ def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9
             assert passes == [npass, npass]
             odd = stream(True, order[:T - 1])                            # an odd number of frames: the last pass holds one frame
             assert len(odd) == T - 1 and all(same(a, b) for a, b in zip(serial, odd))
+            # the caller changes lookahead_frames between two calls: the frame announced under the old value is still taken from its pass,
+            # and nothing stays queued afterwards
+            del log[:]
+            det.run(frames[0], prefetch=frames[1:2 * npass])
+            det.lookahead_frames = 1
+            det.run(frames[1], prefetch=None)
+            det.run(frames[T - 1], prefetch=None)
+            det.lookahead_frames = npass
+            assert len(log) == 3 and same(log[0], serial[0]) and same(log[1], serial[1]) and same(log[2], serial[T - 1]) and not det._ahead_busy()
         assert len({tuple(x[1]) for x in serial[:T]}) == T               # the frames really differ
         # announce frame 1, then pass frame 3: the announced pass is dropped, frame 3 is what gets processed
         del log[:]
