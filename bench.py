@@ -596,7 +596,12 @@ def main():
     if not args.no_check and not args.standin:
         if rank == 0:
             first = 0 if world == 1 or not gather else min(HIST, B - 1)    # (with N ranks frame 0's history lives on the last rank's shard)
-            parity = parity_gate(cfg, wl, (first, 17) if B > 17 else (first, B - 1) if B > 1 + first else (first,))
+            try:
+                parity = parity_gate(cfg, wl, (first, 17) if B > 17 else (first, B - 1) if B > 1 + first else (first,))
+            except Exception as e:                        # the checker must not take the measured line down with it: a gate that could not run
+                import traceback                          # is reported as a FAILED gate with the reason
+                parity = {"pass": False, "pass_up_to_roundoff_ties": False, "error": "%s: %s" % (type(e).__name__, e),
+                          "traceback": traceback.format_exc().splitlines()[-6:]}
         else:
             step(images)                                  # (the gate runs one more step: it contains the all-gather)
 
