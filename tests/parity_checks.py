@@ -1472,6 +1472,12 @@ def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9
             assert passes == [npass, npass]
             odd = stream(True, order[:T - 1])                            # an odd number of frames: the last pass holds one frame
             assert len(odd) == T - 1 and all(same(a, b) for a, b in zip(serial, odd))
+            # Detector.track_stream: the same loop without hand-made prefetch lists -- whole stream, a stream shorter than the read-ahead
+            # window, an empty one
+            for upto in (T, 2, 0):
+                del log[:]
+                outs = list(det.track_stream(iter(frames[:upto]), frames_per_pass=npass))
+                assert len(outs) == len(log) == upto and all(same(a, b) for a, b in zip(serial, log)) and not det._ahead_busy()
             # the caller changes lookahead_frames between two calls: the frame announced under the old value is still taken from its pass,
             # and nothing stays queued afterwards
             del log[:]
