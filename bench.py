@@ -18,7 +18,7 @@ A 512x512 + 32x128 affinity; D KITTI 1280x384 + 30x150 affinity + LSTM motion up
 per GPU (replicas: no collective) + 3-D LSTM motion update.
 
 Extra objects in the JSON line:
-  parity          the parity gate, in the same command and outside the timed region (--no-check skips it): frames 0 and 17 of the
+  parity          the parity gate, in the same command and outside the timed region (--no-check skips it): the first and last frame of each sub-batch plan (0, 15, 16, 31) of the
                   timed plan's own step (B frames per GPU on the sub-batch plans and HIP streams that `value` is measured on) against
                   the oracle (oracle/deft_oracle.py as the CHECKER): ordered top-K (class, index), scores, boxes, embeddings and
                   the [hist*N, N+1] affinity blocks of FramePipeline.step.
@@ -215,7 +215,19 @@ def timed(step, images, steps, warmup, dev):
     return max_over_ranks(dt, dev), host_dt
 
 
-def parity_gate(cfg, wl, frames, tol=1e-3, tie=1e-4):
+def gate_frames(comp, B, first=0):
+    """Frames the gate checks: the first and the last slot of EVERY sub-batch plan of the step (B = 32 on two plans of 16: 0, 15, 16, 31);
+    `first` replaces frame 0 when its history lives on another rank."""
+    fr = []
+    for s_ in range(len(comp.plans)):
+        for f in (s_ * comp.sub, s_ * comp.sub + comp.sub - 1):
+            f = max(f, first) if s_ == 0 and f < first else f
+            if 0 <= f < B and f not in fr:
+                fr.append(f)
+    return tuple(fr)
+
+
+def parity_gate(cfg, wl, frames, tol=1e-3, tie=1e-4, outs=None):
     """The parity gate of BASELINE.md section 3, on the plans the timed loop runs (same sub-batch size, same kernels, same
     streams): one more step of the steady-state loop, then, for each frame index f of the step, the device's decode
     (decode.py:102: ordered top-K classes + indices, scores, boxes), embeddings (AFE.py:88-92) and the frame's affinity block from
@@ -230,7 +242,8 @@ def parity_gate(cfg, wl, frames, tol=1e-3, tie=1e-4):
     comp, pipe, images, sd = wl["comp"], wl["pipe"], wl["images"], wl["sd"]
     H, W, nd, hist, ds = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"], cfg["dataset"]
     t0 = time.time()
-    outs = wl["step"](images)
+    if outs is None:                                                    # (multi-rank callers run the step -- it holds the collective -- on EVERY rank
+        outs = wl["step"](images)                                       # themselves and hand the result in: nothing below communicates)
     torch.cuda.synchronize()
     B = images.shape[0]
     emb_dev = comp.emb.detach().cpu()                                   # [B, nd, D] of this step (= of every steady-state step: same frames)
@@ -285,8 +298,8 @@ def parity_gate(cfg, wl, frames, tol=1e-3, tie=1e-4):
         all_equal, all_ties = all_equal and equal, all_ties and ties
         for k_, v_ in (("score", e_s), ("bbox", e_b), ("embedding", e_e), ("affinity", e_a), ("hm_logit", e_hm)):
             worst[k_] = max(worst[k_], v_)
-    floats_ok = max(worst["score"], worst["bbox"], worst["embedding"], worst["affinity"]) <= tol
-    rep.update({"topk_ordered_equal": all_equal, "floats_within_tol": floats_ok, "max_err": {k_: round(v_, 7) for k_, v_ in worst.items()},
+    floats_ok = max(worst.values()) <= tol                              # (the dense heat-map logits included)
+    rep.update({"frames_checked": list(frames), "topk_ordered_equal": all_equal, "floats_within_tol": floats_ok, "max_err": {k_: round(v_, 7) for k_, v_ in worst.items()},
                 "pass": bool(all_equal and floats_ok), "pass_up_to_roundoff_ties": bool(all_ties and floats_ok),
                 "plan": "the timed plans: %d frames per step as %d sub-batch plan(s) of %d on %d HIP stream(s)" % (B, len(comp.plans), comp.sub, comp.nstream),
                 "seconds": round(time.time() - t0, 2)})
@@ -353,15 +366,19 @@ def roofline_of(wl, lib, rank, dt_step, config):
     dominant = {"name": "%s %s" % (dk_entry, dk_info), "launches": dk_n, "avg_us": round(dk_ms / dk_n * 1e3, 2), "ms_per_step": round(dk_ms, 3),
                 "gflop": round(dk_fl / 1e9, 2), "tflops": round(dk_fl / (dk_ms * 1e-3) / 1e12, 2), "ceiling_tflops": round(dk_ceil, 1),
                 "frac": round(dk_fl / (dk_ms * 1e-3) / 1e12 / dk_ceil, 4), "mfma_busy": busy}
-    roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak_w, 1), "unit": "TFLOP/s",
-            "frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
+    pipe_ach = gemm_fl / dt_step / 1e12
+    # headline = the same FLOPs over the TIMED step (both sub-batch streams overlapped, every other kernel of the step included in the time);
+    # `serialized_*` = over the per-launch HIP-event durations of the profiled one-stream step (what rocprofv3's per-kernel averages match)
+    roof = {"bound": "mfma", "achieved": round(pipe_ach, 3), "peak": round(peak_w, 1), "unit": "TFLOP/s",
+            "frac": round(pipe_ach / peak_w, 4), "frac_basis": "algorithmic FLOPs of the step's matrix-core launches / the timed two-stream step",
+            "serialized_achieved": round(ach, 3), "serialized_frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
             "traffic_bytes_per_step": tstep, "algorithmic_bytes_per_step_lower_bound": ALG_BYTES_PER_STEP.get(config),
             "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
             "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel (conv, DCNv2, pair loaders; fp32 results)",
             "peak_note": "time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split-bf16 kernels (2500 / 6 = 416.7 TFLOP/s of "
                          "fp32-equivalent work: 3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product), the rest on v_mfma_f32_32x32x2_f32 (157.3)"
                          % (100.0 * split_ms / max(gemm_ms, 1e-9)),
-            "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4),
+            "frac_of_fp32_mfma_peak": round(pipe_ach / FP32_MFMA_PEAK_TF, 4),
             "max_per_launch_frac": round(worst[0], 4), "max_per_launch_frac_shape": worst[1],
             "dominant_kernel": dominant,
             "launches_per_step": n_launch, "gflop_per_step": round(gemm_fl / 1e9, 2),
@@ -370,8 +387,8 @@ def roofline_of(wl, lib, rank, dt_step, config):
             "achieved_minus_bracket_overhead": round(ach_corr, 3),
             "ms_per_step_in_kernel": round(gemm_ms, 3), "ms_per_step_all_kernels": round(all_ms, 3),
             # the same FLOPs over the TIMED steps (sub-batches overlapped on their streams, every other kernel included)
-            "pipeline_achieved": round(gemm_fl / dt_step / 1e12, 3),
-            "pipeline_frac": round(gemm_fl / dt_step / 1e12 / peak_w, 4)}
+            "pipeline_achieved": round(pipe_ach, 3),
+            "pipeline_frac": round(pipe_ach / peak_w, 4)}
     by = {}
     for r in rows:
         by.setdefault(r[0], [0.0, 0, 0.0]); by[r[0]][0] += r[2]; by[r[0]][1] += 1; by[r[0]][2] += r[1]
@@ -389,12 +406,13 @@ def side_config(name, args, dev, lib, rank):
     roof, _ = roofline_of(wl, lib, rank, dt / steps, name)
     par = None
     if not args.no_check:
-        pr = parity_gate(cfg, wl, (0,))
-        par = {k: pr[k] for k in ("pass", "pass_up_to_roundoff_ties", "topk_ordered_equal", "floats_within_tol", "max_err")}
+        pr = parity_gate(cfg, wl, gate_frames(wl["comp"], args.batch))
+        par = {k: pr[k] for k in ("pass", "pass_up_to_roundoff_ties", "topk_ordered_equal", "floats_within_tol", "max_err", "frames_checked")}
     what = "detect+embed+affinity" + ("+LSTM" if cfg["lstm"] else "")
     out = {"metric": "frames/sec (%s) at %dx%d" % (what, cfg["W"], cfg["H"]), "workload": cfg["workload"],
            "value": round(steps * args.batch / dt, 3), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
            "frames_per_step": args.batch, "roofline_frac": roof["frac"] if roof else None, "roofline_achieved_tflops": roof["achieved"] if roof else None,
+           "roofline_serialized_frac": roof["serialized_frac"] if roof else None,
            "parity": par}
     if name in E2E:
         del wl
@@ -575,6 +593,32 @@ def main():
             extras["config_C"] = {"workload": "one stream, 1 frame per GPU per step, records + affinity-block all-gathers, %dx%d affinity" % (NDET, NDET * HIST),
                                   "steps": nc, "ms_per_step": round(d1 / nc * 1e3, 3), "value": round(nc * world / d1, 3), "unit": "frames/s",
                                   "collectives_per_step": 2 if stc.collective else 0, "bytes_gathered_per_step": stc.bytes_gathered // (nc + HIST + 4)}
+            # the same stream WITH the association rank's tracker in the loop: frames in -> tracks out.  One stream is association-bound
+            # (every frame of the ONE stream goes through rank 0's update in order): this, not the per-GPU step above, is config C's rate.
+            if rank == 0 or world > 1:
+                from types import SimpleNamespace
+                from deft_amd.mot_tracker import Tracker2D
+                trk = None
+                if rank == 0:
+                    trk = Tracker2D(SimpleNamespace(dataset=cfg["dataset"], track_buffer=30, max_object=100, lstm=False), SimpleNamespace(AFE=afe), h=H, w=W)
+                stt = ShardedStream(dd, afe, afe.plan.D, tracker=trk, dataset=cfg["dataset"], kmax=KDET, img_h=H, img_w=W, batch=1, device=dev)
+                for i in range(12):
+                    stt.step([images[(i * world + rank) % B:(i * world + rank) % B + 1]])
+                sync()
+                nct = 60
+                t1 = time.perf_counter()
+                ntr = 0
+                for i in range(nct):
+                    o_ = stt.step([images[(i * world + rank) % B:(i * world + rank) % B + 1]])
+                    ntr += sum(len(t_) for _, t_ in o_)
+                sync()
+                d2 = max_over_ranks(time.perf_counter() - t1, dev)
+                extras["config_C"]["tracked"] = {"what": "the same loop with rank 0's ArrayTracker.update inside (frames in -> tracks out, <= 50 stored frames)",
+                                                 "steps": nct, "ms_per_step": round(d2 / nct * 1e3, 3), "value": round(nct * world / d2, 3), "unit": "tracked frames/s",
+                                                 "tracks_per_frame": round(ntr / float(nct * world), 1),
+                                                 "note": "one stream: every frame is associated in order on rank 0, so this is bounded by 1 / (tracker ms) "
+                                                         "whatever N is; FramePipeline (`value`) and per-video replicas (config E) are the forms that scale"}
+                del stt
             del stc, dd, afe
         # ---- frame in -> tracks out on ONE stream: deft_amd.detector.Detector.run = process (hipGraph) -> vectorised
         #      post-process -> deft_amd.mot_tracker.Tracker2D.update (embedding extraction, affinity chain against the stored frames,
@@ -594,16 +638,23 @@ def main():
     # ---- parity gate on the timed plans (outside the timed region; rank 0's frames) ----
     parity = None
     if not args.no_check and not args.standin:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        try:
+            import deft_oracle  # noqa: F401  (imported BEFORE the gated step, on every rank: an import error cannot strand a collective)
+            gate_err = None
+        except Exception as e:
+            gate_err = e
+        gouts = step(images)                              # EVERY rank runs the gate's extra step (it contains the all-gather) -- unconditionally
         if rank == 0:
             first = 0 if world == 1 or not gather else min(HIST, B - 1)    # (with N ranks frame 0's history lives on the last rank's shard)
             try:
-                parity = parity_gate(cfg, wl, (first, 17) if B > 17 else (first, B - 1) if B > 1 + first else (first,))
+                if gate_err is not None:
+                    raise gate_err
+                parity = parity_gate(cfg, wl, gate_frames(comp, B, first), outs=gouts)
             except Exception as e:                        # the checker must not take the measured line down with it: a gate that could not run
                 import traceback                          # is reported as a FAILED gate with the reason
                 parity = {"pass": False, "pass_up_to_roundoff_ties": False, "error": "%s: %s" % (type(e).__name__, e),
                           "traceback": traceback.format_exc().splitlines()[-6:]}
-        else:
-            step(images)                                  # (the gate runs one more step: it contains the all-gather)
 
     # ---- BASELINE configs A / D / E next to the headline config (compact) ----
     sides = None
@@ -654,6 +705,26 @@ def main():
         out.update(extras)
         if sides is not None:
             out["configs"] = sides
+        # ---- what the driver keeps of this line is `config` / `roofline` / `cpu_baseline`: the gate's verdict and the side numbers go there too ----
+        if parity is not None:
+            me = parity.get("max_err", {})
+            out["config"]["parity"] = {"pass": parity.get("pass"), "pass_up_to_roundoff_ties": parity.get("pass_up_to_roundoff_ties"),
+                                       "topk_ordered_equal": parity.get("topk_ordered_equal"), "frames": parity.get("frames_checked"),
+                                       "max_err": {k_: float("%.2g" % v_) for k_, v_ in me.items()}, "error": parity.get("error")}
+        side = {}
+        for name, sc in (sides or {}).items():
+            pr = sc.get("parity") or {}
+            side[name] = {"value": round(sc["value"], 1), "frac": sc["roofline_frac"], "parity_pass": pr.get("pass"), "ties_only": pr.get("pass_up_to_roundoff_ties")}
+            if "end_to_end" in sc:
+                side[name]["e2e"] = round(sc["end_to_end"]["value"], 1)
+        if "end_to_end" in extras:
+            side["B_e2e"] = {"value": round(extras["end_to_end"]["value"], 1), "one_frame_lookahead": round(1e3 / extras["end_to_end"]["one_frame_lookahead"]["ms_per_frame"], 1)}
+        if "latency_mode" in extras:
+            side["latency_ms"] = extras["latency_mode"]["ms_per_step"]
+        if "config_C" in extras:
+            side["C"] = {"ms_per_step": extras["config_C"]["ms_per_step"], "tracked_value": (extras["config_C"].get("tracked") or {}).get("value")}
+        if side:
+            out["config"]["side"] = side
     # RCCL prints its version banner through C stdio on every rank; it would otherwise be flushed at process exit,
     # AFTER the JSON line.  Flush it everywhere first, then rank 0 prints the JSON as the last stdout line.
     try:

@@ -255,6 +255,20 @@ class ArrayTracker(object):
             self._pending = None
             self.fut_arr[rows] = res() if callable(res) else res
 
+    def close(self):
+        """End of a video: land the pending motion step and hand this tracker's MotionBank slots back (the bank is shared -- model.motion --
+        by every tracker built on the model; without this its h / c / last tensors double with every sequence of an evaluation)."""
+        if self.use_lstm and self.bank is not None:
+            try:
+                self._resolve()
+            except Exception:
+                self._pending = None
+            if self.cols.n:
+                for s_ in self.cols["slot"][:self.cols.n].tolist():
+                    self.bank.free(int(s_))
+            self.cols.keep(np.zeros(self.cols.n, bool))
+            self.fut_arr = self.fut_arr[:0]
+
     def _prediction_at(self, idx, fid):
         """STrack.prediction_at_frame (tracker.py:254-262): the predicted (cx, cy, a, h) / 3-D box of pool rows `idx` for frame `fid`."""
         self._resolve()

@@ -12,8 +12,10 @@
 //    column potentials over the n x m matrix, every row carrying an implicit private "stay unmatched" column at cost_limit (`Sap`
 //    below; O(m) per scan step instead of the O((n + m)^2) scans of the square extension, whose constant blocks are one big tie:
 //    1.5 ms -> 0.06 ms at 118 x 100).  Without a limit: the published dense algorithm (column reduction + reduction transfer,
-//    augmenting row reduction, augmentation) on the zero-padded square (`Jv` below).  No code of `lap` is available; both are
-//    restated from the literature so that the order in which ties are broken is fixed and this repository's own: rows in index order,
+//    augmenting row reduction, augmentation) on the zero-padded square (`Jv` below).  No code of `lap` is available here; `Jv`'s phase
+//    structure (ccrrt / carr with its `rr_cnt < current * n` guard / find / scan / augment) follows the dense solver of the `lap` package
+//    (github.com/gatagat/lap, BSD-2-Clause, itself after Jonker & Volgenant's published Pascal code) as remembered, re-written so that
+//    the order in which ties are broken is fixed and this repository's own: rows in index order,
 //    among equally near columns the lowest index, a real column before "unmatched".  tests/test_association.py: optimal against brute
 //    force and scipy, equal-cost ties resolved reproducibly.
 //  * deft_iou3d_matrix: matching.iou_ddd_distance (matching.py:107-131) = 1 - iou3d for every (track box, detection box) pair, with
@@ -158,7 +160,10 @@ struct Jv {
             }
             if (final_j == -1) final_j = scan(lo, hi);
         }
-        const cost_t mind = d[cols[lo]];
+        // the level the search ended on = d of the free column it reached.  (NOT d[cols[lo]]: scan() advances `lo` past the column it was
+        // expanding when it returns, so cols[lo] may already be a TODO column with a larger d -- the dual update was then wrong and LATER
+        // augmentations could end non-optimal: 276 of 9304 random tall matrices, and wide ones with negative costs)
+        const cost_t mind = d[final_j];
         for (int k = 0; k < n_ready; ++k) {
             const int j = cols[k];
             v[j] += d[j] - mind;

@@ -489,6 +489,9 @@ class Detector(object):
         frame counter must not survive into the next sequence), no previous image, and no lookahead pass left over from the last video."""
         self._drop_ahead()
         if self.tracker is not None:
+            for t in (self.tracker.values() if isinstance(self.tracker, dict) else (self.tracker,)):
+                if hasattr(t, "close"):
+                    t.close()                       # the old trackers' MotionBank slots go back to the (shared) bank
             fac = getattr(self, "_tracker_factory", None)
             if fac is not None:
                 self.tracker = fac(opt, self.img_height, self.img_width)

@@ -1311,19 +1311,24 @@ class AfePlan(_Plan):
 
     def _staged_ints(self, values):
         """A small int32 host list as a device tensor without a blocking copy: written into one of a few pinned staging rows, copied
-        non_blocking on the plan's stream.  Eight rows in rotation: a row is rewritten eight calls later, long after its copy ran (every
-        caller reads results back -- i.e. synchronises -- at least once per frame)."""
+        non_blocking on the plan's stream.  Eight rows in rotation, each guarded by an event recorded behind its copy."""
         n = len(values)
         if self.device.type != "cuda":
             return torch.tensor(values, dtype=torch.int32, device=self.device)
         st = getattr(self, "_stage", None)
         if st is None or st[0].shape[1] < n:
-            st = self._stage = (torch.empty(8, max(64, 2 * n), dtype=torch.int32).pin_memory(), [0])
-        buf, turn = st
-        row = buf[turn[0] % 8]
+            st = self._stage = (torch.empty(8, max(64, 2 * n), dtype=torch.int32).pin_memory(), [0], [None] * 8)
+        buf, turn, evs = st
+        k = turn[0] % 8
         turn[0] += 1
+        if evs[k] is not None:
+            evs[k].synchronize()                   # the copy that read this row eight calls ago (warm-up loops call this back to back)
+        row = buf[k]
         row[:n] = torch.as_tensor(values, dtype=torch.int32)
-        return row[:n].to(self.device, non_blocking=True)
+        out = row[:n].to(self.device, non_blocking=True)
+        evs[k] = torch.cuda.Event()
+        evs[k].record(torch.cuda.current_stream(self.device))
+        return out
 
     def _work(self, name, numel):
         """Grow-only fp32 device workspace `name` of at least `numel` elements (1.5x headroom on growth)."""

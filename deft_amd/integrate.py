@@ -121,19 +121,24 @@ class AfeSeam:
         return out
 
     def _to_device_f32(self, t):
-        """Host -> device through PINNED staging (a ring of 4 buffers; the tracker's per-frame stream sync retires a slot long before it comes
-        round again).  A pageable source makes the copy synchronous, and on this runtime it then also waits for whatever else the device is
+        """Host -> device through PINNED staging (a ring of 4 buffers, each guarded by an event recorded behind the copy that reads it).  A pageable source makes the copy synchronous, and on this runtime it then also waits for whatever else the device is
         running -- e.g. a whole lookahead pass on another stream (profiles/r4_hw_queue_stall.md)."""
         if self.device.type != "cuda" or t.device.type == "cuda":
             return t.to(self.device, torch.float32)
         ring = getattr(self, "_pin_ring", None)
-        if ring is None or ring[0].numel() < t.numel():
-            ring = self._pin_ring = [torch.empty(max(1024, 2 * t.numel()), dtype=torch.float32).pin_memory() for _ in range(4)]
+        if ring is None or ring[0][0].numel() < t.numel():
+            ring = self._pin_ring = [[torch.empty(max(1024, 2 * t.numel()), dtype=torch.float32).pin_memory(), None] for _ in range(4)]
             self._pin_turn = 0
         self._pin_turn = (self._pin_turn + 1) % len(ring)
-        stage = ring[self._pin_turn][:t.numel()].view(t.shape)
+        slot = ring[self._pin_turn]
+        if slot[1] is not None:                    # the copy that last read this slot (an event recorded behind it): normally long done -- but seven
+            slot[1].synchronize()                  # per-class trackers on one seam call this 7 times a frame, with nothing in between on frame 1
+        stage = slot[0][:t.numel()].view(t.shape)
         stage.copy_(t)
-        return stage.to(self.device, non_blocking=True)
+        out = stage.to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
+        return out
 
     def forward_feature_extracter(self, s, l):
         """AFE.py:88-92.  s: FeatureMaps (13), l: centres [1,N,1,1,2] in [-1,1] -> [1,N,D]."""

@@ -209,11 +209,21 @@ class MotionBank:
             pred = self.step(slots, boxes, frame_id)[1]
             return lambda: pred
         T = len(slots)
-        if getattr(self, "_pin", None) is None or self._pin[0].shape[0] < T:
+        # One pinned (in, out) pair PER CALL in flight: several trackers share a bank (the seven per-class nuScenes trackers, two 2-D
+        # trackers on one model) and each reads its result a frame later -- a single pair would be rewritten by the next caller before the
+        # first one has copied its predictions out (and its H2D source while that copy may still be queued).  The pair goes back to the
+        # pool only when its own event has completed, i.e. when both copies are done; a closure that is dropped unread just frees it.
+        pool = self.__dict__.setdefault("_pin_pool", [])
+        pair = None
+        for i, pr in enumerate(pool):
+            if pr[0].shape[0] >= T:
+                pair = pool.pop(i)
+                break
+        if pair is None:
             cap = max(128, 2 * T)
-            self._pin = (torch.empty(cap, 1 + self.dim, dtype=torch.float64).pin_memory(),
-                         torch.empty(cap, self.fut, self.dim, dtype=torch.float64).pin_memory())
-        hin, hout = self._pin
+            pair = (torch.empty(cap, 1 + self.dim, dtype=torch.float64).pin_memory(),
+                    torch.empty(cap, self.fut, self.dim, dtype=torch.float64).pin_memory())
+        hin, hout = pair
         hin[:T, 0] = torch.as_tensor(list(slots), dtype=torch.float64)
         hin[:T, 1:] = torch.from_numpy(boxes)
         din = hin[:T].to(dev, non_blocking=True)
@@ -224,10 +234,15 @@ class MotionBank:
         hout[:T].copy_(pred, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
+        done = []
 
         def wait():
-            ev.synchronize()
-            return hout[:T].numpy().copy()
+            if not done:
+                ev.synchronize()
+                done.append(hout[:T].numpy().copy())
+                if len(pool) < 16:
+                    pool.append(pair)
+            return done[0]
         return wait
 
     # ---- deferred form used by the STrack adapter ----

@@ -1003,19 +1003,19 @@ def check_conv_fold(lib, device, N, H, W, Ci, Cm, fn, p3, tile=0, seed=0):
 
 # ---------------------------------------------------------------------------
 # top-K index parity on arbitrary frames
-def compare_topk_with_oracle(plan, out, K, logit_tol=2e-4, tie=1e-4, details=None):
-    """Device decode of frame 0 of `plan` against the oracle's head maps `out` of the same frame.  Returns
+def compare_topk_with_oracle(plan, out, K, logit_tol=2e-4, tie=1e-4, details=None, frame=0):
+    """Device decode of frame `frame` of `plan` against the oracle's head maps `out` of the same frame.  Returns
     (indices_identical, max abs heat-map logit error).  When the ordered indices differ, every difference must be a
     round-off tie: the oracle's OWN heat map puts the index within 1e-4 (logit) of its 3x3 neighbourhood maximum or of
     the K-th score, the device's order is non-increasing in the oracle's scores up to 1e-4, and every detection both
     sides report carries the same floats (scores 1e-5, boxes 1e-3)."""
     od = O.generic_decode(O.sigmoid_output(out), K=K)
-    gi, oi = plan.inds[0].cpu().long(), od["inds"][0]
-    gc, oc = plan.clses[0].cpu().long(), od["clses"][0].long()
-    gs, os_ = plan.scores[0].cpu(), od["scores"][0]
-    gb, ob = plan.bboxes[0].cpu(), od["bboxes"][0]
+    gi, oi = plan.inds[frame].cpu().long(), od["inds"][0]
+    gc, oc = plan.clses[frame].cpu().long(), od["clses"][0].long()
+    gs, os_ = plan.scores[frame].cpu(), od["scores"][0]
+    gb, ob = plan.bboxes[frame].cpu(), od["bboxes"][0]
     logit = out["hm"][0]                                         # [C, h, w]
-    dev_logit = plan.dense["hm"].to_nchw().cpu()[0]
+    dev_logit = plan.dense["hm"].to_nchw()[frame].cpu()
     err = maxabs(dev_logit, logit)
     assert err <= logit_tol, err
     if tie is None:
@@ -1606,6 +1606,105 @@ def check_co_residency(lib, H=512, W=512, N=16, reps=4):
     assert checked > 60 and "deft_dcn_v2_nhwc" in kinds and "deft_conv2d_nhwc" in kinds
     assert any(d.p3_kernel == 0 for e, _, d in p0._gemms if e == "deft_dcn_v2_nhwc"), "no igemm.hip MODE_DCN launch in this plan"
     return checked
+
+
+class _BesideForeign:
+    """Proxy of a HipLib: every `call` waits for the device, queues `reps` launches of a heavy matrix-core kernel of ANOTHER plan on a second
+    stream and then issues the real launch on the caller's stream -- so each launch of a chain runs co-resident with a foreign kernel."""
+
+    def __init__(self, lib, foreign, side, reps=6):
+        self._lib, self._foreign, self._side, self._reps = lib, foreign, side, reps
+        self.calls = []
+
+    def __getattr__(self, k):
+        return getattr(self._lib, k)
+
+    def call(self, name, *args):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self._side):
+            for _ in range(self._reps):
+                self._foreign()
+        self.calls.append(name)
+        return self._lib.call(name, *args)
+
+
+def check_co_residency_afe_lstm(lib, H=256, W=256, N=8, K=100, ndet=32, hist=4):
+    """VERDICT r4: the product also overlaps the AfePlan chain (embedding extraction: deft_embed_rows / deft_conv2d_group / deft_embed_blend;
+    affinity: the U' / V' layer-1 products, deft_pair_layer, layers 3 - 4, deft_affinity_finish -- ring form and list form) and
+    LstmPlan.motion_step / step with the NEXT step's detection on the other stream (pipeline.py cross-step overlap).  Each of those launches
+    beside a foreign matrix-core launch (a 3x3 conv of another sub-batch plan), every output and every intermediate buffer bit for bit against
+    the same chain run alone."""
+    from deft_amd import engine, hiplib
+    sd = O.synth_state_dict("mot")
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2 * N, 3, H, W, generator=g).cuda()
+    p0 = engine.DlaSegPlan(sd, N, H, W, "mot", K=K, device="cuda", lib=lib)
+    p1 = engine.DlaSegPlan(sd, N, H, W, "mot", K=K, device="cuda", lib=lib)
+    p0.forward(x[:N]); p1.forward(x[N:]); torch.cuda.synchronize()
+    heavy = [i for i, (_, nm, _, _) in enumerate(p1.ops) if nm == "base.level4.tree1.tree1.conv2"][0]
+    side = torch.cuda.Stream()
+
+    def foreign():
+        p1._stream_cache = hiplib.stream_ptr(p1.device)
+        p1.ops[heavy][2]()
+        p1._stream_cache = None
+    beside = _BesideForeign(lib, foreign, side)
+    lsd = O.synth_lstm_state_dict("mot")
+    lsd3 = O.synth_lstm_state_dict("nuscenes")
+
+    def chain(L):
+        """The whole chain on library handle L; returns every tensor it produced (cloned)."""
+        outs = {}
+        afe = engine.AfePlan(sd, 100, dev, L)
+        emb = afe.extract(p0.fmaps, p0.centers[:, :ndet])
+        torch.cuda.synchronize()
+        outs["emb"] = emb.clone()
+        grp = list(afe._egroups.values())[-1]
+        outs["emb_tmp"], outs["emb_bw"], outs["emb_rowmap"] = grp["tmp"].clone(), grp["bw"].clone(), grp["rowmap"].clone()
+        ring = (torch.rand(hist + N, ndet, afe.D, generator=torch.Generator().manual_seed(5)) * 3).cuda()
+        blk = afe.affinity_ring(ring, hist, N, hist)
+        torch.cuda.synchronize()
+        outs["ring_out"] = blk.clone()
+        for k_, v_ in afe._ring[(hist + N, ndet, N, hist)].items():
+            outs["ring_" + k_] = v_.clone()
+        lst, starts = afe.affinity([ring[t][: 20 + 3 * t] for t in range(hist)], ring[hist])
+        torch.cuda.synchronize()
+        outs["list_out"] = lst.clone()
+        Tl, Ql = starts[-1], ring.shape[1]
+        used = {"xh": Tl * afe.Kd, "xc": Ql * afe.Kd, "U": Tl * 512, "V": Ql * 512, "h2": Tl * Ql * 256, "h3": Tl * Ql * 128, "h4": Tl * Ql * 64}
+        for k_, v_ in afe._workspaces.items():            # (grow-only torch.empty workspaces: only the part this call wrote is defined)
+            outs["list_" + k_] = v_[:used[k_]].clone()
+        for tag, sdl, dim in (("2d", lsd, 4), ("3d", lsd3, 7)):
+            lp = engine.LstmPlan(sdl, dev, L)
+            T = 64
+            gg = torch.Generator().manual_seed(9)
+            slot = torch.arange(T, dtype=torch.int32, device=dev)
+            h = torch.zeros(T, 128, device=dev); c = torch.zeros(T, 128, device=dev)
+            last = torch.zeros(T, 9, dtype=torch.float64, device=dev)
+            for fid in (1, 2, 3):
+                box = (torch.rand(T, dim, generator=gg, dtype=torch.float64) * 50 + 5).to(dev)
+                feat, pred = lp.motion_step(slot, box, fid, h, c, last)
+                torch.cuda.synchronize()
+                outs["%s_feat%d" % (tag, fid)], outs["%s_pred%d" % (tag, fid)] = feat.clone(), pred.clone()
+            xs = torch.randn(T, lp.nin, generator=gg).to(dev)
+            outs[tag + "_step"] = lp.step(xs, h, c).clone()
+            torch.cuda.synchronize()
+            outs[tag + "_h"], outs[tag + "_c"] = h.clone(), c.clone()
+        return outs
+    clean = chain(lib)
+    again = chain(lib)
+    for k_ in clean:
+        assert torch.equal(clean[k_], again[k_]), "the chain alone is not deterministic: %s" % k_
+    co = chain(beside)
+    bad = {k_: int((clean[k_] != co[k_]).sum()) for k_ in clean if not torch.equal(clean[k_].view(torch.uint8) if clean[k_].dtype != torch.int32 else clean[k_],
+                                                                                     co[k_].view(torch.uint8) if co[k_].dtype != torch.int32 else co[k_])}
+    assert not bad, "launches of the AFE / LSTM chain differ beside a foreign matrix-core kernel: %s" % bad
+    names = set(beside.calls)
+    for want in ("deft_embed_rows", "deft_conv2d_group", "deft_embed_blend", "deft_conv2d_nhwc", "deft_pair_layer", "deft_affinity_finish",
+                 "deft_motion_step", "deft_lstm_step"):
+        assert want in names, "the chain never launched %s" % want
+    return len(beside.calls), sorted(names)
 
 
 def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64, W=96, K=12, T=4, seed=6, pairs=False):
