@@ -337,6 +337,7 @@ def roofline_of(wl, lib, rank, dt_step, config):
     # ceiling of the instructions each launch issues: split-bf16 launches 2500/6, fp32-MFMA launches 157.3 (hiplib marks each call)
     peak_w = sum(r[2] * r[5] for r in gemm) / max(gemm_ms, 1e-9)
     split_ms = sum(r[2] for r in gemm if r[5] > FP32_MFMA_PEAK_TF)
+    np_ = getattr(lib, "pieces", 3)
     worst = max((r[1] / (r[2] * 1e-3) / 1e12 / r[5], r[3]) for r in gemm)
     traffic, tsrc, tstep = None, None, None       # HBM bytes per launch from the committed PMC passes of this build, if any
     tfile = os.path.join(ROOT, "profiles", TRAFFIC_FILE)       # written by tools/prof.sh + tools/summarize_prof.py for THIS build; absent -> null
@@ -375,9 +376,12 @@ def roofline_of(wl, lib, rank, dt_step, config):
             "traffic_bytes_per_step": tstep, "algorithmic_bytes_per_step_lower_bound": ALG_BYTES_PER_STEP.get(config),
             "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
             "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel (conv, DCNv2, pair loaders; fp32 results)",
-            "peak_note": "time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split-bf16 kernels (2500 / 6 = 416.7 TFLOP/s of "
-                         "fp32-equivalent work: 3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product), the rest on v_mfma_f32_32x32x2_f32 (157.3)"
-                         % (100.0 * split_ms / max(gemm_ms, 1e-9)),
+            "peak_note": ("time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split kernels (" % (100.0 * split_ms / max(gemm_ms, 1e-9)))
+                         + ("2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work: 3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product" if np_ == 3 else
+                            "2500 / 3 = 833.3 TFLOP/s of fp32-equivalent work: 2 fp16 pieces per operand, 3 fp16 MFMAs per fp32 product; the 16-channel "
+                            "full-resolution layers keep 3 bf16 pieces: 416.7")
+                         + "), the rest on v_mfma_f32_32x32x2_f32 (157.3)",
+            "frac_of_bf16x3_ceiling": round(pipe_ach / (BF16_MFMA_PEAK_TF / 6), 4),       # the same FLOPs priced against rounds 1-4's ceiling (continuity)
             "frac_of_fp32_mfma_peak": round(pipe_ach / FP32_MFMA_PEAK_TF, 4),
             "max_per_launch_frac": round(worst[0], 4), "max_per_launch_frac_shape": worst[1],
             "dominant_kernel": dominant,
@@ -666,6 +670,25 @@ def main():
             torch.cuda.empty_cache()
             sides[name] = side_config(name, args, dev, lib, rank)
 
+    # ---- the same step on the three-bf16-piece build of the same sources (six products per fp32 product: the arithmetic of rounds 1-4), in its
+    #      own process: value + parity gate, so the line carries both arithmetics next to each other ----
+    alt = None
+    alt_so = os.path.join(ROOT, "deft_amd", "lib", "libdeft_bf16x3.so")
+    if (rank == 0 and world == 1 and not args.standin and not args.no_extras and args.config == "B" and getattr(lib, "pieces", 3) == 2
+            and os.path.exists(alt_so) and "DEFT_HIP_LIB" not in os.environ and "alt" not in skip):
+        import subprocess
+        torch.cuda.synchronize()
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", str(max(10, min(args.steps, 30))),
+                            "--warmup", str(args.warmup), "--batch", str(B), "--streams", str(args.streams)] + (["--no-check"] if args.no_check else []),
+                           capture_output=True, text=True, env=dict(os.environ, DEFT_HIP_LIB=alt_so), timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            a_ = json.loads(line[-1])
+            alt = {"library": "libdeft_bf16x3.so (DEFT_PIECES=3)", "contraction": a_["config"]["contraction"], "value": a_["value"], "ms_per_step": a_["ms_per_step"],
+                   "roofline_frac": a_["roofline"]["frac"], "parity": a_["config"].get("parity")}
+        else:
+            alt = {"error": (r.stderr or r.stdout)[-300:]}
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.standin:
         # the CPU side in its own process with the GPU hidden (the reference's modules move tensors to CUDA whenever
@@ -691,7 +714,9 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic" if not args.standin else "INVALID: --standin (CPU stand-in compute, launch-path test only)",
                "config": {"workload": cfg["workload"], "config": args.config,
-                          "contraction": None if args.standin else ("split-bf16 x6, fp32 accumulate (fp32-equivalent)" if engine_prec == 1 else "fp32 MFMA"),
+                          "contraction": None if args.standin else ("fp32 MFMA" if engine_prec != 1 else
+                                                                   "split-bf16 x6, fp32 accumulate (fp32-equivalent)" if lib.pieces == 3 else
+                                                                   "split-fp16 x3 (2 fp16 pieces/operand, 2^-24 rel.), fp32 accumulate"),
                           "frames_per_step_per_gpu": B,
                           "hip_streams": args.streams, "hip_graphs": bool(args.graphs), "detections": NDET, "history_frames": HIST,
                           "lstm_motion_update_in_step": bool(cfg["lstm"]),
@@ -723,6 +748,11 @@ def main():
             side["latency_ms"] = extras["latency_mode"]["ms_per_step"]
         if "config_C" in extras:
             side["C"] = {"ms_per_step": extras["config_C"]["ms_per_step"], "tracked_value": (extras["config_C"].get("tracked") or {}).get("value")}
+        if alt is not None:
+            out["bf16x3"] = alt
+            pa = alt.get("parity") or {}
+            side["bf16x3"] = {"value": alt.get("value"), "frac": alt.get("roofline_frac"), "parity_pass": pa.get("pass"), "ties_only": pa.get("pass_up_to_roundoff_ties"),
+                              "max_err": pa.get("max_err")} if "error" not in alt else {"error": alt["error"][:80]}
         if side:
             out["config"]["side"] = side
     # RCCL prints its version banner through C stdio on every rank; it would otherwise be flushed at process exit,

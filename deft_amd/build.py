@@ -24,34 +24,51 @@ NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 _NOISE = "'-packed-fp32-ops' is not a recognized feature for this target"      # (the HOST pass of hipcc sees the switch too and says so)
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ_DIR, exist_ok=True)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in DEPS):
-        return OUT
+# The split arithmetic is a compile-time property of a build (csrc/common.h DEFT_PIECES): the product library uses two fp16 pieces per
+# operand (three matrix instructions per fp32 product); `libdeft_bf16x3.so` is the same sources with three bf16 pieces (six products, the
+# arithmetic of rounds 1-4) -- kept buildable as the cross-check of the two-piece arithmetic (DEFT_HIP_LIB selects it; bench.py reports both).
+VARIANTS = {"hip": [], "bf16x3": ["-DDEFT_PIECES=3"]}
+
+
+def build(force=False, verbose=True, variant="hip"):
+    flags = VARIANTS[variant]
+    out = os.path.join(HERE, "lib", "libdeft_%s.so" % variant)
+    obj_dir = OBJ_DIR if variant == "hip" else os.path.join(HERE, "lib", "obj_" + variant)
+    os.makedirs(obj_dir, exist_ok=True)
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in DEPS):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-    objs = []
+    objs, jobs = [], []
     for src in SRCS:                      # one object per source: per-file flags (EXTRA), and only the edited file recompiles
-        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
         deps = [src] + DEPS[len(SRCS):]
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
             continue
-        cmd = base + NO_PK_F32 + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        cmd = base + NO_PK_F32 + flags + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-        err = "\n".join(ln for ln in r.stderr.splitlines() if _NOISE not in ln)
+        jobs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))      # (the files compile side by side)
+    failed = None
+    for cmd, pr in jobs:
+        _, stderr = pr.communicate()
+        err = "\n".join(ln for ln in stderr.splitlines() if _NOISE not in ln)
         if err.strip():
             sys.stderr.write(err + "\n")
-        if r.returncode != 0:
-            raise subprocess.CalledProcessError(r.returncode, cmd)
-    cmd = base + ["-shared", "-o", OUT] + objs
+        if pr.returncode != 0 and failed is None:
+            failed = subprocess.CalledProcessError(pr.returncode, cmd)
+    if failed is not None:
+        raise failed
+    cmd = base + ["-shared", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    force = "--force" in sys.argv
+    names = [a for a in sys.argv[1:] if a in VARIANTS] or (list(VARIANTS) if "--all" in sys.argv else ["hip"])
+    for v in names:
+        print(build(force=force, variant=v))

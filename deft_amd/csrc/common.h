@@ -49,6 +49,59 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
     }
 }
 
+// ---- the operand pieces of the split arithmetic (DeftGemmDesc.prec = 1) -------------------------------------------------------------
+// DEFT_PIECES = 3: x = hi + mid + lo as three bf16 pieces (exact), six v_mfma_f32_32x32x16_bf16 products per fp32 product (rounds 1-4).
+// DEFT_PIECES = 2: x ~ h1 + h2 as two FP16 pieces (11 + 11 significant bits, round-to-nearest each: |x - h1 - h2| <= 2^-24 |x|, half an
+//   fp32 ulp, while h2 is a normal fp16 number; below that 2^-25 absolute in the scaled domain), THREE v_mfma_f32_32x32x16_f16 products per fp32
+//   product (h1 g1, h1 g2, h2 g1; the dropped h2 g2 is <= 2^-24 relative), fp32 accumulation.  fp16 has 5 exponent bits, so the operands are
+//   brought into range by exact powers of two: activations are multiplied by DEFT_ASCALE = 2^4 where they are split (any |x| < 4094 is
+//   representable; a residual keeps full precision down to |x| = 2^-6, and 2^-29 absolute below) and every kernel that does so multiplies its
+//   per-column epilogue scale by 2^-4; weight rows are scaled by the HOST (engine.py: 2^k per output channel so that the row's largest
+//   entry lands in [2^12, 2^13), folded into DeftGemmDesc.scale).  An activation beyond the range becomes +-inf in h1 and NaN downstream --
+//   loud, never silently wrong.  Half the matrix-core work and 2/3 of the piece bytes of the three-piece form.
+#ifndef DEFT_PIECES
+#define DEFT_PIECES 2
+#endif
+constexpr int DEFT_NP = DEFT_PIECES;
+constexpr int DEFT_NPROD = DEFT_NP == 3 ? 6 : 3;
+#if DEFT_PIECES == 3
+typedef __bf16 deft_piece_t;
+#define DEFT_ASCALE 1.f
+#define DEFT_ASCALE_INV 1.f
+#elif DEFT_PIECES == 2
+typedef _Float16 deft_piece_t;
+#define DEFT_ASCALE 16.f
+#define DEFT_ASCALE_INV 0.0625f
+#else
+#error "DEFT_PIECES is 2 (fp16 pieces) or 3 (bf16 pieces)"
+#endif
+typedef deft_piece_t pcx8 __attribute__((ext_vector_type(8)));
+typedef deft_piece_t pcx4 __attribute__((ext_vector_type(4)));
+// products of an fp32 product, smallest terms first: (piece of A, piece of B)
+__device__ __forceinline__ constexpr int deft_qa(int q) { return DEFT_NP == 3 ? (q == 0 ? 1 : q == 1 ? 2 : q == 2 ? 0 : q == 3 ? 1 : 0) : (q == 0 ? 1 : 0); }
+__device__ __forceinline__ constexpr int deft_qb(int q) { return DEFT_NP == 3 ? (q == 0 ? 1 : q == 1 ? 0 : q == 2 ? 2 : q == 3 ? 0 : q == 4 ? 1 : 0) : (q == 1 ? 1 : 0); }
+typedef float deft_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ deft_f32x16 deft_mfma_pc(const pcx8 a, const pcx8 b, const deft_f32x16 c) {
+#if DEFT_PIECES == 3
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+// the pieces of four values (A operands: pass scale = DEFT_ASCALE; weights arrive scaled by the host: scale = 1)
+__device__ __forceinline__ void deft_split(const f32x4 v, pcx4 (&pc)[DEFT_NP], const float scale = 1.f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float r = DEFT_NP == 2 ? v[e] * scale : v[e];
+#pragma unroll
+        for (int q = 0; q < DEFT_NP; ++q) {
+            const deft_piece_t h = (deft_piece_t)r;
+            pc[q][e] = h;
+            r -= (float)h;
+        }
+    }
+}
+
 // Raw buffer loads (SRD in SGPRs + 32-bit byte offset in a VGPR).  An offset >= num_records
 // returns 0 from the hardware: im2col zero padding / invalid tile rows cost one v_cndmask on
 // the OFFSET instead of a select on the loaded data (which would pull the s_waitcnt vmcnt in
@@ -162,16 +215,16 @@ static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1)
 // ---- LDS-transposed epilogue shared by the MFMA kernels ----------------------------------------------------------
 // Phase 1: every wave parks its TM x TN grid of 32x32 accumulators, scaled and shifted, in the LDS tile T[BM][LDT]
 // (D reg r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31: a half-wave writes 32 consecutive floats).
-typedef float deft_f32x16 __attribute__((ext_vector_type(16)));
+// `post`: what the kernel's own operand scaling left in the accumulators (DEFT_ASCALE_INV for the kernels that split their A operand).
 template <int TM, int TN>
 __device__ __forceinline__ void deft_epilogue_stage(float* T, int LDT, const deft_f32x16 (&acc)[TM][TN], int wm, int wn, int lane,
-                                                    const DeftGemmDesc& p, int n0) {
+                                                    const DeftGemmDesc& p, int n0, const float post = DEFT_ASCALE_INV) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int cl = (wn * TN + j) * 32 + (lane & 31);
         const int co = n0 + cl;
         const int coc = co < p.Cout ? co : p.Cout - 1;
-        const float sc = p.scale ? p.scale[coc] : 1.f;
+        const float sc = (p.scale ? p.scale[coc] : 1.f) * post;
         const float sh = p.shift ? p.shift[coc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -182,7 +235,7 @@ __device__ __forceinline__ void deft_epilogue_stage(float* T, int LDT, const def
     }
 }
 // Phase 2 (after a barrier): every thread owns 8 consecutive channels of an output row: residual (16-byte loads), ReLU,
-// fp32 store (p.y, nullable) and the three bf16 pieces (p.y3, nullable) as 16-byte stores.  row_to_m(row) -> the output
+// fp32 store (p.y, nullable) and the operand pieces (p.y3, nullable; DEFT_PIECES of them) as 16-byte stores.  row_to_m(row) -> the output
 // row (pixel index) of tile row `row`, or -1.
 template <int BM, int BN, int NT, typename RowFn>
 __device__ __forceinline__ void deft_epilogue_rows(const float* T, const DeftGemmDesc& p, int n0, int tid, RowFn row_to_m) {
@@ -254,15 +307,29 @@ __device__ __forceinline__ void deft_epilogue_rows(const float* T, const DeftGem
             *(f32x4*)(yp + 4) = v1;
         }
         if (p.y3 != nullptr) {
-            bf16x4 h0, m0_, l0, h1, m1, l1;
-            split3(v0, h0, m0_, l0);
-            split3(v1, h1, m1, l1);
-            __bf16* yp = (__bf16*)p.y3 + m * p.ldy3 * 3 + (co >> 5) * 96 + (co & 31);
-            *(bf16x8*)yp = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-            *(bf16x8*)(yp + 32) = __builtin_shufflevector(m0_, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-            *(bf16x8*)(yp + 64) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            pcx4 c0[DEFT_NP], c1[DEFT_NP];
+            deft_split(v0, c0, DEFT_ASCALE);
+            deft_split(v1, c1, DEFT_ASCALE);
+            deft_piece_t* yp = (deft_piece_t*)p.y3 + m * p.ldy3 * DEFT_NP + (co >> 5) * (32 * DEFT_NP) + (co & 31);
+#pragma unroll
+            for (int q = 0; q < DEFT_NP; ++q) *(pcx8*)(yp + 32 * q) = __builtin_shufflevector(c0[q], c1[q], 0, 1, 2, 3, 4, 5, 6, 7);
         }
     }
+}
+
+// ---- LDS images of the pre-split operands: where the 16-byte slot (piece q, k-slot ks) of row r sits ------------------------------------
+// im2col chunk rows (32 k): DEFT_NP * 4 slots = DEFT_NP * 64 B per row.  A ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15,
+// 20-27}, {4-11, 16-19, 28-31}, + 32) over 64 banks of 4 B; a fragment read has one row per lane, fixed (q, ks).
+//   3 pieces, 192-byte rows: physical slot q*4 + (ks ^ ((r >> 2) & 3)) (rounds 2-4).
+//   2 pieces, 128-byte rows: a row covers half the banks, so the 16 rows of a lane group must spread over all 8 slots of both halves:
+//   physical slot (q*4 + ks) ^ ((r >> 1) & 7) -- the eight even (odd) rows of either lane group have eight different (r >> 1) & 7.
+__device__ __forceinline__ constexpr int deft_p3_phys(int q, int ks, int r) {
+    return DEFT_NP == 3 ? q * 4 + (ks ^ ((r >> 2) & 3)) : (q * 4 + ks) ^ ((r >> 1) & 7);
+}
+// the inverse: which (piece, k-slot) the DMA deposits at physical slot ps of row r
+__device__ __forceinline__ void deft_p3_logical(int ps, int r, int& q, int& ks) {
+    if (DEFT_NP == 3) { q = ps >> 2; ks = (ps & 3) ^ ((r >> 2) & 3); }
+    else { const int lg = ps ^ ((r >> 1) & 7); q = lg >> 2; ks = lg & 3; }
 }
 
 // igemm3.hip (pre-split operands, DeftGemmDesc.x3): validation, tile choice and launch, called from deft_conv2d_nhwc

@@ -43,9 +43,9 @@ typedef deft_f32x16 f32x16;
 #else
 #define DCNP_SCHED(TN)                                                        \
     do {                                                                      \
-        _Pragma("unroll") for (int i_ = 0; i_ < 6 * (TN); ++i_) {             \
+        _Pragma("unroll") for (int i_ = 0; i_ < DEFT_NPROD * (TN); ++i_) {    \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x002, (TN) == 1 ? 7 : 12 / (TN), 0); \
+            __builtin_amdgcn_sched_group_barrier(0x002, (TN) == 1 ? 7 : (DEFT_NP == 3 ? 12 : 16) / (TN), 0); \
         }                                                                     \
     } while (0)
 #endif
@@ -59,7 +59,7 @@ typedef deft_f32x16 f32x16;
 #define DP_PARTS_(R) ((DP_NPIX_(R) + 63) / 64)            // 1 KB DMA pieces per plane (64 pixels x 16 B each)
 #define DP_PLANE_(R) (DP_PARTS_(R) * 1024)                // one 4-channel plane of the patch: [pixel][16 B]
 #define DP_PBUF_(R) (4 * DP_PLANE_(R))                    // one patch buffer: 16 channels = 4 planes
-#define DP_WBLK 6144                                  // one K chunk (16) of 64 output channels: [3 pieces][2 k groups][64 rows][8 bf16]
+#define DP_WBLK (DEFT_NP * 2048)                      // one K chunk (16) of 64 output channels: [DEFT_NP pieces][2 k groups][64 rows][8 halves]
 
 // ---- round-4 experiment switches (all OFF in the product build; each was A/B'd on MI355X against the build without it, same call,
 // 64 -> 64 @152x272 x 16 frames, offsets of sigma 1.5 px: profiles/r4_dcn_experiments.md) -------------------------------------------
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                   DP_PBUF = DP_PBUF_(DP_R);
     constexpr bool BREG = dcnp_breg<TN>();
     constexpr int BN = TN * 32, NBLK = (BN + 63) / 64;
-    constexpr int NBP = NBLK * 6;                     // weight DMA pieces per chunk
+    constexpr int NBP = NBLK * DEFT_NP * 2;           // weight DMA pieces (1 KB) per chunk
     constexpr int BSTAGE = NBLK * DP_WBLK;
     constexpr int NPP = 4 * DP_PARTS / 2;             // patch DMA pieces per wave (waves 2 and 3 issue them)
 
@@ -200,19 +200,21 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     const int ncb = p.Cin >> 4, nchunks = ncb * 9;
     const unsigned vB = (unsigned)((n0 >> 6) * nchunks * DP_WBLK + lane * 16);       // (+ piece and chunk terms in the scalar offset)
     // the first three weight chunks and the first patch are on their way while the records are computed
-    constexpr int NB_A = NBP / 3, NB_B = NBP / 6;              // weight pieces per step: waves 0, 1 / waves 2, 3
+    // weight pieces per step and wave: waves 0, 1 / waves 2, 3 (which also carry the patch).  3 pieces: 6 * NBLK in all = 2 * (2 + 1) * NBLK;
+    // 2 pieces: 4 * NBLK = 2 * (1 + 1) * NBLK
+    constexpr int NB_A = DEFT_NP == 3 ? NBP / 3 : NBP / 4, NB_B = DEFT_NP == 3 ? NBP / 6 : NBP / 4;
     auto issue_b3 = [&](int kc, int st) {
         if (wave < 2) {
 #pragma unroll
             for (int i = 0; i < NB_A; ++i) {
                 const int jp = wave + 2 * i;
-                deft_buffer_load_lds_x4s(rw, Bd + st * BSTAGE + jp * 1024, vB, (unsigned)((jp / 6) * nchunks + kc) * (unsigned)DP_WBLK + (unsigned)(jp % 6) * 1024u);
+                deft_buffer_load_lds_x4s(rw, Bd + st * BSTAGE + jp * 1024, vB, (unsigned)((jp / (DEFT_NP * 2)) * nchunks + kc) * (unsigned)DP_WBLK + (unsigned)(jp % (DEFT_NP * 2)) * 1024u);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NB_B; ++i) {
                 const int jp = 2 * NB_A + (wave - 2) + 2 * i;
-                deft_buffer_load_lds_x4s(rw, Bd + st * BSTAGE + jp * 1024, vB, (unsigned)((jp / 6) * nchunks + kc) * (unsigned)DP_WBLK + (unsigned)(jp % 6) * 1024u);
+                deft_buffer_load_lds_x4s(rw, Bd + st * BSTAGE + jp * 1024, vB, (unsigned)((jp / (DEFT_NP * 2)) * nchunks + kc) * (unsigned)DP_WBLK + (unsigned)(jp % (DEFT_NP * 2)) * 1024u);
             }
         }
     };
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
         for (int tap = 0; tap < 9; ++tap) {
             if (!DEFORM) {          // plain conv: tap (r, s) of the lane's pixel, always inside the margin-less patch (zeros outside the map)
                 const int r = tap / 3, s = tap - 3 * r;
-                rw0[tap] = 1.f; rw1[tap] = rw2[tap] = rw3[tap] = 0.f;
+                rw0[tap] = DEFT_ASCALE; rw1[tap] = rw2[tap] = rw3[tap] = 0.f;
                 rc[tap] = (unsigned)(g * 2 * DP_PLANE) + (unsigned)((((oy - ty0) + r) * DP_PW + (ox - tx0) + s) * 16);
                 continue;
             }
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
             const float hh = 1.f - lh, hw_ = 1.f - lw;
             const int h_low = (int)hl, w_low = (int)wl;
             const int h_high = h_low + 1, w_high = w_low + 1;
-            const float mask = inside ? DEFT_FAST_RCP(1.f + expf(-ml)) : 0.f;
+            const float mask = inside ? DEFT_FAST_RCP(1.f + expf(-ml)) * DEFT_ASCALE : 0.f;     // (the operand scale of the split rides on the corner weights: exact, a power of two)
             const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
             float w1 = (t_ok && l_ok) ? hh * hw_ * mask : 0.f;
             float w2 = (t_ok && r_ok) ? hh * lw * mask : 0.f;
@@ -356,10 +358,10 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
             v[3][0] = deft_buffer_load_x4(rx, o2 + dyb); v[3][1] = deft_buffer_load_x4(rx, o2 + dyb + 16u);
         }
     };
-    // blend the four corners, split into the three bf16 pieces: the lane's A fragment (8 k of its row)
-    auto blend_split = [&](const f32x4 (&v)[4][2], float w0, float w1, float w2, float w3, bf16x8 (&pa)[3]) {
+    // blend the four corners, split into the operand pieces: the lane's A fragment (8 k of its row)
+    auto blend_split = [&](const f32x4 (&v)[4][2], float w0, float w1, float w2, float w3, pcx8 (&pa)[DEFT_NP]) {
         f32x4 b0, b1;
-        if (!DEFORM) { b0 = v[0][0]; b1 = v[0][1]; }
+        if (!DEFORM) { b0 = v[0][0] * w0; b1 = v[0][1] * w0; }          // (w0 = DEFT_ASCALE: 1 with three pieces -- exact either way)
         else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -370,21 +372,33 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
         // the three bf16 pieces (common.h split3: round-to-nearest-even each, exact), two elements at a time so that every conversion
         // is one v_cvt_pk_bf16_f32 of a PAIR and the pieces come back as floats by a shift / a mask: 11 VALU per pair
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 ph, pm, pl;
+        if constexpr (DEFT_NP == 3) {
+            u32x4 ph, pm, pl;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], x1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
-            unsigned h = dcnp_cvt_pk(x0, x1);
-            DEFT_OPAQUE_NV(h);                   // (otherwise the compiler converts the low element a second time instead of shifting the pair)
-            const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-            unsigned m = dcnp_cvt_pk(r0, r1);
-            DEFT_OPAQUE_NV(m);
-            const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-            ph[e] = h; pm[e] = m; pl[e] = dcnp_cvt_pk(s0, s1);
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], x1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
+                unsigned h = dcnp_cvt_pk(x0, x1);
+                DEFT_OPAQUE_NV(h);                   // (otherwise the compiler converts the low element a second time instead of shifting the pair)
+                const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+                unsigned m = dcnp_cvt_pk(r0, r1);
+                DEFT_OPAQUE_NV(m);
+                const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+                ph[e] = h; pm[e] = m; pl[e] = dcnp_cvt_pk(s0, s1);
+            }
+            pa[0] = __builtin_bit_cast(pcx8, ph);
+            pa[1] = __builtin_bit_cast(pcx8, pm);
+            pa[DEFT_NP - 1] = __builtin_bit_cast(pcx8, pl);
+        } else {
+            // two fp16 pieces (the corner weights carry DEFT_ASCALE already): h1 = fp16(x), h2 = fp16(x - h1) -- the residual is exact in
+            // fp32 and the matrix instructions' fp16 -> fp32 widening is exact, so this is common.h deft_split element by element
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = e < 4 ? b0[e] : b1[e - 4];
+                const deft_piece_t h = (deft_piece_t)x;
+                pa[0][e] = h;
+                pa[1][e] = (deft_piece_t)(x - (float)h);
+            }
         }
-        pa[0] = __builtin_bit_cast(bf16x8, ph);
-        pa[1] = __builtin_bit_cast(bf16x8, pm);
-        pa[2] = __builtin_bit_cast(bf16x8, pl);
     };
 
     // ---- K loop, software-pipelined.  Chunk kc = (16-channel block cb, tap).  Step kc starts with A(kc) AND the B fragments of kc in
@@ -395,27 +409,28 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     //   B fragments of kc + 1 (LDS; its weights landed two steps ago, visible since this step's barrier)
     //   DMA: weights of kc + 3 into the stage whose fragments were read one step ago; patch pieces of the NEXT block (taps 0..6)
     // Three weight stages, two patch buffers; two blocks per loop iteration, so that buffers and stages are immediates. ----
-    bf16x8 pa[3], pb[TN][3];
-    auto read_b = [&](int st, bf16x8 (&o)[TN][3]) {
+    pcx8 pa[DEFT_NP], pb[TN][DEFT_NP];
+    auto read_b = [&](int st, pcx8 (&o)[TN][DEFT_NP]) {
         const char* const bs = Bd + st * BSTAGE + brow;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const char* const bj = bs + (j >> 1) * DP_WBLK + (j & 1) * 512;
-            o[j][0] = *(const bf16x8*)(bj); o[j][1] = *(const bf16x8*)(bj + 2048); o[j][2] = *(const bf16x8*)(bj + 4096);
+#pragma unroll
+            for (int q = 0; q < DEFT_NP; ++q) o[j][q] = *(const pcx8*)(bj + q * 2048);
         }
     };
     // BREG: this lane's B fragments of chunk kc straight from the weight image (global / L2 / L1: the four waves of a workgroup and
     // the workgroups of a pixel row read the same 6 KB chunk) into registers
     const unsigned vBr = (unsigned)((n0 >> 6) * nchunks * DP_WBLK + brow);
-    auto load_b = [&](int kc, bf16x8 (&o)[TN][3]) {
+    auto load_b = [&](int kc, pcx8 (&o)[TN][DEFT_NP]) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const unsigned base = vBr + (unsigned)(((j >> 1) * nchunks + kc) * DP_WBLK + (j & 1) * 512);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) o[j][q] = __builtin_bit_cast(bf16x8, deft_buffer_load_x4(rw, base + (unsigned)(q * 2048)));
+            for (int q = 0; q < DEFT_NP; ++q) o[j][q] = __builtin_bit_cast(pcx8, deft_buffer_load_x4(rw, base + (unsigned)(q * 2048)));
         }
     };
-    bf16x8 pbr[2][TN][3];                                  // BREG: the fragments of chunk kc in pbr[kc & 1] (loaded at the end of step kc - 2)
+    pcx8 pbr[2][TN][DEFT_NP];                                  // BREG: the fragments of chunk kc in pbr[kc & 1] (loaded at the end of step kc - 2)
     DCNP_T(2);
     f32x4 vq[GA][4][2];                                    // corner values in flight: vq[0] = the next chunk's, vq[1] = the one after (GA = 2)
     {
@@ -490,11 +505,10 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 // six products per fp32 product, smallest terms first (as igemm.hip); product-major so that consecutive MFMAs go to
                 // DIFFERENT accumulators (a dependent MFMA waits for its predecessor's full latency, more with VALU slotted between them)
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    constexpr int qa[6] = {1, 2, 0, 1, 0, 0}, qb[6] = {1, 0, 2, 0, 1, 0};
+                for (int q = 0; q < DEFT_NPROD; ++q) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[qa[q]], BREG ? pbr[(half * 9 + tap) & 1][j][qb[q]] : pb[j][qb[q]], acc[0][j], 0, 0, 0);
+                        acc[0][j] = deft_mfma_pc(pa[deft_qa(q)], BREG ? pbr[(half * 9 + tap) & 1][j][deft_qb(q)] : pb[j][deft_qb(q)], acc[0][j]);
                 }
 #endif
 #ifdef DCNP_ABL_NOVALU
@@ -502,12 +516,14 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
 #else
                 if (more) {
 #endif
-                    bf16x8 pn[3];
+                    pcx8 pn[DEFT_NP];
                     blend_split(vq[GS == 2 ? (gslot ^ 1) : 0], rw0[ntap], rw1[ntap], rw2[ntap], rw3[ntap], pn);
-                    pa[0] = pn[0]; pa[1] = pn[1]; pa[2] = pn[2];
+#pragma unroll
+                    for (int q = 0; q < DEFT_NP; ++q) pa[q] = pn[q];
                 }
                 DCNP_SCHED(TN);
-                DEFT_OPAQUE(pa[0]); DEFT_OPAQUE(pa[1]); DEFT_OPAQUE(pa[2]);      // A(kc + 1) is finished HERE, under the MFMAs -- not after the next barrier
+#pragma unroll
+                for (int q = 0; q < DEFT_NP; ++q) DEFT_OPAQUE(pa[q]);      // A(kc + 1) is finished HERE, under the MFMAs -- not after the next barrier
 #ifdef DCNP_TIMING
                 const long long tC = __builtin_readcyclecounter();
                 tsum[1] += tC - tB;
@@ -614,37 +630,41 @@ int deft_conv3p_dispatch(const DeftGemmDesc* d, hipStream_t s) {
 // ---- weight image of the patch form -----------------------------------------------------------------------------------------------
 // w [CoutPad][9 * Cin] fp32 in the DCN K order of deft_dcn_v2_nhwc (k = ((c / 32) * 9 + tap) * 32 + c % 32) ->
 // w3 [CoutPad / 64][Cin / 16 * 9 chunks][3 pieces][2 k groups][64 rows][8 bf16]: chunk (cb, tap) = channels 16 cb .. 16 cb + 15 of tap.
-__global__ __launch_bounds__(256) void split_weights_dcn_kernel(const float* __restrict__ w, __bf16* __restrict__ w3, int CoutPad, int Cin) {
+__global__ __launch_bounds__(256) void split_weights_dcn_kernel(const float* __restrict__ w, deft_piece_t* __restrict__ w3, int CoutPad, int Cin) {
+    constexpr int PER = DEFT_NP * 128;                 // 16-byte slots of one chunk image: [DEFT_NP pieces][2 k groups][64 rows]
     const int nchunks = (Cin >> 4) * 9;
-    const long long total = (long long)(CoutPad >> 6) * nchunks * 384;
+    const long long total = (long long)(CoutPad >> 6) * nchunks * PER;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int row = (int)(idx & 63);
-    const int sub = (int)((idx >> 6) % 6);
-    const int kc = (int)((idx / 384) % nchunks);
-    const int blk = (int)(idx / (384ll * nchunks));
+    const int sub = (int)((idx >> 6) % (DEFT_NP * 2));
+    const int kc = (int)((idx / PER) % nchunks);
+    const int blk = (int)(idx / ((long long)PER * nchunks));
     const int q = sub >> 1, g = sub & 1;
     const int cb = kc / 9, tap = kc - 9 * cb;
     const float* wr = w + (size_t)(blk * 64 + row) * (size_t)(9 * Cin);
-    bf16x8 o;
+    pcx8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = cb * 16 + g * 8 + e;
-        const float v = wr[((c >> 5) * 9 + tap) * 32 + (c & 31)];
-        const __bf16 hh = (__bf16)v;
-        const float r1 = v - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        const __bf16 ll = (__bf16)(r1 - (float)mm);
-        o[e] = q == 0 ? hh : (q == 1 ? mm : ll);
+        float r = wr[((c >> 5) * 9 + tap) * 32 + (c & 31)];
+        deft_piece_t pc = (deft_piece_t)0.f;
+#pragma unroll
+        for (int qq = 0; qq < DEFT_NP; ++qq) {
+            const deft_piece_t h = (deft_piece_t)r;
+            if (qq == q) pc = h;
+            r -= (float)h;
+        }
+        o[e] = pc;
     }
-    *(bf16x8*)(w3 + idx * 8) = o;
+    *(pcx8*)(w3 + idx * 8) = o;
 }
 
 extern "C" int deft_split_weights_dcn(const float* w, void* w3, int CoutPad, int Cin, void* stream) {
     DEFT_CHECK(w && w3 && CoutPad > 0 && (CoutPad & 63) == 0 && Cin > 0 && (Cin & 31) == 0 && (((size_t)w3) & 15) == 0, -76,
                "deft_split_weights_dcn: need CoutPad %% 64 == 0, Cin %% 32 == 0, w3 16-byte aligned (%d, %d)", CoutPad, Cin);
-    const long long total = (long long)(CoutPad >> 6) * (Cin >> 4) * 9 * 384;
-    hipLaunchKernelGGL(split_weights_dcn_kernel, dim3((unsigned)deft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, CoutPad, Cin);
+    const long long total = (long long)(CoutPad >> 6) * (Cin >> 4) * 9 * (DEFT_NP * 128);
+    hipLaunchKernelGGL(split_weights_dcn_kernel, dim3((unsigned)deft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (deft_piece_t*)w3, CoutPad, Cin);
     DEFT_CHECK_LAUNCH("split_weights_dcn");
     return 0;
 }

@@ -40,7 +40,7 @@ enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 template <int BM, int BN, int WK, int NSTAGE, int MODE, int PREC = 0>
 constexpr int igemm_lds_floats() {
     constexpr int ld = (MODE == MODE_CONV && NSTAGE == 2) ? 32 : LDS_STRIDE;      // LDS-DMA image is unpadded
-    constexpr int stage = (PREC >= 2 ? (3 * BM * LDB * 2 + 2 * BN * 192) / 4 : PREC ? 3 * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 5 : 0);
+    constexpr int stage = (PREC >= 2 ? (DEFT_NP * BM * LDB * 2 + 2 * BN * (DEFT_NP * 64)) / 4 : PREC ? DEFT_NP * (BM + BN) * LDB / 2 : NSTAGE * (BM + BN) * ld) + (MODE == MODE_DCN ? 9 * BM * 5 : 0);
     constexpr int red = (WK - 1) * (BM / 32) * (BN / 32) * 1024;
     return stage > red ? stage : red;
 }
@@ -86,10 +86,11 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     constexpr bool BDMA = PREC >= 2;
     static_assert(!(BDMA && MODE == MODE_DCN), "the DCN reads pre-split weights on its patch form only (dcn.hip)");
     constexpr int NBS = 2;                               // weight stages of the DMA form
-    float* const prm = BDMA ? smem + (3 * BM * LDB * 2 + NBS * BN * 192) / 4 : PREC ? smem + 3 * (BM + BN) * LDB / 2 : Bs + NSTAGE * BN * LD;   // DCN only
-    __bf16* const Ap = (__bf16*)smem;            // PREC >= 1: A planes [3][BM][LDB], then B planes [3][BN][LDB] (PREC 2: two DMA stages [BN][192 B])
-    __bf16* const Bp = Ap + 3 * BM * LDB;
-    char* const Bd = (char*)(Ap + 3 * BM * LDB);
+    constexpr int BROW = DEFT_NP * 64;                   // bytes per row of the pre-split weight image (igemm3.hip P3_ROW)
+    float* const prm = BDMA ? smem + (DEFT_NP * BM * LDB * 2 + NBS * BN * BROW) / 4 : PREC ? smem + DEFT_NP * (BM + BN) * LDB / 2 : Bs + NSTAGE * BN * LD;   // DCN only
+    deft_piece_t* const Ap = (deft_piece_t*)smem;   // PREC >= 1: A planes [NP][BM][LDB], then B planes [NP][BN][LDB] (PREC 2: two DMA stages [BN][BROW B])
+    deft_piece_t* const Bp = Ap + DEFT_NP * BM * LDB;
+    char* const Bd = (char*)(Ap + DEFT_NP * BM * LDB);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -251,13 +252,14 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     f32x4 s0[GA], s1[GA], s2[GA], s3[GA], sw[GA], vb[GB];
 
     // PREC 2: this wave's pieces of the weight chunk image (1 KB each; piece j of the tile = 64-row block j / 12)
-    constexpr int NBP = BDMA ? BN * 3 / 64 : 1;
+    constexpr int BSLOTS = DEFT_NP * 4;                  // 16-byte slots per weight row
+    constexpr int NBP = BDMA ? BN * DEFT_NP / 64 : 1;
     const deft_rsrc_t rw3 = deft_make_rsrc(BDMA ? p.w3 : (const void*)p.w);
     unsigned vB3[NBP];
 #pragma unroll
     for (int i = 0; i < NBP; ++i) {
         const int j = wave + i * 4;
-        vB3[i] = (unsigned)(((n0 >> 6) + j / 12) * (p.Kpad >> 5) * 12 + j % 12) * 1024u + (unsigned)lane * 16u;
+        vB3[i] = (unsigned)(((n0 >> 6) + j / BSLOTS) * (p.Kpad >> 5) * BSLOTS + j % BSLOTS) * 1024u + (unsigned)lane * 16u;
     }
     int bdma_stage = 0;                              // PREC 2: the B stage the next issue_loads() fills
     int dma_stage = 0;                               // DMA form: LDS stage the next issue_loads() fills
@@ -268,10 +270,10 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         // only younger register loads, and completions within one kind are in order); with the DMAs younger, a DMA that lands early
         // could satisfy the count while the register load is still in flight.
         if (BDMA) {
-            const unsigned soff = (unsigned)(kload >> 5) * 12288u;
+            const unsigned soff = (unsigned)(kload >> 5) * (unsigned)(64 * BROW);
 #pragma unroll
             for (int i = 0; i < NBP; ++i)
-                deft_buffer_load_lds_x4s(rw3, Bd + bdma_stage * BN * 192 + (wave + i * 4) * 1024, vB3[i], soff);
+                deft_buffer_load_lds_x4s(rw3, Bd + bdma_stage * BN * BROW + (wave + i * 4) * 1024, vB3[i], soff);
             bdma_stage ^= 1;
         }
         if (MODE == MODE_CONV) {
@@ -360,17 +362,18 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
             f32x4 v;
             if (MODE == MODE_CONV) {
                 v = s0[i];
-            } else if (MODE == MODE_DCN) {
+            } else if (MODE == MODE_DCN) {      // (with PREC the operand scale DEFT_ASCALE is applied by deft_split below)
                 v = sw[i].x * s0[i] + sw[i].y * s1[i] + sw[i].z * s2[i] + sw[i].w * s3[i];
             } else {
                 const f32x4 t = s0[i] + s1[i];
                 v = f32x4{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)};
             }
             if (PREC) {
-                bf16x4 h, m, l;
-                split3(v, h, m, l);
-                __bf16* ap = Ap + (rbase + 32 * i) * LDB + g * 4;
-                *(bf16x4*)ap = h; *(bf16x4*)(ap + BM * LDB) = m; *(bf16x4*)(ap + 2 * BM * LDB) = l;
+                pcx4 pc[DEFT_NP];
+                deft_split(v, pc, DEFT_ASCALE);
+                deft_piece_t* ap = Ap + (rbase + 32 * i) * LDB + g * 4;
+#pragma unroll
+                for (int q = 0; q < DEFT_NP; ++q) *(pcx4*)(ap + q * BM * LDB) = pc[q];
             } else {
                 *(f32x4*)&as[32 * i * LDS_STRIDE] = v;
             }
@@ -380,10 +383,11 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
             if (BDMA) {
                 // weights arrive by DMA
             } else if (PREC) {
-                bf16x4 h, m, l;
-                split3(vb[i], h, m, l);
-                __bf16* bp = Bp + (rbase + 32 * i) * LDB + g * 4;
-                *(bf16x4*)bp = h; *(bf16x4*)(bp + BN * LDB) = m; *(bf16x4*)(bp + 2 * BN * LDB) = l;
+                pcx4 pc[DEFT_NP];
+                deft_split(vb[i], pc);
+                deft_piece_t* bp = Bp + (rbase + 32 * i) * LDB + g * 4;
+#pragma unroll
+                for (int q = 0; q < DEFT_NP; ++q) *(pcx4*)(bp + q * BN * LDB) = pc[q];
             } else {
                 *(f32x4*)&bs[32 * i * LDS_STRIDE] = vb[i];
             }
@@ -437,31 +441,26 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
     // PREC = 1: the two K = 16 halves of the chunk; a lane's fragment = 8 consecutive k of its row (k group lane>>5)
     auto split_chunk = [&](int bstage) {
         const int fkg = (lane >> 5) * 8;
-        const char* const bdr = Bd + bstage * BN * 192 + (wn * TN * 32 + frow) * 192;
-        const int bsw = (frow >> 2) & 3;
+        const char* const bdr = Bd + bstage * BN * BROW + (wn * TN * 32 + frow) * BROW;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            bf16x8 pa[TM][3], pb[TN][3];
+            pcx8 pa[TM][DEFT_NP], pb[TN][DEFT_NP];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < DEFT_NP; ++pl) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) pa[i][pl] = *(const bf16x8*)(Ap + pl * BM * LDB + ((wm * TM + i) * 32 + frow) * LDB + kh * 16 + fkg);
+                for (int i = 0; i < TM; ++i) pa[i][pl] = *(const pcx8*)(Ap + pl * BM * LDB + ((wm * TM + i) * 32 + frow) * LDB + kh * 16 + fkg);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    pb[j][pl] = BDMA ? *(const bf16x8*)(bdr + j * 32 * 192 + pl * 64 + ((kh * 2 + (lane >> 5)) ^ bsw) * 16)
-                                     : *(const bf16x8*)(Bp + pl * BN * LDB + ((wn * TN + j) * 32 + frow) * LDB + kh * 16 + fkg);
+                    pb[j][pl] = BDMA ? *(const pcx8*)(bdr + j * 32 * BROW + deft_p3_phys(pl, kh * 2 + (lane >> 5), frow) * 16)
+                                     : *(const pcx8*)(Bp + pl * BN * LDB + ((wn * TN + j) * 32 + frow) * LDB + kh * 16 + fkg);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];                                           // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][2], pb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb[j][0], c, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < DEFT_NPROD; ++q) c = deft_mfma_pc(pa[i][deft_qa(q)], pb[j][deft_qb(q)], c);
                     acc[i][j] = c;
                 }
         }
@@ -577,7 +576,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         if (p.y3 != nullptr) {
             float* const T = smem;
             __syncthreads();
-            deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
+            deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0, PREC ? DEFT_ASCALE_INV : 1.f);
             __syncthreads();
             deft_epilogue_rows<BM, BN, 256>(T, p, n0, tid, [&](int row) -> long long { return m0 + row < p.M ? (long long)(m0 + row) : -1; });
             return;
@@ -593,7 +592,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
         const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
         const bool cok = co < p.Cout;
         const int coc = cok ? co : p.Cout - 1;
-        const float sc = p.scale ? p.scale[coc] : 1.f;
+        const float sc = (p.scale ? p.scale[coc] : 1.f) * (PREC ? DEFT_ASCALE_INV : 1.f);      // (the split path scaled its A operand by DEFT_ASCALE)
         const float sh = p.shift ? p.shift[coc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {

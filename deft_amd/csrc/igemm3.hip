@@ -21,8 +21,9 @@
 
 typedef deft_f32x16 f32x16;
 
-#define P3_ROW 192            // bytes per staged row: 3 pieces x 32 bf16
-#define P3_WBLK 12288         // 64 weight rows of one chunk
+#define P3_SLOTS (DEFT_NP * 4)      // 16-byte slots per staged row
+#define P3_ROW (DEFT_NP * 64)       // bytes per staged row: DEFT_NP pieces x 32 k x 2 B
+#define P3_WBLK (64 * P3_ROW)       // 64 weight rows of one chunk
 
 // NS = 1: ONE stage and no overlap inside a workgroup -- the DMA latency of a chunk is covered by the OTHER workgroups of the CU
 // (48 KB at 128 x 128: three of them, against one for the 2-stage ring); the epilogue tile is then staged in WM passes of
@@ -40,12 +41,12 @@ template <int BM, int BN, int WM, int WN, int NS, bool SPLIT>
 __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int mtiles, int ntiles) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int NA = BM * 12 / NT;             // A slots (16 B) per thread and chunk
-    constexpr int NBI = BN * 12 / 64;            // B DMA pieces (1 KB) per chunk
+    constexpr int NA = BM * P3_SLOTS / NT;       // A slots (16 B) per thread and chunk
+    constexpr int NBI = BN * P3_SLOTS / 64;      // B DMA pieces (1 KB) per chunk
     constexpr int NB = (NBI + NW - 1) / NW;      // ... per wave
     constexpr int STAGE = (BM + BN) * P3_ROW;
     constexpr int PER = NA + NB;                 // DMA pieces a wave issues per chunk (vmcnt bookkeeping)
-    static_assert(BM * 12 % NT == 0 && TM >= 1 && TN >= 1 && BN % 64 == 0, "tile shape");
+    static_assert(BM * P3_SLOTS % NT == 0 && TM >= 1 && TN >= 1 && BN % 64 == 0, "tile shape");
     static_assert(NS == 1 || NS == 2 || (NS == 3 && NBI % NW == 0), "3 stages need the same DMA count in every wave");
 
     DEFT_DYN_LDS(char, smem);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
 
     const deft_rsrc_t rx = deft_make_rsrc(p.x3);
     const deft_rsrc_t rw = deft_make_rsrc(p.w3);       // (no tile reaches past the 128-padded weight rows: deft_p3_dispatch checks)
-    const unsigned pb = (unsigned)p.ldx3 * 6u;       // bytes per pixel: 3 pieces x ld channels x 2
+    const unsigned pb = (unsigned)p.ldx3 * (2u * DEFT_NP);       // bytes per pixel: DEFT_NP pieces x ld channels x 2
     const int taps = p.KH * p.KW;
 
     // ---- per-slot loader state, fixed for the whole K loop: byte offset of (window top-left pixel, this slot's
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int P = i * NT + tid;
-        const int row = P / 12, ps = P - row * 12;
-        const int q = ps >> 2, sl = (ps & 3) ^ ((row >> 2) & 3);
+        const int row = P / P3_SLOTS, ps = P - row * P3_SLOTS;
+        int q, sl;
+        deft_p3_logical(ps, row, q, sl);
         const int m = m0 + row;
         rb[i] = 0; vm[i] = 0;
         if (m < p.M) {
@@ -98,13 +100,13 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
             vm[i] = v;
         }
     }
-    // weights: piece j of the chunk image = 1 KB of the 64-row block j / 12
+    // weights: piece j of the chunk image = 1 KB of the 64-row block j / P3_SLOTS
     const int nk_all = p.Kpad >> 5;
     unsigned vB[NB];
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb) {
         const int j = wave + jb * NW;
-        vB[jb] = (unsigned)(((n0 >> 6) + j / 12) * nk_all * 12 + j % 12) * 1024u + (unsigned)lane * 16u;
+        vB[jb] = (unsigned)(((n0 >> 6) + j / P3_SLOTS) * nk_all * P3_SLOTS + j % P3_SLOTS) * 1024u + (unsigned)lane * 16u;
     }
 
     // this workgroup's share of the K chunks
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
     auto issue = [&](int stage) {
         char* const as = smem + stage * STAGE;
         char* const bs = as + BM * P3_ROW;
-        const unsigned toff = (unsigned)(cr * p.W + cs) * pb + (unsigned)(cc >> 5) * 192u;     // scalar unit
+        const unsigned toff = (unsigned)(cr * p.W + cs) * pb + (unsigned)(cc >> 5) * (unsigned)P3_ROW;     // scalar unit
         const unsigned tbit = 1u << (cr * p.KW + cs);
 #pragma unroll
         for (int i = 0; i < NA; ++i)
@@ -158,33 +160,28 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm3_kernel(DeftGemmDesc p, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int frow = lane & 31;
-    const int fsw = (frow >> 2) & 3;
+    const int frow = lane & 31;              // (rows frow + 32 i of a tile share frow's swizzle term: 32 is a multiple of its period)
     auto compute = [&](int stage) {
         const char* const as = smem + stage * STAGE + (wm * TM * 32 + frow) * P3_ROW;
         const char* const bs = smem + stage * STAGE + BM * P3_ROW + (wn * TN * 32 + frow) * P3_ROW;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            const int so = ((kh * 2 + (lane >> 5)) ^ fsw) * 16;
-            bf16x8 pa[TM][3], pb_[TN][3];
+            pcx8 pa[TM][DEFT_NP], pb_[TN][DEFT_NP];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < DEFT_NP; ++q) {
+                const int so = deft_p3_phys(q, kh * 2 + (lane >> 5), frow) * 16;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) pa[i][q] = *(const bf16x8*)(as + i * 32 * P3_ROW + q * 64 + so);
+                for (int i = 0; i < TM; ++i) pa[i][q] = *(const pcx8*)(as + i * 32 * P3_ROW + so);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) pb_[j][q] = *(const bf16x8*)(bs + j * 32 * P3_ROW + q * 64 + so);
+                for (int j = 0; j < TN; ++j) pb_[j][q] = *(const pcx8*)(bs + j * 32 * P3_ROW + so);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];                                           // smallest terms first (as igemm.hip)
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb_[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][2], pb_[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb_[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][0], c, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < DEFT_NPROD; ++q) c = deft_mfma_pc(pa[i][deft_qa(q)], pb_[j][deft_qb(q)], c);
                     acc[i][j] = c;
                 }
         }
@@ -335,8 +332,8 @@ int deft_p3_check(const DeftGemmDesc* d, const char* who) {
     DEFT_CHECK(d->fold_y == nullptr || (d->fold_w != nullptr && d->fold_n >= 1 && d->fold_n <= 16 && d->fold_ld >= d->fold_n && d->splitk <= 1 && (((size_t)d->fold_w) & 15) == 0
                                         && (d->tile & 0xffff) != 0),
                -59, "%s: fold_y needs fold_w (16-byte aligned), 1 <= fold_n <= 16, fold_ld >= fold_n, no split-K and a forced tile (the part count is ceil(Cout / BN))", who);
-    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx3 * 6 < (1ll << 31), -67, "%s: x3 map exceeds 2 GiB (split the batch)", who);
-    DEFT_CHECK((long long)deft_cdiv(d->Cout, 128) * 128 * d->Kpad * 6 < (1ll << 31), -68, "%s: w3 exceeds 2 GiB", who);
+    DEFT_CHECK((long long)d->N * d->H * d->W * d->ldx3 * 2 * DEFT_NP < (1ll << 31), -67, "%s: x3 map exceeds 2 GiB (split the batch)", who);
+    DEFT_CHECK((long long)deft_cdiv(d->Cout, 128) * 128 * d->Kpad * 2 * DEFT_NP < (1ll << 31), -68, "%s: w3 exceeds 2 GiB", who);
     return 0;
 }
 
@@ -371,7 +368,7 @@ int deft_p3_dispatch(const DeftGemmDesc* d, hipStream_t s) {
 // ---------------------------------------------------------------------------
 // fp32 -> P3 converters
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ y3, long long rows, int C, int ldx, int ldy3) {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, deft_piece_t* __restrict__ y3, long long rows, int C, int ldx, int ldy3) {
     const int g = C >> 3;                                      // 8-channel groups per row
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * g) return;
@@ -379,13 +376,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const int c = (int)(i - row * g) * 8;
     const float* xp = x + row * ldx + c;
     const f32x4 v0 = *(const f32x4*)xp, v1 = *(const f32x4*)(xp + 4);
-    bf16x4 h0, m0, l0, h1, m1, l1;
-    split3(v0, h0, m0, l0);
-    split3(v1, h1, m1, l1);
-    __bf16* yp = y3 + row * ldy3 * 3 + (c >> 5) * 96 + (c & 31);
-    *(bf16x8*)yp = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    *(bf16x8*)(yp + 32) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-    *(bf16x8*)(yp + 64) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    pcx4 c0[DEFT_NP], c1[DEFT_NP];
+    deft_split(v0, c0, DEFT_ASCALE);
+    deft_split(v1, c1, DEFT_ASCALE);
+    deft_piece_t* yp = y3 + row * ldy3 * DEFT_NP + (c >> 5) * (32 * DEFT_NP) + (c & 31);
+#pragma unroll
+    for (int q = 0; q < DEFT_NP; ++q) *(pcx8*)(yp + 32 * q) = __builtin_shufflevector(c0[q], c1[q], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 extern "C" int deft_split_planes(const float* x, void* y3, long long rows, int C, int ldx, int ldy3, void* stream) {
@@ -394,34 +390,35 @@ extern "C" int deft_split_planes(const float* x, void* y3, long long rows, int C
     DEFT_CHECK((((size_t)x | (size_t)y3) & 15) == 0, -2, "deft_split_planes: x / y3 must be 16-byte aligned");
     const long long tot = rows * (C >> 3);
     DEFT_CHECK(tot < (1ll << 39), -3, "deft_split_planes: too many rows");
-    hipLaunchKernelGGL(split_planes_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y3, rows, C, ldx, ldy3);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, (deft_piece_t*)y3, rows, C, ldx, ldy3);
     DEFT_CHECK_LAUNCH("split_planes");
     return 0;
 }
 
 // one thread per 16-byte slot of the weight image
-__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ w3, int CoutPad, int Kpad) {
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, deft_piece_t* __restrict__ w3, int CoutPad, int Kpad) {
     const int nk = Kpad >> 5;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (block, chunk, row, physical slot)
-    if (i >= (long long)CoutPad * nk * 12) return;
-    const int ps = (int)(i % 12);
-    const long long t = i / 12;
+    if (i >= (long long)CoutPad * nk * P3_SLOTS) return;
+    const int ps = (int)(i % P3_SLOTS);
+    const long long t = i / P3_SLOTS;
     const int r = (int)(t & 63);
     const long long bc = t >> 6;
     const int chunk = (int)(bc % nk), blk = (int)(bc / nk);
-    const int q = ps >> 2, s = (ps & 3) ^ ((r >> 2) & 3);
+    int q, s;
+    deft_p3_logical(ps, r, q, s);
     const float* wp = w + (size_t)(blk * 64 + r) * Kpad + chunk * 32 + s * 8;
-    bf16x4 pc[2][3];
-    split3(*(const f32x4*)wp, pc[0][0], pc[0][1], pc[0][2]);
-    split3(*(const f32x4*)(wp + 4), pc[1][0], pc[1][1], pc[1][2]);
-    *(bf16x8*)(w3 + i * 8) = __builtin_shufflevector(pc[0][q], pc[1][q], 0, 1, 2, 3, 4, 5, 6, 7);
+    pcx4 pc[2][DEFT_NP];
+    deft_split(*(const f32x4*)wp, pc[0]);
+    deft_split(*(const f32x4*)(wp + 4), pc[1]);
+    *(pcx8*)(w3 + i * 8) = __builtin_shufflevector(pc[0][q], pc[1][q], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 extern "C" int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpad, void* stream) {
     DEFT_CHECK(w && w3 && CoutPad > 0 && (CoutPad & 63) == 0 && Kpad > 0 && (Kpad & 31) == 0, -1,
                "deft_split_weights: need CoutPad %% 64 == 0 and Kpad %% 32 == 0 (%d, %d)", CoutPad, Kpad);
-    const long long tot = (long long)CoutPad * (Kpad >> 5) * 12;
-    hipLaunchKernelGGL(split_weights_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, CoutPad, Kpad);
+    const long long tot = (long long)CoutPad * (Kpad >> 5) * P3_SLOTS;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, w, (deft_piece_t*)w3, CoutPad, Kpad);
     DEFT_CHECK_LAUNCH("split_weights");
     return 0;
 }
@@ -452,12 +449,35 @@ extern "C" int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpa
 // 8 LDS cycles instead of 4 -- tools/probe/p3h_timing.py, profiles/r4_p3h_timing.md).
 template <int TW>
 __device__ __forceinline__ int p3h_swz(int hp, int hy) { return TW == 32 ? (hp >> 3) & 1 : hy & 1; }
+// TWO fp16 pieces: rows are 64 B = 4 slots (piece q, k-group g at logical slot q*2 + g), four rows per 64 banks.  The patch rows are PITCHED to
+// a multiple of 4 pixels (TW + 2 -> 36 / 20), so a pixel's bank quarter is hx % 4 whatever its patch row, and the physical slot is
+// logical ^ ((hx >> 2) & 3): the 16 lanes of a ds_read_b128 group read 16 different hx (TW = 32: x0 + {0-3, 12-15, 20-27}; TW = 16: the two tile
+// rows of a fragment give x0 + {0-3, 12-15} and x0 + {4-11}), i.e. four per bank quarter with four different hx >> 2 (mod 4): conflict-free at
+// every tap offset.  Weight rows (32 consecutive rows per fragment): logical ^ ((row >> 2) & 3), same argument.
+#define P3H_RB (DEFT_NP * 32)        // bytes per staged row (patch pixel or weight row): DEFT_NP pieces x 16 k x 2 B
+#define P3H_SL (DEFT_NP * 2)         // 16-byte slots per row
+#define P3H_WB (64 * P3H_RB)         // one (64-row block, 16-channel block, tap) slice of the weight image
+template <int TW>
+constexpr int p3h_pitch() { return DEFT_NP == 3 ? TW + 2 : (TW + 2 + 3) / 4 * 4; }
+template <int TW>
+__device__ __forceinline__ int p3h_phys(int q, int g, int hp, int hy, int hx) {
+    return DEFT_NP == 3 ? q * 2 + (g ^ p3h_swz<TW>(hp, hy)) : (q * 2 + g) ^ ((hx >> 2) & 3);
+}
+__device__ __forceinline__ int p3h_wphys(int q, int g, int row) { return DEFT_NP == 3 ? q * 2 + (g ^ ((row >> 3) & 1)) : (q * 2 + g) ^ ((row >> 2) & 3); }
 
 template <int TH, int BN, int TPI, int TW>
+constexpr int p3h_stage_bytes(int nsb) {
+    const int apieces = ((TH + 2) * p3h_pitch<TW>() * P3H_SL + 63) / 64;
+    return 2 * apieces * 1024 + nsb * TPI * BN * P3H_RB;
+}
+// The epilogue tile (BM x (BN + 4) floats) is staged in WM passes of one wave row each when a single pass would need more LDS than the K loop:
+// with two fp16 pieces the loop of the 128-column tiles takes 50 KB and the one-pass tile 68 KB -- two workgroups per CU instead of three.
+template <int TH, int BN, int TPI, int TW, int WM>
+constexpr bool p3h_epilogue_passes() { return WM > 1 && TH * TW * (BN + 4) * 4 > p3h_stage_bytes<TH, BN, TPI, TW>(3); }
+template <int TH, int BN, int TPI, int TW, int WM>
 constexpr int p3h_lds_bytes(int nsb) {
-    const int apieces = ((TH + 2) * (TW + 2) * 6 + 63) / 64;
-    const int stage = 2 * apieces * 1024 + nsb * TPI * BN * 96;
-    const int tile = TH * TW * (BN + 4) * 4;
+    const int stage = p3h_stage_bytes<TH, BN, TPI, TW>(nsb);
+    const int tile = (p3h_epilogue_passes<TH, BN, TPI, TW, WM>() ? TH * TW / WM : TH * TW) * (BN + 4) * 4;
     return stage > tile ? stage : tile;
 }
 
@@ -487,18 +507,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     static_assert(TPI == 1 || TPI == 3, "one tap or one filter row per interval");
     static_assert(TW == 32 || (TW == 16 && TH % 2 == 0), "tile width 32, or 16 with an even number of rows");
     constexpr int NW = WM * WN, NT = NW * 64;
-    constexpr int P3H_HW = TW + 2;                     // staged patch width
+    constexpr int P3H_HW = p3h_pitch<TW>();            // staged patch row pitch (TW + 2 pixels used)
     constexpr int BM = TH * TW;
     constexpr int TM = BM / 32 / WM, TN = BN / (WN * 32);
     constexpr int HP = (TH + 2) * P3H_HW;              // staged input pixels
-    constexpr int ASLOTS = HP * 6;
+    constexpr int ASLOTS = HP * P3H_SL;
     constexpr int NAP = (ASLOTS + 63) / 64;            // A pieces per 16-channel block
     constexpr int NA = (NAP + NW - 1) / NW;
-    constexpr int PPT = BN * 6 / 64;                   // B pieces per tap
+    constexpr int PPT = BN * P3H_SL / 64;              // B pieces per tap
     constexpr int NBI = TPI * PPT;                     // B pieces per interval
     constexpr int NB = (NBI + NW - 1) / NW;
-    constexpr int ABYTES = NAP * 1024, BBYTES = TPI * BN * 96;
-    static_assert(TM >= 1 && TN >= 1 && (BM / 32) % WM == 0 && BN % (WN * 32) == 0 && (BN * 6) % 64 == 0, "tile shape");
+    constexpr int ABYTES = NAP * 1024, BBYTES = TPI * BN * P3H_RB;
+    static_assert(TM >= 1 && TN >= 1 && (BM / 32) % WM == 0 && BN % (WN * 32) == 0 && (BN * P3H_SL) % 64 == 0, "tile shape");
 
     DEFT_DYN_LDS(char, smem);
     char* const Abase = smem;
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
 
     const deft_rsrc_t rx = deft_make_rsrc(p.x3);
     const deft_rsrc_t rw = deft_make_rsrc(p.w3);       // (no tile reaches past the 128-padded weight rows: deft_p3_dispatch checks)
-    const unsigned pb = (unsigned)p.ldx3 * 6u;
+    const unsigned pb = (unsigned)p.ldx3 * (2u * DEFT_NP);
     const int nC16 = p.Cin >> 4;
 
     // ---- loader state: all of it fixed for the whole K loop (the 16-channel block and the tap move by SGPR offsets) ----
@@ -537,11 +557,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
             ++pa_w;
             const int P = jp * 64 + lane;
             if (P < ASLOTS) {
-                const int hp = P / 6, ps = P - hp * 6;
+                const int hp = P / P3H_SL, ps = P - hp * P3H_SL;
                 const int hy = hp / P3H_HW, hx = hp - hy * P3H_HW;
-                const int q = ps >> 1, g = (ps & 1) ^ p3h_swz<TW>(hp, hy);
+                int q, g;                                // which (piece, k-group) lands in physical slot ps of this pixel's row
+                if (DEFT_NP == 3) { q = ps >> 1; g = (ps & 1) ^ p3h_swz<TW>(hp, hy); }
+                else { const int lg = ps ^ ((hx >> 2) & 3); q = lg >> 1; g = lg & 1; }
                 const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                if (hx < TW + 2 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)      // (pitch padding and the map border arrive as zeros)
                     offA[ia] = (unsigned)((n * p.H + iy) * p.W + ix) * pb + (unsigned)(q * 64 + g * 16);
             }
         }
@@ -554,16 +576,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
         vB[ib] = 0;
         if (jb < NBI) {
             ++pb_w;
-            // stage byte b is row (n0 + b / 96) of the weight matrix: 64-row block (n0 + b/96) / 64, byte (..% 64) * 96 + b % 96 of its slice
-            const int tl = jb / PPT, jj = jb - tl * PPT;                                   // tap of the interval, piece of its BN x 96 B slice
-            const unsigned byte = (unsigned)(n0 & 63) * 96u + (unsigned)jj * 1024u;      // offset inside the first block of the tile
-            vB[ib] = (unsigned)((n0 >> 6) + (int)(byte / 6144u)) * (unsigned)(nC16 * 9) * 6144u + byte % 6144u + (unsigned)tl * 6144u + (unsigned)lane * 16u;
+            // stage byte b is row (n0 + b / RB) of the weight matrix: 64-row block (n0 + b/RB) / 64, byte (..% 64) * RB + b % RB of its slice
+            const int tl = jb / PPT, jj = jb - tl * PPT;                                   // tap of the interval, piece of its BN x RB-byte slice
+            const unsigned byte = (unsigned)(n0 & 63) * (unsigned)P3H_RB + (unsigned)jj * 1024u;      // offset inside the first block of the tile
+            vB[ib] = (unsigned)((n0 >> 6) + (int)(byte / (unsigned)P3H_WB)) * (unsigned)(nC16 * 9) * (unsigned)P3H_WB + byte % (unsigned)P3H_WB + (unsigned)tl * (unsigned)P3H_WB
+                     + (unsigned)lane * 16u;
         }
     }
 
     auto issueA = [&](int c16) {
         char* const as = Abase + (c16 & 1) * ABYTES;
-        const unsigned soff = (unsigned)(c16 >> 1) * 192u + (unsigned)(c16 & 1) * 32u;
+        const unsigned soff = (unsigned)(c16 >> 1) * (unsigned)(DEFT_NP * 64) + (unsigned)(c16 & 1) * 32u;
 #pragma unroll
         for (int ia = 0; ia < NA; ++ia) {
             const int jp = wave + ia * NW;
@@ -572,11 +595,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
     };
     auto issueB = [&](int it, int stage) {
         char* const bs = Bbase + stage * BBYTES;
-        const unsigned soff = (unsigned)(it * TPI) * 6144u;    // it * TPI = c16 * 9 + first tap: the (block, tap) slices of a 64-row block are consecutive
+        const unsigned soff = (unsigned)(it * TPI) * (unsigned)P3H_WB;    // it * TPI = c16 * 9 + first tap: the (block, tap) slices of a 64-row block are consecutive
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
             const int jb = wave + ib * NW;
-            if (NBI % NW == 0 || jb < NBI) deft_buffer_load_lds_x4s(rw, bs + (jb / PPT) * BN * 96 + (jb % PPT) * 1024, vB[ib], soff);
+            if (NBI % NW == 0 || jb < NBI) deft_buffer_load_lds_x4s(rw, bs + (jb / PPT) * BN * P3H_RB + (jb % PPT) * 1024, vB[ib], soff);
         }
     };
 
@@ -589,11 +612,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fg = lane >> 5;
-    int boff[TN];                                        // byte offset of this lane's B fragment row, slot of piece 0
+    int boff[TN][DEFT_NP];                               // byte offset of this lane's B fragment of piece q (row + its swizzled slot)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = (wn * TN + j) * 32 + frow;
-        boff[j] = row * 96 + ((fg ^ ((row >> 3) & 1)) * 16);
+#pragma unroll
+        for (int q = 0; q < DEFT_NP; ++q) boff[j][q] = row * P3H_RB + p3h_wphys(q, fg, row) * 16;
     }
 
     pa_w = __builtin_amdgcn_readfirstlane(pa_w);      // wave-uniform by construction; tell the compiler (scalar branches in p3_wait_vm)
@@ -627,21 +651,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
             const int tp = tap * TPI + ts;
             const int r = tp / 3, s = tp - 3 * r;
             const char* const as = Abase + (c16 & 1) * ABYTES;
-            const char* const bs = Bbase + bst * BBYTES + ts * BN * 96;
-            bf16x8 pa[TM][3], pb_[TN][3];
+            const char* const bs = Bbase + bst * BBYTES + ts * BN * P3H_RB;
+            pcx8 pa[TM][DEFT_NP], pb_[TN][DEFT_NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 // row block (wm * TM + i) of the tile: tile row = block, column = frow (TW = 32); rows 2 * block + (frow >> 4), column frow & 15 (TW = 16)
                 const int hy = TW == 32 ? wm * TM + i + r : 2 * (wm * TM + i) + (frow >> 4) + r;        // patch row
-                const int hr = hy * P3H_HW + (TW == 32 ? frow : (frow & 15)) + s;
-                const char* ap = as + hr * 96 + ((fg ^ p3h_swz<TW>(hr, hy)) * 16);
+                const int hx = (TW == 32 ? frow : (frow & 15)) + s;
+                const int hr = hy * P3H_HW + hx;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) pa[i][q] = *(const bf16x8*)(ap + q * 32);
+                for (int q = 0; q < DEFT_NP; ++q) pa[i][q] = *(const pcx8*)(as + hr * P3H_RB + p3h_phys<TW>(q, fg, hr, hy, hx) * 16);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) pb_[j][q] = *(const bf16x8*)(bs + boff[j] + q * 32);
+                for (int q = 0; q < DEFT_NP; ++q) pb_[j][q] = *(const pcx8*)(bs + boff[j][q]);
 #ifdef P3H_TIMING
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             P3H_T(3, tcur);                              // fragment reads, issue to return
@@ -651,12 +675,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb_[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][2], pb_[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][1], pb_[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][0], pb_[j][0], c, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < DEFT_NPROD; ++q) c = deft_mfma_pc(pa[i][deft_qa(q)], pb_[j][deft_qb(q)], c);
                     acc[i][j] = c;
                 }
 #ifdef P3H_TIMING
@@ -687,17 +707,32 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3h_kernel(DeftGemmDesc p, int
 
     // ---- epilogue through LDS (common.h): tile row (ty, tx) -> output pixel, clipped at the map border ----
     float* const T = (float*)smem;
-    deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
-    __syncthreads();
-    deft_epilogue_rows<BM, BN, NT>(T, p, n0, tid, [&](int row) -> long long {
-        const int y = y0 + row / TW, x = x0 + row % TW;       // (TW = 16: row block b holds tile rows 2b, 2b+1 -- the same formula)
-        return (y < p.H && x < p.W) ? (long long)(n * p.H + y) * p.W + x : -1;
-    });
+    if constexpr (p3h_epilogue_passes<TH, BN, TPI, TW, WM>()) {
+        constexpr int BMH = BM / WM;                           // one wave row of the tile per pass
+#pragma unroll 1
+        for (int half = 0; half < WM; ++half) {
+            if (wm == half) deft_epilogue_stage<TM, TN>(T, BN + 4, acc, 0, wn, lane, p, n0);
+            __syncthreads();
+            deft_epilogue_rows<BMH, BN, NT>(T, p, n0, tid, [&](int row) -> long long {
+                const int rr = half * BMH + row;
+                const int y = y0 + rr / TW, x = x0 + rr % TW;
+                return (y < p.H && x < p.W) ? (long long)(n * p.H + y) * p.W + x : -1;
+            });
+            __syncthreads();
+        }
+    } else {
+        deft_epilogue_stage<TM, TN>(T, BN + 4, acc, wm, wn, lane, p, n0);
+        __syncthreads();
+        deft_epilogue_rows<BM, BN, NT>(T, p, n0, tid, [&](int row) -> long long {
+            const int y = y0 + row / TW, x = x0 + row % TW;       // (TW = 16: row block b holds tile rows 2b, 2b+1 -- the same formula)
+            return (y < p.H && x < p.W) ? (long long)(n * p.H + y) * p.W + x : -1;
+        });
+    }
 }
 
 template <int TH, int BN, int WM, int WN, int TPI, int TW>
 static int launch_p3h(const DeftGemmDesc& d, hipStream_t s) {
-    constexpr int lds = p3h_lds_bytes<TH, BN, TPI, TW>(3);
+    constexpr int lds = p3h_lds_bytes<TH, BN, TPI, TW, WM>(3);
     const int tiles_x = deft_cdiv(d.W, TW), tiles_y = deft_cdiv(d.H, TH), ntiles = deft_cdiv(d.Cout, BN);
     const long long grid = (long long)d.N * tiles_x * tiles_y * ntiles;
     DEFT_CHECK(grid < (1ll << 31), -70, "conv3h: too many tiles");
@@ -735,28 +770,30 @@ int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s) {
 }
 
 // one thread per 16-byte slot of the halo-form weight image [CoutPad/64][Cin/16][9][64 rows][6 slots]
-__global__ __launch_bounds__(256) void split_weights_h_kernel(const float* __restrict__ w, __bf16* __restrict__ w3, int CoutPad, int Kpad) {
+__global__ __launch_bounds__(256) void split_weights_h_kernel(const float* __restrict__ w, deft_piece_t* __restrict__ w3, int CoutPad, int Kpad) {
     const int nC16 = Kpad / 144;                                         // Kpad = 9 * Cin
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)CoutPad * nC16 * 9 * 6) return;
-    const int ps = (int)(i % 6);
-    long long t = i / 6;
+    if (i >= (long long)CoutPad * nC16 * 9 * P3H_SL) return;
+    const int ps = (int)(i % P3H_SL);
+    long long t = i / P3H_SL;
     const int r = (int)(t & 63); t >>= 6;
     const int tap = (int)(t % 9); t /= 9;
     const int c16 = (int)(t % nC16), blk = (int)(t / nC16);
-    const int q = ps >> 1, g = (ps & 1) ^ ((r >> 3) & 1);
+    int q, g;                                                            // (inverse of p3h_wphys)
+    if (DEFT_NP == 3) { q = ps >> 1; g = (ps & 1) ^ ((r >> 3) & 1); }
+    else { const int lg = ps ^ ((r >> 2) & 3); q = lg >> 1; g = lg & 1; }
     const float* wp = w + (size_t)(blk * 64 + r) * Kpad + ((c16 >> 1) * 9 + tap) * 32 + (c16 & 1) * 16 + g * 8;     // korder 1
-    bf16x4 pc[2][3];
-    split3(*(const f32x4*)wp, pc[0][0], pc[0][1], pc[0][2]);
-    split3(*(const f32x4*)(wp + 4), pc[1][0], pc[1][1], pc[1][2]);
-    *(bf16x8*)(w3 + i * 8) = __builtin_shufflevector(pc[0][q], pc[1][q], 0, 1, 2, 3, 4, 5, 6, 7);
+    pcx4 pc[2][DEFT_NP];
+    deft_split(*(const f32x4*)wp, pc[0]);
+    deft_split(*(const f32x4*)(wp + 4), pc[1]);
+    *(pcx8*)(w3 + i * 8) = __builtin_shufflevector(pc[0][q], pc[1][q], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 extern "C" int deft_split_weights_halo(const float* w, void* w3, int CoutPad, int Kpad, void* stream) {
     DEFT_CHECK(w && w3 && CoutPad > 0 && (CoutPad & 63) == 0 && Kpad > 0 && Kpad % 288 == 0, -1,
                "deft_split_weights_halo: need CoutPad %% 64 == 0 and Kpad = 9 * Cin with Cin %% 32 == 0 (%d, %d)", CoutPad, Kpad);
-    const long long tot = (long long)CoutPad * (Kpad / 144) * 9 * 6;
-    hipLaunchKernelGGL(split_weights_h_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, CoutPad, Kpad);
+    const long long tot = (long long)CoutPad * (Kpad / 144) * 9 * P3H_SL;
+    hipLaunchKernelGGL(split_weights_h_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, w, (deft_piece_t*)w3, CoutPad, Kpad);
     DEFT_CHECK_LAUNCH("split_weights_halo");
     return 0;
 }

@@ -16,6 +16,7 @@ void deft_set_error(const char* fmt, ...) {
 }
 extern "C" const char* deft_last_error(void) { return g_err; }
 extern "C" int deft_version(void) { return DEFT_ABI_VERSION; }
+extern "C" int deft_pieces(void) { return DEFT_NP; }
 
 // ---------------------------------------------------------------------------
 // layout adapters
@@ -160,7 +161,7 @@ extern "C" int deft_maxpool2x2(const float* x, float* y, int N, int H, int W, in
 // out[oy] gathers in[iy]*w[ky] with ky = oy + f/2 - iy*f in [0,2f): two rows, two cols.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ wup,
-                                                           const float* __restrict__ skip, float* __restrict__ y, __bf16* __restrict__ y3,
+                                                           const float* __restrict__ skip, float* __restrict__ y, deft_piece_t* __restrict__ y3,
                                                            int N, int H, int W, int C4, int f, int ldx, int lds, int ldy, int ldy3) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int OH = H * f, OW = W * f;
@@ -195,12 +196,13 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
     const float4 s = *(const float4*)(skip + o * lds + 4 * c4);
     const f32x4 r = {acc[0] + s.x, acc[1] + s.y, acc[2] + s.z, acc[3] + s.w};
     *(f32x4*)(y + o * ldy + 4 * c4) = r;
-    if (y3 != nullptr) {                       // the three bf16 pieces for a following pre-split conv (DeftGemmDesc.x3 layout)
-        bf16x4 h, m, l;
-        split3(r, h, m, l);
+    if (y3 != nullptr) {                       // the operand pieces for a following pre-split conv (DeftGemmDesc.x3 layout)
+        pcx4 pc[DEFT_NP];
+        deft_split(r, pc, DEFT_ASCALE);
         const int c = 4 * c4;
-        __bf16* yp = y3 + o * ldy3 * 3 + (c >> 5) * 96 + (c & 31);
-        *(bf16x4*)yp = h; *(bf16x4*)(yp + 32) = m; *(bf16x4*)(yp + 64) = l;
+        deft_piece_t* yp = y3 + o * ldy3 * DEFT_NP + (c >> 5) * (32 * DEFT_NP) + (c & 31);
+#pragma unroll
+        for (int q = 0; q < DEFT_NP; ++q) *(pcx4*)(yp + 32 * q) = pc[q];
     }
 }
 
@@ -211,7 +213,7 @@ extern "C" int deft_upsample_add(const float* x, const float* wup, const float* 
     DEFT_CHECK(x && wup && skip && y && (C & 3) == 0 && f >= 2 && (f & 1) == 0, -1, "deft_upsample_add: bad arguments (C=%d f=%d)", C, f);
     DEFT_CHECK((ldx & 3) == 0 && (lds & 3) == 0 && (ldy & 3) == 0, -2, "deft_upsample_add: ld %% 4 != 0");
     const long long tot = (long long)N * H * f * W * f * (C / 4);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, wup, skip, y, (__bf16*)y3, N, H, W, C / 4, f, ldx, lds, ldy, ldy3);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(deft_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, wup, skip, y, (deft_piece_t*)y3, N, H, W, C / 4, f, ldx, lds, ldy, ldy3);
     DEFT_CHECK_LAUNCH("upsample_add");
     return 0;
 }

@@ -203,6 +203,25 @@ DATAFLOW = int(_os.environ.get("DEFT_DATAFLOW", "2"))
 DATAFLOW_MAX_N = int(_os.environ.get("DEFT_DATAFLOW_MAX_N", "1"))
 
 
+def weight_row_shift(w):
+    """Per-row power-of-two exponents k for a packed weight matrix w [rows, K] (any device): the row's largest |entry| times 2^k lies in
+    [2^12, 2^13) -- what the two-piece fp16 split (csrc/common.h, DEFT_PIECES = 2) wants: the first piece a normal fp16 number with 3 binades
+    of headroom below 65504, the second piece (<= 2^-11 of it) normal for every entry within 2^-10 of the row's largest.  All-zero rows: 0."""
+    m = w.abs().amax(1)
+    e = torch.frexp(torch.where(m > 0, m, torch.ones_like(m)))[1]           # m = mant * 2^e, mant in [0.5, 1)
+    return torch.where(m > 0, 13 - e, torch.zeros_like(e)).to(torch.int32)
+
+
+def scale_weight_rows(w, scale, cout):
+    """(w * 2^k per row, scale * 2^-k): the same GEMM result bit for bit (powers of two commute with every rounding), weights in fp16 range.
+    scale None -> ones.  Used by _Plan.prescale for every split-arithmetic launch of a two-piece build; tests that drive the C ABI
+    directly with their own descriptors call it themselves."""
+    k = weight_row_shift(w)
+    w2 = torch.ldexp(w, k.view(-1, 1))
+    sc = torch.ones(cout, dtype=torch.float32, device=w.device) if scale is None else scale
+    return w2.contiguous(), torch.ldexp(sc, -k[:cout]).contiguous()
+
+
 class _P3Out:
     """A producer's optional P3 (three bf16 pieces) output: written only if some pre-split conv reads it (`used`)."""
 
@@ -269,7 +288,12 @@ class _Plan:
         if (self.device.type == "cuda") == bool(getattr(self.lib, "host_pointers", False)):
             raise hiplib.DeftHipError("deft_amd runs on an MI355X only: device %s with %s (there is no CPU path)"
                                       % (self.device, self.lib.path))
-        self._p3 = {}          # id(fp32 buffer) -> bf16 tensor holding its three-piece (P3) form
+        self.np = int(getattr(self.lib, "pieces", 3))      # operand pieces of the library's split arithmetic: 3 (bf16) or 2 (fp16), csrc/common.h
+        self._by_ptr = {}      # data_ptr -> device tensor uploaded through dev() (prescale looks weights / scales up by descriptor pointer)
+        self._wscaled = {}     # packed weight data_ptr -> (row-scaled copy, exponents) of a two-piece build
+        self._wscaled_ptrs = set()
+        self._sscaled = {}     # (weight data_ptr, scale data_ptr or None, Cout) -> compensated epilogue scale
+        self._p3 = {}          # id(fp32 buffer) -> 16-bit tensor holding its piece (P3) form
         self._p3_cover = {}    # id(fp32 buffer) -> [(ch_lo, ch_hi, producing descriptor or None)] channel ranges with valid P3 data
         self._p3_outs = []     # _P3Out records of every producer that can write a P3 copy of its output
         self._w3 = {}          # packed fp32 weight data_ptr -> P3 weight image
@@ -284,7 +308,42 @@ class _Plan:
     def dev(self, t):
         t = t.contiguous().to(self.device)
         self._keep.append(t)
+        self._by_ptr[t.data_ptr()] = t
         return t
+
+    def _scaled_weight(self, w):
+        """Two-piece builds: the row-scaled copy of a packed weight matrix (cached) and its exponents; else (w, None)."""
+        if self.np != 2 or PREC != 1:
+            return w, None
+        hit = self._wscaled.get(w.data_ptr())
+        if hit is None:
+            k = weight_row_shift(w)
+            hit = self._wscaled[w.data_ptr()] = (torch.ldexp(w, k.view(-1, 1)).contiguous(), k)
+            self._wscaled_ptrs.add(hit[0].data_ptr())
+            self._keep.append(w)
+            self._by_ptr[hit[0].data_ptr()] = hit[0]
+        return hit
+
+    def prescale(self, d):
+        """Two-piece (fp16) builds: point a split-arithmetic descriptor at the row-scaled weights and the compensated epilogue scale
+        (weight_row_shift).  Idempotent; a no-op for three-piece builds and fp32-MFMA descriptors."""
+        if self.np != 2 or d.prec != 1 or not d.w:
+            return
+        if d.w in self._wscaled_ptrs:
+            return                                                       # already scaled
+        w = self._by_ptr.get(d.w)
+        if w is None:
+            raise hiplib.DeftHipError("prescale: weight matrix %#x was not uploaded through _Plan.dev()" % d.w)
+        w2, k = self._scaled_weight(w)
+        key = (w.data_ptr(), d.scale or 0, d.Cout)
+        sc2 = self._sscaled.get(key)
+        if sc2 is None:
+            sc = self._by_ptr.get(d.scale) if d.scale else None
+            if d.scale and sc is None:
+                raise hiplib.DeftHipError("prescale: scale vector %#x was not uploaded through _Plan.dev()" % d.scale)
+            base = torch.ones(d.Cout, dtype=torch.float32, device=self.device) if sc is None else sc[:d.Cout]
+            sc2 = self._sscaled[key] = torch.ldexp(base, -k[:d.Cout]).contiguous()
+        d.w, d.scale = w2.data_ptr(), sc2.data_ptr()
 
     def alloc(self, N, H, W, C, ld=None):
         ld = _rup(C, 4) if ld is None else ld
@@ -524,10 +583,10 @@ class _Plan:
         assert self.p3_capable(v)
         t = self._p3.get(id(v.buf))
         if t is None:
-            t = torch.zeros(v.buf.numel() * 3, dtype=torch.bfloat16, device=self.device)
+            t = torch.zeros(v.buf.numel() * self.np, dtype=torch.int16, device=self.device)      # (bf16 or fp16 pieces: the kernels' business)
             self._p3[id(v.buf)] = t
         pix, ch = divmod(v.c0, v.ld)
-        return t.data_ptr() + 2 * (pix * 3 * v.ld + (ch // 32) * 96)
+        return t.data_ptr() + 2 * (pix * self.np * v.ld + (ch // 32) * 32 * self.np)
 
     def _p3_input(self, name, v):
         """P3 address of an input view; channel ranges no producer has written in P3 form yet are converted now
@@ -557,7 +616,8 @@ class _Plan:
         halo = "dcn": the patch form's image of a DCN weight matrix (pack_dcn_weight)."""
         key = (w_packed.data_ptr(), halo)
         if key not in self._w3:
-            w3 = torch.empty(w_packed.numel() * 3, dtype=torch.bfloat16, device=self.device)
+            w3 = torch.empty(w_packed.numel() * self.np, dtype=torch.int16, device=self.device)
+            w_packed = self._scaled_weight(w_packed)[0]              # (two-piece builds: the row-scaled matrix; prescale() compensates in the epilogue scale)
             if halo == "dcn":
                 self.lib.call("deft_split_weights_dcn", ptr(w_packed), C.c_void_p(w3.data_ptr()), w_packed.shape[0], w_packed.shape[1] // 9,
                               hiplib.stream_ptr(self.device))
@@ -587,6 +647,7 @@ class _Plan:
     # ---- op builders -------------------------------------------------------
     def gemm(self, entry, name, desc, flops, reads=None, writes=None):
         desc.prec = PREC
+        self.prescale(desc)
         self._keep.append(desc)
         lib, ref = self.lib, C.byref(desc)
         self._op_desc[len(self.ops)] = desc
@@ -683,6 +744,9 @@ class _Plan:
         if res is not None:
             assert (res.H, res.W, res.C) == (OH, OW, Cout), name
         d = GemmDesc()
+        for t_ in (w_packed, scale):                     # (callers outside the plans hand over tensors that did not go through dev())
+            if t_ is not None:
+                self._by_ptr.setdefault(t_.data_ptr(), t_)
         d.x = x.addr; d.x2 = None; d.w = w_packed.data_ptr()
         d.scale = scale.data_ptr() if scale is not None else None
         d.shift = shift.data_ptr() if shift is not None else None
@@ -1307,6 +1371,7 @@ class AfePlan(_Plan):
         d.relu = int(relu); d.Q = 0; d.ldom = 0; d.tile = 0; d.prec = PREC
         if BDMA and PREC == 1 and Cout >= 128:
             d.w3 = self.weights_p3(wp).data_ptr()
+        self.prescale(d)
         self.lib.call("deft_conv2d_nhwc", C.byref(d), self._stream())
 
     def _staged_ints(self, values):
@@ -1381,6 +1446,7 @@ class AfePlan(_Plan):
         d.relu = 1; d.Q = Q; d.ldom = 0; d.tile = 0; d.prec = PREC
         if BDMA and PREC == 1:
             d.w3 = self.weights_p3(w2).data_ptr()
+        self.prescale(d)
         self.lib.call("deft_pair_layer", C.byref(d), self._stream())
         h3 = self._work("h3", M * c3).view(M, c3)
         self._lin(h2, M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, h3, c3)
@@ -1434,6 +1500,7 @@ class AfePlan(_Plan):
             d.relu = 1; d.Q = K; d.ldom = 0; d.tile = 0; d.prec = PREC
             if BDMA and PREC == 1:
                 d.w3 = self.weights_p3(w2).data_ptr()
+            self.prescale(d)
             d.Tper, d.u0, d.du, d.v0, d.dv = hist * K, (g0 + c0 - hist) * K, K, (g0 + c0) * K, K
             self.lib.call("deft_pair_layer", C.byref(d), self._stream())
             self._lin(b["h2"], M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, b["h3"], c3)

@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
 
 _SIGS = {
     "deft_version": (C.c_int, []),
+    "deft_pieces": (C.c_int, []),
     "deft_last_error": (C.c_char_p, []),
     "deft_conv2d_nhwc": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "deft_conv2d_group": (C.c_int, [C.POINTER(GemmDesc), c_fp, C.c_int, c_fp]),
@@ -77,7 +78,7 @@ _SIGS = {
     "deft_iou3d_matrix": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class DeftHipError(RuntimeError):
@@ -103,6 +104,8 @@ class HipLib:
         v = self.cdll.deft_version()
         if v != ABI_VERSION:
             raise DeftHipError("libdeft_hip ABI version %d, expected %d -- rebuild: python -m deft_amd.build" % (v, ABI_VERSION))
+        # operand pieces of the split arithmetic of this build: 3 = bf16 x 3 (six products), 2 = fp16 x 2 (three products); sizes the piece buffers
+        self.pieces = int(self.cdll.deft_pieces())
 
     profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1, shape, algorithmic_bytes) per call
 
@@ -136,10 +139,11 @@ class HipLib:
                 nbytes = alg_bytes(d)
                 info = "M=%d N=%d K=%d %dx%d s%d @%dx%d" % (d.M, d.Cout, d.Ktot, d.KH, d.KW, d.stride, d.H, d.W)
                 if name == "deft_conv_direct":
-                    ceil = 2500.0 / 6   # six v_mfma_f32_16x16x32_bf16 per fp32 product
+                    ceil = 2500.0 / 6   # six v_mfma_f32_16x16x32_bf16 per fp32 product (three bf16 pieces in every build)
                     info += " split direct"
                 elif self.split_arithmetic(name, d):
-                    ceil = 2500.0 / 6   # ... or six v_mfma_f32_32x32x16_bf16 per fp32 product (bf16 dense peak / 6)
+                    # ... or six v_mfma_f32_32x32x16_bf16 (three bf16 pieces) / three v_mfma_f32_32x32x16_f16 (two fp16 pieces) per fp32 product
+                    ceil = 2500.0 / (6 if self.pieces == 3 else 3)
                     info += " split" + (" patch" if d.p3_kernel in (2, 3) else " halo" if d.p3_kernel else (" x3" if d.x3 else ""))
             prof.append((name, fl, e0, e1, info, nbytes, ceil))
 

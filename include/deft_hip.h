@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 9
+#define DEFT_ABI_VERSION 10
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -124,6 +124,10 @@ typedef struct DeftGemmDesc {
 } DeftGemmDesc;
 
 int deft_version(void);
+/* operand pieces of the split arithmetic (DeftGemmDesc.prec = 1) of THIS build: 3 = three bf16 pieces, six v_mfma_f32_32x32x16_bf16 products per
+   fp32 product; 2 = two fp16 pieces, three v_mfma_f32_32x32x16_f16 products (csrc/common.h DEFT_PIECES).  Sizes every x3 / y3 / w3 buffer:
+   pieces * 2 bytes per element.  With 2 pieces the host scales every weight row by a power of two (deft_amd/engine.py weight_row_shift). */
+int deft_pieces(void);
 const char* deft_last_error(void);
 
 /* Conv2d (+folded BatchNorm, +residual, +ReLU) as an FP32-MFMA implicit GEMM.

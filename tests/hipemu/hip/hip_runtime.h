@@ -347,6 +347,24 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_bf16x
     }
     return c;
 }
+// 32x32x16 f16 (gfx950): same fragment layout; products of fp16 values (11 x 11 significant bits) are exact in fp32 too.
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c, int, int, int) {
+    hipemu::State& s = hipemu::S();
+    const int p = s.parity ^ 1, lane = s.lane;
+    for (int e = 0; e < 8; ++e) { s.xf[p][e][lane] = (float)a[e]; s.xf[p][8 + e][lane] = (float)b[e]; }
+    hipemu::yield(hipemu::Y_WAVE);
+    hipemu::State& t = hipemu::S();
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kg = 0; kg < 2; ++kg)
+            for (int e = 0; e < 8; ++e) acc = fmaf(t.xf[p][e][row + 32 * kg], t.xf[p][8 + e][col + 32 * kg], acc);
+        c[r] = acc;
+    }
+    return c;
+}
 // 16x16x32 bf16 (gfx950): lane l feeds row/col l&15 with the 8 consecutive k of group l>>4; D reg r of lane l is row 4*(l>>4)+r, col l&15.
 static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c, int, int, int) {
     hipemu::State& s = hipemu::S();

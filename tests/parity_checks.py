@@ -54,7 +54,7 @@ def check_conv(lib, device, N, H, W, Ci, Co, k, stride, pad, tile, res=False, re
         assert plan._gemms[-1][2].p3_kernel == 1 and plan._gemms[-1][2].x3
     plan.run()
     if p3 == "halo" and plan._gemms[-1][2].y3:
-        assert torch.equal(p3_to_float(plan, out).cpu(), out.to_nchw().permute(0, 2, 3, 1).cpu()), "P3 epilogue output != fp32 output"
+        assert p3_equals(plan, out), "P3 epilogue output != fp32 output"
     ref = F.conv2d(x, w, None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if res:
         ref = ref + r
@@ -63,6 +63,40 @@ def check_conv(lib, device, N, H, W, Ci, Co, k, stride, pad, tile, res=False, re
     err = maxabs(out.to_nchw(), ref)
     assert err <= 2e-5 * max(1.0, float(ref.abs().max())), ("conv", N, H, W, Ci, Co, k, stride, tile, err)
     return err
+
+
+def check_split_identity(lib, device):
+    """prec = 1 carries every fp32 operand through the matrix cores as pieces: a 1x1 conv with an identity weight matrix returns its input.
+    Three bf16 pieces (DEFT_PIECES = 3): bit for bit over 60 binades, full 24-bit mantissas.  Two fp16 pieces (DEFT_PIECES = 2): to half an
+    fp32 ulp (2^-24 relative, 2^-29 absolute below |x| = 2^-6) for every |x| < 4094 -- and +-inf / NaN, never a wrong finite value, beyond
+    that range (the statement of csrc/common.h, checked here element by element)."""
+    g = torch.Generator().manual_seed(5)
+    C = 64
+    plan = engine._Plan(device, lib)
+    lo, hi = (-30, 30) if plan.np == 3 else (-30, 11)
+    x = torch.randn(1, C, 6, 8, generator=g).clamp(-1.99, 1.99) * torch.exp2(torch.randint(lo, hi, (1, C, 6, 8), generator=g).float())
+    x[0, 0, 0, 0] = 1.0 + 2.0 ** -23; x[0, 1, 0, 0] = -(2.0 - 2.0 ** -23); x[0, 2, 0, 0] = 0.0
+    if plan.np == 2:
+        x[0, 3, 0, 0] = 4093.0; x[0, 4, 0, 0] = -4093.5; x[0, 5, 0, 0] = 1e6; x[0, 6, 0, 0] = -3e38       # the edge of the range, and beyond it
+    xv = plan.alloc(1, 6, 8, C); fill_view(xv, x)
+    wp, K = engine.pack_conv_weight(torch.eye(C).view(C, C, 1, 1), C)
+    out = plan.conv("id", xv, plan.dev(wp), K, 1, 1, 1, 0, C, None, None, False, tile=T(64, 64))
+    assert plan._gemms[-1][2].prec == 1
+    plan.run()
+    if device != "cpu":
+        torch.cuda.synchronize()
+    y = out.to_nchw().cpu()
+    if plan.np == 3:
+        assert torch.equal(y, x)
+        return 0.0
+    far = x.abs() >= 4094.0
+    assert not torch.isfinite(y[far]).any(), "an operand beyond the fp16 range must not come back as a finite value"
+    # (a NaN lane poisons nothing else here: the identity matrix multiplies it by zero only in OTHER output columns -- 0 * inf = NaN there)
+    ok = ~far.any(dim=1, keepdim=True).expand_as(far)          # pixels (GEMM rows) none of whose channels overflowed
+    err = (y - x).abs()
+    lim = x.abs() * 2.0 ** -23 + 2.0 ** -29
+    assert bool((err[ok] <= lim[ok]).all()), float((err[ok] / lim[ok]).max())
+    return float(err[ok].max())
 
 
 def check_conv_pair(lib, device, Ci, k, N=2, H=6, W=10, Co=16, seed=0):
@@ -870,10 +904,23 @@ def stable_frame(sd, dataset, H, W, K=100, seed0=0, delta=2e-4, trials=4, max_tr
 # ---------------------------------------------------------------------------
 # pre-split operands (DeftGemmDesc.x3 / w3 / y3, igemm3.hip)
 def p3_to_float(plan, v):
-    """fp32 value of a view's P3 companion: hi + mid + lo, [N,H,W,C]."""
-    t = plan._p3[id(v.buf)].view(-1, v.ld // 32, 3, 32).float().sum(2)           # exact: the pieces do not overlap
+    """fp32 value of a view's piece-form (P3) companion, [N,H,W,C]: hi + mid + lo of the three bf16 pieces (exact), or (h1 + h2) / 16 of
+    the two fp16 pieces of a DEFT_PIECES = 2 build (the value to half an fp32 ulp, csrc/common.h)."""
+    n = plan.np
+    t = plan._p3[id(v.buf)].view(torch.bfloat16 if n == 3 else torch.float16).view(-1, v.ld // 32, n, 32).float().sum(2)
+    if n == 2:
+        t = t / 16.0
     pix, ch = divmod(v.c0, v.ld)
     return t.reshape(-1, v.ld)[pix:pix + v.N * v.H * v.W, ch:ch + v.C].reshape(v.N, v.H, v.W, v.C)
+
+
+def p3_equals(plan, v):
+    """Does the piece form of a view carry its fp32 values?  Three bf16 pieces: bit for bit.  Two fp16 pieces: |x - (h1 + h2)| <= 2^-24 |x|
+    while h2 is a normal fp16 number, 2^-25 / 16 absolute below that (|x| < 2^-6), and every |x| < 4094 representable."""
+    a, b = p3_to_float(plan, v).cpu(), v.to_nchw().permute(0, 2, 3, 1).cpu()
+    if plan.np == 3:
+        return torch.equal(a, b)
+    return bool(((a - b).abs() <= b.abs() * 2.0 ** -23 + 2.0 ** -29).all())
 
 
 def refresh_p3(plan, v):
@@ -927,7 +974,7 @@ def _check_conv_p3(lib, device, N, H, W, Ci, Cm, Co, k, stride, tile, tile2, see
         plan.finalize_p3()
         plan.run()
         if p3 is None:
-            assert torch.equal(p3_to_float(plan, t).cpu(), t.to_nchw().permute(0, 2, 3, 1).cpu()), "P3 epilogue output != fp32 output"
+            assert p3_equals(plan, t), "P3 epilogue output != fp32 output"
             assert float(cat.buf.view(N, OH, OW, cat.ld)[..., :32].abs().max()) == 0.0
         outs.append((t.to_nchw().cpu(), o.to_nchw().cpu()))
     ref1 = F.relu(F.conv2d(x, w1, None, stride, pad) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
@@ -964,7 +1011,7 @@ def check_conv_inloop_y3(lib, device, N=2, H=13, W=18, Ci=32, Cm=64, Co=64, k=3,
     assert not d1.x3 and d1.y3 and d2.x3, "expected: in-loop conv with a piece-form output feeding a pre-split conv"
     assert "deft_split_planes" not in [op[0] for op in plan.ops]
     plan.run()
-    assert torch.equal(p3_to_float(plan, t).cpu(), t.to_nchw().permute(0, 2, 3, 1).cpu()), "piece-form output != fp32 output"
+    assert p3_equals(plan, t), "piece-form output != fp32 output"
     ref1 = F.relu(F.conv2d(x, w1, None, stride, pad) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1) + r)
     ref2 = F.relu(F.conv2d(ref1, w2, None, 1, 1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
     assert maxabs(t.to_nchw(), ref1) <= 2e-5 * max(1.0, float(ref1.abs().max()))
@@ -1145,7 +1192,7 @@ def check_weight_dma_identical(lib, device, seed=0):
             dd = dplan._gemms[-1][2]
             assert not dd.w3 and dd.p3_kernel == 0 and dd.y3           # the DCN also writes its output as bf16 pieces ...
             plan.run(); dplan.run()
-            assert torch.equal(p3_to_float(dplan, od).cpu(), od.to_nchw().permute(0, 2, 3, 1).cpu())   # ... which equal the fp32 map exactly
+            assert p3_equals(dplan, od)   # ... which equal the fp32 map exactly
             outs.append([r.to_nchw().cpu() for r in res] + [od.to_nchw().cpu()])
         finally:
             engine.BDMA, engine.P3_HALO, engine.DCN_PATCH = saved

@@ -701,22 +701,11 @@ def test_conv_presplit_splitk(gpu_lib):
 
 
 def test_split_is_exact_identity_conv(gpu_lib):
-    """prec = 1: the three-way bf16 split of an fp32 operand is exact and the matrix core adds the pieces without
-    loss -- a 1x1 conv with an identity weight matrix returns its input bit for bit (60 binades, full mantissas)."""
+    """prec = 1: the operand pieces carry fp32 values through the matrix cores -- exactly (three bf16 pieces) or to half an fp32 ulp inside
+    the fp16 range and loudly beyond it (two fp16 pieces).  See parity_checks.check_split_identity."""
     from deft_amd import engine
     assert engine.PREC == 1
-    g = torch.Generator().manual_seed(5)
-    C = 64
-    x = torch.randn(1, C, 6, 8, generator=g) * torch.exp2(torch.randint(-30, 30, (1, C, 6, 8), generator=g).float())
-    x[0, 0, 0, 0] = 1.0 + 2.0 ** -23; x[0, 1, 0, 0] = -(2.0 - 2.0 ** -23); x[0, 2, 0, 0] = 0.0
-    plan = engine._Plan("cuda", gpu_lib)
-    xv = plan.alloc(1, 6, 8, C); pc.fill_view(xv, x)
-    wp, K = engine.pack_conv_weight(torch.eye(C).view(C, C, 1, 1), C)
-    out = plan.conv("id", xv, plan.dev(wp), K, 1, 1, 1, 0, C, None, None, False, tile=pc.T(64, 64))
-    assert plan._gemms[-1][2].prec == 1
-    plan.run()
-    torch.cuda.synchronize()
-    assert torch.equal(out.to_nchw().cpu(), x)
+    pc.check_split_identity(gpu_lib, "cuda")
 
 
 @pytest.mark.parametrize("N,H,W", [(1, 608, 1088), (2, 96, 160)])
@@ -784,6 +773,33 @@ def test_afe_and_lstm_launches_bit_exact_beside_another_kernel(gpu_lib):
     forms of the affinity chain, the LSTM step and the fused motion step -- each beside a foreign matrix-core launch, bit for bit."""
     n, names = pc.check_co_residency_afe_lstm(gpu_lib)
     print("co-residency, AFE / LSTM chain: %d launches beside a foreign kernel, bit-exact; entries %s" % (n, names))
+
+
+def test_motion_bank_shared_by_two_callers(gpu_lib):
+    """several trackers share one MotionBank (model.motion: the seven per-class nuScenes trackers, two 2-D trackers on one model) and
+    each reads its asynchronous step a frame later.  With ONE pinned (in, out) pair per bank the second caller's copies landed in the first
+    caller's buffers before it had read them; every call in flight owns its pair now.  Two interleaved callers against the blocking step()."""
+    import numpy as np
+    from deft_amd import engine, tracker as DT
+    lsd = O.synth_lstm_state_dict("mot")
+    shared = DT.MotionBank(engine.LstmPlan(lsd, "cuda", gpu_lib))
+    ref = DT.MotionBank(engine.LstmPlan(lsd, "cuda", gpu_lib))
+    sa, sb = [shared.alloc() for _ in range(40)], [shared.alloc() for _ in range(70)]
+    ra, rb = [ref.alloc() for _ in range(40)], [ref.alloc() for _ in range(70)]
+    g = np.random.RandomState(3)
+    pend = None
+    for fid in range(1, 6):
+        ba, bb = g.rand(40, 4) * 80 + 5, g.rand(70, 4) * 80 + 5
+        wa = shared.step_async(sa, ba, fid)
+        wb = shared.step_async(sb, bb, fid)               # the second caller steps before the first has read its result ...
+        ea, eb = ref.step(ra, ba, fid)[1], ref.step(rb, bb, fid)[1]
+        if pend is not None:                              # ... and results are read a frame later, like ArrayTracker._resolve does
+            (pa, xa), (pb, xb) = pend
+            assert np.array_equal(pa(), xa) and np.array_equal(pb(), xb)
+            assert np.array_equal(pa(), xa)               # (a second read returns the same array)
+        pend = ((wa, ea), (wb, eb))
+    (pa, xa), (pb, xb) = pend
+    assert np.array_equal(pb(), xb) and np.array_equal(pa(), xa)
 
 
 @pytest.mark.parametrize("tag", ["mot", "mot_lstm", "nuscenes"])
