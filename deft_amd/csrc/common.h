@@ -88,11 +88,54 @@ __device__ __forceinline__ deft_f32x16 deft_mfma_pc(const pcx8 a, const pcx8 b, 
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 #endif
 }
+#if DEFT_PIECES == 2
+// Two fp16 pieces of a PAIR of values in 3 (4 with a scale) VALU instructions: h = (fp16(x0), fp16(x1)) packed, m = (fp16(x0 - h.lo),
+// fp16(x1 - h.hi)) -- v_fma_mix{lo,hi}_f16 computes x - h in fp32 (exact: the residual of a round-to-nearest fp16 conversion is an fp32
+// number) and rounds ONCE to fp16 into one half of the destination: the same bits as `(_Float16)(x - (float)(_Float16)x)`.  hipcc's own code
+// for that expression is 9-10 instructions per pair inside the kernels (separate conversions, v_cvt_f32_f16 + v_sub, canonicalising v_max);
+// tools/probe/f16_split_asm.hip checks these sequences against the C++ expression on the hardware, bit for bit.  `sc` (a power of two) is
+// folded into the same instructions.  (Outputs feed LDS / global stores or, a K step later, matrix instructions: no asm-to-MFMA adjacency.)
+#ifndef DEFT_F16_SPLIT_HOOK    /* the unit-test SIMT emulator pre-defines this hook with the C++ expression */
+__device__ __forceinline__ void deft_split2_pair(float x0, float x1, unsigned& h, unsigned& m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(m) : "v"(h), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(h), "v"(x1));
+#else
+    h = m = 0; (void)x0; (void)x1;
+#endif
+}
+__device__ __forceinline__ void deft_split2_pair_scaled(float x0, float x1, float sc, unsigned& h, unsigned& m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "s"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "s"(sc));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(x0), "s"(sc), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(x1), "s"(sc), "v"(h));
+#else
+    h = m = 0; (void)x0; (void)x1; (void)sc;
+#endif
+}
+#endif
+#endif
 // the pieces of four values (A operands: pass scale = DEFT_ASCALE; weights arrive scaled by the host: scale = 1)
 __device__ __forceinline__ void deft_split(const f32x4 v, pcx4 (&pc)[DEFT_NP], const float scale = 1.f) {
+#if DEFT_PIECES == 2
+    typedef unsigned deft_u32x2 __attribute__((ext_vector_type(2)));
+    unsigned h0, m0, h1, m1;
+    if (scale == 1.f) {
+        deft_split2_pair(v[0], v[1], h0, m0);
+        deft_split2_pair(v[2], v[3], h1, m1);
+    } else {
+        deft_split2_pair_scaled(v[0], v[1], scale, h0, m0);
+        deft_split2_pair_scaled(v[2], v[3], scale, h1, m1);
+    }
+    const deft_u32x2 h = {h0, h1}, m = {m0, m1};
+    pc[0] = __builtin_bit_cast(pcx4, h);
+    pc[1] = __builtin_bit_cast(pcx4, m);
+#else
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float r = DEFT_NP == 2 ? v[e] * scale : v[e];
+        float r = v[e];
 #pragma unroll
         for (int q = 0; q < DEFT_NP; ++q) {
             const deft_piece_t h = (deft_piece_t)r;
@@ -100,6 +143,8 @@ __device__ __forceinline__ void deft_split(const f32x4 v, pcx4 (&pc)[DEFT_NP], c
             r -= (float)h;
         }
     }
+    (void)scale;
+#endif
 }
 
 // Raw buffer loads (SRD in SGPRs + 32-bit byte offset in a VGPR).  An offset >= num_records
@@ -114,26 +159,6 @@ __device__ __forceinline__ deft_rsrc_t deft_make_rsrc(const void* base) {
 }
 __device__ __forceinline__ f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-}
-// A register load the COMPILER'S vmcnt SCOREBOARD DOES NOT SEE (inline asm; the inactive lanes of `dst` keep their values: "+v").  For loads
-// issued under a divergent branch inside a software pipeline whose waits are written by hand (DEFT_WAIT_VM): hipcc must give a
-// conditionally issued, tracked load the wait that is right on EVERY path -- the count of the path that skipped the branch -- and so
-// makes the consumer of LAST step's loads wait for THIS step's (dcn.hip: every step of every wave sat out a global round trip).
-// The caller orders the load's completion before its first use (in-order return: everything but the N youngest operations is
-// complete behind DEFT_WAIT_VM(N)).  IMM: immediate byte offset (0 .. 4095).
-typedef int deft_rsrc_words_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ deft_rsrc_words_t deft_make_rsrc_words(const void* base) {
-    const unsigned long long a = (unsigned long long)base;
-    deft_rsrc_words_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
-    r[2] = 0x7FFFFFFF;
-    r[3] = 0x00020000;
-    return r;
-}
-template <int IMM>
-__device__ __forceinline__ void deft_buffer_load_x4_untracked(f32x4& dst, deft_rsrc_words_t r, unsigned byte_off) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "+v"(dst) : "v"(byte_off), "s"(r), "n"(IMM));
 }
 // LDS-DMA (`buffer_load_dwordx4 ... lds`): lane l of the wave deposits its 16 bytes at
 // lds_wave_base + 16*l (wave-uniform base in M0, lane-linear image); out-of-range lanes deposit

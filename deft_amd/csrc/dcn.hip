@@ -37,8 +37,8 @@ typedef deft_f32x16 f32x16;
 #endif
 
 // Instruction-order request for the pipelined step: one MFMA, then a few VALU instructions of the next chunk's blend + split, repeated
-// (the matrix pipe works 32 cycles per MFMA: the VALU work issues under it).  DCNP_NOSCHED: leave the order to the compiler.
-#if defined(DCNP_NOSCHED) || !defined(__HIP_DEVICE_COMPILE__)
+// (the matrix pipe works 32 cycles per MFMA: the VALU work issues under it).
+#if !defined(__HIP_DEVICE_COMPILE__)
 #define DCNP_SCHED(TN) do {} while (0)
 #else
 #define DCNP_SCHED(TN)                                                        \
@@ -61,37 +61,13 @@ typedef deft_f32x16 f32x16;
 #define DP_PBUF_(R) (4 * DP_PLANE_(R))                    // one patch buffer: 16 channels = 4 planes
 #define DP_WBLK (DEFT_NP * 2048)                      // one K chunk (16) of 64 output channels: [DEFT_NP pieces][2 k groups][64 rows][8 halves]
 
-// ---- round-4 experiment switches (all OFF in the product build; each was A/B'd on MI355X against the build without it, same call,
-// 64 -> 64 @152x272 x 16 frames, offsets of sigma 1.5 px: profiles/r4_dcn_experiments.md) -------------------------------------------
-//   DCNP_BREG           weights global -> registers, ONE barrier per 16-channel block instead of one per tap, no weight DMA, no
-//                       fragment reads: 0.507 -> 0.513 ms.  The barriers, the DMA issue cost and the fragment reads are hidden already.
-//   DCNP_FAR_UNTRACKED  the far samples' global loads outside hipcc's vmcnt scoreboard (the tracked form makes the blend of the previous
-//                       step's values wait for this step's loads: the count must be right on the path that skipped the far branch):
-//                       0.491 -> 0.483 ms, but test_dcn_patch fails on the hardware (a hand-counted wait is short somewhere): off.
-//   DCNP_ACC_AGPR       accumulators in AGPRs (hipcc picks the VGPR form of the MFMAs for a kernel under 256 registers): 0.506 -> 0.505 ms.
-// What stays in: corner reads first and far loads second (one if, not if / else: the only wait between them is for LDS), and the
-// two-slot ring of corner values with static slots (no register copies at the end of a step).  Time: unchanged.  The kernel is not
-// limited by waits, barriers, LDS traffic or where the accumulators live; SQ counters of the launch: VALU port 48 %, matrix pipe 31 %,
-// LDS array 26 % busy, 165 instructions per wave and step.
-// Weights of the 32- and 64-column tiles (TN <= 2) go global -> REGISTERS (each lane loads its own B fragments, 16 bytes per piece and
-// n-tile, two steps ahead): no weight stages in LDS, no weight DMA, no fragment reads, and with them no reason for a barrier per tap --
-// one barrier per 16-channel block is left (the patch double buffer).  Round 4, DCNP_TIMING per step of the LDS form: wait + barrier
-// 330, DMA issue 230 (an LDS-DMA piece costs ~100 cycles to issue beside MFMAs), fragment reads 235 of ~1850 cycles.
-#ifndef DCNP_BREG
-#define DCNP_BREG 0
-#endif
-#ifndef DCNP_FAR_UNTRACKED
-#define DCNP_FAR_UNTRACKED 0
-#endif
-#ifndef DCNP_ACC_AGPR
-#define DCNP_ACC_AGPR 0
-#endif
-template <int TN>
-constexpr bool dcnp_breg() { return DCNP_BREG && TN <= 2; }
+// (Round-4 / round-5 experiment arms -- weights global -> registers, far loads outside the compiler's vmcnt scoreboard, accumulators in
+// AGPRs, the ablation and in-kernel timing builds -- are kept as profiles/r5_dcn_experiment_switches.patch, not in this file; what they
+// measured: profiles/r4_dcn_experiments.md.)
 
 template <int TN, int R>
 constexpr int dcnp_lds_bytes() {
-    constexpr int loop = 2 * DP_PBUF_(R) + (dcnp_breg<TN>() ? 0 : 3 * ((TN + 1) / 2) * DP_WBLK);
+    constexpr int loop = 2 * DP_PBUF_(R) + 3 * ((TN + 1) / 2) * DP_WBLK;
     constexpr int tile = 128 * (TN * 32 + 4) * 4;                 // epilogue tile
     return loop > tile ? loop : tile;
 }
@@ -123,19 +99,11 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     static_assert(DEFORM || (TN == 1 && DP_R == 0), "the plain form is the 32-column conv without margin");
     constexpr int DP_PH = DP_PH_(DP_R), DP_PW = DP_PW_(DP_R), DP_NPIX = DP_NPIX_(DP_R), DP_PARTS = DP_PARTS_(DP_R), DP_PLANE = DP_PLANE_(DP_R),
                   DP_PBUF = DP_PBUF_(DP_R);
-    constexpr bool BREG = dcnp_breg<TN>();
     constexpr int BN = TN * 32, NBLK = (BN + 63) / 64;
     constexpr int NBP = NBLK * DEFT_NP * 2;           // weight DMA pieces (1 KB) per chunk
     constexpr int BSTAGE = NBLK * DP_WBLK;
     constexpr int NPP = 4 * DP_PARTS / 2;             // patch DMA pieces per wave (waves 2 and 3 issue them)
 
-#ifdef DCNP_TIMING
-    long long tstamp[8];
-    tstamp[0] = __builtin_readcyclecounter();
-#define DCNP_T(i) tstamp[i] = __builtin_readcyclecounter()
-#else
-#define DCNP_T(i) do {} while (0)
-#endif
     DEFT_DYN_LDS(char, smem);
     char* const patch = smem;                          // [2 buffers][4 planes][DP_PARTS * 64 pixels][16 B]
     char* const Bd = smem + 2 * DP_PBUF;               // [3 stages][BSTAGE]
@@ -173,9 +141,6 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     f32x4 om[7];
     if (DEFORM) {
         const float* omp = p.x2 + (size_t)(rowok ? img + oy * p.W + ox : 0) * p.ldom;
-#ifdef DCNP_ABL_NOOM
-        omp = p.x2 + (lane & 31) * p.ldom;
-#endif
 #pragma unroll
         for (int q = 0; q < 7; ++q) om[q] = *(const f32x4*)(omp + 4 * q);
     }
@@ -184,10 +149,6 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     // `plane` of patch pixel 64 part + l; pixels outside the map (and beyond the patch) arrive as zeros.  Weights (waves 0, 1). ----
     const deft_rsrc_t rx = deft_make_rsrc(p.x);
     const deft_rsrc_t rw = deft_make_rsrc(p.w3);
-    // the far samples' global loads outside the compiler's vmcnt scoreboard (common.h deft_buffer_load_x4_untracked): only in the form
-    // whose corner values are consumed a step after they are requested, behind that step's hand-written wait + barrier
-    constexpr bool FAR_UNTRACKED = DCNP_FAR_UNTRACKED && DEFORM && TN == 2 && DCNP_GA == 2 && !dcnp_breg<TN>();
-    const deft_rsrc_words_t rxw = deft_make_rsrc_words(p.x);
     unsigned pv[DP_PARTS];
 #pragma unroll
     for (int i = 0; i < DP_PARTS; ++i) {
@@ -241,16 +202,13 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     auto ps_of = [](int t) { return t >= PT ? NPP : NPP * t / PT; };
     static_assert(NB_B + (NPP + PT - 1) / PT <= 6 && NB_A <= 6, "wait_vm cases");
 
-    if (!BREG) {
-        issue_b3(0, 0);
-        if (nchunks > 1) issue_b3(1, 1);
-        if (nchunks > 2) issue_b3(2, 2);
-    }
+    issue_b3(0, 0);
+    if (nchunks > 1) issue_b3(1, 1);
+    if (nchunks > 2) issue_b3(2, 2);
     if (wave >= 2) {
 #pragma unroll
         for (int i = 0; i < NPP; ++i) issue_patch_piece(0, 0, i);
     }
-    DCNP_T(1);
     // ---- sampling records of the row, all nine taps, in registers.  Near (all four corners inside the patch): rc = LDS byte address,
     // inside patch buffer 0, of the lane's first 16 bytes (plane 2 g) of the BASE pixel b; the corners are b, b + 1, b + PW, b + PW + 1
     // with the weights rw0..rw3 (a corner clamped at the map border is folded away: the base moves one pixel / line back and the weight
@@ -305,12 +263,6 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
         }
     }
 
-#if DCNP_ACC_AGPR && defined(__HIP_DEVICE_COMPILE__)
-    // Accumulators in the ACC half of the register file.  A kernel under 256 registers that has no 'a'-constrained inline asm is compiled
-    // with the VGPR form of every MFMA (accumulators v[..]); this empty statement makes hipcc allocate AGPRs, and the matrix
-    // instructions' C / D traffic stops competing with the blend's VALU operand reads for the VGPR banks.
-    { float agpr_hint = 0.f; asm volatile("; accumulators in AGPRs" :: "a"(agpr_hint)); }
-#endif
     f32x16 acc[1][TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -344,14 +296,6 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
             const unsigned o1 = ((c & 0x7fffffffu) >> 2) * far_x + (unsigned)(cb * 64 + g * 32);
             const unsigned o2 = o1 + ((c & 1u) ? far_x : 0u);
             const unsigned dyb = (c & 2u) ? far_y : 0u;
-            if (FAR_UNTRACKED) {
-                // (consumed one step on, behind that step's DEFT_WAIT_VM(<pieces issued after these loads>) + barrier: see the loop)
-                deft_buffer_load_x4_untracked<0>(v[0][0], rxw, o1); deft_buffer_load_x4_untracked<16>(v[0][1], rxw, o1);
-                deft_buffer_load_x4_untracked<0>(v[1][0], rxw, o2); deft_buffer_load_x4_untracked<16>(v[1][1], rxw, o2);
-                deft_buffer_load_x4_untracked<0>(v[2][0], rxw, o1 + dyb); deft_buffer_load_x4_untracked<16>(v[2][1], rxw, o1 + dyb);
-                deft_buffer_load_x4_untracked<0>(v[3][0], rxw, o2 + dyb); deft_buffer_load_x4_untracked<16>(v[3][1], rxw, o2 + dyb);
-                return;
-            }
             v[0][0] = deft_buffer_load_x4(rx, o1); v[0][1] = deft_buffer_load_x4(rx, o1 + 16u);
             v[1][0] = deft_buffer_load_x4(rx, o2); v[1][1] = deft_buffer_load_x4(rx, o2 + 16u);
             v[2][0] = deft_buffer_load_x4(rx, o1 + dyb); v[2][1] = deft_buffer_load_x4(rx, o1 + dyb + 16u);
@@ -391,13 +335,15 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
         } else {
             // two fp16 pieces (the corner weights carry DEFT_ASCALE already): h1 = fp16(x), h2 = fp16(x - h1) -- the residual is exact in
             // fp32 and the matrix instructions' fp16 -> fp32 widening is exact, so this is common.h deft_split element by element
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = e < 4 ? b0[e] : b1[e - 4];
-                const deft_piece_t h = (deft_piece_t)x;
-                pa[0][e] = h;
-                pa[1][e] = (deft_piece_t)(x - (float)h);
-            }
+#if DEFT_PIECES == 2
+            unsigned h0, h1, h2, h3, m0, m1, m2, m3;
+            deft_split2_pair(b0[0], b0[1], h0, m0);
+            deft_split2_pair(b0[2], b0[3], h1, m1);
+            deft_split2_pair(b1[0], b1[1], h2, m2);
+            deft_split2_pair(b1[2], b1[3], h3, m3);
+            pa[0] = __builtin_bit_cast(pcx8, u32x4{h0, h1, h2, h3});
+            pa[1] = __builtin_bit_cast(pcx8, u32x4{m0, m1, m2, m3});
+#endif
         }
     };
 
@@ -419,37 +365,16 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
             for (int q = 0; q < DEFT_NP; ++q) o[j][q] = *(const pcx8*)(bj + q * 2048);
         }
     };
-    // BREG: this lane's B fragments of chunk kc straight from the weight image (global / L2 / L1: the four waves of a workgroup and
-    // the workgroups of a pixel row read the same 6 KB chunk) into registers
-    const unsigned vBr = (unsigned)((n0 >> 6) * nchunks * DP_WBLK + brow);
-    auto load_b = [&](int kc, pcx8 (&o)[TN][DEFT_NP]) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const unsigned base = vBr + (unsigned)(((j >> 1) * nchunks + kc) * DP_WBLK + (j & 1) * 512);
-#pragma unroll
-            for (int q = 0; q < DEFT_NP; ++q) o[j][q] = __builtin_bit_cast(pcx8, deft_buffer_load_x4(rw, base + (unsigned)(q * 2048)));
-        }
-    };
-    pcx8 pbr[2][TN][DEFT_NP];                                  // BREG: the fragments of chunk kc in pbr[kc & 1] (loaded at the end of step kc - 2)
-    DCNP_T(2);
     f32x4 vq[GA][4][2];                                    // corner values in flight: vq[0] = the next chunk's, vq[1] = the one after (GA = 2)
     {
         DEFT_WAIT_VM(0);
         DEFT_PIPE_BARRIER_ONLY();
         f32x4 v[4][2];
         gather(rc[0], 0, 0, v);
-        if (FAR_UNTRACKED) DEFT_WAIT_VM(0);               // (chunk 0 is blended at once: its far samples' loads are waited for here, by hand)
         blend_split(v, rw0[0], rw1[0], rw2[0], rw3[0], pa);
-        if (BREG) { load_b(0, pbr[0]); load_b(1, pbr[1]); }
-        else read_b(0, pb);
+        read_b(0, pb);
         if (GA == 2) gather(rc[1], 0, 0, vq[1]);          // (chunk 1 exists: Cin >= 32 -> at least 18 chunks); slot of an ODD chunk, see the loop
-        // chunk 1 is blended in step 0, whose wait counts the DMA pieces a steady-state step issues BEHIND its corner reads -- none here
-        if (FAR_UNTRACKED) DEFT_WAIT_VM(0);
     }
-    DCNP_T(3);
-#ifdef DCNP_TIMING
-    long long tsum[4] = {0, 0, 0, 0}, tprev = tstamp[3];
-#endif
     for (int cb2 = 0; cb2 < ncb; cb2 += 2) {
         const bool lastpair = cb2 + 2 >= ncb;                        // the odd block of this pair is the last block
 #pragma unroll
@@ -463,32 +388,13 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 const bool last_blk = half == 1 && lastpair;           // (runtime only in the odd half)
                 const bool more = !(tap == 8 && last_blk);             // is there a chunk kc + 1?
                 const bool moreg = !(tap + GA >= 9 && last_blk);       // ... a chunk kc + GA?
-#ifdef DCNP_TIMING
-                const long long tA = __builtin_readcyclecounter();
-                tsum[3] += tA - tprev;
-#endif
                 // ---- wait + barrier (step 0 too: everybody has read the B fragments of chunk 0 before its stage is refilled) ----
-                if (BREG) {
-                    // ONE barrier per 16-channel block, in front of the first corner read that reaches into the next block's patch: that
-                    // patch has landed (its pieces were issued in taps 0 .. PT - 1: vmcnt(0), then the rendezvous), and every wave has
-                    // finished reading the block before this one -- whose buffer the DMA of the block after next refills from tap 0 on
-                    if (tap == 9 - GA && !last_blk) {
-                        DEFT_WAIT_VM(0);
-                        DEFT_PIPE_BARRIER_ONLY();
-                    }
-                } else {
-#ifndef DCNP_ABL_NOBARRIER
+                {
                     const int pt = tap == 0 ? 8 : tap - 1;             // the previous step's tap; it is in the last block iff this one is and tap > 0
                     if (tap > 0 && last_blk) wait_vm(pt < 6 ? (wave < 2 ? NB_A : NB_B) : 0);
                     else wait_vm(wave < 2 ? NB_A : NB_B + (ps_of(pt + 1) - ps_of(pt)));
                     DEFT_PIPE_BARRIER_ONLY();
-#endif
                 }
-#ifdef DCNP_TIMING
-                const long long tB = __builtin_readcyclecounter();
-                tsum[0] += tB - tA;
-#endif
-#ifndef DCNP_ABL_NOGATHER
                 // GA = 2: the corner values live in a two-slot ring with STATIC slots (the 18 steps of an iteration are unrolled, the first chunk
                 // of an iteration is even): the reads issued in step kc (chunk kc + 2) go to slot kc & 1 and are blended in step kc + 1,
                 // which reads slot (kc + 1) & 1 ^ 1.  (Round 3 copied slot 1 to slot 0 at the end of every step: the compiler hoisted those
@@ -496,26 +402,15 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 constexpr int GS = GA == 2 ? 2 : 1;
                 const int gslot = GA == 2 ? ((half * 9 + tap) & 1) : 0;
                 if (moreg) gather(rc[gtap], ((half + gblk) & 1) * DP_PBUF, cb + gblk, vq[gslot]);
-#else
-                constexpr int GS = GA == 2 ? 2 : 1;
-                const int gslot = GA == 2 ? ((half * 9 + tap) & 1) : 0;
-                for (int a_ = 0; a_ < 4; ++a_) { vq[gslot][a_][0] = f32x4{rw0[ntap], 1.f, 2.f, 3.f}; vq[gslot][a_][1] = f32x4{rw1[ntap], 1.f, 2.f, 3.f}; }
-#endif
-#ifndef DCNP_ABL_NOMFMA
                 // six products per fp32 product, smallest terms first (as igemm.hip); product-major so that consecutive MFMAs go to
                 // DIFFERENT accumulators (a dependent MFMA waits for its predecessor's full latency, more with VALU slotted between them)
 #pragma unroll
                 for (int q = 0; q < DEFT_NPROD; ++q) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[0][j] = deft_mfma_pc(pa[deft_qa(q)], BREG ? pbr[(half * 9 + tap) & 1][j][deft_qb(q)] : pb[j][deft_qb(q)], acc[0][j]);
+                        acc[0][j] = deft_mfma_pc(pa[deft_qa(q)], pb[j][deft_qb(q)], acc[0][j]);
                 }
-#endif
-#ifdef DCNP_ABL_NOVALU
-                if (false) {
-#else
                 if (more) {
-#endif
                     pcx8 pn[DEFT_NP];
                     blend_split(vq[GS == 2 ? (gslot ^ 1) : 0], rw0[ntap], rw1[ntap], rw2[ntap], rw3[ntap], pn);
 #pragma unroll
@@ -524,60 +419,27 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 DCNP_SCHED(TN);
 #pragma unroll
                 for (int q = 0; q < DEFT_NP; ++q) DEFT_OPAQUE(pa[q]);      // A(kc + 1) is finished HERE, under the MFMAs -- not after the next barrier
-#ifdef DCNP_TIMING
-                const long long tC = __builtin_readcyclecounter();
-                tsum[1] += tC - tB;
-#endif
-#ifndef DCNP_ABL_NODMA
-                if (!BREG && (tap < 6 || !last_blk)) issue_b3(kc + 3, st);            // (kc + 3 < nchunks)
+                if (tap < 6 || !last_blk) issue_b3(kc + 3, st);            // (kc + 3 < nchunks)
                 if (wave >= 2 && !last_blk) {
 #pragma unroll
                     for (int i = ps_of(tap); i < ps_of(tap + 1); ++i) issue_patch_piece(cb + 1, half ^ 1, i);
                 }
-#endif
-#ifdef DCNP_TIMING
-                tprev = __builtin_readcyclecounter();
-                tsum[2] += tprev - tC;
-#endif
-                if (BREG) {
-                    if (!(tap + 2 >= 9 && last_blk)) load_b(kc + 2, pbr[(half * 9 + tap) & 1]);      // (its registers were read by this step's MFMAs)
-                } else if (more) {
-                    read_b((tap + 1) % 3, pb);
-                }
+                if (more) read_b((tap + 1) % 3, pb);
             }
         }
     }
-    DCNP_T(4);
     __syncthreads();                                   // nobody reads the stages any more, no DMA in flight (the last chunk issued none)
 
     // ---- epilogue through LDS (common.h): the whole 128-row tile fits the loop's LDS ----
     float* const T = (float*)smem;
-#ifdef DCNP_ABL_NOSTORE
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
-#ifdef DCNP_ABL_NOY3
-    p.y3 = nullptr;
-#endif
     deft_epilogue_stage<1, TN>(T, BN + 4, acc, wave, 0, lane, p, n0);
     DEFT_PIPE_BARRIER_ONLY();
-    DCNP_T(5);
     deft_epilogue_rows<128, BN, 256>(T, p, n0, tid, [&](int R) -> long long {
         int tr, txx;
         dcnp_row_to_pixel(R & 31, tr, txx);
         const int y = ty0 + 2 * (R >> 5) + tr, x = tx0 + txx;
         return (y < p.H && x < p.W) ? (long long)(img + y * p.W + x) : -1;
     });
-#ifdef DCNP_TIMING
-    DCNP_T(6);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    DCNP_T(7);
-    if (lane == 0 && p.ws != nullptr) {
-        long long* o = (long long*)p.ws + ((size_t)blockIdx.x * 4 + wave) * 8;
-        for (int i = 0; i < 8; ++i) o[i] = tstamp[i];
-        long long* o2 = (long long*)p.ws + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + wave) * 4;
-        for (int i = 0; i < 4; ++i) o2[i] = tsum[i];
-    }
-#endif
 }
 
 template <int TN, int R, bool DEFORM = true>

@@ -464,13 +464,6 @@ static inline hipemu_f32x4 deft_buffer_load_x4(deft_rsrc_t r, unsigned byte_off)
     if (byte_off < r.n && byte_off + 16u <= r.n) memcpy(&v, r.base + byte_off, 16);
     return v;
 }
-// the "untracked" register load of common.h (inline asm on the hardware: the compiler's vmcnt scoreboard does not see it): here a plain load
-struct deft_rsrc_words_t { const char* base; };
-static inline deft_rsrc_words_t deft_make_rsrc_words(const void* base) { return deft_rsrc_words_t{(const char*)base}; }
-template <int IMM>
-static inline void deft_buffer_load_x4_untracked(hipemu_f32x4& dst, deft_rsrc_words_t r, unsigned byte_off) {
-    dst = deft_buffer_load_x4(deft_rsrc_t{r.base, 0x7FFFFFFFu}, byte_off + (unsigned)IMM);
-}
 static inline void hipemu_dma_deposit(void* dst, const hipemu_f32x4& v) {
     hipemu::State& s = hipemu::S();
     if (s.dmaq.empty()) { memcpy(dst, &v, 16); return; }          // default: delivered at issue
@@ -493,6 +486,18 @@ static inline void deft_buffer_load_lds_x4s(deft_rsrc_t r, void* lds_wave_base, 
 extern "C" __attribute__((weak, visibility("default"))) void hipemu_set_late_dma(int on) { hipemu::late_dma() = on; }
 #define DEFT_OPAQUE(v) ((void)(v))
 #define DEFT_OPAQUE_NV(v) ((void)(v))
+// the two-fp16-piece split of a pair of values (csrc/common.h: v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16 on the device), as the C++ expression
+#define DEFT_F16_SPLIT_HOOK 1
+static inline void deft_split2_pair_scaled(float x0, float x1, float sc, unsigned& h, unsigned& m) {
+    const float y0 = x0 * sc, y1 = x1 * sc;                        // (sc is a power of two: exact)
+    const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+    const _Float16 m0 = (_Float16)(y0 - (float)h0), m1 = (_Float16)(y1 - (float)h1);
+    unsigned short b[4];
+    __builtin_memcpy(&b[0], &h0, 2); __builtin_memcpy(&b[1], &h1, 2); __builtin_memcpy(&b[2], &m0, 2); __builtin_memcpy(&b[3], &m1, 2);
+    h = (unsigned)b[0] | ((unsigned)b[1] << 16);
+    m = (unsigned)b[2] | ((unsigned)b[3] << 16);
+}
+static inline void deft_split2_pair(float x0, float x1, unsigned& h, unsigned& m) { deft_split2_pair_scaled(x0, x1, 1.f, h, m); }
 #define DEFT_FAST_RCP(x) (1.0f / (x))
 #define DEFT_RINT_HOOK 1
 static inline int deft_rint(double v) { return (int)std::nearbyint(v); }

@@ -17,7 +17,7 @@ tot = sum(r[1] for r in rows.values())
 out = ["# Per-layer timing of one profiled step (`profiles/%s`, 32 frames = 2 sub-batches of 16, launches serialised on one stream)\n" % tag,
        "HIP-event bracket per launch (includes ≈6 µs of bracket overhead); FLOPs are algorithmic (no padding). Total %.2f ms.\n" % tot,
        "Ceiling = what the launch's matrix instructions can do: 416.7 TFLOP/s fp32-equivalent for the split-bf16 launches (2500 / 6), "
-       "157.3 for v_mfma_f32_32x32x2_f32.\n",
+       "157.3 for v_mfma_f32_32x32x2_f32; 833.3 for the two-fp16-piece launches (2500 / 3).\n",
        "| entry | shape | launches | ms | % | TFLOP/s | ceiling | frac |", "|---|---|---|---|---|---|---|---|"]
 for (name, info), (n, ms, fl, ceil) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     tf = fl / ms / 1e9 if fl else None
