@@ -328,6 +328,8 @@ class ArrayTracker(object):
             d[:, 2] -= d[:, 0]; d[:, 3] -= d[:, 1]
             d[:, 0] /= self.img_width; d[:, 2] /= self.img_width; d[:, 1] /= self.img_height; d[:, 3] /= self.img_height
             centers = torch.from_numpy(((2 * d[:, 0:2] + d[:, 2:4]) - 1.0).astype(float)).float().view(1, -1, 1, 1, 2)
+            if FeatureMaps[0].shape[0] == 2:                              # flip-test pair: the un-flipped frame's maps (tracker.py:821-825)
+                FeatureMaps = [fm[0].unsqueeze(0) for fm in FeatureMaps]
             feats = self.model.AFE.forward_feature_extracter(FeatureMaps, centers)
             needed = set(np.unique(sel_all[0][sel_all[2]]).tolist()) if self.lazy_blocks else None
             self.recorder.update(self.model, fid, feats.data, org, needed=needed)

@@ -30,7 +30,7 @@ typedef deft_f32x16 f32x16;
 #define DCNP_R2 3
 #endif
 #ifndef DCNP_R4
-#define DCNP_R4 2
+#define DCNP_R4 (DEFT_NP == 2 ? 3 : 2)      // 128-column tiles: the margin that still leaves two workgroups per CU (72 KB with two fp16 pieces; 76 KB at R = 2 with three bf16 pieces)
 #endif
 #ifndef DCNP_GA
 #define DCNP_GA 2          // corner reads run this many chunks ahead of the MFMAs (1 or 2): a far sample's global loads have a whole step to land
@@ -472,7 +472,7 @@ int deft_dcnp_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     if (bn == 0) bn = d->Cout > 64 ? 128 : 64;
     DEFT_CHECK(bn == 64 || bn == 128, -75, "deft_dcn_v2_nhwc: the patch form has 64- and 128-column tiles (tile & 0xffff = %d)", bn);
     // (the weight image has ceil(Cout / 128) * 128 rows: no n-tile reaches past it)
-    // margin: 3 pixels where two workgroups per CU still fit (64-column tiles: 66 KB of LDS), else 2 (128-column tiles: 76 KB)
+    // margin: as many pixels as still leave two workgroups per CU (DCNP_R2 / DCNP_R4; MI355X A/B of round 5: profiles/r5_dcn_margin_ab.log)
     return bn == 128 ? launch_dcnp<4, DCNP_R4>(*d, s) : launch_dcnp<2, DCNP_R2>(*d, s);
 }
 

@@ -111,6 +111,8 @@ class Detector(object):
         output = {"hm": dense sigmoid'ed map as an NHWC View}, dets = generic_decode's dict as
         numpy (one D2H), FeatureMaps = the 13 NHWC Views consumed by AFE (tracker.py:826)."""
         assert pre_images is None and pre_hms is None, "DEFT inference never passes pre_img/pre_hm (detector.py:153,162)"
+        if getattr(self.opt, "flip_test", False):
+            return self._process_flip(images, pre_inds, return_time)
         N, _, H, W = images.shape
         plan = self._plan(N, H, W)
         assert plan.ops[0][0] == "deft_nchw_to_nhwc", "process() needs the fp32-input plan"
@@ -135,6 +137,60 @@ class Detector(object):
             import time
             return output, dets, time.time(), plan.fmaps
         return output, dets, plan.fmaps
+
+    # heads `_flip_output` (detector.py:496-528) averages over the frame and its mirror image / averages with the odd channels negated; every
+    # other head of DEFT's configurations is taken from the un-flipped frame ("single_flips")
+    FLIP_AVERAGE = ("hm", "wh", "dep", "dim")
+    FLIP_NEG_AVERAGE = ("amodel_offset",)
+
+    def _process_flip(self, images, pre_inds=None, return_time=False):
+        """`--flip_test` on the device (detector.py:396-399, 536-540, 496-528): the frame and its mirror image are the two frames of ONE
+        plan (images [2,3,H,W] as Detector.pre_process stacks them, or [1,3,H,W]: mirrored here on the device), every head evaluated densely,
+        `_sigmoid_output` + `_flip_output` as elementwise device operations on the head maps, then peak NMS / top-K / the K-row gathers of
+        `generic_decode` on the device (integrate.generic_decode).  FeatureMaps are the 13 maps of BOTH frames as the reference returns
+        them -- its tracker keeps the un-flipped frame (tracker.py:821-825), and so does ArrayTracker."""
+        from . import integrate
+        images = images.to(self.device, torch.float32)
+        if images.shape[0] == 1:
+            images = torch.cat([images, images.flip(3)], 0)
+        assert images.shape[0] == 2, "flip_test runs one frame (and its mirror image) per call (detector.py:396-399)"
+        _, _, H, W = images.shape
+        key = ("flip", 2, H, W)
+        if key not in self._plans:
+            self._plans[key] = engine.DlaSegPlan(self.sd, 2, H, W, self.dataset, K=self.K, device=self.device, lib=self.lib, dense_heads=True)
+            self._plans[key]._gkey = key
+        plan = self._plans[key]
+        if not self.hip_graphs or key not in self._graphs:
+            plan.forward(images)
+            self._graphs.setdefault(key, None)
+        else:
+            if self._graphs[key] is None:
+                self._graphs[key] = plan.capture_graph()
+            plan.image.copy_(images, non_blocking=True)
+            self._graphs[key].replay()
+        out = {}
+        for h, v in plan.dense.items():
+            y = v.to_nchw()                                              # [2, C, h, w] (a device tensor)
+            if h == "hm":
+                y = torch.sigmoid(y)                                     # _sigmoid_output, detector.py:488-493
+            elif h == "dep":
+                y = (1.0 / (torch.sigmoid(y) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
+            if h in self.FLIP_AVERAGE:                                   # detector.py:510-512 (flip_tensor = mirror along x)
+                y = (y[0:1] + y[1:2].flip(3)) / 2
+            elif h in self.FLIP_NEG_AVERAGE:                             # detector.py:513-516
+                f = y[1:2].flip(3).clone()
+                f[:, 0::2] *= -1
+                y = (y[0:1] + f) / 2
+            else:                                                        # detector.py:517-518
+                y = y[0:1]
+            out[h] = y.contiguous()
+        d = integrate.generic_decode(out, K=self.K, opt=self.opt, lib=self.lib)
+        dets = _fetch(d)
+        out["pre_inds"] = pre_inds
+        if return_time:
+            import time
+            return out, dets, time.time(), plan.fmaps
+        return out, dets, plan.fmaps
 
     # ---- between process() and Tracker.update(): the reference's post-processing, vectorised (deft_amd/postprocess.py) ----
     def post_process(self, dets, meta, scale=1):
@@ -185,7 +241,8 @@ class Detector(object):
           * the prefetch-loader dict of src/test.py:106-112, 213 ({"image", "images": {scale: [tensor]}, "meta": {scale: {...}}});
           * a path: read with cv2 when that is importable (it is not in this image).
         Then process() -> post_process() -> merge_outputs() -> nuScenes branch / `self.tracker.update(results, FeatureMaps)`.
-        One test scale, no flip test (asserted like detector.py:578).
+        One test scale (asserted like detector.py:578); `opt.flip_test` runs the frame and its mirror image as one two-frame plan
+        (_process_flip) without lookahead.
         prefetch: the NEXT uint8 frame of the stream (same size), if the caller has it already: its network pass is queued on a second
         set of plan buffers BEFORE this frame's post-processing and tracker run, so the GPU works on frame k+1 while the host associates
         frame k (the reference's loop is strictly serial: detector.py:112-344).  The next run() call must pass that same array object,
@@ -194,7 +251,7 @@ class Detector(object):
         import time
         opt = self.opt
         scales = list(getattr(opt, "test_scales", [1.0]))
-        assert len(scales) == 1 and not getattr(opt, "flip_test", False), "the fused run() is the single-scale, no-flip configuration (detector.py:578)"
+        assert len(scales) == 1, "the fused run() is the single-scale configuration (detector.py:578)"
         scale = scales[0]
         t_start = time.time()
         pre_processed, frame = False, None
@@ -216,7 +273,19 @@ class Detector(object):
             assert inp_h > 0 and inp_w > 0, "the device pre-processing is the fix_res mode (opt.input_h / input_w)"
             meta = self._meta_for(sh, sw, inp_h, inp_w, meta)
             akey = (inp_h, inp_w, sh, sw)
-            if prefetch is not None or any(sl.frame is frame for slots in self._ahead.values() for sl in slots):
+            if getattr(opt, "flip_test", False):
+                # detector.py:396-399 mirrors the PRE-PROCESSED network input (not the camera frame: cv2's fixed-point warp is not mirror
+                # symmetric): warp + normalise on the device with the one-frame plan's first launch, mirror that tensor, two-frame plan
+                if self._ahead_busy():
+                    self._drop_ahead()
+                plan = self._plan_u8(1, inp_h, inp_w, sh, sw)
+                t_pre = time.time()
+                plan.image_u8.copy_(torch.from_numpy(np.ascontiguousarray(frame)).unsqueeze(0).to(self.device, non_blocking=True), non_blocking=True)
+                plan.ops[0][2]()
+                x4 = plan._x4
+                img = x4.buf.view(1, inp_h, inp_w, x4.ld)[..., :3].permute(0, 3, 1, 2).contiguous()
+                output, dets, t_fwd, fmaps = self._process_flip(img, None, return_time=True)
+            elif prefetch is not None or any(sl.frame is frame for slots in self._ahead.values() for sl in slots):
                 t_pre = time.time()
                 output, dets, t_fwd, fmaps = self._process_ahead(akey, frame, prefetch)
             else:

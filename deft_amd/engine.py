@@ -184,6 +184,17 @@ def halo_waste(H, W, th=4, tw=32):
 P3H_W16 = 1 << 28          # halo tile flag: TH x 16 pixels instead of TH x 32
 
 
+def _parse_tile(spec):
+    if not spec:
+        return 0
+    dims, _, st = spec.partition(":")
+    bm, bn = (int(v) for v in dims.split("x"))
+    return (bm << 16) | bn | {"1": 1 << 30, "2": 0, "3": 1 << 29}[st or "1"]
+
+
+P3_IM2COL_TILE = _parse_tile(_os.environ.get("DEFT_P3_IM2COL_TILE", ""))
+
+
 _T = lambda bm, bn: (bm << 16) | bn
 P3_3STAGE = 1 << 29
 P3_1STAGE = 1 << 30
@@ -255,6 +266,8 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
     # the ONE-stage loop with several workgroups per CU (48 / 37 KB of LDS: 3 / 4 of them) beats the 2-stage ring with one 8-wave
     # workgroup on every shape (profiles/r2_bench_p3.log: 256->256 @38x68 179 vs 150 TFLOP/s, 64->64 @152x272 148 vs 120)
     tile = (_T(64, 128) if Cout >= 128 else _T(128, 64)) | P3_1STAGE
+    if P3_IM2COL_TILE and Cout >= 128:          # tuning aid: "BMxBN[:stages]" for the deep 128+-column layers
+        tile = P3_IM2COL_TILE
     bm, bn = (tile >> 16) & 0x1fff, tile & 0xffff
     if -(-M // bm) * -(-Cout // bn) < P3_MIN_TILES:
         return None                     # few tiles (one frame per GPU): igemm.hip's cross-workgroup split-K fills the chip better

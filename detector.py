@@ -6,8 +6,8 @@ replaced:
   * the model is `deft_amd.integrate.create_model` (HIP kernels) instead of `create_model` + `load_model`
     (detector.py:78-83); `model.AFE` carries the two tracker-facing methods (tracker.py:776, 826, 87);
   * `process()` is the fused launch list of `deft_amd.detector.Detector` (sigmoid, peak NMS, top-K and the regression heads
-    at the K peaks on the device, ONE device->host copy) -- the reference's own `process` still runs, through the same
-    model object, for `--flip_test`;
+    at the K peaks on the device, ONE device->host copy); with `--flip_test` the frame and its mirror image run as one two-frame
+    plan and `_flip_output` (detector.py:496-528) is applied on the device (deft_amd.detector.Detector._process_flip);
   * the tracker's per-frame forms are bound (`deft_amd.tracker.accelerate`: one affinity chain per frame, device-side
     similarity medians, vectorised gating / assignment, and with `--lstm` one motion-update launch per frame).
 
@@ -57,6 +57,6 @@ class Detector(_ref.Detector):
         self._fused = FusedDetector(opt, sd)
 
     def process(self, images, pre_images=None, pre_hms=None, pre_inds=None, return_time=False):
-        if self.opt.flip_test or pre_images is not None or pre_hms is not None:
+        if pre_images is not None or pre_hms is not None:              # (never at inference: detector.py:153, 162)
             return super().process(images, pre_images, pre_hms, pre_inds, return_time)
         return self._fused.process(images, None, None, pre_inds, return_time)

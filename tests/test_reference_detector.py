@@ -240,3 +240,70 @@ def test_nuscenes_run_matches_reference_detector(emu_lib, tmp_path, monkeypatch,
     finally:
         torch.set_grad_enabled(True)
         sys.modules.pop("dcn_v2", None)
+
+
+def test_flip_test_on_the_fused_path_matches_reference_process(emu_lib, tmp_path, monkeypatch):
+    """`--flip_test` (detector.py:396-399, 469-476, 536-540, `_flip_output` :496-528) on the fused path -- the frame and
+    its mirror image as the two frames of one plan, `_sigmoid_output` + `_flip_output` as device operations, decode on the device -- against
+    the reference's OWN Detector.process on the same two-frame batch (its DLASeg with the oracle's DCN, its generic_decode): ordered indices /
+    classes identical, scores and boxes to 1e-4; MOT heads (hm / wh averaged, the rest from the un-flipped frame) and the nuScenes heads (dep,
+    dim averaged, amodel_offset averaged with negated x).  FeatureMaps come back for both frames, as the reference returns them."""
+    import deft_oracle as O
+    import make_golden as MG
+    import ref_import
+    import ref_shims
+    ref_shims.install()
+    ref_import.install_stubs(MG.OracleDCN)
+    ref_shims.install_detector_stubs()
+    monkeypatch.setenv("DEFT_HIP_LIB", emu_lib.path)
+    from deft_amd import hiplib
+    monkeypatch.setattr(hiplib, "_lib", emu_lib)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        from opts import opts
+        from dataset.dataset_factory import dataset_factory
+        spec = importlib.util.spec_from_file_location("detector", os.path.join(ROOT, "detector.py"))
+        shim = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(shim)
+    finally:
+        sys.argv = argv
+    RD = sys.modules["deft_reference_detector"]
+    from deft_amd import checkpoint, detector as FD
+    H, W = 64, 96
+    torch.set_grad_enabled(False)
+    try:
+        for dataset, extra in (("mot", ["--ltrb_amodal"]), ("nuscenes", [])):
+            sd = dict(O.synth_state_dict(dataset))
+            ck = str(tmp_path / ("model_%s.pth" % dataset))
+            torch.save({"epoch": 1, "state_dict": {"module." + k: v for k, v in sd.items()}}, ck)
+            opt = opts().parse(["tracking" if dataset == "mot" else "tracking,ddd", "--dataset", dataset, "--gpus", "-1", "--load_model", ck, "--K", "12",
+                                "--input_h", str(H), "--input_w", str(W), "--flip_test"] + extra)
+            opt = opts().update_dataset_info_and_set_heads(opt, dataset_factory[opt.test_dataset])
+            assert opt.flip_test
+            x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(21))
+            x2 = torch.cat([x, x.flip(3)], 0)                               # Detector.pre_process, detector.py:396-399
+            ref = RD.Detector(opt)
+            try:
+                ro, rd, rmaps = ref.process(x2)
+            finally:
+                pass
+            fd = FD.Detector(opt, checkpoint.load_model_state(ck, opt, log=lambda *_: None))
+            fo, fdets, fmaps = fd.process(x2)
+            fo1, fdets1, _ = fd.process(x)                                  # one frame in: mirrored on the device
+            for got in (fdets, fdets1):
+                assert set(got) >= set(rd), (sorted(got), sorted(rd))
+                hw = (H // 4) * (W // 4)
+                key = lambda d: (np.asarray(d["clses"]).astype(np.int64) * hw + np.round(np.asarray(d["ys"]) * (W // 4) + np.asarray(d["xs"])).astype(np.int64)).tolist()
+                # (a map with fewer than K NMS peaks: the reference's top-K fills up with zero-score entries in torch.topk's unspecified tie order)
+                npk = int((np.asarray(rd["scores"])[0] > 0).sum())
+                assert npk >= 6 and (np.asarray(got["scores"])[0, npk:] <= 0).all()
+                assert [r[:npk] for r in key(got)] == [r[:npk] for r in key(rd)], dataset
+                for k, v in rd.items():
+                    assert np.allclose(np.asarray(got[k], np.float64)[:, :npk], np.asarray(v, np.float64)[:, :npk], atol=1e-4, rtol=1e-5), (dataset, k)
+            assert float((fo["hm"].cpu() - ro["hm"]).abs().max()) <= 1e-5
+            assert len(fmaps) == 13 and fmaps[0].shape[0] == 2 and tuple(fmaps[0].shape) == tuple(rmaps[0].shape)
+            a = fmaps[3][0].unsqueeze(0).to_nchw().cpu()
+            assert float((a - rmaps[3][0:1]).abs().max()) <= 1e-4 * max(1.0, float(rmaps[3].abs().max()))
+    finally:
+        torch.set_grad_enabled(True)
