@@ -74,21 +74,25 @@ typedef struct DeftGemmDesc {
     float* ws;
     int* ws_cnt;
     /* arithmetic of the contraction: 0 = v_mfma_f32_32x32x2_f32, bitwise a k-ordered fp32 fmaf chain; 1 = every fp32
-     * operand split into three bf16 pieces and every product formed as six v_mfma_f32_32x32x16_bf16 products (all
-     * terms down to 2^-24 relative), fp32 accumulation: the accuracy of an fp32 chain at 16/6 of the fp32 MFMA rate.
+     * operand split into NP = deft_pieces() 16-bit pieces and every fp32 product formed on the 16-bit matrix instructions, fp32
+     * accumulation.  NP = 2 (this library): two fp16 pieces (operand to 2^-24 relative inside the fp16 range, csrc/common.h),
+     * three v_mfma_f32_32x32x16_f16 products -- 16/3 of the fp32 MFMA rate; the CALLER scales every weight row by a power of two
+     * into fp16 range and folds the inverse into `scale` (deft_amd.engine.scale_weight_rows), the kernels scale the activations
+     * by 2^4 themselves.  NP = 3 (libdeft_bf16x3.so, the same sources with -DDEFT_PIECES=3): three bf16 pieces (exact), six
+     * v_mfma_f32_32x32x16_bf16 products (all terms down to 2^-24 relative) -- 16/6 of the fp32 MFMA rate, no scaling.
      * Honoured by the tiles with one wave per output sub-tile, BN >= 64 and the 1-stage loop (the 128x32 / 64x32 /
      * 32x32 tiles and the 2-stage form stay on the fp32 instruction: measured no faster there). */
     int prec;
-    /* conv, pre-split operands ("P3" format; prec = 1 only).  x3 != NULL selects the LDS-DMA kernel (igemm3.hip): the
-     * input map and the weights are read as their three bf16 pieces straight into LDS -- no operand split and no
-     * register staging in the K loop; results are bit-identical to the prec = 1 path above (same pieces, same six
-     * products, same k order).  Layouts (bf16 elements):
-     *   map   element (pixel p, channel c, piece q in {hi, mid, lo}) at  p*3*ld + (c/32)*96 + q*32 + c%32,
+    /* conv, pre-split operands (the piece or "P3" format; prec = 1 only).  x3 != NULL selects the LDS-DMA kernel (igemm3.hip): the
+     * input map and the weights are read as their NP pieces straight into LDS -- no operand split and no register staging in the
+     * K loop; results are bit-identical to the prec = 1 path above (same pieces, same products, same k order).  Layouts (16-bit elements):
+     *   map   element (pixel p, channel c, piece q < NP) at  p*NP*ld + (c/32)*(32*NP) + q*32 + c%32,
      *         ld = channels per pixel of the underlying (concat) buffer, ld % 32 == 0; x3 / y3 point at the first
      *         channel block of the view (channel offsets are multiples of 32);
-     *   w3    [CoutPad/64][Kpad/32][64 rows][12 slots of 8 bf16]: 64 output channels x one 32-wide K chunk, slot
-     *         (piece q, k-slot s) of row r stored at slot q*4 + (s ^ ((r >> 2) & 3)) -- the LDS image of the
-     *         chunk, copied verbatim (deft_split_weights builds it from the packed fp32 matrix `w`).
+     *   w3    [CoutPad/64][Kpad/32][64 rows][4*NP slots of 8 halves]: 64 output channels x one 32-wide K chunk, slot
+     *         (piece q, k-slot s) of row r stored at the physical slot csrc/common.h deft_p3_phys gives (NP = 3: q*4 + (s ^ ((r >> 2) & 3));
+     *         NP = 2: (q*4 + s) ^ ((r >> 1) & 7)) -- the LDS image of the chunk, copied verbatim (deft_split_weights builds it from the
+     *         packed, row-scaled fp32 matrix `w`).
      * Needs Cin % 32 == 0, Kpad == Ktot, KH*KW <= 32, no rowmap, Cout % 8 == 0, ldy % 4 == 0.
      * y3 (nullable): the output is ALSO written in P3 form (pixel stride ldy3 channels) for a following conv;
      * y may then be NULL when no fp32 consumer exists.  y3 is honoured by the pre-split conv kernels and by deft_dcn_v2_nhwc. */
@@ -179,8 +183,8 @@ int deft_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, int ld
 /* Depthwise ConvTranspose2d(k=2f, stride f, pad f/2) + skip add:
  * y = up(x) + skip  -- IDAUp.forward dla.py:696-699 (`upsample(project(l[i])) + l[i-1]`).
  * x is [N,H,W,C]; skip and y are [N,f*H,f*W,C]; wup is the module's weight transposed to
- * [2f*2f][C] (tap-major, so 4 channels of one tap are one 16-byte load).  y3 (nullable): the result also as its three
- * bf16 pieces (DeftGemmDesc.x3 layout, pixel stride ldy3 channels) for a following pre-split conv. */
+ * [2f*2f][C] (tap-major, so 4 channels of one tap are one 16-byte load).  y3 (nullable): the result also as its NP
+ * pieces (DeftGemmDesc.x3 layout, pixel stride ldy3 channels) for a following pre-split conv. */
 int deft_upsample_add(const float* x, const float* wup, const float* skip, float* y,
                       int N, int H, int W, int C, int f, int ldx, int lds, int ldy, void* y3, int ldy3, void* stream);
 
@@ -306,22 +310,22 @@ int deft_motion_step(const int* slot, const double* box, int T, int dim, int fra
 int deft_track_similarity(const float* sim, int rows, int Q, const int* node_row, const float* node_scale,
                           const int* node_cnt, int T, int L, float* out, void* stream);
 
-/* fp32 -> P3 (three bf16 pieces, DeftGemmDesc.x3 layout) for maps produced by kernels without a P3 epilogue.
- * x [rows][ldx] fp32 (C channels used, C % 32 == 0), y3 [rows][3*ldy3] bf16.  The split is exact:
- * hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round-to-nearest-even each. */
+/* fp32 -> piece form (DeftGemmDesc.x3 layout, NP = deft_pieces()) for maps produced by kernels without a piece epilogue.
+ * x [rows][ldx] fp32 (C channels used, C % 32 == 0), y3 [rows][NP*ldy3] halves.  NP = 3: hi = bf16(x), mid = bf16(x - hi),
+ * lo = bf16(x - hi - mid), round-to-nearest-even each (exact).  NP = 2: h1 = fp16(16 x), h2 = fp16(16 x - h1). */
 int deft_split_planes(const float* x, void* y3, long long rows, int C, int ldx, int ldy3, void* stream);
 
-/* Packed fp32 weights [CoutPad(128)][Kpad] (DeftGemmDesc.w) -> the P3 weight image (DeftGemmDesc.w3),
- * CoutPad * Kpad * 3 bf16.  Done once per layer at load time. */
+/* Packed fp32 weights [CoutPad(128)][Kpad] (DeftGemmDesc.w; row-scaled by the caller when NP = 2) -> the weight image
+ * (DeftGemmDesc.w3), CoutPad * Kpad * NP halves.  Done once per layer at load time. */
 int deft_split_weights(const float* w, void* w3, int CoutPad, int Kpad, void* stream);
 
 /* The same for the halo form (DeftGemmDesc.p3_kernel = 1): `w` must be packed with korder 1, Kpad = 9 * Cin;
- * image [CoutPad/64][Cin/16][9 taps][64 rows][6 slots of 8 bf16]. */
+ * image [CoutPad/64][Cin/16][9 taps][64 rows][2*NP slots of 8 halves]. */
 int deft_split_weights_halo(const float* w, void* w3, int CoutPad, int Kpad, void* stream);
 
 /* The same for the patch form of deft_dcn_v2_nhwc (DeftGemmDesc.p3_kernel = 2): `w` [CoutPad][9 * Cin] in the DCN K order
  * (k = ((c / 32) * 9 + tap) * 32 + c % 32), CoutPad % 64 == 0, Cin % 32 == 0; image [CoutPad / 64][Cin / 16 * 9 chunks]
- * [3 pieces][2 k groups][64 rows][8 bf16] -- chunk (cb, tap) = channels 16 cb .. 16 cb + 15 of tap -- CoutPad * 9 * Cin * 3 bf16. */
+ * [NP pieces][2 k groups][64 rows][8 halves] -- chunk (cb, tap) = channels 16 cb .. 16 cb + 15 of tap -- CoutPad * 9 * Cin * NP halves. */
 int deft_split_weights_dcn(const float* w, void* w3, int CoutPad, int Cin, void* stream);
 
 /* y[m][c] = bias[c] + sum over the `nparts` partial maps part[(i * M + m) * ldp + c] of a folded 1x1 conv (DeftGemmDesc.fold_y),
