@@ -351,6 +351,8 @@ int deft_p3_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     P3_TILE(128, 64, 2, 2, 1)
     P3_TILE(64, 128, 2, 2, 1)
     P3_TILE(64, 64, 2, 2, 1)
+    P3_TILE(64, 128, 2, 2, 2)
+    P3_TILE(64, 128, 2, 2, 3)
     P3_TILE(256, 128, 4, 2, 2)
     P3_TILE(128, 256, 2, 4, 2)
     P3_TILE(128, 128, 2, 2, 2)
@@ -746,13 +748,13 @@ static int launch_p3h(const DeftGemmDesc& d, hipStream_t s) {
 int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     DEFT_CHECK(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->OH == d->H && d->OW == d->W && d->korder == 1 && d->splitk <= 1, -71,
                "deft_conv2d_nhwc: the halo form (p3_kernel = 1) is 3x3 / stride 1 / pad 1, korder 1, no split-K");
-    int th = (d->tile >> 16) & 0xfff, bn = d->tile & 0xffff;
+    int th = (d->tile >> 16) & 0x7ff, bn = d->tile & 0xffff;
     const int tw = (d->tile >> 28) & 1 ? 16 : 32;
     if (th == 0) {
         th = tw == 16 ? 8 : 4;
         bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
     }
-    const int tpi = (d->tile >> 29) & 1 ? 1 : 0;                 // bit 29: force one tap per interval where the tile defaults to three
+    const int tpi = (d->tile >> 29) & 1 ? 1 : ((d->tile >> 27) & 1 ? 3 : 0);      // bit 29: force one tap per interval where the tile defaults to three; bit 27: force three
 #define P3H_TILE(TH_, BN_, WM_, WN_, TPI_, TW_) \
     if (th == TH_ && tw == TW_ && bn == BN_ && (tpi == 0 || tpi == TPI_)) return launch_p3h<TH_, BN_, WM_, WN_, TPI_, TW_>(*d, s);
     P3H_TILE(4, 128, 2, 2, 1, 32)
@@ -762,6 +764,7 @@ int deft_p3h_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     P3H_TILE(8, 128, 4, 2, 1, 32)
     P3H_TILE(8, 64, 4, 2, 1, 32)
     P3H_TILE(8, 128, 2, 2, 1, 16)
+    if (tpi == 3) { P3H_TILE(8, 64, 4, 1, 3, 16) }
     P3H_TILE(8, 64, 4, 1, 1, 16)
     P3H_TILE(8, 32, 4, 1, 3, 16)
 #undef P3H_TILE

@@ -193,13 +193,15 @@ def _parse_tile(spec):
 
 
 P3_IM2COL_TILE = _parse_tile(_os.environ.get("DEFT_P3_IM2COL_TILE", ""))
+P3H_TPI3 = 1 << 27         # halo tile flag: a filter row (three taps) per weight stage and barrier
+P3H_TPI3_64 = _os.environ.get("DEFT_P3H_TPI3_64", "0") == "1"      # tuning aid: the 64-column 8 x 16 tiles on three taps per interval
 
 
 _T = lambda bm, bn: (bm << 16) | bn
 P3_3STAGE = 1 << 29
 P3_1STAGE = 1 << 30
 P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAGE, _T(128, 64), _T(128, 64) | P3_3STAGE, _T(256, 64),
-            _T(64, 64), _T(64, 64) | P3_3STAGE, _T(128, 128) | P3_1STAGE, _T(128, 64) | P3_1STAGE, _T(64, 128) | P3_1STAGE, _T(64, 64) | P3_1STAGE}       # igemm3.hip deft_p3_dispatch; a forced tile outside this set keeps the conv on igemm.hip
+            _T(64, 128), _T(64, 128) | P3_3STAGE, _T(64, 64), _T(64, 64) | P3_3STAGE, _T(128, 128) | P3_1STAGE, _T(128, 64) | P3_1STAGE, _T(64, 128) | P3_1STAGE, _T(64, 64) | P3_1STAGE}       # igemm3.hip deft_p3_dispatch; a forced tile outside this set keeps the conv on igemm.hip
 
 # cross-workgroup split-K for launches too small to fill the chip (DeftGemmDesc.splitk); DEFT_SPLITK=0 turns it off
 # the two 16-channel full-resolution layers (base_layer 7x7, level0 3x3) on the patch-in-LDS kernel (csrc/direct.hip) instead of the
@@ -260,7 +262,7 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
         narrow = Cout <= 32
         if waste <= (P3_HALO_WASTE_NARROW if narrow else P3_HALO_WASTE) and (Cout >= 128 or narrow or use16) \
                 and (M // (H * W)) * -(-H // th) * -(-W // tw) * -(-Cout // bn) >= (P3_MIN_TILES * 3 // 4 if narrow else P3_MIN_TILES):
-            return ("halo", ((th << 16) | bn | P3H_W16) if use16 else 0)
+            return ("halo", (((th << 16) | bn | P3H_W16) if use16 else 0) | (P3H_TPI3 if (P3H_TPI3_64 and bn == 64 and use16) else 0))
     if Cout < 64 or Cin < 64 or stride != 1:
         return None                     # stride-2 and 1x1 layers are no faster on 6-byte pieces (HBM- or issue-bound, tools/bench_p3.py)
     # the ONE-stage loop with several workgroups per CU (48 / 37 KB of LDS: 3 / 4 of them) beats the 2-stage ring with one 8-wave

@@ -775,6 +775,20 @@ def test_afe_and_lstm_launches_bit_exact_beside_another_kernel(gpu_lib):
     print("co-residency, AFE / LSTM chain: %d launches beside a foreign kernel, bit-exact; entries %s" % (n, names))
 
 
+def test_fp16_split_sequences_equal_the_cpp_expression(gpu_lib):
+    """csrc/common.h deft_split2_pair / deft_split2_pair_scaled: the two-fp16-piece split as v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16 (3 - 4 VALU
+    per pair of values) must give the bits of `h = (_Float16)y; m = (_Float16)(y - (float)h)` -- the emulator runs the C++ expression, so only
+    the hardware can check the instruction sequences: tools/probe/f16_split_asm.hip (built by __graft_entry__.build()), 1024 values over
+    several binades incl. fp16-subnormal residuals, with and without the power-of-two scale."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "probe", "f16_split_asm.bin")
+    if gpu_lib.pieces != 2:
+        pytest.skip("the library under test uses three bf16 pieces")
+    assert os.path.exists(exe), "run __graft_entry__.build() (it compiles tools/probe/f16_split_asm.hip)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
 def test_motion_bank_shared_by_two_callers(gpu_lib):
     """several trackers share one MotionBank (model.motion: the seven per-class nuScenes trackers, two 2-D trackers on one model) and
     each reads its asynchronous step a frame later.  With ONE pinned (in, out) pair per bank the second caller's copies landed in the first
