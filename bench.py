@@ -426,8 +426,8 @@ def side_config(name, args, dev, lib, rank):
     return out
 
 
-TRAFFIC_FILE = "r4_traffic.json"
-COUNTER_FILE = "r4_dominant_counters.json"
+TRAFFIC_FILE = "r5_traffic.json"
+COUNTER_FILE = "r5_dominant_counters.json"
 # SURVEY 8(d)'s lower bound of the HBM bytes one step has to move: every frame's image read once (4 B x 3 x H x W), the weights once per
 # step (85 MB), detections + embeddings + affinity blocks written once
 ALG_BYTES_PER_STEP = {"B": 32 * (608 * 1088 * 3 * 4 + 100 * 416 * 4 + 500 * 101 * 4) + 85_000_000}

@@ -237,6 +237,11 @@ __device__ __forceinline__ int deft_rint(double v) { return __double2int_rn(v); 
 
 static inline int deft_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ReLU that PROPAGATES NaN (as torch.relu does; fmaxf(NaN, 0) = 0 would launder it): an operand beyond the fp16-piece range turns its
+// products into inf - inf = NaN, and that NaN has to reach the heat map, where the host checks for it (deft_amd/detector.py _check_finite) --
+// with fmaxf an out-of-range activation became a silent zero.  Same bits as fmaxf for every non-NaN input but -0 (kept; fmaxf gives +0).
+__device__ __forceinline__ float deft_relu(const float v) { return v < 0.f ? 0.f : v; }
+
 // ---- LDS-transposed epilogue shared by the MFMA kernels ----------------------------------------------------------
 // Phase 1: every wave parks its TM x TN grid of 32x32 accumulators, scaled and shifted, in the LDS tile T[BM][LDT]
 // (D reg r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31: a half-wave writes 32 consecutive floats).
@@ -284,7 +289,7 @@ __device__ __forceinline__ void deft_epilogue_rows(const float* T, const DeftGem
             }
             if (p.relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                for (int e = 0; e < 4; ++e) { v0[e] = deft_relu(v0[e]); v1[e] = deft_relu(v1[e]); }
             }
             if (!cok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
             if (p.y != nullptr && cok && ml >= 0) {
@@ -324,7 +329,7 @@ __device__ __forceinline__ void deft_epilogue_rows(const float* T, const DeftGem
         }
         if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+            for (int e = 0; e < 4; ++e) { v0[e] = deft_relu(v0[e]); v1[e] = deft_relu(v1[e]); }
         }
         if (p.y != nullptr) {
             float* yp = p.y + m * p.ldy + co;

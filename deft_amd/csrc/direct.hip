@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void direct_conv_kernel(c
                 const int ox = ox0 + (mt & 1) * 16 + 4 * g + i;
                 if (ox < p.OW) {
                     float r = acc[mt][i] * sc + sh;
-                    if (p.relu) r = fmaxf(r, 0.f);
+                    if (p.relu) r = deft_relu(r);
                     yr[(size_t)ox * p.ldy] = r;
                 }
             }

@@ -366,7 +366,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 v = sw[i].x * s0[i] + sw[i].y * s1[i] + sw[i].z * s2[i] + sw[i].w * s3[i];
             } else {
                 const f32x4 t = s0[i] + s1[i];
-                v = f32x4{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)};
+                v = f32x4{deft_relu(t.x), deft_relu(t.y), deft_relu(t.z), deft_relu(t.w)};
             }
             if (PREC) {
                 pcx4 pc[DEFT_NP];
@@ -612,7 +612,7 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 float v1 = acc[i][j][4 * q + 1] * sc + sh + rv1;
                 float v2 = acc[i][j][4 * q + 2] * sc + sh + rv2;
                 float v3 = acc[i][j][4 * q + 3] * sc + sh + rv3;
-                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (p.relu) { v0 = deft_relu(v0); v1 = deft_relu(v1); v2 = deft_relu(v2); v3 = deft_relu(v3); }
                 float* yp = p.y + (size_t)mq * p.ldy + co;
                 if (cok && mq + 0 < p.M) yp[0] = v0;
                 if (cok && mq + 1 < p.M) yp[(size_t)p.ldy] = v1;

@@ -43,6 +43,23 @@ def _fetch(d):
 _NP = {torch.float32: np.float32, torch.float64: np.float64, torch.int64: np.int64, torch.int32: np.int32}
 
 
+def _flag_finite(plan, d, lib):
+    """Two-fp16-piece builds carry activations of |x| < 4094 (csrc/common.h); beyond that an operand is +-inf, the frame's heat map NaN -- and a
+    NaN map has no peaks: the frame would come back EMPTY, silently.  One more field in the frame's record (is every heat-map logit finite?)
+    turns that into an error in _check_finite.  Three-bf16-piece builds have no range limit: no flag."""
+    if getattr(lib, "pieces", 3) == 2:
+        d["_finite"] = torch.isfinite(plan.dense["hm"].buf).all().to(torch.float32).reshape(1)
+    return d
+
+
+def _check_finite(dets):
+    f = dets.pop("_finite", None)
+    if f is not None and not bool(np.all(f)):
+        raise FloatingPointError("non-finite heat map: an activation left the range of the two-fp16-piece arithmetic (|x| >= 4094, csrc/common.h) -- "
+                                 "run this model on the three-bf16-piece build: DEFT_HIP_LIB=<repo>/deft_amd/lib/libdeft_bf16x3.so")
+    return dets
+
+
 class _null:
     def __enter__(self):
         return self
@@ -131,7 +148,7 @@ class Detector(object):
         d = plan.dets()
         if "dep" in d:      # _sigmoid_output, detector.py:491-493, applied at the K peaks
             d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
-        dets = _fetch(d)
+        dets = _check_finite(_fetch(_flag_finite(plan, d, self.lib)))
         output = {"hm": plan.dense["hm"], "pre_inds": pre_inds}
         if return_time:
             import time
@@ -185,7 +202,7 @@ class Detector(object):
                 y = y[0:1]
             out[h] = y.contiguous()
         d = integrate.generic_decode(out, K=self.K, opt=self.opt, lib=self.lib)
-        dets = _fetch(d)
+        dets = _check_finite(_fetch(_flag_finite(plan, d, self.lib)))
         out["pre_inds"] = pre_inds
         if return_time:
             import time
@@ -385,7 +402,7 @@ class Detector(object):
         d = plan.dets()
         if "dep" in d:
             d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
-        dets = _fetch(d)
+        dets = _check_finite(_fetch(_flag_finite(plan, d, self.lib)))
         return {"hm": plan.dense["hm"], "pre_inds": None}, dets, time.time(), plan.fmaps
 
     # ---- one frame of lookahead: two sets of plan buffers, frame k+1's network pass beside frame k's host work ---------------------------
@@ -452,7 +469,7 @@ class Detector(object):
             else:
                 p.run()
                 sl.warm = True
-            d = p.dets()
+            d = _flag_finite(p, p.dets(), self.lib)
             if "dep" in d:
                 d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
             # every decoded field in ONE contiguous record (float64 holds the int64 indices exactly), ONE D2H into pinned memory
@@ -508,8 +525,9 @@ class Detector(object):
         rec, dets, o = cur.host.numpy(), {}, 0                         # (the pinned record is rewritten two passes on: copies)
         for k, shape, cnt, dt in cur.fields:
             a = rec[o:o + cnt].astype(dt).reshape(shape)
-            dets[k] = a[j:j + 1] if shape and shape[0] == cur.n else a
+            dets[k] = a[j:j + 1] if shape and shape[0] == cur.n and k != "_finite" else a
             o += cnt
+        _check_finite(dets)
         fmaps = cur.plan.fmaps if cur.n == 1 else [fm[j] for fm in cur.plan.fmaps]
         hm = cur.plan.dense["hm"] if cur.n == 1 else cur.plan.dense["hm"][j]
         cur.pos += 1

@@ -489,3 +489,25 @@ def test_fused_run_array_tracker(emu_lib, dataset, lstm):
 @pytest.mark.parametrize("tag", ["mot", "mot_lstm", "nuscenes"])
 def test_tracks_against_reference_trace(emu_lib, tag):
     pc.check_tracks_against_reference_trace(emu_lib, "cpu", tag)
+
+
+def test_out_of_range_activation_is_an_error_not_an_empty_frame(emu_lib, monkeypatch):
+    """The two-fp16-piece arithmetic carries activations of |x| < 4094 (csrc/common.h).  Beyond that an operand is +-inf and the heat map NaN --
+    and a NaN map has no peaks: without a check the frame would come back EMPTY.  The fused Detector carries one more field per frame (is
+    every heat-map logit finite?) and raises; a normal frame passes, and so does the same out-of-range frame on a three-bf16-piece build
+    (no range limit) -- checked on the hardware builds by the same function through `lib.pieces`."""
+    from types import SimpleNamespace
+    import deft_oracle as O
+    from deft_amd import detector as FD, hiplib
+    monkeypatch.setattr(hiplib, "_lib", emu_lib)
+    opt = SimpleNamespace(dataset="mot", K=8, max_object=100, gpus=[-1], hip_graphs=False, depth_scale=1.0, flip_test=False)
+    fd = FD.Detector(opt, O.synth_state_dict("mot"))
+    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(2))
+    _, dets, _ = fd.process(x)
+    assert "_finite" not in dets and np.isfinite(dets["scores"]).all() and float(dets["scores"][0, 0]) > 0
+    if emu_lib.pieces == 2:
+        with pytest.raises(FloatingPointError, match="two-fp16-piece"):
+            fd.process(x * 3.0e4)
+    else:
+        _, dets, _ = fd.process(x * 3.0e4)
+        assert np.isfinite(dets["scores"]).all()

@@ -82,6 +82,14 @@ def main():
           % (W, H, float(s[0]), float(s[-1]), float((b[:, 2:] - b[:, :2]).min()), float((b[:, 2:] - b[:, :2]).max()), float(emb.abs().max()),
              float(aff[:, :-1].diagonal().mean()), fin))
     ok = ok and fin
+    # the two-fp16-piece arithmetic carries activations of |x| < 4094 (csrc/common.h); beyond that an operand becomes +-inf and the frame NaN:
+    # report how far this checkpoint's activations are from that edge (the 13 feature maps cover every stage of the trunk and the neck)
+    amax = max(float(fm.buf.abs().max()) for fm in plan.fmaps)
+    print("largest |activation| over the 13 feature maps: %.3g (split arithmetic of this library: %d pieces%s)"
+          % (amax, lib.pieces, "; fp16 range 4094" if lib.pieces == 2 else ""))
+    if lib.pieces == 2 and (not fin or amax >= 1024.0):
+        print("WARNING: activations within two binades of the fp16-piece range (or non-finite results): run this checkpoint on the three-bf16-piece "
+              "build (DEFT_HIP_LIB=.../deft_amd/lib/libdeft_bf16x3.so), which has no range limit")
     if a.oracle:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import deft_oracle as O
