@@ -636,7 +636,7 @@ def main():
         roof, ops = roofline_of(wl, lib, rank, dt / args.steps, args.config)
         if rank == 0:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
+            with open(os.path.join(ROOT, "gpurun_out", os.environ.get("DEFT_BENCH_OPS", "bench_ops.json")), "w") as f:     # (the bf16x3 side run writes its own file)
                 json.dump(ops, f)
 
     # ---- parity gate on the timed plans (outside the timed region; rank 0's frames) ----
@@ -680,7 +680,7 @@ def main():
         torch.cuda.synchronize()
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", str(max(10, min(args.steps, 30))),
                             "--warmup", str(args.warmup), "--batch", str(B), "--streams", str(args.streams)] + (["--no-check"] if args.no_check else []),
-                           capture_output=True, text=True, env=dict(os.environ, DEFT_HIP_LIB=alt_so), timeout=900)
+                           capture_output=True, text=True, env=dict(os.environ, DEFT_HIP_LIB=alt_so, DEFT_BENCH_OPS="bench_ops_bf16x3.json"), timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode == 0 and line:
             a_ = json.loads(line[-1])

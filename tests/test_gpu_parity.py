@@ -305,7 +305,7 @@ def test_topk_seed_sweep_both_arithmetics(gpu_lib, dataset, H, W, nseeds):
                                          # a detection only ONE side reports, above the threshold: the tracker would see another detection set
                                          "another_detection_reaches_the_tracker": any(d["score"] > out_thresh and d["only_in"] != "order" for d in det)})
     rep = {"dataset": dataset, "H": H, "W": W, "frames": nseeds, "K": 100,
-           "frames_with_tie_level_index_differences": {"prec0_fp32_mfma": len(diff[0]), "prec1_split_bf16": len(diff[1]),
+           "frames_with_tie_level_index_differences": {"prec0_fp32_mfma": len(diff[0]), "prec1_split": len(diff[1]),
                                                        "timed_plans_2x16_frames_2_streams": len(diff["timed"])},
            "seeds": {"prec0": diff[0], "prec1": diff[1], "timed": diff["timed"]},
            "max_abs_logit_error": {"prec0": worst[0], "prec1": worst[1], "timed": worst["timed"]},
