@@ -378,8 +378,7 @@ def roofline_of(wl, lib, rank, dt_step, config):
             "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel (conv, DCNv2, pair loaders; fp32 results)",
             "peak_note": ("time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split kernels (" % (100.0 * split_ms / max(gemm_ms, 1e-9)))
                          + ("2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work: 3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product" if np_ == 3 else
-                            "2500 / 3 = 833.3 TFLOP/s of fp32-equivalent work: 2 fp16 pieces per operand, 3 fp16 MFMAs per fp32 product; the 16-channel "
-                            "full-resolution layers keep 3 bf16 pieces: 416.7")
+                            "2500 / 3 = 833.3 TFLOP/s of fp32-equivalent work: 2 fp16 pieces per operand, 3 fp16 MFMAs per fp32 product")
                          + "), the rest on v_mfma_f32_32x32x2_f32 (157.3)",
             "frac_of_bf16x3_ceiling": round(pipe_ach / (BF16_MFMA_PEAK_TF / 6), 4),       # the same FLOPs priced against rounds 1-4's ceiling (continuity)
             "frac_of_fp32_mfma_peak": round(pipe_ach / FP32_MFMA_PEAK_TF, 4),

@@ -117,6 +117,14 @@ __device__ __forceinline__ void deft_split2_pair_scaled(float x0, float x1, floa
 }
 #endif
 #endif
+// the 16 x 16 x 32 form (direct.hip: 16 pixels x 16 output channels)
+__device__ __forceinline__ f32x4 deft_mfma16_pc(const pcx8 a, const pcx8 b, const f32x4 c) {
+#if DEFT_PIECES == 3
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
 // the pieces of four values (A operands: pass scale = DEFT_ASCALE; weights arrive scaled by the host: scale = 1)
 __device__ __forceinline__ void deft_split(const f32x4 v, pcx4 (&pc)[DEFT_NP], const float scale = 1.f) {
 #if DEFT_PIECES == 2

@@ -5,10 +5,10 @@
 // the first two together 6.2 GFLOP per 1088x608 frame on 661 504 pixels -- 16 channels wide, so an implicit GEMM has 16 (32 as pixel
 // pairs) columns and a 147 / 144-deep contraction: on igemm.hip they run on v_mfma_f32_32x32x2_f32 at 61-70 TFLOP/s with the
 // matrix pipe 62 % busy (profiles/r2_summary.md), 1/3 of it on padding.  Here a workgroup stages the (8 + KH - 1) x (32 + KW - 1)
-// fp32 input patch of an 8 x 32 output tile ONCE, splits it into the three bf16 pieces (x = hi + mid + lo, exact) on the way
-// into LDS -- one split per input element instead of one per (output pixel, tap) -- and takes every tap out of the patch as
-// a shifted fragment read feeding v_mfma_f32_16x16x32_bf16 (16 pixels x 16 output channels x 32 k): six products per
-// fp32 product, fp32 accumulation, the same arithmetic as DeftGemmDesc.prec = 1.
+// fp32 input patch of an 8 x 32 output tile ONCE, splits it into the operand pieces of the split arithmetic (common.h DEFT_PIECES: two fp16
+// pieces in the product build, three bf16 pieces in libdeft_bf16x3.so) on the way into LDS -- one split per input element instead of one per
+// (output pixel, tap) -- and takes every tap out of the patch as a shifted fragment read feeding v_mfma_f32_16x16x32_{f16,bf16} (16 pixels x
+// 16 output channels x 32 k): three (six) products per fp32 product, fp32 accumulation, the same arithmetic as DeftGemmDesc.prec = 1.
 //
 // K order inside one MFMA (lane l: row/col l & 15, k-group g = l >> 4 holding 8 consecutive k):
 //   Cin = 16:  step t covers taps 2t and 2t+1:  tap = 2t + (g >> 1), channels 8 (g & 1) .. +7     (3x3: 5 steps, tap 9 = zero weights)
@@ -39,7 +39,7 @@ struct DcCfg {
     static constexpr int PXB = CIN == 16 ? (STRIDE == 1 ? 48 : 40) : 8;
     static constexpr int PLANE = PH * PW * PXB;
     static constexpr int STEPS = CIN == 16 ? (KH * KW + 1) / 2 : KH;
-    static constexpr int LDS = 3 * PLANE;
+    static constexpr int LDS = DEFT_NP * PLANE;
     static constexpr int ITEMS = CIN == 16 ? PH * PW * 4 : PH * PW;      // 16-byte global loads per patch
     static constexpr int NI = (ITEMS + 255) / 256;
 };
@@ -65,15 +65,15 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void direct_conv_kernel(c
     const int wrow = C::NB == 1 ? 2 * wave : 2 * (wave >> 1);   // ... and its first output row of the tile
 
     // ---- weights: this lane's B fragments of every step (L2-resident, lane-linear) ----
-    const bf16x8* const wf = (const bf16x8*)p.w3 + cb * C::STEPS * 192;
-    bf16x8 Bf[C::STEPS][3];
+    const pcx8* const wf = (const pcx8*)p.w3 + cb * C::STEPS * (DEFT_NP * 64);
+    pcx8 Bf[C::STEPS][DEFT_NP];
 #pragma unroll
     for (int t = 0; t < C::STEPS; ++t)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) Bf[t][q] = wf[(t * 3 + q) * 64 + lane];
+        for (int q = 0; q < DEFT_NP; ++q) Bf[t][q] = wf[(t * DEFT_NP + q) * 64 + lane];
 
     const int co = cb * 16 + (lane & 15);          // epilogue constants, fetched ahead of everything that waits
-    const float sc = p.scale ? p.scale[co < p.Cout ? co : 0] : 1.f, sh = p.shift ? p.shift[co < p.Cout ? co : 0] : 0.f;
+    const float sc = (p.scale ? p.scale[co < p.Cout ? co : 0] : 1.f) * DEFT_ASCALE_INV, sh = p.shift ? p.shift[co < p.Cout ? co : 0] : 0.f;     // (the patch is split with DEFT_ASCALE)
 
     // ---- stage the patch: fp32 NHWC -> three bf16 piece planes in LDS (zero outside the image) ----
     {
@@ -94,12 +94,11 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void direct_conv_kernel(c
             const int it = i * 256 + tid;
             if (it < C::ITEMS) {
                 const int px = CIN == 16 ? it >> 2 : it, cq = CIN == 16 ? it & 3 : 0;
-                bf16x4 h, m, l;
-                split3(v[i], h, m, l);
+                pcx4 pc[DEFT_NP];
+                deft_split(v[i], pc, DEFT_ASCALE);
                 char* const dst = smem + px * C::PXB + cq * 8;
-                *(bf16x4*)dst = h;
-                *(bf16x4*)(dst + C::PLANE) = m;
-                *(bf16x4*)(dst + 2 * C::PLANE) = l;
+#pragma unroll
+                for (int q = 0; q < DEFT_NP; ++q) *(pcx4*)(dst + q * C::PLANE) = pc[q];
             }
         }
     }
@@ -121,26 +120,26 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void direct_conv_kernel(c
         } else {
             a0 = ((wrow + t) * C::PW + prow + 2 * g) * C::PXB;
         }
-        bf16x8 Af[4][3];
+        pcx8 Af[4][DEFT_NP];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const char* const ap = smem + a0 + ((mt >> 1) * C::PW + (mt & 1) * 16) * STRIDE * C::PXB;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < DEFT_NP; ++q) {
                 if (CIN == 16 && STRIDE == 1) {
-                    Af[mt][q] = *(const bf16x8*)(ap + q * C::PLANE);
+                    Af[mt][q] = *(const pcx8*)(ap + q * C::PLANE);
                 } else {                                // 8-byte aligned only: two 8-byte reads (Cin = 4: two pixels)
-                    const bf16x4 u0 = *(const bf16x4*)(ap + q * C::PLANE), u1 = *(const bf16x4*)(ap + q * C::PLANE + 8);
+                    const pcx4 u0 = *(const pcx4*)(ap + q * C::PLANE), u1 = *(const pcx4*)(ap + q * C::PLANE + 8);
                     Af[mt][q] = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
             }
         }
-        // six products, smallest terms first (as the other split-bf16 kernels); the four m-tiles interleaved so that no MFMA
+        // the products of the split, smallest terms first (as the other split kernels); the four m-tiles interleaved so that no MFMA
         // waits on the one before it
-#define DC_PROD(QA, QB)                                                                                             \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[mt][QA], Bf[t][QB], acc[mt], 0, 0, 0);
-        DC_PROD(1, 1) DC_PROD(2, 0) DC_PROD(0, 2) DC_PROD(1, 0) DC_PROD(0, 1) DC_PROD(0, 0)
-#undef DC_PROD
+#pragma unroll
+        for (int q = 0; q < DEFT_NPROD; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = deft_mfma16_pc(Af[mt][deft_qa(q)], Bf[t][deft_qb(q)], acc[mt]);
     }
 
     // ---- epilogue: D reg i of lane l is pixel 4 (l >> 4) + i of the m-tile, output channel l & 15 ----
@@ -182,13 +181,14 @@ int launch_direct(const DeftGemmDesc& d, hipStream_t s) {
     return 0;
 }
 
-// one thread per bf16x8 of the fragment image [Cout/16 column blocks][steps][3][64 lanes]
-__global__ __launch_bounds__(256) void split_weights_direct_kernel(const float* __restrict__ w, __bf16* __restrict__ w3, int Cout, int Kpad, int KH, int KW,
+// one thread per 16-byte slot of the fragment image [Cout/16 column blocks][steps][DEFT_NP pieces][64 lanes]
+__global__ __launch_bounds__(256) void split_weights_direct_kernel(const float* __restrict__ w, deft_piece_t* __restrict__ w3, int Cout, int Kpad, int KH, int KW,
                                                                    int Cin, int steps) {
+    constexpr int PER = DEFT_NP * 64;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int nb = (Cout + 15) / 16;
-    if (i >= nb * steps * 3 * 64) return;
-    const int lane = i & 63, q = (i >> 6) % 3, t = (i / 192) % steps, cb = i / (192 * steps);
+    if (i >= nb * steps * PER) return;
+    const int lane = i & 63, q = (i >> 6) % DEFT_NP, t = (i / PER) % steps, cb = i / (PER * steps);
     const int co = cb * 16 + (lane & 15), g = lane >> 4;
     float v[8];
 #pragma unroll
@@ -203,10 +203,10 @@ __global__ __launch_bounds__(256) void split_weights_direct_kernel(const float* 
         }
         v[e] = (k >= 0 && co < Cout) ? w[(size_t)co * Kpad + k] : 0.f;
     }
-    bf16x4 pc[2][3];
-    split3(f32x4{v[0], v[1], v[2], v[3]}, pc[0][0], pc[0][1], pc[0][2]);
-    split3(f32x4{v[4], v[5], v[6], v[7]}, pc[1][0], pc[1][1], pc[1][2]);
-    *(bf16x8*)(w3 + (size_t)i * 8) = __builtin_shufflevector(pc[0][q], pc[1][q], 0, 1, 2, 3, 4, 5, 6, 7);
+    pcx4 pc[2][DEFT_NP];
+    deft_split(f32x4{v[0], v[1], v[2], v[3]}, pc[0]);
+    deft_split(f32x4{v[4], v[5], v[6], v[7]}, pc[1]);
+    *(pcx8*)(w3 + (size_t)i * 8) = __builtin_shufflevector(pc[0][q], pc[1][q], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 int direct_steps(int KH, int KW, int Cin) { return Cin == 16 ? (KH * KW + 1) / 2 : KH; }
@@ -233,14 +233,14 @@ extern "C" int deft_conv_direct(const DeftGemmDesc* d, void* stream) {
 
 extern "C" long long deft_direct_weight_bytes(int KH, int KW, int Cin, int Cout) {
     if (!((Cin == 16 && KH * KW >= 1) || (Cin == 4 && KW <= 8)) || KH < 1 || KW < 1 || Cout < 1 || Cout > 32) return -1;
-    return (long long)((Cout + 15) / 16) * direct_steps(KH, KW, Cin) * 3 * 64 * 16;
+    return (long long)((Cout + 15) / 16) * direct_steps(KH, KW, Cin) * DEFT_NP * 64 * 16;
 }
 
 extern "C" int deft_split_weights_direct(const float* w, void* w3, int Cout, int Kpad, int KH, int KW, int Cin, void* stream) {
     DEFT_CHECK(w && w3 && Cout >= 1 && Cout <= 32 && (Cin == 16 || (Cin == 4 && KW <= 8)) && KH >= 1 && KW >= 1 && Kpad >= KH * KW * Cin, -1,
                "deft_split_weights_direct: need Cout <= 32, Cin 16 (or 4 with KW <= 8), Kpad >= KH*KW*Cin (%d %d %d %d %d)", Cout, Kpad, KH, KW, Cin);
     const int steps = direct_steps(KH, KW, Cin);
-    hipLaunchKernelGGL(split_weights_direct_kernel, dim3(deft_cdiv(((Cout + 15) / 16) * steps * 192, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)w3, Cout, Kpad, KH,
+    hipLaunchKernelGGL(split_weights_direct_kernel, dim3(deft_cdiv(((Cout + 15) / 16) * steps * DEFT_NP * 64, 256)), dim3(256), 0, (hipStream_t)stream, w, (deft_piece_t*)w3, Cout, Kpad, KH,
                        KW, Cin, steps);
     DEFT_CHECK_LAUNCH("split_weights_direct");
     return 0;

@@ -874,7 +874,8 @@ class _Plan:
             nb = self.lib.cdll.deft_direct_weight_bytes(KH, KH, x.C, Cout)
             assert nb > 0
             w3 = torch.empty(nb, dtype=torch.uint8, device=self.device)
-            self.lib.call("deft_split_weights_direct", ptr(w_packed), ptr(w3), Cout, w_packed.shape[1], KH, KH, x.C, hiplib.stream_ptr(self.device))
+            self._by_ptr.setdefault(w_packed.data_ptr(), w_packed)
+            self.lib.call("deft_split_weights_direct", ptr(self._scaled_weight(w_packed)[0]), ptr(w3), Cout, w_packed.shape[1], KH, KH, x.C, hiplib.stream_ptr(self.device))
             self._w3[key] = w3
             self._keep.append(w_packed)
         d = GemmDesc()
@@ -890,6 +891,9 @@ class _Plan:
         d.relu = int(relu)
         d.flop_k = KH * KH * true_cin
         d.prec = 1
+        if scale is not None:
+            self._by_ptr.setdefault(scale.data_ptr(), scale)
+        self.prescale(d)                     # (two-piece builds: the image above was built from the row-scaled matrix; the scale compensates)
         self._keep.append(d)
         lib, ref = self.lib, C.byref(d)
         self.add("deft_conv_direct", name, lambda: lib.call("deft_conv_direct", ref, self._stream()), 2.0 * d.M * Cout * KH * KH * true_cin,

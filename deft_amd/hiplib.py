@@ -139,7 +139,7 @@ class HipLib:
                 nbytes = alg_bytes(d)
                 info = "M=%d N=%d K=%d %dx%d s%d @%dx%d" % (d.M, d.Cout, d.Ktot, d.KH, d.KW, d.stride, d.H, d.W)
                 if name == "deft_conv_direct":
-                    ceil = 2500.0 / 6   # six v_mfma_f32_16x16x32_bf16 per fp32 product (three bf16 pieces in every build)
+                    ceil = 2500.0 / (6 if self.pieces == 3 else 3)   # six v_mfma_f32_16x16x32_bf16 / three v_mfma_f32_16x16x32_f16 per fp32 product
                     info += " split direct"
                 elif self.split_arithmetic(name, d):
                     # ... or six v_mfma_f32_32x32x16_bf16 (three bf16 pieces) / three v_mfma_f32_32x32x16_f16 (two fp16 pieces) per fp32 product

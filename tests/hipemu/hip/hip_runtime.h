@@ -382,6 +382,23 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipemu_bf16x8
     }
     return c;
 }
+// 16x16x32 f16 (gfx950): the same fragment layout on fp16 inputs
+static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x4 c, int, int, int) {
+    hipemu::State& s = hipemu::S();
+    const int p = s.parity ^ 1, lane = s.lane;
+    for (int e = 0; e < 8; ++e) { s.xf[p][e][lane] = (float)a[e]; s.xf[p][8 + e][lane] = (float)b[e]; }
+    hipemu::yield(hipemu::Y_WAVE);
+    hipemu::State& t = hipemu::S();
+    const int col = lane & 15, q = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = q * 4 + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg)
+            for (int e = 0; e < 8; ++e) acc = fmaf(t.xf[p][e][row + 16 * kg], t.xf[p][8 + e][col + 16 * kg], acc);
+        c[r] = acc;
+    }
+    return c;
+}
 static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
     const float *A, *B;
     const int lane = hipemu::S().lane;
