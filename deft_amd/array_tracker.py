@@ -189,8 +189,12 @@ class ArrayTracker(object):
         sel = pos >= (L - nsel)[:, None]
         return nf, ni, sel
 
-    def _similarity(self, fid, rows_idx, nd, sel_all):
-        """deft_amd.tracker.get_similarity on the node arrays: float64 [len(rows_idx), nd + 1]."""
+    def _similarity(self, fid, rows_idx, nd, sel_all, defer=False):
+        """deft_amd.tracker.get_similarity on the node arrays: float64 [len(rows_idx), nd + 1].  defer: queue the launch and the copy back, return
+        a callable that waits for them -- update() does host work that does not need the matrix (Kalman prediction, the motion gate) in between."""
+        if defer:
+            got = self._similarity(fid, rows_idx, nd, sel_all, defer=None)
+            return got if callable(got) else (lambda: got)
         T = len(rows_idx)
         if T == 0:
             return np.array([])
@@ -243,8 +247,12 @@ class ArrayTracker(object):
         if dev.type == "cuda":
             land = pin[1][:T * (nd + 1)].view(T, nd + 1)
             land.copy_(out, non_blocking=True)
-            torch.cuda.current_stream(dev).synchronize()               # THE device round trip of the frame
-            return land.numpy().astype(np.float64)
+            stream = torch.cuda.current_stream(dev)
+
+            def wait():
+                stream.synchronize()                                   # THE device round trip of the frame
+                return land.numpy().astype(np.float64)
+            return wait if defer is None else wait()
         return out.numpy().astype(np.float64)
 
     # ---- LSTM side --------------------------------------------------------------------------------------------------------------
@@ -336,6 +344,9 @@ class ArrayTracker(object):
         else:
             tlwh = xyah = tlbr = np.zeros((0, 4)); dscore = np.zeros(0, np.float32)
         T0 = c.n
+        # 2-D configurations: the pool of the embedding association is every track, so the similarity launch can be queued NOW and read after the
+        # host work that does not depend on it (prediction, motion gate) -- the device round trip hides behind ~0.15 ms of numpy
+        sim_wait = self._similarity(fid, np.arange(T0), nd0, sel_all, defer=True) if (not self.ddd and T0 and nd0) else None
         if not self.use_lstm and T0:                                   # STrack.multi_predict, tracker.py:193-207 (every pool track is Tracked)
             c.a["mean"], c.a["cov"] = kf_multi_predict(c["mean"], c["cov"])
         matched_t, matched_d = [], []                                  # pool row, detection index -- in the reference's output order
@@ -353,7 +364,13 @@ class ArrayTracker(object):
             det_left = np.asarray(u_d, dtype=int)
             pool = np.concatenate([new[np.asarray(u_t, dtype=int)], old]).astype(int)
         # ---- embedding association fused with the motion gate (tracker.py:886-925) ----
-        sim = self._similarity(fid, pool, nd0, sel_all) if len(pool) and len(det_left) else None
+        g_pre = None
+        if sim_wait is not None and not self.use_lstm:                 # the Kalman gate of matching.fuse_motion (:330-338) while the device works
+            g_pre = A._maha2(c["mean"][pool][:, :2], c["cov"][pool][:, :2, :2], xyah[det_left][:, :2])
+        if sim_wait is not None:
+            sim = sim_wait()
+        else:
+            sim = self._similarity(fid, pool, nd0, sel_all) if len(pool) and len(det_left) else None
         self._device_done()
         dists = np.zeros((len(pool), len(det_left)), dtype=float)
         if dists.size:
@@ -370,7 +387,7 @@ class ArrayTracker(object):
                 dists[g > thr[:, None]] = np.inf
                 dists = lam * dists + 0.001 * g
             elif not self.use_lstm:                                    # matching.fuse_motion, Kalman: :330-338
-                g = A._maha2(c["mean"][pool][:, :2], c["cov"][pool][:, :2, :2], xyah[det_left][:, :2])
+                g = g_pre if g_pre is not None else A._maha2(c["mean"][pool][:, :2], c["cov"][pool][:, :2, :2], xyah[det_left][:, :2])
                 dists[g > 5.0 * A.chi2inv95[2]] = np.inf
                 dists = lam * dists + 0.05 * (1 - lam) * g
             else:                                                      # LSTM: :339-366

@@ -193,6 +193,7 @@ def _parse_tile(spec):
 
 
 P3_IM2COL_TILE = _parse_tile(_os.environ.get("DEFT_P3_IM2COL_TILE", ""))
+P3_STRIDE2 = _os.environ.get("DEFT_P3_STRIDE2", "0") == "1"      # tuning aid: stride-2 3x3 convs with Cin >= 64 on the im2col piece kernel
 P3H_TPI3 = 1 << 27         # halo tile flag: a filter row (three taps) per weight stage and barrier
 P3H_TPI3_64 = _os.environ.get("DEFT_P3H_TPI3_64", "0") == "1"      # tuning aid: the 64-column 8 x 16 tiles on three taps per interval
 
@@ -263,8 +264,8 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
         if waste <= (P3_HALO_WASTE_NARROW if narrow else P3_HALO_WASTE) and (Cout >= 128 or narrow or use16) \
                 and (M // (H * W)) * -(-H // th) * -(-W // tw) * -(-Cout // bn) >= (P3_MIN_TILES * 3 // 4 if narrow else P3_MIN_TILES):
             return ("halo", (((th << 16) | bn | P3H_W16) if use16 else 0) | (P3H_TPI3 if (P3H_TPI3_64 and bn == 64 and use16) else 0))
-    if Cout < 64 or Cin < 64 or stride != 1:
-        return None                     # stride-2 and 1x1 layers are no faster on 6-byte pieces (HBM- or issue-bound, tools/bench_p3.py)
+    if Cout < 64 or Cin < 64 or (stride != 1 and not (P3_STRIDE2 and stride == 2)):
+        return None                     # stride-2 and 1x1 layers are no faster on the piece form (HBM- or issue-bound, tools/bench_p3.py; round 5 A/B with two pieces: below)
     # the ONE-stage loop with several workgroups per CU (48 / 37 KB of LDS: 3 / 4 of them) beats the 2-stage ring with one 8-wave
     # workgroup on every shape (profiles/r2_bench_p3.log: 256->256 @38x68 179 vs 150 TFLOP/s, 64->64 @152x272 148 vs 120)
     tile = (_T(64, 128) if Cout >= 128 else _T(128, 64)) | P3_1STAGE
