@@ -87,6 +87,8 @@ class _Columns(object):
 
 class ArrayTracker(object):
     lazy_blocks = True             # score the new frame only against the stored frames the pool's selected nodes live in
+    native_assoc = True            # 2-D datasets: the association cascade of a frame in ONE host call (deft_associate_2d); False = the numpy
+    #                                stages below (what the nuScenes trackers run: their 3-D stages differ), kept as the cross-check of the native call
     after_device_work = None       # set by a caller (Detector.run's lookahead): called ONCE per update(), as soon as the frame's last
     #                                result-bearing device step has been read back; what follows is host work (plus one tiny motion launch)
 
@@ -194,7 +196,7 @@ class ArrayTracker(object):
         a callable that waits for them -- update() does host work that does not need the matrix (Kalman prediction, the motion gate) in between."""
         if defer:
             got = self._similarity(fid, rows_idx, nd, sel_all, defer=None)
-            return got if callable(got) else (lambda: got)
+            return got if callable(got) else (lambda raw=False: got)
         T = len(rows_idx)
         if T == 0:
             return np.array([])
@@ -211,21 +213,22 @@ class ArrayTracker(object):
         rows = np.zeros((T, L), np.int32); scale = np.zeros((T, L), np.float32)
         cnt = sel.sum(1).astype(np.int32)
         if sel.any():
-            frames = np.unique(nf[sel])
-            lut = {}
-            for f in frames.tolist():
-                blk, delta = index[f]                                  # KeyError like the reference for an unknown frame
-                lut[f] = (starts[blk], starts[blk + 1] - starts[blk], delta)
-            st = np.zeros(nf.shape, np.int64); ln = np.ones(nf.shape, np.int64); dl = np.zeros(nf.shape, np.float32)
-            for f, (s0, l0, d0) in lut.items():
-                m = sel & (nf == f)
-                st[m], ln[m], dl[m] = s0, l0, d0
+            f0, f1 = int(nf[sel].min()), int(nf[sel].max())
+            # frame -> (first row of its block, its length, its decay): dense tables over the frames the selected nodes span
+            st_t = np.zeros(f1 - f0 + 1, np.int64); ln_t = np.full(f1 - f0 + 1, -1, np.int64); dl_t = np.zeros(f1 - f0 + 1, np.float32)
+            for f, (blk, delta) in index.items():
+                if f0 <= f <= f1:
+                    st_t[f - f0], ln_t[f - f0], dl_t[f - f0] = starts[blk], starts[blk + 1] - starts[blk], delta
+            fr = np.where(sel, nf - f0, 0)
+            ln = ln_t[fr]
+            if (sel & (ln < 0)).any():
+                raise KeyError(int(nf[sel & (ln < 0)][0]))                 # KeyError like the reference for a frame without a block
             if (sel & ((ni < 0) | (ni >= ln))).any():
                 raise IndexError("node id outside its frame")
-            # left-align the selected nodes of every row (the kernel reads node_row[t][0 .. cnt - 1])
-            order = np.argsort(~sel, axis=1, kind="stable")
-            rows = np.take_along_axis(np.where(sel, st + ni, 0), order, 1).astype(np.int32)
-            scale = np.take_along_axis(np.where(sel, dl, 0), order, 1).astype(np.float32)
+            # the selected nodes are a suffix of every row (newest at column L - 1): reversed they are left-aligned, which is what the kernel
+            # reads (node_row[t][0 .. cnt - 1]; a median does not care about the order)
+            rows = np.where(sel, st_t[fr] + ni, 0)[:, ::-1].astype(np.int32)
+            scale = np.where(sel, dl_t[fr], np.float32(0))[:, ::-1].astype(np.float32)
         plan = self.model.AFE.plan
         dev = sim.device
         n1 = T * L
@@ -249,11 +252,12 @@ class ArrayTracker(object):
             land.copy_(out, non_blocking=True)
             stream = torch.cuda.current_stream(dev)
 
-            def wait():
+            def wait(raw=False):
                 stream.synchronize()                                   # THE device round trip of the frame
-                return land.numpy().astype(np.float64)
+                return land.numpy() if raw else land.numpy().astype(np.float64)
             return wait if defer is None else wait()
-        return out.numpy().astype(np.float64)
+        host = out.numpy()
+        return (lambda raw=False: host if raw else host.astype(np.float64)) if defer is None else host.astype(np.float64)
 
     # ---- LSTM side --------------------------------------------------------------------------------------------------------------
     def _resolve(self):
@@ -295,6 +299,78 @@ class ArrayTracker(object):
             step_async = getattr(self.bank, "step_async", None)
             res = step_async(slots, boxes, fid) if step_async is not None else self.bank.step(slots, boxes, fid)[1]
             self._pending = (np.asarray(rows), res)
+
+    def _kf(self, entry, *args):
+        """deft_kf_predict(T) / deft_kf_update(rows, measurements) on the pool's mean / cov columns, in place."""
+        mean, cov = self.cols["mean"], self.cols["cov"]
+        assert mean.flags.c_contiguous and cov.flags.c_contiguous and mean.dtype == cov.dtype == np.float64
+        lib = self.model.AFE.plan.lib
+        if entry == "deft_kf_predict":
+            lib.call(entry, C.c_void_p(mean.ctypes.data), C.c_void_p(cov.ctypes.data), int(args[0]))
+        else:
+            rows, meas = args
+            try:
+                lib.call(entry, C.c_void_p(mean.ctypes.data), C.c_void_p(cov.ctypes.data), C.c_void_p(rows.ctypes.data), len(rows),
+                         C.c_void_p(meas.ctypes.data))
+            except Exception as e:
+                if "not positive definite" in str(e):
+                    raise np.linalg.LinAlgError(str(e))
+                raise
+
+    def _associate_2d(self, fid, T, N, sim_wait, xyah, tlbr):
+        """tracker.py:886-1030 for mot / kitti_tracking through deft_associate_2d: the per-row inputs (gate centre, Cholesky factor of the 2 x 2
+        position covariance, which rows the Mahalanobis gate applies to, which rows may enter the IoU stage, the box the IoU stage compares) are
+        O(T) numpy; the O(T x N) matrices and the three assignments are the native call.  -> (matched rows, matched detections, IoU-stage rows left
+        unmatched, detections left unmatched)."""
+        c = self.cols
+        lam = 0.9
+        if T:
+            if self.use_lstm:
+                gated = c["nobs"][:T] >= 300                                # matching.py:342
+                mean2 = np.zeros((T, 2)); cov2 = np.tile(np.eye(2), (T, 1, 1))
+                pred = self._prediction_at(np.arange(T), fid).astype(np.float32)        # (float32 like the reference's arrays, tracker.py:254-280)
+                if gated.any():
+                    mean2[gated] = pred[gated].astype(np.float64)[:, :2]
+                    cov2[gated] = (c["om2"][:T][gated] / (c["nobs"][:T][gated] - 1)[:, None, None])[:, :2, :2]
+                p = pred.copy()
+                p[:, 2] *= p[:, 3]
+                p[:, :2] -= p[:, 2:] / 2
+                p[:, 2:] += p[:, :2]
+                a_tlbr = p.astype(np.float64)
+            else:
+                gated = np.ones(T, bool)
+                mean2 = np.ascontiguousarray(c["mean"][:T, :2])
+                cov2 = c["cov"][:T, :2, :2]
+                a_tlbr = self._tlwh_rows(slice(0, T))
+                a_tlbr[:, 2:] += a_tlbr[:, :2]
+            with np.errstate(invalid="ignore", divide="ignore"):            # the 2 x 2 Cholesky factor of gating_distance (kalman_filter.py:266-275)
+                l00 = np.sqrt(cov2[:, 0, 0])
+                l10 = cov2[:, 1, 0] / l00
+                l11 = np.sqrt(cov2[:, 1, 1] - l10 * l10)
+            chol = np.stack([l00, l10, l11], 1)
+            if N and not (np.isfinite(chol).all() and (l00 > 0).all() and (l11 > 0).all()):
+                raise np.linalg.LinAlgError("Matrix is not positive definite")
+            iou_ok = np.abs(fid - c["fid"][:T]) < 6 if self.dataset == "kitti_tracking" else np.ones(T, bool)
+            gated = np.ascontiguousarray(gated, dtype=np.uint8); iou_ok = np.ascontiguousarray(iou_ok, dtype=np.uint8)
+            a_tlbr = np.ascontiguousarray(a_tlbr, dtype=np.float64)
+        else:
+            mean2 = chol = a_tlbr = np.zeros((0, 4)); gated = iou_ok = np.zeros(0, np.uint8)
+        meas2 = np.ascontiguousarray(xyah[:, :2], dtype=np.float64)
+        d_tlbr = np.ascontiguousarray(tlbr, dtype=np.float64)
+        k = min(T, N)
+        out = np.empty(2 * k + T + N + 3, np.int32)
+        mt, md, lost, new_d, cnt = out[:k], out[k:2 * k], out[2 * k:2 * k + T], out[2 * k + T:2 * k + T + N], out[2 * k + T + N:]
+        sim = sim_wait(raw=True) if sim_wait is not None else None     # everything above is host work the device round trip hides behind
+        self._device_done()
+        if sim is not None:
+            assert sim.dtype == np.float32 and sim.shape == (T, N + 1) and sim.flags.c_contiguous
+        ptr = lambda a: C.c_void_p(a.ctypes.data if a.size else 0)
+        self.model.AFE.plan.lib.call(
+            "deft_associate_2d", ptr(sim) if sim is not None else None, N + 1, T, N, ptr(mean2), ptr(chol), ptr(gated), ptr(meas2),
+            C.c_double(5.0 * A.chi2inv95[2]), C.c_double(lam), C.c_double(0.05 * (1 - lam)), int(self.dataset == "kitti_tracking"),
+            ptr(iou_ok), ptr(a_tlbr), ptr(d_tlbr), C.c_double(0.9), C.c_double(0.9), ptr(mt), ptr(md), C.c_void_p(cnt.ctypes.data),
+            ptr(lost), C.c_void_p(cnt.ctypes.data + 4), ptr(new_d), C.c_void_p(cnt.ctypes.data + 8))
+        return mt[:cnt[0]].astype(int), md[:cnt[0]].astype(int), lost[:cnt[1]].astype(int), new_d[:cnt[2]].astype(int)
 
     # ---- one frame --------------------------------------------------------------------------------------------------------------
     def _device_done(self):
@@ -348,7 +424,10 @@ class ArrayTracker(object):
         # host work that does not depend on it (prediction, motion gate) -- the device round trip hides behind ~0.15 ms of numpy
         sim_wait = self._similarity(fid, np.arange(T0), nd0, sel_all, defer=True) if (not self.ddd and T0 and nd0) else None
         if not self.use_lstm and T0:                                   # STrack.multi_predict, tracker.py:193-207 (every pool track is Tracked)
-            c.a["mean"], c.a["cov"] = kf_multi_predict(c["mean"], c["cov"])
+            if self.native_assoc:
+                self._kf("deft_kf_predict", T0)
+            else:
+                c.a["mean"], c.a["cov"] = kf_multi_predict(c["mean"], c["cov"])
         matched_t, matched_d = [], []                                  # pool row, detection index -- in the reference's output order
         pool = np.arange(T0)
         det_left = np.arange(nd0)
@@ -363,6 +442,20 @@ class ArrayTracker(object):
                 matched_t += new[m[:, 0]].tolist(); matched_d += m[:, 1].tolist()
             det_left = np.asarray(u_d, dtype=int)
             pool = np.concatenate([new[np.asarray(u_t, dtype=int)], old]).astype(int)
+        native = self.native_assoc and not self.ddd
+        if native:                                                     # 2-D: the three stages below in one host call
+            mt, md, lost, new_d = self._associate_2d(fid, T0, nd0, sim_wait, xyah, tlbr)
+            removed = lost[fid - c["fid"][lost] > self.max_time_lost].tolist()
+        else:
+            mt, md, removed, new_d = self._associate_stages(fid, T0, nd0, sim_wait, sel_all, pool, det_left, matched_t, matched_d, xyah, tlbr,
+                                                            det_ddd if self.ddd else None)
+        new_d = new_d[dscore[new_d] >= self.det_thresh] if len(new_d) else new_d
+        return self._commit(fid, T0, mt, md, removed, new_d, dscore, tlwh, xyah, det_ddd if self.ddd else None, det_depth if self.ddd else None,
+                            ddd_org_boxes, submission)
+
+    def _associate_stages(self, fid, T0, nd0, sim_wait, sel_all, pool, det_left, matched_t, matched_d, xyah, tlbr, det_ddd):
+        """The association stages in numpy (tracker.py:886-1030): every configuration; what the nuScenes trackers run."""
+        c = self.cols
         # ---- embedding association fused with the motion gate (tracker.py:886-925) ----
         g_pre = None
         if sim_wait is not None and not self.use_lstm:                 # the Kalman gate of matching.fuse_motion (:330-338) while the device works
@@ -442,9 +535,12 @@ class ArrayTracker(object):
             matched_t += rest[m[:, 0]].tolist(); matched_d += left2[m[:, 1]].tolist()
         removed = [int(g) for g in rest[np.asarray(u_t, dtype=int)] if fid - c["fid"][g] > self.max_time_lost]
         new_d = left2[np.asarray(u_d, dtype=int)]
-        new_d = new_d[dscore[new_d] >= self.det_thresh] if len(new_d) else new_d
+        return np.asarray(matched_t, dtype=int), np.asarray(matched_d, dtype=int), removed, new_d
+
+    def _commit(self, fid, T0, mt, md, removed, new_d, dscore, tlwh, xyah, det_ddd, det_depth, ddd_org_boxes, submission):
+        """What a frame's association changes: STrack.update of the matched tracks, STrack.activate of the new ones, the motion step, the pool."""
+        c = self.cols
         # ---- state update of the matched tracks: STrack.update (tracker.py:371-400), all at once ----
-        mt = np.asarray(matched_t, dtype=int); md = np.asarray(matched_d, dtype=int)
         if len(mt):
             c["fid"][mt] = fid
             c["tlen"][mt] += 1
@@ -461,6 +557,8 @@ class ArrayTracker(object):
                 c["tlwh"][mt] = tlwh[md]
                 if not self.ddd:
                     self._observe(mt, xyah[md])
+            elif self.native_assoc:
+                self._kf("deft_kf_update", np.ascontiguousarray(mt, dtype=np.int32), np.ascontiguousarray(xyah[md], dtype=np.float64))
             else:
                 c["mean"][mt], c["cov"][mt] = kf_multi_update(c["mean"][mt], c["cov"][mt], xyah[md])
         # ---- new tracks: STrack.activate (tracker.py:285-311) ----

@@ -343,6 +343,36 @@ double iou3d(const double (*c1)[3], const double (*c2)[3]) {
     return inter_vol / (vol1 + vol2 - inter_vol);
 }
 
+// linear_assignment (matching.py:40-55) with a finite cost_limit on an n x m matrix: x[i] = column of row i or -1, y[j] = row of column j or
+// -1.  +inf / NaN entries (gated pairs) are replaced by a value no optimal solution can afford and never reported as matches.
+double assign_limited(const double* cost, int n_rows, int n_cols, double cost_limit, int* x, int* y) {
+    for (int i = 0; i < n_rows; ++i) x[i] = -1;
+    for (int j = 0; j < n_cols; ++j) y[j] = -1;
+    if (n_rows == 0 || n_cols == 0) return 0.0;
+    const size_t nm = (size_t)n_rows * n_cols;
+    double big = 0.0;
+    for (size_t k = 0; k < nm; ++k)
+        if (std::isfinite(cost[k]) && std::fabs(cost[k]) > big) big = std::fabs(cost[k]);
+    big = big * (n_rows + n_cols + 1) + 1.0;
+    if (big < cost_limit + 1.0) big = cost_limit + 1.0;
+    std::vector<cost_t> fin(nm);
+    for (size_t k = 0; k < nm; ++k) fin[k] = std::isfinite(cost[k]) ? cost[k] : big;
+    Sap sap;
+    sap.n = n_rows; sap.m = n_cols; sap.c = fin.data(); sap.limit = cost_limit;
+    sap.solve();
+    double sum = 0.0;
+    for (int i = 0; i < n_rows; ++i) {
+        const int j = sap.col4row[i];
+        if (j >= 0 && std::isfinite(cost[(size_t)i * n_cols + j])) {
+            x[i] = j;
+            y[j] = i;
+            sum += cost[(size_t)i * n_cols + j];
+        }
+    }
+    return sum;
+}
+
+
 }  // namespace
 
 extern "C" int deft_lapjv(const double* cost, int n_rows, int n_cols, double cost_limit, int* x, int* y, double* total) {
@@ -354,28 +384,15 @@ extern "C" int deft_lapjv(const double* cost, int n_rows, int n_cols, double cos
     if (total) *total = 0.0;
     if (n_rows == 0 || n_cols == 0) return 0;
     const bool limited = cost_limit < LARGE && !std::isinf(cost_limit);
-    // largest finite entry: +inf / NaN entries (gated pairs) are replaced by a value no optimal solution can afford
-    double big = 0.0;
-    for (long long k = 0; k < (long long)n_rows * n_cols; ++k)
-        if (std::isfinite(cost[k]) && std::fabs(cost[k]) > big) big = std::fabs(cost[k]);
-    big = big * (n_rows + n_cols + 1) + 1.0;
-    if (limited && big < cost_limit + 1.0) big = cost_limit + 1.0;
     double sum = 0.0;
     if (limited) {
-        std::vector<cost_t> fin((size_t)n_rows * n_cols);
-        for (long long k = 0; k < (long long)n_rows * n_cols; ++k) fin[k] = std::isfinite(cost[k]) ? cost[k] : big;
-        Sap sap;
-        sap.n = n_rows; sap.m = n_cols; sap.c = fin.data(); sap.limit = cost_limit;
-        sap.solve();
-        for (int i = 0; i < n_rows; ++i) {
-            const int j = sap.col4row[i];
-            if (j >= 0 && std::isfinite(cost[(size_t)i * n_cols + j])) {
-                x[i] = j;
-                y[j] = i;
-                sum += cost[(size_t)i * n_cols + j];
-            }
-        }
+        sum = assign_limited(cost, n_rows, n_cols, cost_limit, x, y);
     } else {                                           // extend_cost without a limit: zero-padded max(n, m) square
+        // largest finite entry: +inf / NaN entries (gated pairs) are replaced by a value no optimal solution can afford
+        double big = 0.0;
+        for (long long k = 0; k < (long long)n_rows * n_cols; ++k)
+            if (std::isfinite(cost[k]) && std::fabs(cost[k]) > big) big = std::fabs(cost[k]);
+        big = big * (n_rows + n_cols + 1) + 1.0;
         Jv jv;
         jv.n = n_rows > n_cols ? n_rows : n_cols;
         const int n = jv.n;
@@ -397,6 +414,182 @@ extern "C" int deft_lapjv(const double* cost, int n_rows, int n_cols, double cos
         }
     }
     if (total) *total = sum;
+    return 0;
+}
+
+// The association cascade of one frame of Tracker.update on the 2-D datasets (tracker.py:886-1030), host memory, float64 like the reference's numpy:
+//   stage 1  embedding distance 1 - similarity, fused with the motion gate (matching.fuse_motion, matching.py:311-371: rows with `gated`:
+//            pairs beyond gate_thr on the squared Mahalanobis distance of the detection centre are excluded, w_gate of it is added; the other
+//            rows -- LSTM tracks with < 300 observations -- are scaled by lambda only), linear_assignment at thr_embed (matching.py:40-55);
+//   stage 2  (second_stage, KITTI: tracker.py:954-980) the same similarities without the motion term on what is left;
+//   stage 3  IoU distance (matching.py:71-104, the inclusive-pixel IoU of cython_bbox) between the left-over tracks with `iou_ok` and the
+//            left-over detections, linear_assignment at thr_iou.
+// Every stage's matches are reported in the order the reference appends them (row index ascending inside a stage).  lost_t: rows of stage 3
+// still unmatched; new_d: detections still unmatched.  The arithmetic is the reference's, operation for operation, with no fused multiply-add.
+#pragma clang fp contract(off)
+extern "C" int deft_associate_2d(const float* sim, int ld, int T, int N, const double* mean2, const double* chol, const unsigned char* gated,
+                                 const double* meas2, double gate_thr, double lambda_, double w_gate, int second_stage,
+                                 const unsigned char* iou_ok, const double* trk_tlbr, const double* det_tlbr, double thr_embed, double thr_iou,
+                                 int* match_t, int* match_d, int* n_match, int* lost_t, int* n_lost, int* new_d, int* n_new) {
+    DEFT_CHECK(T >= 0 && N >= 0 && T + N <= 4096 && ld >= N, -93, "deft_associate_2d: T=%d N=%d ld=%d", T, N, ld);
+    DEFT_CHECK(n_match && n_lost && n_new && (T == 0 || (mean2 && chol && gated && iou_ok && trk_tlbr && lost_t)) &&
+               (N == 0 || (meas2 && det_tlbr && new_d)) && (T == 0 || N == 0 || (sim && match_t && match_d)), -93, "deft_associate_2d: null pointer");
+    int nm = 0;
+    std::vector<int> rows(T), cols(N), x(T), y(N), r2, c2;
+    for (int t = 0; t < T; ++t) rows[t] = t;
+    for (int d = 0; d < N; ++d) cols[d] = d;
+    std::vector<double> cost((size_t)T * N);
+    // keep the rows / columns of the current stage that stayed unmatched (ascending, like np.where(x < 0))
+    auto assign = [&](double thr) {
+        const int n = (int)rows.size(), m = (int)cols.size();
+        r2.clear(); c2.clear();
+        if (n == 0 || m == 0) return;                              // linear_assignment on an empty matrix: everything stays
+        assign_limited(cost.data(), n, m, thr, x.data(), y.data());
+        for (int i = 0; i < n; ++i)
+            if (x[i] >= 0) { match_t[nm] = rows[i]; match_d[nm] = cols[x[i]]; ++nm; }
+            else r2.push_back(rows[i]);
+        for (int j = 0; j < m; ++j) if (y[j] < 0) c2.push_back(cols[j]);
+        rows.swap(r2); cols.swap(c2);
+    };
+    // ---- stage 1 ----
+    if (T && N) {
+        for (int t = 0; t < T; ++t) {
+            const float* st = sim + (size_t)t * ld;
+            double* ct = cost.data() + (size_t)t * N;
+            if (gated[t]) {
+                const double l00 = chol[3 * t], l10 = chol[3 * t + 1], l11 = chol[3 * t + 2], m0 = mean2[2 * t], m1 = mean2[2 * t + 1];
+                for (int d = 0; d < N; ++d) {
+                    const double z0 = (meas2[2 * d] - m0) / l00;
+                    const double z1 = ((meas2[2 * d + 1] - m1) - l10 * z0) / l11;
+                    const double g = z0 * z0 + z1 * z1;
+                    double dist = 1.0 - (double)st[d];
+                    if (g > gate_thr) dist = INFINITY;
+                    ct[d] = lambda_ * dist + w_gate * g;
+                }
+            } else {
+                for (int d = 0; d < N; ++d) ct[d] = lambda_ * (1.0 - (double)st[d]) + 0.0;
+            }
+        }
+        assign(thr_embed);
+    }
+    // ---- stage 2 ----
+    if (second_stage && !rows.empty() && !cols.empty() && T && N) {
+        const int n = (int)rows.size(), m = (int)cols.size();
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < m; ++j) cost[(size_t)i * m + j] = 1.0 - (double)sim[(size_t)rows[i] * ld + cols[j]];
+        assign(thr_embed);
+    }
+    // ---- stage 3 ----
+    r2.clear();
+    for (int t : rows) if (iou_ok[t]) r2.push_back(t);
+    rows.swap(r2);
+    if (!rows.empty() && !cols.empty()) {
+        const int n = (int)rows.size(), m = (int)cols.size();
+        for (int i = 0; i < n; ++i) {
+            const double* b = trk_tlbr + 4 * rows[i];
+            const double area_b = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+            for (int j = 0; j < m; ++j) {
+                const double* q = det_tlbr + 4 * cols[j];
+                const double iw = std::fmin(b[2], q[2]) - std::fmax(b[0], q[0]) + 1;
+                const double ih = std::fmin(b[3], q[3]) - std::fmax(b[1], q[1]) + 1;
+                const double area_q = (q[2] - q[0] + 1) * (q[3] - q[1] + 1);
+                const double inter = iw * ih;
+                const double ua = area_b + area_q - inter;
+                cost[(size_t)i * m + j] = 1.0 - ((iw > 0 && ih > 0) ? inter / ua : 0.0);
+            }
+        }
+        assign(thr_iou);
+    }
+    *n_match = nm;
+    *n_lost = (int)rows.size();
+    for (size_t i = 0; i < rows.size(); ++i) lost_t[i] = rows[i];
+    *n_new = (int)cols.size();
+    for (size_t j = 0; j < cols.size(); ++j) new_d[j] = cols[j];
+    return 0;
+}
+
+// The DeepSORT Kalman filter of the 2-D trackers on the pool's arrays (utils/tracking_utils/kalman_filter.py), in place, host memory:
+// mean [T][8] (x, y, a, h and their velocities), cov [T][8][8].
+//  * deft_kf_predict = multi_predict (:165-205): F = [[I, I], [0, I]] written out as block sums (the products by 1 and 0 of np.dot are exact),
+//    process noise from the height BEFORE the step -- bit for bit what the reference computes.
+//  * deft_kf_update = update (:207-240) for the rows `rows[0 .. n)` with measurement meas[k] (x, y, a, h): project (:143-163), Cholesky factor of
+//    the 4 x 4 innovation covariance, gain by two triangular solves (scipy cho_factor / cho_solve in the reference), mean + K (z - H mean),
+//    cov - K S K^T.  Equal to the reference to round-off (another summation order than BLAS).  -94: a projected covariance that is not positive
+//    definite (numpy raises LinAlgError there).
+extern "C" int deft_kf_predict(double* mean, double* cov, int T) {
+    DEFT_CHECK(T >= 0 && (T == 0 || (mean && cov)), -94, "deft_kf_predict: null pointer or negative size");
+    const double SP = 1.0 / 20, SV = 1.0 / 160;                      // kalman_filter.py:50-51
+    for (int t = 0; t < T; ++t) {
+        double* m = mean + 8 * (size_t)t;
+        double* P = cov + 64 * (size_t)t;
+        const double h = m[3];
+        const double sd[8] = {SP * h, SP * h, 1e-2 * 1.0, SP * h, SV * h, SV * h, 1e-5 * 1.0, SV * h};
+        for (int j = 0; j < 4; ++j) m[j] += m[j + 4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 8; ++j) P[8 * i + j] += P[8 * (i + 4) + j];          // F P
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 4; ++j) P[8 * i + j] += P[8 * i + j + 4];            // (F P) F^T
+        for (int i = 0; i < 8; ++i) P[9 * i] += sd[i] * sd[i];
+    }
+    return 0;
+}
+
+extern "C" int deft_kf_update(double* mean, double* cov, const int* rows, int n, const double* meas) {
+    DEFT_CHECK(n >= 0 && (n == 0 || (mean && cov && rows && meas)), -94, "deft_kf_update: null pointer or negative size");
+    const double SP = 1.0 / 20;
+    for (int k = 0; k < n; ++k) {
+        double* m = mean + 8 * (size_t)rows[k];
+        double* P = cov + 64 * (size_t)rows[k];
+        const double* z = meas + 4 * (size_t)k;
+        const double h = m[3];
+        const double sd[4] = {SP * h, SP * h, 1e-1 * 1.0, SP * h};
+        double S[4][4], L[4][4] = {};
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) S[i][j] = P[8 * i + j] + (i == j ? sd[i] * sd[i] : 0.0);
+        for (int j = 0; j < 4; ++j) {                                // S = L L^T
+            double d = S[j][j];
+            for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q];
+            DEFT_CHECK(d > 0.0 && std::isfinite(d), -94, "deft_kf_update: projected covariance of row %d is not positive definite", rows[k]);
+            L[j][j] = std::sqrt(d);
+            for (int i = j + 1; i < 4; ++i) {
+                double v = S[i][j];
+                for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q];
+                L[i][j] = v / L[j][j];
+            }
+        }
+        double X[4][8];                                              // S X = (P H^T)^T
+        for (int c = 0; c < 8; ++c) {
+            double y[4];
+            for (int i = 0; i < 4; ++i) {
+                double v = P[8 * c + i];
+                for (int q = 0; q < i; ++q) v -= L[i][q] * y[q];
+                y[i] = v / L[i][i];
+            }
+            for (int i = 3; i >= 0; --i) {
+                double v = y[i];
+                for (int q = i + 1; q < 4; ++q) v -= L[q][i] * X[q][c];
+                X[i][c] = v / L[i][i];
+            }
+        }
+        double innov[4], KS[8][4];
+        for (int i = 0; i < 4; ++i) innov[i] = z[i] - m[i];
+        for (int j = 0; j < 8; ++j) {                                // K[j][i] = X[i][j]
+            double a = 0.0;
+            for (int i = 0; i < 4; ++i) a += innov[i] * X[i][j];
+            m[j] += a;
+            for (int i = 0; i < 4; ++i) {
+                double v = 0.0;
+                for (int q = 0; q < 4; ++q) v += X[q][j] * S[q][i];
+                KS[j][i] = v;
+            }
+        }
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 8; ++j) {
+                double v = 0.0;
+                for (int q = 0; q < 4; ++q) v += KS[i][q] * X[q][j];
+                P[8 * i + j] -= v;
+            }
+    }
     return 0;
 }
 

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 10
+#define DEFT_ABI_VERSION 11
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -350,7 +350,7 @@ int deft_conv_direct(const DeftGemmDesc* d, void* stream);
 int deft_split_weights_direct(const float* w, void* w3, int Cout, int Kpad, int KH, int KW, int Cin, void* stream);
 long long deft_direct_weight_bytes(int KH, int KW, int Cin, int Cout);
 
-/* ---- host-side association helpers (csrc/assoc.hip): the ONLY entry points that take HOST pointers; synchronous, no stream ---- */
+/* ---- host-side association helpers (csrc/assoc.hip): the only entry points that take HOST pointers; synchronous, no stream ---- */
 
 /* matching.linear_assignment's solver (matching.py:40-55: `lap.lapjv(cost_matrix, extend_cost=True, cost_limit=thresh)`; `lap` is a
  * third-party package the reference does not vendor): Jonker-Volgenant on lap's extension of the n_rows x n_cols problem
@@ -363,6 +363,28 @@ int deft_lapjv(const double* cost, int n_rows, int n_cols, double cost_limit, in
  * (h, w, l, x, y, z, rot_y) [.][7] double -- convert_3dbox_to_8corner (:207-243), Sutherland-Hodgman clip of the two ground-plane
  * rectangles (:162-204), intersection area x vertical overlap over the union of the volumes. */
 int deft_iou3d_matrix(const double* trk, int T, const double* det, int N, float* out);
+
+/* One frame's association cascade of Tracker.update on the 2-D datasets (tracker.py:886-1030) in one call, float64 like the reference:
+ *   stage 1: cost = lambda * (1 - sim[t][d]) + w_gate * g[t][d] for rows with gated[t] (g = squared Mahalanobis distance of the detection centre
+ *            meas2[d] to mean2[t] under the Cholesky factor chol[t] = (l00, l10, l11) of the 2 x 2 position covariance; pairs with g > gate_thr are
+ *            excluded) and lambda * (1 - sim) for the others (matching.fuse_motion, matching.py:311-371), linear_assignment at thr_embed (:40-55);
+ *   stage 2: (second_stage != 0: KITTI, tracker.py:954-980) 1 - sim on what is left, same threshold;
+ *   stage 3: 1 - IoU (matching.py:71-104, cython_bbox's inclusive-pixel IoU) of the left-over rows with iou_ok[t] (trk_tlbr [T][4]) and the
+ *            left-over detections (det_tlbr [N][4]), linear_assignment at thr_iou.
+ * sim [T][ld] float32 (columns 0 .. N-1 read; the landing buffer of deft_track_similarity).  match_t / match_d [min(T, N)]: the matched
+ * (track row, detection) pairs in the order the reference appends them; lost_t [T]: rows of stage 3 still unmatched; new_d [N]: detections
+ * still unmatched.  HOST pointers, synchronous. */
+int deft_associate_2d(const float* sim, int ld, int T, int N, const double* mean2, const double* chol, const unsigned char* gated,
+                      const double* meas2, double gate_thr, double lambda_, double w_gate, int second_stage,
+                      const unsigned char* iou_ok, const double* trk_tlbr, const double* det_tlbr, double thr_embed, double thr_iou,
+                      int* match_t, int* match_d, int* n_match, int* lost_t, int* n_lost, int* new_d, int* n_new);
+
+/* The Kalman filter of the 2-D trackers on the pool's arrays, in place (utils/tracking_utils/kalman_filter.py): mean [T][8], cov [T][8][8] double.
+ * deft_kf_predict = multi_predict (:165-205) for every row; deft_kf_update = update (:207-240) of the rows rows[0 .. n) with the measurements
+ * meas [n][4] (x, y, a, h) -- Cholesky solve of the 4 x 4 innovation covariance like the reference; -94 when it is not positive definite.
+ * HOST pointers, synchronous. */
+int deft_kf_predict(double* mean, double* cov, int T);
+int deft_kf_update(double* mean, double* cov, const int* rows, int n, const double* meas);
 
 #ifdef __cplusplus
 }

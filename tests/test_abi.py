@@ -26,7 +26,7 @@ def test_gfx950_library_exports_every_symbol():
     lib = hiplib.HipLib(so)                                # binds every symbol; raises if one is missing
     for name in _declared():
         assert hasattr(lib.cdll, name)
-    assert lib.cdll.deft_version() == hiplib.ABI_VERSION == 10
+    assert lib.cdll.deft_version() == hiplib.ABI_VERSION == 11
     # the code object is gfx950-only (no other offload arch, no host fallback path)
     blob = open(so, "rb").read()
     assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob

@@ -267,3 +267,85 @@ def test_lapjv_ties_are_resolved_reproducibly():
             assert x[i] < 0 or y[x[i]] == i
     print("lapjv tie cases: [[.2,.5],[.2,.5]] -> x = %s; 1x1 at the limit -> x = %s; %d of 40 tied random problems: another optimal assignment than scipy's"
           % (first, at_limit, diff))
+
+
+def _associate_numpy(sim, mean2, cov2, gated, meas2, second, iou_ok, a_tlbr, d_tlbr):
+    """The three stages of tracker.py:886-1030 from this module's numpy pieces (what ArrayTracker._associate_stages composes)."""
+    T, N = len(mean2), len(meas2)
+    lam = 0.9
+    mt, md = [], []
+    rows, cols = np.arange(T), np.arange(N)
+    s64 = sim.astype(np.float64) if sim is not None else None
+    if T and N:
+        d = 1 - s64[:, :N]
+        g = A._maha2(mean2, cov2, meas2)
+        gi = gated.astype(bool)
+        sub = d[gi]
+        sub[g[gi] > 5.0 * A.chi2inv95[2]] = np.inf
+        d[gi] = lam * sub + 0.05 * (1 - lam) * g[gi]
+        d[~gi] = lam * d[~gi] + 0.0005 * (1 - lam) * 0.0
+        m, u_t, u_d = A.linear_assignment(d, 0.9)
+        if len(m):
+            mt += rows[m[:, 0]].tolist(); md += cols[m[:, 1]].tolist()
+        rows, cols = rows[np.asarray(u_t, dtype=int)], cols[np.asarray(u_d, dtype=int)]
+        if second and len(rows) and len(cols):
+            m, u_t, u_d = A.linear_assignment(1 - s64[rows][:, cols], 0.9)
+            if len(m):
+                mt += rows[m[:, 0]].tolist(); md += cols[m[:, 1]].tolist()
+            rows, cols = rows[np.asarray(u_t, dtype=int)], cols[np.asarray(u_d, dtype=int)]
+    rows = rows[iou_ok[rows].astype(bool)]
+    if len(rows) and len(cols):
+        m, u_t, u_d = A.linear_assignment(1 - A.bbox_overlaps(a_tlbr[rows], d_tlbr[cols]), 0.9)
+        if len(m):
+            mt += rows[m[:, 0]].tolist(); md += cols[m[:, 1]].tolist()
+        rows, cols = rows[np.asarray(u_t, dtype=int)], cols[np.asarray(u_d, dtype=int)]
+    return mt, md, rows.tolist(), cols.tolist()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_associate_2d_equals_the_numpy_stages(seed):
+    """deft_associate_2d (one host call: gate + fuse + three assignments + IoU) against the same cascade composed from fuse / linear_assignment /
+    bbox_overlaps: identical matches in identical order, identical left-overs -- empty sides, rows outside the gate, rows without a gate (young
+    LSTM tracks), the KITTI second stage and its age filter in front of the IoU stage."""
+    import ctypes as C
+    rng = np.random.default_rng(900 + seed)
+    T = int(rng.integers(0, 40)) if seed % 6 else 0
+    N = int(rng.integers(0, 40)) if seed % 7 else 0
+    second = seed % 2
+    boxes = lambda n: np.concatenate([(xy := rng.uniform(0, 300, (n, 2))), xy + rng.uniform(10, 80, (n, 2))], 1)
+    d_tlbr = boxes(N)
+    a_tlbr = boxes(T)
+    k = min(T, N)
+    if k:                                                               # some tracks sit on detections: real matches in every stage
+        pick = rng.permutation(N)[:k]
+        a_tlbr[:k] = d_tlbr[pick] + rng.normal(0, 3, (k, 4))
+    centre = lambda b: np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2], 1)
+    meas2 = centre(d_tlbr) if N else np.zeros((0, 2))
+    mean2 = centre(a_tlbr) + rng.normal(0, 2, (T, 2)) if T else np.zeros((0, 2))
+    L = rng.normal(0, 4, (T, 2, 2)) + 6 * np.eye(2)
+    cov2 = L @ L.transpose(0, 2, 1)
+    gated = (rng.random(T) < 0.8).astype(np.uint8)
+    iou_ok = (rng.random(T) < 0.8).astype(np.uint8)
+    sim = rng.random((T, N + 1)).astype(np.float32) * 0.4
+    if k:
+        sim[np.arange(k), pick] = (0.5 + 0.5 * rng.random(k)) * (rng.random(k) < 0.7)
+    if seed % 5 == 0 and T and N:
+        sim[:, :] = 0.25                                                # every embedding cost equal: ties
+    with np.errstate(invalid="ignore"):
+        chol = np.stack([np.sqrt(cov2[:, 0, 0]), cov2[:, 1, 0] / np.sqrt(cov2[:, 0, 0]),
+                         np.sqrt(cov2[:, 1, 1] - (cov2[:, 1, 0] / np.sqrt(cov2[:, 0, 0])) ** 2)], 1) if T else np.zeros((0, 3))
+    out = np.full(2 * k + T + N + 3, -7, np.int32)
+    mt, md, lost, new_d, cnt = out[:k], out[k:2 * k], out[2 * k:2 * k + T], out[2 * k + T:2 * k + T + N], out[2 * k + T + N:]
+    ptr = lambda a: C.c_void_p(a.ctypes.data if a.size else 0)
+    lam = 0.9
+    lib = A._host_lib()
+    arrs = [np.ascontiguousarray(a) for a in (mean2, chol, meas2, a_tlbr, d_tlbr)]
+    lib.call("deft_associate_2d", ptr(sim) if T and N else None, N + 1, T, N, ptr(arrs[0]), ptr(arrs[1]), ptr(gated), ptr(arrs[2]),
+             C.c_double(5.0 * A.chi2inv95[2]), C.c_double(lam), C.c_double(0.05 * (1 - lam)), second, ptr(iou_ok), ptr(arrs[3]), ptr(arrs[4]),
+             C.c_double(0.9), C.c_double(0.9), ptr(mt), ptr(md), C.c_void_p(cnt.ctypes.data), ptr(lost), C.c_void_p(cnt.ctypes.data + 4), ptr(new_d),
+             C.c_void_p(cnt.ctypes.data + 8))
+    want = _associate_numpy(sim if T and N else None, mean2, cov2, gated, meas2, second, iou_ok, a_tlbr, d_tlbr)
+    got = (mt[:cnt[0]].tolist(), md[:cnt[0]].tolist(), lost[:cnt[1]].tolist(), new_d[:cnt[2]].tolist())
+    assert got == want
+    if seed % 6 and seed % 7 and seed % 5:
+        assert cnt[0] > 0

@@ -212,6 +212,78 @@ def test_lazy_affinity_blocks_change_nothing(emu_lib):
     assert len(trk.lost_stracks) + len(trk.removed_stracks) >= 0 and MT.TrackIds.count >= 30
 
 
+@pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
+def test_native_association_equals_the_numpy_stages(emu_lib, dataset):
+    """ArrayTracker.native_assoc: the cascade of a frame through deft_associate_2d + deft_kf_predict / deft_kf_update (one host call each) against the
+    numpy stages (which the reference-tracker tests above pin) on the crowded random scene with drop-outs and re-finds: the same tracks in the same
+    order frame by frame (ids, activation, length, score identical; boxes to 1e-9: the native Kalman update sums in another order than BLAS)."""
+    from deft_amd import mot_tracker as MT
+    opt = types.SimpleNamespace(dataset=dataset, track_buffer=30, max_object=100, lstm=False)
+    g = np.random.RandomState(11)
+    base = np.concatenate([g.rand(30, 2) * np.array([170.0, 90.0]), g.rand(30, 2) * 8 + 10], 1)
+    vel = g.randn(30, 2) * 0.6
+    gone = {i: (int(g.randint(5, 40)), int(g.randint(2, 9))) for i in range(0, 30, 3)}
+    frames = []
+    for t in range(55):
+        rows = []
+        for i in range(30):
+            if i in gone and gone[i][0] <= t < gone[i][0] + gone[i][1]:
+                continue
+            x, y = base[i, :2] + vel[i] * t
+            w, h = base[i, 2:]
+            rows.append({"score": float(0.6 + 0.01 * i), "class": 2 if i % 4 else 1, "bbox": np.array([x, y, x + w, y + h], np.float32)})
+        frames.append(rows)
+
+    def run(native):
+        MT.TrackIds.count = 0
+        afe = FakeAFE()
+        calls = []
+        lib = types.SimpleNamespace(call=lambda name, *a: (calls.append(name), emu_lib.call(name, *a))[1])
+        afe.plan = types.SimpleNamespace(lib=lib, _stream=lambda: None)
+        trk = MT.Tracker2D(opt, types.SimpleNamespace(AFE=afe), h=H, w=W)
+        trk.native_assoc = native
+        return [_log(trk.update([dict(r) for r in rows], [torch.zeros(1)])) for rows in frames], calls
+
+    a, calls_a = run(True)
+    b, calls_b = run(False)
+    assert "deft_associate_2d" in calls_a and "deft_kf_update" in calls_a and "deft_associate_2d" not in calls_b
+    assert sum(len(f) for f in a) > 500
+    for t, (fa, fb) in enumerate(zip(a, b)):
+        assert [x[:3] + (x[4],) for x in fa] == [x[:3] + (x[4],) for x in fb], t
+        for x, y in zip(fa, fb):
+            assert np.abs(np.array(x[3]) - np.array(y[3])).max() <= 1e-9, (t, x, y)
+
+
+def test_native_kalman_matches_reference_filter(emu_lib):
+    """deft_kf_predict / deft_kf_update against utils/tracking_utils/kalman_filter.py: predict bit for bit, update to round-off; a projected
+    covariance that is not positive definite is an error (-94), as numpy's Cholesky raises."""
+    import ctypes as C
+    _reference("mot", types.SimpleNamespace(AFE=FakeAFE()))
+    from utils.tracking_utils.kalman_filter import KalmanFilter
+    kf = KalmanFilter()
+    g = np.random.default_rng(3)
+    meas = np.stack([g.uniform(10, 500, 9), g.uniform(10, 300, 9), g.uniform(0.3, 0.6, 9), g.uniform(40, 200, 9)], 1)
+    ms, cs = zip(*[kf.initiate(m) for m in meas])
+    mean, cov = np.stack(ms), np.stack(cs)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    for step in range(6):
+        rm, rc = kf.multi_predict(mean.copy(), cov.copy())
+        emu_lib.call("deft_kf_predict", p(mean), p(cov), len(mean))
+        assert np.array_equal(rm, mean) and np.array_equal(rc, cov)
+        rows = np.ascontiguousarray(g.permutation(9)[:6], dtype=np.int32)
+        z = np.ascontiguousarray((meas + g.normal(0, 2.0, meas.shape) * [1, 1, 0.01, 1])[rows])
+        for k, i in enumerate(rows.tolist()):
+            rm[i], rc[i] = kf.update(rm[i], rc[i], z[k])
+        emu_lib.call("deft_kf_update", p(mean), p(cov), p(rows), len(rows), p(z))
+        assert np.allclose(rm, mean, rtol=0, atol=1e-9) and np.allclose(rc, cov, rtol=0, atol=1e-9)
+        untouched = np.setdiff1d(np.arange(9), rows)
+        assert np.array_equal(rm[untouched], mean[untouched])
+    bad = cov.copy()
+    bad[2, :4, :4] = -np.eye(4) * 1e6
+    with pytest.raises(Exception, match="not positive definite"):
+        emu_lib.call("deft_kf_update", p(mean), p(bad), p(np.array([2], np.int32)), 1, p(np.ascontiguousarray(meas[:1])))
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # round 4: the LSTM configuration (BASELINE configs[3]) and the nuScenes 3-D association (configs[4]) of the array tracker, against the
 # reference's own Tracker with its own KalmanFilterLSTM (synthetic LSTM weights on both sides)
