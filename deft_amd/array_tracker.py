@@ -49,6 +49,12 @@ class TrackView(object):
     __slots__ = ("track_id", "is_activated", "tracklet_len", "score", "tlwh", "frame_id", "start_frame", "state", "ddd_bbox", "depth",
                  "org_ddd_box", "ddd_submission", "classe")
 
+    def __init__(self, track_id=None, is_activated=None, tracklet_len=None, score=None, tlwh=None, frame_id=None, start_frame=None,
+                 ddd_bbox=None, depth=None, org_ddd_box=None, ddd_submission=None, classe=None):
+        self.track_id, self.is_activated, self.tracklet_len, self.score, self.tlwh = track_id, is_activated, tracklet_len, score, tlwh
+        self.frame_id, self.start_frame, self.state = frame_id, start_frame, TRACKED
+        self.ddd_bbox, self.depth, self.org_ddd_box, self.ddd_submission, self.classe = ddd_bbox, depth, org_ddd_box, ddd_submission, classe
+
     end_frame = property(lambda self: self.frame_id)
 
     @property
@@ -155,17 +161,10 @@ class ArrayTracker(object):
         score = c["score"][idx] if self.ddd else c["score"][idx].astype(np.float32)      # (the 2-D datasets' rows are float32, tracker.py:790-803)
         if self.ddd:
             ddd, depth, org, sub = c["ddd"][idx], c["depth"][idx], c["org"][idx], c["sub"][idx]
-        out = []
-        for k in range(len(idx)):
-            v = TrackView()
-            v.track_id, v.is_activated, v.tracklet_len, v.score, v.tlwh = tid[k], act[k], tlen[k], score[k], tl[k]
-            v.frame_id, v.start_frame, v.state = fid[k], start[k], TRACKED
-            if self.ddd:
-                v.ddd_bbox, v.depth, v.org_ddd_box, v.ddd_submission, v.classe = ddd[k].copy(), depth[k], org[k], sub[k], self.classe
-            else:
-                v.ddd_bbox = v.depth = v.org_ddd_box = v.ddd_submission = v.classe = None
-            out.append(v)
-        return out
+        if not self.ddd:
+            return [TrackView(tid[k], act[k], tlen[k], score[k], tl[k], fid[k], start[k]) for k in range(len(idx))]
+        return [TrackView(tid[k], act[k], tlen[k], score[k], tl[k], fid[k], start[k], ddd[k].copy(), depth[k], org[k], sub[k], self.classe)
+                for k in range(len(idx))]
 
     @property
     def tracked_stracks(self):
