@@ -137,6 +137,7 @@ class ArrayTracker(object):
         self.fut_arr = np.zeros((0, self.fut, od))          # LSTM: predictions of the pool rows [T, fut, dim] on the host ...
         self._pending = None                                  # ... and the motion step whose result has not been read back yet
         self.removed_ids = []
+        self._begun = None                                    # begin(): the device half of the next frame, already queued
         self.lost_stracks = []
         self.classe = None
 
@@ -269,6 +270,9 @@ class ArrayTracker(object):
     def close(self):
         """End of a video: land the pending motion step and hand this tracker's MotionBank slots back (the bank is shared -- model.motion --
         by every tracker built on the model; without this its h / c / last tensors double with every sequence of an evaluation)."""
+        if self._begun is not None:
+            self._undo(self._begun)
+            self._begun = None
         if self.use_lstm and self.bank is not None:
             try:
                 self._resolve()
@@ -377,14 +381,36 @@ class ArrayTracker(object):
         if cb is not None:
             cb()
 
-    def update(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None, ddd_org_boxes=None, submission=None, classe=None):
-        """tracker.py:723-1056.  2-D: results = the frame's post-processed detections ({"bbox" tlbr, "score", "class"}).  nuScenes: results =
-        rows (x1, y1, x2, y2, score) of this tracker's class with ddd_boxes (h, w, l, x, y, z, rot_y), depths_by_class, ddd_org_boxes,
-        submission (detector.py:313-338).  Returns the tracks matched or started in this frame (TrackView)."""
-        self.frame_id += 1
-        fid = self.frame_id
-        self.classe = classe if classe is not None else self.classe
+    # ---- the device half of a frame, which may run ahead of update() --------------------------------------------------------------------
+    def begin(self, results, FeatureMaps):
+        """The part of update(results, FeatureMaps) that depends only on the frame's detections, its feature maps and the track table as the previous
+        update() left it -- detections as arrays, embedding extraction, the affinity blocks against the stored frames the pool reads, the
+        similarity medians and their copy back (tracker.py:786-848, 663-688) -- queued NOW.  A caller that already holds the next frame's detections
+        (Detector.run with a lookahead pass that has finished) calls this right behind update(k); update(k + 1) must then be given the SAME
+        `results` object and finds its device round trip already under way (another object: the early work is taken back and redone).
+        2-D datasets; a no-op for the nuScenes per-class trackers."""
+        if self.ddd:
+            return
+        if self._begun is not None:
+            self._undo(self._begun)
+        rec = self.recorder
+        snap = (rec.all_frame_index, dict(rec.all_features), dict(rec.all_boxes), dict(rec.all_similarity), rec._dev)
+        self._begun = self._first_half(results, FeatureMaps, None, None)
+        self._begun["snap"] = snap
+
+    def _undo(self, b):
+        snap = b.get("snap")
+        if snap is not None:
+            rec = self.recorder
+            rec.all_frame_index, rec.all_features, rec.all_boxes, rec.all_similarity, rec._dev = snap
+        w = b.get("sim_wait")
+        if w is not None:
+            w(raw=True)                                                # let the queued launches finish with the staging buffers they read
+
+    def _first_half(self, results, FeatureMaps, ddd_boxes, depths_by_class):
+        fid = self.frame_id + 1
         c = self.cols
+        det_ddd = det_depth = None
         # ---- detections as arrays ----
         if self.ddd:
             dets = np.array(results)
@@ -422,6 +448,24 @@ class ArrayTracker(object):
         # 2-D configurations: the pool of the embedding association is every track, so the similarity launch can be queued NOW and read after the
         # host work that does not depend on it (prediction, motion gate) -- the device round trip hides behind ~0.15 ms of numpy
         sim_wait = self._similarity(fid, np.arange(T0), nd0, sel_all, defer=True) if (not self.ddd and T0 and nd0) else None
+        return {"results": results, "fid": fid, "nd0": nd0, "sel_all": sel_all, "tlwh": tlwh, "xyah": xyah, "tlbr": tlbr, "dscore": dscore, "T0": T0,
+                "sim_wait": sim_wait, "det_ddd": det_ddd, "det_depth": det_depth}
+
+    def update(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None, ddd_org_boxes=None, submission=None, classe=None):
+        """tracker.py:723-1056.  2-D: results = the frame's post-processed detections ({"bbox" tlbr, "score", "class"}).  nuScenes: results =
+        rows (x1, y1, x2, y2, score) of this tracker's class with ddd_boxes (h, w, l, x, y, z, rot_y), depths_by_class, ddd_org_boxes,
+        submission (detector.py:313-338).  Returns the tracks matched or started in this frame (TrackView)."""
+        self.classe = classe if classe is not None else self.classe
+        b, self._begun = self._begun, None
+        if b is not None and b["results"] is not results:              # another frame than the one begin() was told about: take its traces back
+            self._undo(b)
+            b = None
+        if b is None:
+            b = self._first_half(results, FeatureMaps, ddd_boxes, depths_by_class)
+        fid = self.frame_id = b["fid"]
+        nd0, sel_all, tlwh, xyah, tlbr, dscore, T0, sim_wait = (b[k] for k in ("nd0", "sel_all", "tlwh", "xyah", "tlbr", "dscore", "T0", "sim_wait"))
+        det_ddd, det_depth = b["det_ddd"], b["det_depth"]
+        c = self.cols
         if not self.use_lstm and T0:                                   # STrack.multi_predict, tracker.py:193-207 (every pool track is Tracked)
             if self.native_assoc:
                 self._kf("deft_kf_predict", T0)
@@ -446,11 +490,9 @@ class ArrayTracker(object):
             mt, md, lost, new_d = self._associate_2d(fid, T0, nd0, sim_wait, xyah, tlbr)
             removed = lost[fid - c["fid"][lost] > self.max_time_lost].tolist()
         else:
-            mt, md, removed, new_d = self._associate_stages(fid, T0, nd0, sim_wait, sel_all, pool, det_left, matched_t, matched_d, xyah, tlbr,
-                                                            det_ddd if self.ddd else None)
+            mt, md, removed, new_d = self._associate_stages(fid, T0, nd0, sim_wait, sel_all, pool, det_left, matched_t, matched_d, xyah, tlbr, det_ddd)
         new_d = new_d[dscore[new_d] >= self.det_thresh] if len(new_d) else new_d
-        return self._commit(fid, T0, mt, md, removed, new_d, dscore, tlwh, xyah, det_ddd if self.ddd else None, det_depth if self.ddd else None,
-                            ddd_org_boxes, submission)
+        return self._commit(fid, T0, mt, md, removed, new_d, dscore, tlwh, xyah, det_ddd, det_depth, ddd_org_boxes, submission)
 
     def _associate_stages(self, fid, T0, nd0, sim_wait, sel_all, pool, det_left, matched_t, matched_d, xyah, tlbr, det_ddd):
         """The association stages in numpy (tracker.py:886-1030): every configuration; what the nuScenes trackers run."""

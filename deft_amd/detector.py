@@ -21,6 +21,9 @@ PRIORITY_TRACKER = _os.environ.get("DEFT_TRACKER_PRIORITY", "1") != "0"      # r
 # "auto": hook for multi-frame passes (measured 2.12 vs 2.19 ms per frame at 4 frames per pass), early for one-frame passes (2.91 vs 3.18:
 # a one-frame pass queued at the hook is not finished when the next call wants it) -- tools/probe/lookahead_probe.py
 LOOKAHEAD_AT = _os.environ.get("DEFT_LOOKAHEAD_AT", "auto")
+# run() on a recorded stream: when the host already holds the NEXT frame's detections (same lookahead pass, or the other slot's finished pass), the
+# tracker's device half for that frame (ArrayTracker.begin) is queued right behind this frame's update().  "0": every frame's device half inside its own update()
+BEGIN_AHEAD = _os.environ.get("DEFT_BEGIN_AHEAD", "1") != "0"
 
 
 def _fetch(d):
@@ -272,6 +275,8 @@ class Detector(object):
         scale = scales[0]
         t_start = time.time()
         pre_processed, frame = False, None
+        self._peek_src, meta_given = None, bool(meta)
+        peeked, self._peeked = getattr(self, "_peeked", None), None
         if isinstance(image_or_path_or_tensor, np.ndarray):
             frame = image_or_path_or_tensor
         elif isinstance(image_or_path_or_tensor, str):
@@ -322,9 +327,13 @@ class Detector(object):
             t_pre = time.time()
             output, dets, t_fwd, fmaps = self.process(images, None, None, None, return_time=True)
         t_dec = time.time()
-        result = self.post_process(dets, meta, scale)
-        t_post = time.time()
-        results = self.merge_outputs([result])
+        if peeked is not None and peeked[0] is frame and not meta_given:
+            results = peeked[1]                                        # post-processed one call ago (_begin_next): the tracker holds THIS list
+            t_post = time.time()
+        else:
+            result = self.post_process(dets, meta, scale)
+            t_post = time.time()
+            results = self.merge_outputs([result])
         t_merge = time.time()
         if getattr(opt, "public_det", False) and pre_processed:
             results = image_or_path_or_tensor["meta"]["cur_dets"]                     # detector.py:190-196
@@ -377,6 +386,9 @@ class Detector(object):
                     nxt()
             else:
                 targets = self.tracker.update(results, fmaps)                              # detector.py:340-342
+            if (BEGIN_AHEAD and self._peek_src is not None and per_class is None and self.tracker is not None and hasattr(self.tracker, "begin")
+                    and not meta_given and not getattr(opt, "public_det", False)):
+                self._begin_next(meta, scale, prio)
         if prio is not None:
             main.wait_stream(prio)
         t_end = time.time()
@@ -500,6 +512,32 @@ class Detector(object):
     #                                results are handed out one per call.  For recorded streams (test.py reads files); a live camera pays
     #                                n-1 frame periods of latency for it
 
+    @staticmethod
+    def _slot_dets(sl, j):
+        """The decoded fields of frame j of slot sl's finished pass, from its pinned host record (rewritten two passes on: copies)."""
+        rec, dets, o = sl.host.numpy(), {}, 0
+        for k, shape, cnt, dt in sl.fields:
+            a = rec[o:o + cnt].astype(dt).reshape(shape)
+            dets[k] = a[j:j + 1] if shape and shape[0] == sl.n and k != "_finite" else a
+            o += cnt
+        return dets
+
+    def _begin_next(self, meta, scale, prio):
+        """The NEXT frame's detections are already on the host (a later frame of the pass this frame came from, or the first frame of the other
+        slot's pass when that has finished): post-process them now and let the tracker queue its device half for them (ArrayTracker.begin) behind
+        this frame's update() -- the next run() call finds the embedding / affinity / similarity round trip under way instead of waiting for it."""
+        sl, j = self._peek_src
+        try:
+            dets = _check_finite(self._slot_dets(sl, j))
+        except FloatingPointError:
+            return                                                     # the next run() call raises it for its own frame
+        results = self.merge_outputs([self.post_process(dets, meta, scale)])
+        fmaps = sl.plan.fmaps if sl.n == 1 else [fm[j] for fm in sl.plan.fmaps]
+        if sl.done is not None:
+            (prio if prio is not None else torch.cuda.current_stream(self.device)).wait_event(sl.done)
+        self.tracker.begin(results, fmaps)
+        self._peeked = (sl.frames[j], results)
+
     def _process_ahead(self, akey, frame, prefetch):
         import time
         n = int(self.lookahead_frames)
@@ -522,12 +560,7 @@ class Detector(object):
         if cur.done is not None:
             cur.done.synchronize()
         j = cur.pos
-        rec, dets, o = cur.host.numpy(), {}, 0                         # (the pinned record is rewritten two passes on: copies)
-        for k, shape, cnt, dt in cur.fields:
-            a = rec[o:o + cnt].astype(dt).reshape(shape)
-            dets[k] = a[j:j + 1] if shape and shape[0] == cur.n and k != "_finite" else a
-            o += cnt
-        _check_finite(dets)
+        dets = _check_finite(self._slot_dets(cur, j))
         fmaps = cur.plan.fmaps if cur.n == 1 else [fm[j] for fm in cur.plan.fmaps]
         hm = cur.plan.dense["hm"] if cur.n == 1 else cur.plan.dense["hm"][j]
         cur.pos += 1
@@ -537,6 +570,13 @@ class Detector(object):
         if cur.done is not None:
             torch.cuda.current_stream(self.device).wait_event(cur.done)    # the tracker's launches read this slot's feature maps
         self._fm_ready = cur.done
+        # whose detections the host holds next: the pass of this frame, or the other slot's when it has finished
+        if cur.frames is not None:
+            self._peek_src = (cur, cur.pos)
+        elif other.frames is not None and (other.done is None or other.done.query()):
+            self._peek_src = (other, other.pos)
+        else:
+            self._peek_src = None
         t_fwd = time.time()
         self._launch_next = None
         if other.frames is None and len(upcoming) > left:              # the free slot takes the frames behind the ones this slot still holds

@@ -1810,6 +1810,9 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
             det.img_height, det.img_width = sh, sw
             det.lookahead_frames = 1
             log, fired = [], []
+            if dataset != "nuscenes":                   # ArrayTracker.begin: the next frame's device half queued behind this frame's update()
+                trk, begin = det.tracker, det.tracker.begin
+                trk.begin = lambda *a: (begun.append(lookahead), begin(*a))[1]
             if lookahead == "pairs":                    # Detector.track_stream: the per-video loop with two frames per lookahead pass
                 outs = det.track_stream(iter(frames), image_infos=[info] * T, frames_per_pass=2)
             else:
@@ -1820,12 +1823,16 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
             launches = model.motion.launches if lstm else 0
             return log, launches
 
+        begun = []
         serial, l0 = run(False)
         ahead, l1 = run(True)
         assert serial == ahead
+        assert not begun                                # (one frame per pass: the next frame's pass is queued during this frame's run -- nothing to begin with)
         if pairs:                       # two frames per lookahead pass (a 2-frame plan: floats to round-off of another reduction split)
             two, l2 = run("pairs")
             assert l2 == l0 and len(two) == len(serial)
+            if dataset != "nuscenes" and device == "cpu":   # (on the device: whenever the other slot's pass has finished by the time it is asked)
+                assert begun.count("pairs") >= (T - 1) // 2, begun      # at least the second frame of every full pass
             for fa, fb in zip(serial, two):
                 assert [x[:3] for x in fa] == [x[:3] for x in fb]
                 for x, y in zip(fa, fb):

@@ -254,6 +254,38 @@ def test_native_association_equals_the_numpy_stages(emu_lib, dataset):
             assert np.abs(np.array(x[3]) - np.array(y[3])).max() <= 1e-9, (t, x, y)
 
 
+@pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
+def test_begin_ahead_changes_nothing(emu_lib, dataset):
+    """ArrayTracker.begin(results, FeatureMaps): the device half of the NEXT frame queued behind update(k).  Same tracks as plain update() calls when
+    every frame is begun ahead; and a begin() for a frame that never comes (update() is handed another frame's detections) is taken back -- the
+    recorder's stored frames, evicted entries included (a stream longer than its 50-frame window), are what they were."""
+    from deft_amd import mot_tracker as MT
+    opt = types.SimpleNamespace(dataset=dataset, track_buffer=30, max_object=100, lstm=False)
+    nframes = 64
+    frames = [[dict(r) for r in _scene(t % 24, dataset)] for t in range(nframes)]
+    wrong = [dict(r) for r in _scene(3, dataset)][:2]
+
+    def run(mode):
+        MT.TrackIds.count = 0
+        afe = FakeAFE()
+        afe.plan = types.SimpleNamespace(lib=emu_lib, _stream=lambda: None)
+        trk = MT.Tracker2D(opt, types.SimpleNamespace(AFE=afe), h=H, w=W)
+        fm = [torch.zeros(1, 1, 1, 1)]
+        log = []
+        for t in range(nframes):
+            log.append(_log(trk.update(frames[t], fm)))
+            if mode == "ahead" and t + 1 < nframes:
+                trk.begin(frames[t + 1], fm)
+            elif mode == "wrong" and t + 1 < nframes:
+                trk.begin(wrong if t % 3 else frames[t + 1], fm)       # two of three announcements are for a frame that never comes
+        assert trk._begun is None
+        return log, sorted(trk.recorder.all_features), trk.frame_id
+
+    plain = run("plain")
+    assert run("ahead") == plain and run("wrong") == plain
+    assert sum(len(f) for f in plain[0]) > 200 and len(plain[1]) == 50 and plain[2] == nframes
+
+
 def test_native_kalman_matches_reference_filter(emu_lib):
     """deft_kf_predict / deft_kf_update against utils/tracking_utils/kalman_filter.py: predict bit for bit, update to round-off; a projected
     covariance that is not positive definite is an error (-94), as numpy's Cholesky raises."""
