@@ -250,10 +250,12 @@ class ArrayTracker(object):
         if dev.type == "cuda":
             land = pin[1][:T * (nd + 1)].view(T, nd + 1)
             land.copy_(out, non_blocking=True)
-            stream = torch.cuda.current_stream(dev)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))               # (an event, not the stream: the per-class trackers of a nuScenes frame queue their
+            #                                                            chains back to back on one stream, each waits for its own copy only)
 
             def wait(raw=False):
-                stream.synchronize()                                   # THE device round trip of the frame
+                done.synchronize()                                     # THE device round trip of the frame
                 return land.numpy() if raw else land.numpy().astype(np.float64)
             return wait if defer is None else wait()
         host = out.numpy()
@@ -382,20 +384,19 @@ class ArrayTracker(object):
             cb()
 
     # ---- the device half of a frame, which may run ahead of update() --------------------------------------------------------------------
-    def begin(self, results, FeatureMaps):
+    def begin(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None):
         """The part of update(results, FeatureMaps) that depends only on the frame's detections, its feature maps and the track table as the previous
         update() left it -- detections as arrays, embedding extraction, the affinity blocks against the stored frames the pool reads, the
         similarity medians and their copy back (tracker.py:786-848, 663-688) -- queued NOW.  A caller that already holds the next frame's detections
         (Detector.run with a lookahead pass that has finished) calls this right behind update(k); update(k + 1) must then be given the SAME
         `results` object and finds its device round trip already under way (another object: the early work is taken back and redone).
-        2-D datasets; a no-op for the nuScenes per-class trackers."""
-        if self.ddd:
-            return
+        The seven per-class trackers of a nuScenes frame are begun one after the other before the first of them is updated: seven device round trips
+        in flight at once instead of one at a time."""
         if self._begun is not None:
             self._undo(self._begun)
         rec = self.recorder
         snap = (rec.all_frame_index, dict(rec.all_features), dict(rec.all_boxes), dict(rec.all_similarity), rec._dev)
-        self._begun = self._first_half(results, FeatureMaps, None, None)
+        self._begun = self._first_half(results, FeatureMaps, ddd_boxes, depths_by_class)
         self._begun["snap"] = snap
 
     def _undo(self, b):
@@ -445,9 +446,9 @@ class ArrayTracker(object):
         else:
             tlwh = xyah = tlbr = np.zeros((0, 4)); dscore = np.zeros(0, np.float32)
         T0 = c.n
-        # 2-D configurations: the pool of the embedding association is every track, so the similarity launch can be queued NOW and read after the
-        # host work that does not depend on it (prediction, motion gate) -- the device round trip hides behind ~0.15 ms of numpy
-        sim_wait = self._similarity(fid, np.arange(T0), nd0, sel_all, defer=True) if (not self.ddd and T0 and nd0) else None
+        # the similarity of EVERY pool row to the frame's detections, queued now and read after the host work that does not depend on it (prediction, motion
+        # gate; nuScenes: the 3-D IoU stage, which only decides which of these rows the embedding stage keeps)
+        sim_wait = self._similarity(fid, np.arange(T0), nd0, sel_all, defer=True) if (T0 and nd0) else None
         return {"results": results, "fid": fid, "nd0": nd0, "sel_all": sel_all, "tlwh": tlwh, "xyah": xyah, "tlbr": tlbr, "dscore": dscore, "T0": T0,
                 "sim_wait": sim_wait, "det_ddd": det_ddd, "det_depth": det_depth}
 
@@ -499,12 +500,12 @@ class ArrayTracker(object):
         c = self.cols
         # ---- embedding association fused with the motion gate (tracker.py:886-925) ----
         g_pre = None
-        if sim_wait is not None and not self.use_lstm:                 # the Kalman gate of matching.fuse_motion (:330-338) while the device works
+        if sim_wait is not None and not self.use_lstm and not self.ddd:   # the Kalman gate of matching.fuse_motion (:330-338) while the device works
             g_pre = A._maha2(c["mean"][pool][:, :2], c["cov"][pool][:, :2, :2], xyah[det_left][:, :2])
+        sim = None
         if sim_wait is not None:
             sim = sim_wait()
-        else:
-            sim = self._similarity(fid, pool, nd0, sel_all) if len(pool) and len(det_left) else None
+            sim = sim[pool] if len(pool) and len(det_left) else None   # (nuScenes: the rows the 3-D stage left, in its order)
         self._device_done()
         dists = np.zeros((len(pool), len(det_left)), dtype=float)
         if dists.size:

@@ -369,7 +369,11 @@ class Detector(object):
                 targets = results
             elif per_class is not None:                                                    # detector.py:198-338
                 targets = []
-                for name, a in per_class.items():
+                for name, a in per_class.items():                                          # every class's device half first (ArrayTracker.begin) ...
+                    begin = getattr(self.tracker[name], "begin", None)
+                    if BEGIN_AHEAD and begin is not None:
+                        begin(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"])
+                for name, a in per_class.items():                                          # ... then the associations, class by class
                     trk = self.tracker[name]
                     if trk is hook_on:
                         trk.after_device_work = nxt

@@ -479,8 +479,14 @@ def test_array_tracker_nuscenes_matches_reference_tracker(emu_lib, classe, lstm)
             rows, ddd, depth, org, sub = _scene3d(t, classe)
             a = _log3(ref.update([list(r) for r in rows], fm, ddd_boxes=[list(d) for d in ddd], depths_by_class=[list(d) for d in depth],
                                  ddd_org_boxes=list(org), submission=list(sub), classe=classe))
-            b = _log3(mine.update([list(r) for r in rows], fm, ddd_boxes=[list(d) for d in ddd], depths_by_class=[list(d) for d in depth],
+            mine_rows, mine_ddd, mine_depth = [list(r) for r in rows], [list(d) for d in ddd], [list(d) for d in depth]
+            if t % 3 == 1:                                               # Detector.run begins every class's device half before the first update()
+                mine.begin(mine_rows, fm, ddd_boxes=mine_ddd, depths_by_class=mine_depth)
+            elif t % 3 == 2:                                             # ... and a begin() for detections that never come is taken back
+                mine.begin([list(r) for r in rows[:1]], fm, ddd_boxes=mine_ddd[:1], depths_by_class=mine_depth[:1])
+            b = _log3(mine.update(mine_rows, fm, ddd_boxes=mine_ddd, depths_by_class=mine_depth,
                                   ddd_org_boxes=list(org), submission=list(sub), classe=classe))
+            assert mine._begun is None
             assert [x[:3] for x in a] == [x[:3] for x in b], (t, [x[:3] for x in a], [x[:3] for x in b])
             for x, y in zip(a, b):
                 assert np.abs(np.array(x[3]) - np.array(y[3])).max() <= 1e-9 and x[4] == y[4], (t, x, y)
