@@ -93,8 +93,8 @@ class _Columns(object):
 
 class ArrayTracker(object):
     lazy_blocks = True             # score the new frame only against the stored frames the pool's selected nodes live in
-    native_assoc = True            # 2-D datasets: the association cascade of a frame in ONE host call (deft_associate_2d); False = the numpy
-    #                                stages below (what the nuScenes trackers run: their 3-D stages differ), kept as the cross-check of the native call
+    native_assoc = True            # the association cascade of a frame in ONE host call (deft_associate_2d / deft_associate_ddd) and the Kalman filter in
+    #                                two (deft_kf_predict / deft_kf_update); False = the numpy stages below, kept as the cross-check of the native calls
     after_device_work = None       # set by a caller (Detector.run's lookahead): called ONCE per update(), as soon as the frame's last
     #                                result-bearing device step has been read back; what follows is host work (plus one tiny motion launch)
 
@@ -383,6 +383,36 @@ class ArrayTracker(object):
         if cb is not None:
             cb()
 
+    def _associate_ddd(self, fid, T, N, sim_wait, det_ddd, tlbr):
+        """tracker.py:850-1030 for one class of a nuScenes frame through deft_associate_ddd (see _associate_2d)."""
+        c = self.cols
+        lam = 0.9
+        if T:
+            recent = np.ascontiguousarray(np.abs(c["fid"][:T] - fid) < 3, dtype=np.uint8)      # :852-856 and the IoU stage's filter (:999-1004)
+            trk_ddd = np.ascontiguousarray(c["ddd"][:T], dtype=np.float64)
+            depth = np.ascontiguousarray(c["depth"][:T], dtype=np.float64)
+            a_tlbr = self._tlwh_rows(slice(0, T))
+            a_tlbr[:, 2:] += a_tlbr[:, :2]
+            a_tlbr = np.ascontiguousarray(a_tlbr, dtype=np.float64)
+        else:
+            recent = np.zeros(0, np.uint8); trk_ddd = depth = a_tlbr = np.zeros((0, 7))
+        d_ddd = np.ascontiguousarray(det_ddd, dtype=np.float64)
+        d_tlbr = np.ascontiguousarray(tlbr, dtype=np.float64)
+        k = min(T, N)
+        out = np.empty(2 * k + T + N + 3, np.int32)
+        mt, md, lost, new_d, cnt = out[:k], out[k:2 * k], out[2 * k:2 * k + T], out[2 * k + T:2 * k + T + N], out[2 * k + T + N:]
+        sim = sim_wait(raw=True) if sim_wait is not None else None
+        self._device_done()
+        if sim is not None:
+            assert sim.dtype == np.float32 and sim.shape == (T, N + 1) and sim.flags.c_contiguous
+        ptr = lambda a: C.c_void_p(a.ctypes.data if a.size else 0)
+        self.model.AFE.plan.lib.call(
+            "deft_associate_ddd", ptr(sim) if sim is not None else None, N + 1, T, N, int(self.classe != "pedestrian"), ptr(recent), ptr(trk_ddd),
+            ptr(d_ddd), ptr(depth), 0 if self.use_lstm else 1, C.c_double(5 if self.classe == "pedestrian" else 10), C.c_double(lam), C.c_double(0.001),
+            ptr(recent), ptr(a_tlbr), ptr(d_tlbr), C.c_double(0.999), C.c_double(0.9), C.c_double(0.0), ptr(mt), ptr(md),
+            C.c_void_p(cnt.ctypes.data), ptr(lost), C.c_void_p(cnt.ctypes.data + 4), ptr(new_d), C.c_void_p(cnt.ctypes.data + 8))
+        return mt[:cnt[0]].astype(int), md[:cnt[0]].astype(int), lost[:cnt[1]].astype(int), new_d[:cnt[2]].astype(int)
+
     # ---- the device half of a frame, which may run ahead of update() --------------------------------------------------------------------
     def begin(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None):
         """The part of update(results, FeatureMaps) that depends only on the frame's detections, its feature maps and the track table as the previous
@@ -472,6 +502,20 @@ class ArrayTracker(object):
                 self._kf("deft_kf_predict", T0)
             else:
                 c.a["mean"], c.a["cov"] = kf_multi_predict(c["mean"], c["cov"])
+        if self.native_assoc:                                          # the stages of the frame in one host call
+            if self.ddd:
+                mt, md, lost, new_d = self._associate_ddd(fid, T0, nd0, sim_wait, det_ddd, tlbr)
+            else:
+                mt, md, lost, new_d = self._associate_2d(fid, T0, nd0, sim_wait, xyah, tlbr)
+            removed = lost[fid - c["fid"][lost] > self.max_time_lost].tolist()
+        else:
+            mt, md, removed, new_d = self._associate_stages(fid, T0, nd0, sim_wait, sel_all, xyah, tlbr, det_ddd)
+        new_d = new_d[dscore[new_d] >= self.det_thresh] if len(new_d) else new_d
+        return self._commit(fid, T0, mt, md, removed, new_d, dscore, tlwh, xyah, det_ddd, det_depth, ddd_org_boxes, submission)
+
+    def _associate_stages(self, fid, T0, nd0, sim_wait, sel_all, xyah, tlbr, det_ddd):
+        """The association stages in numpy (tracker.py:850-1030), every configuration: the cross-check of the native calls."""
+        c = self.cols
         matched_t, matched_d = [], []                                  # pool row, detection index -- in the reference's output order
         pool = np.arange(T0)
         det_left = np.arange(nd0)
@@ -486,18 +530,6 @@ class ArrayTracker(object):
                 matched_t += new[m[:, 0]].tolist(); matched_d += m[:, 1].tolist()
             det_left = np.asarray(u_d, dtype=int)
             pool = np.concatenate([new[np.asarray(u_t, dtype=int)], old]).astype(int)
-        native = self.native_assoc and not self.ddd
-        if native:                                                     # 2-D: the three stages below in one host call
-            mt, md, lost, new_d = self._associate_2d(fid, T0, nd0, sim_wait, xyah, tlbr)
-            removed = lost[fid - c["fid"][lost] > self.max_time_lost].tolist()
-        else:
-            mt, md, removed, new_d = self._associate_stages(fid, T0, nd0, sim_wait, sel_all, pool, det_left, matched_t, matched_d, xyah, tlbr, det_ddd)
-        new_d = new_d[dscore[new_d] >= self.det_thresh] if len(new_d) else new_d
-        return self._commit(fid, T0, mt, md, removed, new_d, dscore, tlwh, xyah, det_ddd, det_depth, ddd_org_boxes, submission)
-
-    def _associate_stages(self, fid, T0, nd0, sim_wait, sel_all, pool, det_left, matched_t, matched_d, xyah, tlbr, det_ddd):
-        """The association stages in numpy (tracker.py:886-1030): every configuration; what the nuScenes trackers run."""
-        c = self.cols
         # ---- embedding association fused with the motion gate (tracker.py:886-925) ----
         g_pre = None
         if sim_wait is not None and not self.use_lstm and not self.ddd:   # the Kalman gate of matching.fuse_motion (:330-338) while the device works

@@ -508,6 +508,116 @@ extern "C" int deft_associate_2d(const float* sim, int ld, int T, int N, const d
     return 0;
 }
 
+// The same cascade for one class of a nuScenes frame (tracker.py:850-1030 with the 3-D branches):
+//   stage 0  (stage0 != 0: every class but pedestrian, :850-884) 1 - iou3d (float32, as iou_ddd_distance returns it) between the rows with `recent`
+//            (seen < 3 frames ago) and every detection, linear_assignment at 0.999; the embedding stage then sees the unmatched recent rows first,
+//            the older rows behind them, and the unmatched detections;
+//   stage 1  lambda * (1 - sim) + 0.001 * g with the "gaussian" distance of fuse_motion_ddd (matching.py:374-415): metric 0 = the centre distance
+//            sqrt(dx^2 + dy^2 + dz^2) of the LSTM filter (kalman_filter_lstm.py:92-95), metric 1 = the squared 7-component distance of the plain
+//            filter (kalman_filter.py:271-273); pairs with g > max(0.2 * depth[t], gate_floor) are excluded;
+//   stage 2  1 - sim on what is left;   stage 3  1 - IoU of the 2-D boxes, rows with iou_ok, threshold thr_iou (0 for nuScenes).
+// trk_ddd [T][7], det_ddd [N][7] = (h, w, l, x, y, z, rot_y).
+extern "C" int deft_associate_ddd(const float* sim, int ld, int T, int N, int stage0, const unsigned char* recent, const double* trk_ddd,
+                                  const double* det_ddd, const double* depth, int metric, double gate_floor, double lambda_, double w_gate,
+                                  const unsigned char* iou_ok, const double* trk_tlbr, const double* det_tlbr, double thr_3d, double thr_embed,
+                                  double thr_iou, int* match_t, int* match_d, int* n_match, int* lost_t, int* n_lost, int* new_d, int* n_new) {
+    DEFT_CHECK(T >= 0 && N >= 0 && T + N <= 4096 && ld >= N, -93, "deft_associate_ddd: T=%d N=%d ld=%d", T, N, ld);
+    DEFT_CHECK(n_match && n_lost && n_new && (T == 0 || (recent && trk_ddd && depth && iou_ok && trk_tlbr && lost_t)) &&
+               (N == 0 || (det_ddd && det_tlbr && new_d)) && (T == 0 || N == 0 || (sim && match_t && match_d)), -93, "deft_associate_ddd: null pointer");
+    int nm = 0;
+    std::vector<int> rows, older, cols(N), x(T), y(N), r2, c2;
+    for (int d = 0; d < N; ++d) cols[d] = d;
+    std::vector<double> cost((size_t)T * N);
+    auto assign = [&](double thr) {
+        const int n = (int)rows.size(), m = (int)cols.size();
+        if (n == 0 || m == 0) return;
+        r2.clear(); c2.clear();
+        assign_limited(cost.data(), n, m, thr, x.data(), y.data());
+        for (int i = 0; i < n; ++i)
+            if (x[i] >= 0) { match_t[nm] = rows[i]; match_d[nm] = cols[x[i]]; ++nm; }
+            else r2.push_back(rows[i]);
+        for (int j = 0; j < m; ++j) if (y[j] < 0) c2.push_back(cols[j]);
+        rows.swap(r2); cols.swap(c2);
+    };
+    // ---- stage 0 ----
+    if (stage0) {
+        for (int t = 0; t < T; ++t) (recent[t] ? rows : older).push_back(t);
+        if (!rows.empty() && N) {
+            const int n = (int)rows.size();
+            std::vector<double> ct((size_t)n * 24), cd((size_t)N * 24);
+            for (int i = 0; i < n; ++i) corners_of(trk_ddd + 7 * rows[i], (double (*)[3])(ct.data() + 24 * i));
+            for (int d = 0; d < N; ++d) corners_of(det_ddd + 7 * d, (double (*)[3])(cd.data() + 24 * d));
+            for (int i = 0; i < n; ++i)
+                for (int d = 0; d < N; ++d) {
+                    const float iou = (float)iou3d((const double (*)[3])(cd.data() + 24 * d), (const double (*)[3])(ct.data() + 24 * i));
+                    cost[(size_t)i * N + d] = (double)(1.0f - iou);
+                }
+            assign(thr_3d);
+        }
+        rows.insert(rows.end(), older.begin(), older.end());
+    } else {
+        for (int t = 0; t < T; ++t) rows.push_back(t);
+    }
+    // ---- stage 1 ----
+    if (!rows.empty() && !cols.empty()) {
+        const int n = (int)rows.size(), m = (int)cols.size();
+        for (int i = 0; i < n; ++i) {
+            const int t = rows[i];
+            const double* a = trk_ddd + 7 * t;
+            const double thr = std::fmax(0.2 * depth[t], gate_floor);
+            for (int j = 0; j < m; ++j) {
+                const double* b = det_ddd + 7 * cols[j];
+                double g;
+                if (metric == 0) {
+                    const double d3 = b[3] - a[3], d4 = b[4] - a[4], d5 = b[5] - a[5];
+                    g = std::sqrt(d3 * d3 + d4 * d4 + d5 * d5);
+                } else {
+                    g = 0.0;
+                    for (int q = 0; q < 7; ++q) { const double dq = b[q] - a[q]; g += dq * dq; }
+                }
+                double dist = 1.0 - (double)sim[(size_t)t * ld + cols[j]];
+                if (g > thr) dist = INFINITY;
+                cost[(size_t)i * m + j] = lambda_ * dist + w_gate * g;
+            }
+        }
+        assign(thr_embed);
+    }
+    // ---- stage 2 ----
+    if (!rows.empty() && !cols.empty() && T && N) {
+        const int n = (int)rows.size(), m = (int)cols.size();
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < m; ++j) cost[(size_t)i * m + j] = 1.0 - (double)sim[(size_t)rows[i] * ld + cols[j]];
+        assign(thr_embed);
+    }
+    // ---- stage 3 ----
+    r2.clear();
+    for (int t : rows) if (iou_ok[t]) r2.push_back(t);
+    rows.swap(r2);
+    if (!rows.empty() && !cols.empty()) {
+        const int n = (int)rows.size(), m = (int)cols.size();
+        for (int i = 0; i < n; ++i) {
+            const double* b = trk_tlbr + 4 * rows[i];
+            const double area_b = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+            for (int j = 0; j < m; ++j) {
+                const double* q = det_tlbr + 4 * cols[j];
+                const double iw = std::fmin(b[2], q[2]) - std::fmax(b[0], q[0]) + 1;
+                const double ih = std::fmin(b[3], q[3]) - std::fmax(b[1], q[1]) + 1;
+                const double area_q = (q[2] - q[0] + 1) * (q[3] - q[1] + 1);
+                const double inter = iw * ih;
+                const double ua = area_b + area_q - inter;
+                cost[(size_t)i * m + j] = 1.0 - ((iw > 0 && ih > 0) ? inter / ua : 0.0);
+            }
+        }
+        assign(thr_iou);
+    }
+    *n_match = nm;
+    *n_lost = (int)rows.size();
+    for (size_t i = 0; i < rows.size(); ++i) lost_t[i] = rows[i];
+    *n_new = (int)cols.size();
+    for (size_t j = 0; j < cols.size(); ++j) new_d[j] = cols[j];
+    return 0;
+}
+
 // The DeepSORT Kalman filter of the 2-D trackers on the pool's arrays (utils/tracking_utils/kalman_filter.py), in place, host memory:
 // mean [T][8] (x, y, a, h and their velocities), cov [T][8][8].
 //  * deft_kf_predict = multi_predict (:165-205): F = [[I, I], [0, I]] written out as block sums (the products by 1 and 0 of np.dot are exact),

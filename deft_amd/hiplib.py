@@ -76,6 +76,8 @@ _SIGS = {
     # host-side association helpers (HOST pointers, synchronous)
     "deft_lapjv": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_double, c_fp, c_fp, c_fp]),
     "deft_iou3d_matrix": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_fp]),
+    "deft_associate_ddd": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                     c_fp, c_fp, c_fp, C.c_double, C.c_double, C.c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "deft_kf_predict": (C.c_int, [c_fp, c_fp, C.c_int]),
     "deft_kf_update": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp]),
     "deft_associate_2d": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_double, C.c_double, C.c_double, C.c_int,

@@ -379,6 +379,17 @@ int deft_associate_2d(const float* sim, int ld, int T, int N, const double* mean
                       const unsigned char* iou_ok, const double* trk_tlbr, const double* det_tlbr, double thr_embed, double thr_iou,
                       int* match_t, int* match_d, int* n_match, int* lost_t, int* n_lost, int* new_d, int* n_new);
 
+/* The cascade for one class of a nuScenes frame (tracker.py:850-1030): stage 0 (stage0 != 0; every class but pedestrian) 1 - iou3d (float32, the
+ * arithmetic of deft_iou3d_matrix) between the rows with recent[t] and all detections, linear_assignment at thr_3d; stage 1 on the unmatched recent
+ * rows, then the other rows, x the unmatched detections: lambda * (1 - sim) + w_gate * g, g = the "gaussian" distance of matching.fuse_motion_ddd
+ * (matching.py:374-415; metric 0: centre distance, kalman_filter_lstm.py:92-95; metric 1: squared 7-component distance, kalman_filter.py:271-273)
+ * of det_ddd [N][7] to trk_ddd [T][7] (h, w, l, x, y, z, rot_y), pairs with g > max(0.2 * depth[t], gate_floor) excluded, thr_embed; stage 2: 1 - sim
+ * on what is left; stage 3: 1 - IoU of the 2-D boxes (rows with iou_ok) at thr_iou.  Outputs as deft_associate_2d.  HOST pointers, synchronous. */
+int deft_associate_ddd(const float* sim, int ld, int T, int N, int stage0, const unsigned char* recent, const double* trk_ddd,
+                       const double* det_ddd, const double* depth, int metric, double gate_floor, double lambda_, double w_gate,
+                       const unsigned char* iou_ok, const double* trk_tlbr, const double* det_tlbr, double thr_3d, double thr_embed,
+                       double thr_iou, int* match_t, int* match_d, int* n_match, int* lost_t, int* n_lost, int* new_d, int* n_new);
+
 /* The Kalman filter of the 2-D trackers on the pool's arrays, in place (utils/tracking_utils/kalman_filter.py): mean [T][8], cov [T][8][8] double.
  * deft_kf_predict = multi_predict (:165-205) for every row; deft_kf_update = update (:207-240) of the rows rows[0 .. n) with the measurements
  * meas [n][4] (x, y, a, h) -- Cholesky solve of the 4 x 4 innovation covariance like the reference; -94 when it is not positive definite.

@@ -349,3 +349,87 @@ def test_associate_2d_equals_the_numpy_stages(seed):
     assert got == want
     if seed % 6 and seed % 7 and seed % 5:
         assert cnt[0] > 0
+
+
+def _associate_ddd_numpy(sim, stage0, recent, trk_ddd, det_ddd, depth, metric, floor, iou_ok, a_tlbr, d_tlbr):
+    """tracker.py:850-1030 from this module's numpy pieces (what ArrayTracker._associate_stages composes for a nuScenes class)."""
+    T, N = len(trk_ddd), len(det_ddd)
+    lam = 0.9
+    mt, md = [], []
+    pool, det_left = np.arange(T), np.arange(N)
+    s64 = sim.astype(np.float64) if sim is not None else None
+    if stage0:
+        new, old = pool[recent.astype(bool)], pool[~recent.astype(bool)]
+        cost = A.iou_ddd_distance(trk_ddd[new], det_ddd)
+        m, u_t, u_d = A.linear_assignment(cost, 0.999)
+        if len(m):
+            mt += new[m[:, 0]].tolist(); md += m[:, 1].tolist()
+        det_left = np.asarray(u_d, dtype=int)
+        pool = np.concatenate([new[np.asarray(u_t, dtype=int)], old]).astype(int)
+    have = len(pool) and len(det_left) and s64 is not None
+    if have:
+        d = 1 - s64[pool][:, det_left]
+        dd = det_ddd[det_left][None, :, :] - trk_ddd[pool][:, None, :]
+        g = np.sqrt(np.sum(dd[..., 3:-1] * dd[..., 3:-1], axis=2)) if metric == 0 else np.sum(dd * dd, axis=2)
+        thr = np.maximum(0.2 * depth[pool], floor)
+        d[g > thr[:, None]] = np.inf
+        d = lam * d + 0.001 * g
+        m, u_t, u_d = A.linear_assignment(d, 0.9)
+        if len(m):
+            mt += pool[m[:, 0]].tolist(); md += det_left[m[:, 1]].tolist()
+        pool, det_left = pool[np.asarray(u_t, dtype=int)], det_left[np.asarray(u_d, dtype=int)]
+        if len(pool) and len(det_left):
+            m, u_t, u_d = A.linear_assignment(1 - s64[pool][:, det_left], 0.9)
+            if len(m):
+                mt += pool[m[:, 0]].tolist(); md += det_left[m[:, 1]].tolist()
+            pool, det_left = pool[np.asarray(u_t, dtype=int)], det_left[np.asarray(u_d, dtype=int)]
+    pool = pool[iou_ok[pool].astype(bool)]
+    if len(pool) and len(det_left):
+        m, u_t, u_d = A.linear_assignment(1 - A.bbox_overlaps(a_tlbr[pool], d_tlbr[det_left]), 0.0)
+        if len(m):
+            mt += pool[m[:, 0]].tolist(); md += det_left[m[:, 1]].tolist()
+        pool, det_left = pool[np.asarray(u_t, dtype=int)], det_left[np.asarray(u_d, dtype=int)]
+    return mt, md, pool.tolist(), det_left.tolist()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_associate_ddd_equals_the_numpy_stages(seed):
+    """deft_associate_ddd (3-D IoU stage, embedding stage with the 3-D gate in both metrics, similarity-only stage, 2-D IoU stage at threshold 0)
+    against the same cascade composed from iou_ddd_distance / linear_assignment / bbox_overlaps: identical matches in identical order, identical
+    left-overs; with and without the 3-D stage (pedestrian), empty sides, rows outside the gate, old rows that skip the 3-D and the IoU stage."""
+    import ctypes as C
+    rng = np.random.default_rng(1700 + seed)
+    T = int(rng.integers(0, 25)) if seed % 6 else 0
+    N = int(rng.integers(0, 25)) if seed % 7 else 0
+    stage0, metric = seed % 2, (seed // 2) % 2
+    floor = 10.0 if stage0 else 5.0
+
+    def boxes3(n):            # (h, w, l, x, y, z, rot_y): cars on a ground plane
+        return np.stack([rng.uniform(1.4, 1.9, n), rng.uniform(1.6, 2.0, n), rng.uniform(3.5, 5.0, n), rng.uniform(-30, 30, n), rng.uniform(1.0, 1.6, n),
+                         rng.uniform(5, 60, n), rng.uniform(-3.1, 3.1, n)], 1)
+    det_ddd, trk_ddd = boxes3(N), boxes3(T)
+    k = min(T, N)
+    pick = rng.permutation(N)[:k]
+    if k:                                                               # tracks near detections: overlapping 3-D boxes, pairs inside the gate
+        trk_ddd[:k] = det_ddd[pick] + rng.normal(0, 0.25, (k, 7)) * [0.02, 0.02, 0.05, 1, 0.05, 1, 0.1]
+    depth = trk_ddd[:, 5].copy() if T else np.zeros(0)
+    box2 = lambda b3: np.stack([b3[:, 3] * 10 + 500, b3[:, 5] * 4, b3[:, 3] * 10 + 500 + 40 + b3[:, 2], b3[:, 5] * 4 + 30 + b3[:, 0]], 1)
+    d_tlbr = box2(det_ddd) if N else np.zeros((0, 4))
+    a_tlbr = box2(trk_ddd) + rng.normal(0, 1.0, (T, 4)) if T else np.zeros((0, 4))
+    recent = (rng.random(T) < 0.7).astype(np.uint8)
+    sim = (rng.random((T, N + 1)) * 0.11).astype(np.float32)           # (few pairs beyond the 0.9 limit of the similarity-only stage: the IoU stage gets work)
+    if k:
+        sim[np.arange(k), pick] = (0.5 + 0.5 * rng.random(k)) * (rng.random(k) < 0.6)
+    out = np.full(2 * k + T + N + 3, -7, np.int32)
+    mt, md, lost, new_d, cnt = out[:k], out[k:2 * k], out[2 * k:2 * k + T], out[2 * k + T:2 * k + T + N], out[2 * k + T + N:]
+    ptr = lambda a: C.c_void_p(a.ctypes.data if a.size else 0)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (trk_ddd, det_ddd, depth, a_tlbr, d_tlbr)]
+    A._host_lib().call("deft_associate_ddd", ptr(sim) if T and N else None, N + 1, T, N, stage0, ptr(recent), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]),
+                       metric, C.c_double(floor), C.c_double(0.9), C.c_double(0.001), ptr(recent), ptr(arrs[3]), ptr(arrs[4]), C.c_double(0.999),
+                       C.c_double(0.9), C.c_double(0.0), ptr(mt), ptr(md), C.c_void_p(cnt.ctypes.data), ptr(lost), C.c_void_p(cnt.ctypes.data + 4),
+                       ptr(new_d), C.c_void_p(cnt.ctypes.data + 8))
+    want = _associate_ddd_numpy(sim if T and N else None, stage0, recent, trk_ddd, det_ddd, depth, metric, floor, recent, a_tlbr, d_tlbr)
+    got = (mt[:cnt[0]].tolist(), md[:cnt[0]].tolist(), lost[:cnt[1]].tolist(), new_d[:cnt[2]].tolist())
+    assert got == want
+    if T > 3 and N > 3:
+        assert cnt[0] > 0
