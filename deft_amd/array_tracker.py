@@ -414,19 +414,20 @@ class ArrayTracker(object):
         return mt[:cnt[0]].astype(int), md[:cnt[0]].astype(int), lost[:cnt[1]].astype(int), new_d[:cnt[2]].astype(int)
 
     # ---- the device half of a frame, which may run ahead of update() --------------------------------------------------------------------
-    def begin(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None):
+    def begin(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None, pre=None, feats=None):
         """The part of update(results, FeatureMaps) that depends only on the frame's detections, its feature maps and the track table as the previous
         update() left it -- detections as arrays, embedding extraction, the affinity blocks against the stored frames the pool reads, the
         similarity medians and their copy back (tracker.py:786-848, 663-688) -- queued NOW.  A caller that already holds the next frame's detections
         (Detector.run with a lookahead pass that has finished) calls this right behind update(k); update(k + 1) must then be given the SAME
         `results` object and finds its device round trip already under way (another object: the early work is taken back and redone).
         The seven per-class trackers of a nuScenes frame are begun one after the other before the first of them is updated: seven device round trips
-        in flight at once instead of one at a time."""
+        in flight at once instead of one at a time.  pre / feats: detections_as_arrays(results, ...) and the frame's embeddings [1, n, D] when the
+        caller has them already (extract_together: one extraction for all classes)."""
         if self._begun is not None:
             self._undo(self._begun)
         rec = self.recorder
         snap = (rec.all_frame_index, dict(rec.all_features), dict(rec.all_boxes), dict(rec.all_similarity), rec._dev)
-        self._begun = self._first_half(results, FeatureMaps, ddd_boxes, depths_by_class)
+        self._begun = self._first_half(results, FeatureMaps, ddd_boxes, depths_by_class, pre, feats)
         self._begun["snap"] = snap
 
     def _undo(self, b):
@@ -438,11 +439,10 @@ class ArrayTracker(object):
         if w is not None:
             w(raw=True)                                                # let the queued launches finish with the staging buffers they read
 
-    def _first_half(self, results, FeatureMaps, ddd_boxes, depths_by_class):
-        fid = self.frame_id + 1
-        c = self.cols
+    def detections_as_arrays(self, results, ddd_boxes=None, depths_by_class=None):
+        """The frame's detections of this tracker as arrays (tracker.py:786-820): rows, boxes in the forms the stages read, and the embedding
+        centres in [-1, 1] (convert_detection, image.py:391-412) as the [1, n, 1, 1, 2] tensor forward_feature_extracter takes."""
         det_ddd = det_depth = None
-        # ---- detections as arrays ----
         if self.ddd:
             dets = np.array(results)
             det_ddd = np.array(ddd_boxes, dtype=np.float64).reshape(-1, 7) if len(dets) else np.zeros((0, 7))
@@ -452,7 +452,7 @@ class ArrayTracker(object):
         else:
             dets = np.array([np.asarray(d["bbox"]).tolist() + [d["score"]] for d in results], np.float32)
         nd0 = len(dets)
-        sel_all = self._selected_nodes(fid)
+        pre = {"results": results, "nd0": nd0, "det_ddd": det_ddd, "det_depth": det_depth, "centers": None, "org": None}
         if nd0 > 0:
             tl = dets[:, :4].copy()                                   # STrack.tlbr_to_tlwh in the dtype of the rows (float32 for the 2-D datasets)
             tl[:, 2:] -= tl[:, :2]
@@ -462,19 +462,49 @@ class ArrayTracker(object):
             xyah[:, 2] /= xyah[:, 3]
             tlbr = tlwh.copy()
             tlbr[:, 2:] += tlbr[:, :2]
-            dscore = dets[:, 4]
             org = np.copy(dets[:, :4])
             d = np.array(org, dtype=np.float64)                           # convert_detection, image.py:391-412
             d[:, 2] -= d[:, 0]; d[:, 3] -= d[:, 1]
             d[:, 0] /= self.img_width; d[:, 2] /= self.img_width; d[:, 1] /= self.img_height; d[:, 3] /= self.img_height
-            centers = torch.from_numpy(((2 * d[:, 0:2] + d[:, 2:4]) - 1.0).astype(float)).float().view(1, -1, 1, 1, 2)
-            if FeatureMaps[0].shape[0] == 2:                              # flip-test pair: the un-flipped frame's maps (tracker.py:821-825)
-                FeatureMaps = [fm[0].unsqueeze(0) for fm in FeatureMaps]
-            feats = self.model.AFE.forward_feature_extracter(FeatureMaps, centers)
-            needed = set(np.unique(sel_all[0][sel_all[2]]).tolist()) if self.lazy_blocks else None
-            self.recorder.update(self.model, fid, feats.data, org, needed=needed)
+            pre.update(tlwh=tlwh, xyah=xyah, tlbr=tlbr, dscore=dets[:, 4], org=org,
+                       centers=torch.from_numpy(((2 * d[:, 0:2] + d[:, 2:4]) - 1.0).astype(float)).float().view(1, -1, 1, 1, 2))
         else:
-            tlwh = xyah = tlbr = np.zeros((0, 4)); dscore = np.zeros(0, np.float32)
+            z = np.zeros((0, 4))
+            pre.update(tlwh=z, xyah=z, tlbr=z, dscore=np.zeros(0, np.float32))
+        return pre
+
+    @staticmethod
+    def extract_together(trackers, pres, FeatureMaps):
+        """The embeddings of several trackers' detections of ONE frame (the per-class trackers of a nuScenes frame) in one forward_feature_extracter
+        call when they share the extractor: [1, n_k, D] per tracker (None for a tracker without detections, or when they do not share it)."""
+        afe = trackers[0].model.AFE
+        counts = [p["nd0"] for p in pres]
+        if sum(counts) == 0 or any(t.model.AFE is not afe for t in trackers):
+            return [None] * len(trackers)
+        if FeatureMaps[0].shape[0] == 2:                                  # flip-test pair: the un-flipped frame's maps (tracker.py:821-825)
+            FeatureMaps = [fm[0].unsqueeze(0) for fm in FeatureMaps]
+        feats = afe.forward_feature_extracter(FeatureMaps, torch.cat([p["centers"] for p in pres if p["nd0"]], 1))
+        out, o = [], 0
+        for n in counts:
+            out.append(feats[:, o:o + n] if n else None)
+            o += n
+        return out
+
+    def _first_half(self, results, FeatureMaps, ddd_boxes, depths_by_class, pre=None, feats=None):
+        fid = self.frame_id + 1
+        c = self.cols
+        if pre is None or pre["results"] is not results:
+            pre, feats = self.detections_as_arrays(results, ddd_boxes, depths_by_class), None
+        nd0, det_ddd, det_depth = pre["nd0"], pre["det_ddd"], pre["det_depth"]
+        tlwh, xyah, tlbr, dscore = pre["tlwh"], pre["xyah"], pre["tlbr"], pre["dscore"]
+        sel_all = self._selected_nodes(fid)
+        if nd0 > 0:
+            if feats is None:
+                if FeatureMaps[0].shape[0] == 2:                          # flip-test pair: the un-flipped frame's maps (tracker.py:821-825)
+                    FeatureMaps = [fm[0].unsqueeze(0) for fm in FeatureMaps]
+                feats = self.model.AFE.forward_feature_extracter(FeatureMaps, pre["centers"])
+            needed = set(np.unique(sel_all[0][sel_all[2]]).tolist()) if self.lazy_blocks else None
+            self.recorder.update(self.model, fid, feats.data, pre["org"], needed=needed)
         T0 = c.n
         # the similarity of EVERY pool row to the frame's detections, queued now and read after the host work that does not depend on it (prediction, motion
         # gate; nuScenes: the 3-D IoU stage, which only decides which of these rows the embedding stage keeps)

@@ -369,10 +369,13 @@ class Detector(object):
                 targets = results
             elif per_class is not None:                                                    # detector.py:198-338
                 targets = []
-                for name, a in per_class.items():                                          # every class's device half first (ArrayTracker.begin) ...
-                    begin = getattr(self.tracker[name], "begin", None)
-                    if BEGIN_AHEAD and begin is not None:
-                        begin(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"])
+                trks = [self.tracker[name] for name in per_class]
+                if BEGIN_AHEAD and all(hasattr(t, "begin") and hasattr(t, "extract_together") for t in trks):
+                    # every class's device half first (ArrayTracker.begin), on ONE embedding extraction for the detections of all classes ...
+                    pres = [t.detections_as_arrays(a["results"], a["ddd_boxes"], a["depths"]) for t, a in zip(trks, per_class.values())]
+                    feats = type(trks[0]).extract_together(trks, pres, fmaps)
+                    for t, a, p, f in zip(trks, per_class.values(), pres, feats):
+                        t.begin(a["results"], fmaps, ddd_boxes=a["ddd_boxes"], depths_by_class=a["depths"], pre=p, feats=f)
                 for name, a in per_class.items():                                          # ... then the associations, class by class
                     trk = self.tracker[name]
                     if trk is hook_on:
