@@ -138,7 +138,6 @@ class ArrayTracker(object):
         self._pending = None                                  # ... and the motion step whose result has not been read back yet
         self.removed_ids = []
         self._begun = None                                    # begin(): the device half of the next frame, already queued
-        self._announced = self._early = None                  # announce(): the next frame's detections / its chain queued during this frame's association
         self.lost_stracks = []
         self.classe = None
 
@@ -181,9 +180,7 @@ class ArrayTracker(object):
         """For every pool row: (frames [T, L], ids [T, L], valid mask [T, L]) of the nodes STrack.get_similarity medians over
         (tracker.py:221-248), oldest first."""
         c = self.cols
-        return c["nf"], c["ni"], self._select(c["nf"], c["nn"], fid)
-
-    def _select(self, nf, nn, fid):
+        nf, ni, nn = c["nf"], c["ni"], c["nn"]
         T, L = nf.shape
         stored = np.minimum(nn, L)
         pos = np.arange(L)[None, :]
@@ -191,7 +188,8 @@ class ArrayTracker(object):
         young = have & (fid - nf < DT.max_track_node)
         q = young.sum(1)                                               # young nodes form a suffix; with all L stored ones young there may be more
         nsel = np.where(q <= self.mm + 1, q, self.mm)
-        return pos >= (L - nsel)[:, None]
+        sel = pos >= (L - nsel)[:, None]
+        return nf, ni, sel
 
     def _similarity(self, fid, rows_idx, nd, sel_all, defer=False):
         """deft_amd.tracker.get_similarity on the node arrays: float64 [len(rows_idx), nd + 1].  defer: queue the launch and the copy back, return
@@ -277,7 +275,6 @@ class ArrayTracker(object):
         if self._begun is not None:
             self._undo(self._begun)
             self._begun = None
-        self._announced = None
         if self.use_lstm and self.bank is not None:
             try:
                 self._resolve()
@@ -385,55 +382,6 @@ class ArrayTracker(object):
         cb, self.after_device_work = self.after_device_work, None
         if cb is not None:
             cb()
-        if self._announced is not None:
-            self._early_next()
-
-    # ---- the NEXT frame's embedding / affinity chain, queued while this frame is being associated -----------------------------------------------
-    def announce(self, results, FeatureMaps):
-        """The caller already holds the NEXT frame's detections and feature maps (Detector.run: a later frame of a finished lookahead pass) and will pass
-        this very `results` object to the update() after the one that follows.  That update() -- of the CURRENT frame -- queues the next frame's
-        embedding extraction and affinity blocks (tracker.py:59-90: they depend on the detections and the stored embeddings only, not on how this
-        frame is associated) as soon as it has read its own similarity matrix back, so that chain runs on the device while the host associates;
-        the next frame's similarity medians -- which need the node lists this frame's association leaves -- follow when it is done.  The blocks
-        are computed against the stored frames the next frame's pool can select whatever this frame's association decides (each track's selection if
-        it stays unmatched, and if it is matched, plus the current frame).  2-D datasets."""
-        if not self.ddd:
-            self._announced = (results, FeatureMaps)
-
-    def _early_next(self):
-        (results, FeatureMaps), self._announced = self._announced, None
-        fid, c = self.frame_id, self.cols                              # (update() has set frame_id to the current frame)
-        pre = self.detections_as_arrays(results)
-        rec = self.recorder
-        early = {"pre": pre, "snap": (rec.all_frame_index, dict(rec.all_features), dict(rec.all_boxes), dict(rec.all_similarity), rec._dev)}
-        if pre["nd0"] > 0:
-            if FeatureMaps[0].shape[0] == 2:
-                FeatureMaps = [fm[0].unsqueeze(0) for fm in FeatureMaps]
-            feats = self.model.AFE.forward_feature_extracter(FeatureMaps, pre["centers"])
-            needed = None
-            if self.lazy_blocks:
-                # what the next frame's pool can select: every track as it is (left unmatched now) and as it will be with a node in this frame
-                # (matched now); tracks born in this frame hold a node of this frame only
-                nf, nn = c["nf"], c["nn"]
-                nf_m = np.concatenate([nf[:, 1:], np.full((nf.shape[0], 1), fid, nf.dtype)], 1)
-                needed = set(np.unique(nf[self._select(nf, nn, fid + 1)]).tolist()) | set(np.unique(nf_m[self._select(nf_m, nn + 1, fid + 1)]).tolist()) | {fid}
-            rec.update(self.model, fid + 1, feats.data, pre["org"], needed=needed)
-        self._early = early
-
-    def _late_next(self):
-        """Behind this frame's commit: the announced frame's similarity medians on the node lists as they are now -- update() finds it begun."""
-        early, self._early = self._early, None
-        pre = early["pre"]
-        fid = self.frame_id + 1
-        sel_all = self._selected_nodes(fid)
-        T0, nd0 = self.cols.n, pre["nd0"]
-        try:
-            sim_wait = self._similarity(fid, np.arange(T0), nd0, sel_all, defer=True) if (T0 and nd0) else None
-        except KeyError:                                               # a selected node in a frame the early chain did not score: redo the frame in its own update()
-            self._undo(early)
-            return
-        self._begun = {"results": pre["results"], "fid": fid, "nd0": nd0, "sel_all": sel_all, "tlwh": pre["tlwh"], "xyah": pre["xyah"], "tlbr": pre["tlbr"],
-                       "dscore": pre["dscore"], "T0": T0, "sim_wait": sim_wait, "det_ddd": None, "det_depth": None, "snap": early["snap"]}
 
     def _associate_ddd(self, fid, T, N, sim_wait, det_ddd, tlbr):
         """tracker.py:850-1030 for one class of a nuScenes frame through deft_associate_ddd (see _associate_2d)."""
@@ -593,10 +541,7 @@ class ArrayTracker(object):
         else:
             mt, md, removed, new_d = self._associate_stages(fid, T0, nd0, sim_wait, sel_all, xyah, tlbr, det_ddd)
         new_d = new_d[dscore[new_d] >= self.det_thresh] if len(new_d) else new_d
-        out = self._commit(fid, T0, mt, md, removed, new_d, dscore, tlwh, xyah, det_ddd, det_depth, ddd_org_boxes, submission)
-        if self._early is not None:
-            self._late_next()
-        return out
+        return self._commit(fid, T0, mt, md, removed, new_d, dscore, tlwh, xyah, det_ddd, det_depth, ddd_org_boxes, submission)
 
     def _associate_stages(self, fid, T0, nd0, sim_wait, sel_all, xyah, tlbr, det_ddd):
         """The association stages in numpy (tracker.py:850-1030), every configuration: the cross-check of the native calls."""

@@ -22,8 +22,7 @@ PRIORITY_TRACKER = _os.environ.get("DEFT_TRACKER_PRIORITY", "1") != "0"      # r
 # a one-frame pass queued at the hook is not finished when the next call wants it) -- tools/probe/lookahead_probe.py
 LOOKAHEAD_AT = _os.environ.get("DEFT_LOOKAHEAD_AT", "auto")
 # run() on a recorded stream: when the host already holds the NEXT frame's detections (same lookahead pass, or the other slot's finished pass), the
-# tracker is told (ArrayTracker.announce) and queues that frame's embedding / affinity chain while it associates this one; the per-class trackers of a
-# nuScenes frame are begun together (ArrayTracker.begin).  "0": every frame's device half inside its own update()
+# tracker's device half for that frame (ArrayTracker.begin) is queued right behind this frame's update().  "0": every frame's device half inside its own update()
 BEGIN_AHEAD = _os.environ.get("DEFT_BEGIN_AHEAD", "1") != "0"
 
 
@@ -366,9 +365,6 @@ class Detector(object):
             else:
                 prio.wait_stream(main)
         with (torch.cuda.stream(prio) if prio is not None else _null()):
-            if (BEGIN_AHEAD and self._peek_src is not None and per_class is None and self.tracker is not None and hasattr(self.tracker, "announce")
-                    and not meta_given and not getattr(opt, "public_det", False)):
-                self._announce_next(meta, scale, prio)
             if self.tracker is None:
                 targets = results
             elif per_class is not None:                                                    # detector.py:198-338
@@ -397,6 +393,9 @@ class Detector(object):
                     nxt()
             else:
                 targets = self.tracker.update(results, fmaps)                              # detector.py:340-342
+            if (BEGIN_AHEAD and self._peek_src is not None and per_class is None and self.tracker is not None and hasattr(self.tracker, "begin")
+                    and not meta_given and not getattr(opt, "public_det", False)):
+                self._begin_next(meta, scale, prio)
         if prio is not None:
             main.wait_stream(prio)
         t_end = time.time()
@@ -530,10 +529,10 @@ class Detector(object):
             o += cnt
         return dets
 
-    def _announce_next(self, meta, scale, prio):
+    def _begin_next(self, meta, scale, prio):
         """The NEXT frame's detections are already on the host (a later frame of the pass this frame came from, or the first frame of the other
-        slot's pass when that has finished): post-process them now and tell the tracker (ArrayTracker.announce) -- its update() of THIS frame queues
-        the next frame's embedding / affinity chain while the host associates, and the next run() call finds the round trip under way."""
+        slot's pass when that has finished): post-process them now and let the tracker queue its device half for them (ArrayTracker.begin) behind
+        this frame's update() -- the next run() call finds the embedding / affinity / similarity round trip under way instead of waiting for it."""
         sl, j = self._peek_src
         try:
             dets = _check_finite(self._slot_dets(sl, j))
@@ -543,7 +542,7 @@ class Detector(object):
         fmaps = sl.plan.fmaps if sl.n == 1 else [fm[j] for fm in sl.plan.fmaps]
         if sl.done is not None:
             (prio if prio is not None else torch.cuda.current_stream(self.device)).wait_event(sl.done)
-        self.tracker.announce(results, fmaps)
+        self.tracker.begin(results, fmaps)
         self._peeked = (sl.frames[j], results)
 
     def _process_ahead(self, akey, frame, prefetch):

@@ -1810,9 +1810,9 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
             det.img_height, det.img_width = sh, sw
             det.lookahead_frames = 1
             log, fired = [], []
-            if dataset != "nuscenes":                   # ArrayTracker.announce: the next frame's chain queued inside this frame's update()
-                trk, announce = det.tracker, det.tracker.announce
-                trk.announce = lambda *a: (begun.append(lookahead), announce(*a))[1]
+            if dataset != "nuscenes":                   # ArrayTracker.begin: the next frame's device half queued behind this frame's update()
+                trk, begin = det.tracker, det.tracker.begin
+                trk.begin = lambda *a: (begun.append(lookahead), begin(*a))[1]
             if lookahead == "pairs":                    # Detector.track_stream: the per-video loop with two frames per lookahead pass
                 outs = det.track_stream(iter(frames), image_infos=[info] * T, frames_per_pass=2)
             else:

@@ -256,9 +256,8 @@ def test_native_association_equals_the_numpy_stages(emu_lib, dataset):
 
 @pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
 def test_begin_ahead_changes_nothing(emu_lib, dataset):
-    """ArrayTracker.begin(results, FeatureMaps): the device half of the NEXT frame queued behind update(k); ArrayTracker.announce(results, FeatureMaps):
-    its embedding / affinity chain queued INSIDE update(k) against a superset of the stored frames, its similarity medians behind the commit.  Same tracks
-    as plain update() calls when every frame is begun / announced ahead; and a begin() for a frame that never comes (update() is handed another frame's detections) is taken back -- the
+    """ArrayTracker.begin(results, FeatureMaps): the device half of the NEXT frame queued behind update(k).  Same tracks as plain update() calls when
+    every frame is begun ahead; and a begin() for a frame that never comes (update() is handed another frame's detections) is taken back -- the
     recorder's stored frames, evicted entries included (a stream longer than its 50-frame window), are what they were."""
     from deft_amd import mot_tracker as MT
     opt = types.SimpleNamespace(dataset=dataset, track_buffer=30, max_object=100, lstm=False)
@@ -274,14 +273,7 @@ def test_begin_ahead_changes_nothing(emu_lib, dataset):
         fm = [torch.zeros(1, 1, 1, 1)]
         log = []
         for t in range(nframes):
-            if mode == "announce" and t + 1 < nframes:
-                trk.announce(frames[t + 1], fm)                        # the next frame's chain is queued inside this update()
-            elif mode == "announce_wrong" and t + 1 < nframes:
-                trk.announce(wrong if t % 3 else frames[t + 1], fm)
             log.append(_log(trk.update(frames[t], fm)))
-            if mode.startswith("announce"):
-                assert (trk._begun is not None) == (t + 1 < nframes) and trk._announced is None and trk._early is None
-                continue
             if mode == "ahead" and t + 1 < nframes:
                 trk.begin(frames[t + 1], fm)
             elif mode == "wrong" and t + 1 < nframes:
@@ -291,7 +283,6 @@ def test_begin_ahead_changes_nothing(emu_lib, dataset):
 
     plain = run("plain")
     assert run("ahead") == plain and run("wrong") == plain
-    assert run("announce") == plain and run("announce_wrong") == plain
     assert sum(len(f) for f in plain[0]) > 200 and len(plain[1]) == 50 and plain[2] == nframes
 
 
