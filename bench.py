@@ -780,7 +780,7 @@ def main():
 E2E = {"B": dict(frame=(1080, 1920), lstm=False), "D": dict(frame=(375, 1242), lstm=True), "E": dict(frame=(900, 1600), lstm=True)}
 
 
-E2E_PER_PASS = 4                # frames per lookahead pass of the end-to-end figure (Detector.lookahead_frames)
+E2E_PER_PASS = int(os.environ.get("DEFT_E2E_PER_PASS", "4"))      # frames per lookahead pass of the end-to-end figure (Detector.lookahead_frames)
 
 
 def end_to_end_fresh(name, dev, lib, local, ne=100):
@@ -862,7 +862,7 @@ def end_to_end(name, dev, lib, local, ne=100):
     ge = np.random.RandomState(11)
     # frames in PINNED host memory, the way a decoder / capture driver delivers them (numpy views of pinned tensors: the lookahead pass
     # copies them to the device without a staging memcpy)
-    keep_pinned = [torch.from_numpy(ge.randint(0, 256, (sh, sw, 3), dtype=np.uint8)).pin_memory() for _ in range(12)]
+    keep_pinned = [torch.from_numpy(ge.randint(0, 256, (sh, sw, 3), dtype=np.uint8)).pin_memory() for _ in range(max(12, 3 * E2E_PER_PASS))]      # (more frames than the lookahead holds at once: every frame in flight is its own array)
     feed = [t.numpy() for t in keep_pinned]
     NF = len(feed)
 
