@@ -12,10 +12,15 @@ sequence of array operations over the pool:
   embeddings          model.AFE (AfeSeam): centres -> embeddings, new frame scored against the stored frames the pool can read
                       (deft_amd.tracker.FeatureRecorder, lazy blocks), tracks x detections similarity medians on the device
                       (deft_track_similarity) -- ONE device round trip per frame, after which `after_device_work` fires
-  gates / costs       association._maha2, the 3-D centre / 7-component gates, bbox_overlaps, deft_iou3d_matrix -- whole matrices
-  assignment          deft_lapjv (own Jonker-Volgenant, fixed tie order)
-  state update        batched Kalman update (mot_tracker.kf_multi_update) or ONE deft_motion_step launch for every track touched
-                      in the frame (features + LSTM + future boxes; fetched lazily, when the next frame first needs a prediction)
+  gates / costs /     ONE native host call per frame (per class for nuScenes): deft_associate_2d / deft_associate_ddd (csrc/assoc.hip) -- the motion
+  assignment          gate, the fused costs, the 3-D and 2-D IoU matrices and the three / four assignments (own Jonker-Volgenant, fixed tie order)
+                      on the similarity matrix as it lands in pinned memory; `native_assoc = False`: the same stages as numpy matrices
+                      (association._maha2, bbox_overlaps, deft_iou3d_matrix, deft_lapjv), kept as the cross-check
+  state update        Kalman predict / update of the pool's mean / covariance columns in place (deft_kf_predict / deft_kf_update) or ONE
+                      deft_motion_step launch for every track touched in the frame (features + LSTM + future boxes; fetched lazily, when the
+                      next frame first needs a prediction)
+  ahead of update()   begin(): everything above that needs only the frame's detections and the track table of the previous frame, queued before
+                      update() is called for it (Detector.run: the next frame of a finished lookahead pass; all per-class trackers of a nuScenes frame)
 
 Semantics are the reference's, statement by statement (tests/test_mot_tracker.py replays scenes through the reference's own Tracker for
 mot / kitti_tracking / nuscenes x Kalman / LSTM and requires identical ids, flags and boxes frame by frame):

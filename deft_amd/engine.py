@@ -520,12 +520,21 @@ class _Plan:
         assert self.device.type == "cuda"
         if self.sched is None and DATAFLOW > 1:
             self.tune_schedule()
+        import gc
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
-            self.run()
-            if then is not None:
-                then()
+        # no cyclic garbage collection while the stream is capturing: a collected object that owns a HIP resource (an event, a stream, another graph of
+        # a Detector that went out of scope) would call into the runtime in the middle of the capture
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
+                self.run()
+                if then is not None:
+                    then()
+        finally:
+            if was_enabled:
+                gc.enable()
         return g
 
     def _run_dataflow(self):
