@@ -422,7 +422,7 @@ def side_config(name, args, dev, lib, rank):
         torch.cuda.empty_cache()
         e = end_to_end_fresh(name, dev, lib, dev.index or 0, ne=60)
         out["end_to_end"] = {k: e[k] for k in ("ms_per_frame", "value", "unit", "frames_per_pass", "runs_ms_per_frame", "stage_ms", "one_frame_lookahead", "serial", "tracks_alive",
-                                               "workload", "process")}
+                                               "workload", "process", "eight_frames_per_pass")}
     return out
 
 
@@ -751,6 +751,9 @@ def main():
                 side[name]["e2e"] = round(sc["end_to_end"]["value"], 1)
         if "end_to_end" in extras:
             side["B_e2e"] = {"value": round(extras["end_to_end"]["value"], 1), "one_frame_lookahead": round(1e3 / extras["end_to_end"]["one_frame_lookahead"]["ms_per_frame"], 1)}
+            e8 = extras["end_to_end"].get("eight_frames_per_pass") or {}
+            if "value" in e8:
+                side["B_e2e"]["eight_per_pass"] = round(e8["value"], 1)
         if "latency_mode" in extras:
             side["latency_ms"] = extras["latency_mode"]["ms_per_step"]
         if "config_C" in extras:
@@ -862,7 +865,7 @@ def end_to_end(name, dev, lib, local, ne=100):
     ge = np.random.RandomState(11)
     # frames in PINNED host memory, the way a decoder / capture driver delivers them (numpy views of pinned tensors: the lookahead pass
     # copies them to the device without a staging memcpy)
-    keep_pinned = [torch.from_numpy(ge.randint(0, 256, (sh, sw, 3), dtype=np.uint8)).pin_memory() for _ in range(max(12, 3 * E2E_PER_PASS))]      # (more frames than the lookahead holds at once: every frame in flight is its own array)
+    keep_pinned = [torch.from_numpy(ge.randint(0, 256, (sh, sw, 3), dtype=np.uint8)).pin_memory() for _ in range(max(24, 3 * E2E_PER_PASS))]      # (more frames than the lookahead holds at once: every frame in flight is its own array)
     feed = [t.numpy() for t in keep_pinned]
     NF = len(feed)
 
@@ -904,6 +907,15 @@ def end_to_end(name, dev, lib, local, ne=100):
         d1, acc1 = e2e(1, ne)
         d4, acc, all4 = median_of(E2E_PER_PASS)          # the reported mode: median of three runs (all three in `runs_ms_per_frame`)
     trk = fdet.tracker
+    eight = None
+    if E2E_PER_PASS != 8 and os.environ.get("DEFT_E2E_REPORTED_MODE_ONLY") != "1":
+        # a larger pass is a more efficient pass (and 7 more frame periods of latency): reported beside the four-frame mode, not instead of it
+        try:
+            d8, acc8 = e2e(8, ne)
+            eight = {"ms_per_frame": round(d8 / ne * 1e3, 3), "value": round(ne / d8, 3), "stage_ms": {k_: round(v_ / ne * 1e3, 3) for k_, v_ in acc8.items()}}
+        except Exception as ex:
+            eight = {"error": repr(ex)[:200]}
+        fdet.set_tracker(trk)
     alive = sum(t.cols.n for t in trk.values()) if isinstance(trk, dict) else trk.cols.n
     stored = max(len(t.recorder.all_frame_index) for t in trk.values()) if isinstance(trk, dict) else len(trk.recorder.all_frame_index)
 
@@ -917,7 +929,7 @@ def end_to_end(name, dev, lib, local, ne=100):
             "frames": ne, "frames_per_pass": E2E_PER_PASS, "ms_per_frame": round(d4 / ne * 1e3, 3), "value": round(ne / d4, 3), "unit": "frames/s",
             "runs_ms_per_frame": all4, "stage_ms": stages(acc),
             "one_frame_lookahead": {"ms_per_frame": round(d1 / ne * 1e3, 3), "stage_ms": stages(acc1)},
-            "serial": {"ms_per_frame": round(d0 / ne * 1e3, 3), "stage_ms": stages(acc0)},
+            "serial": {"ms_per_frame": round(d0 / ne * 1e3, 3), "stage_ms": stages(acc0)}, "eight_frames_per_pass": eight,
             "tracks_alive": int(alive), "stored_frames": int(stored), "detections_tracked_last_frame": len(fdet.last_results)}
 
 
