@@ -208,3 +208,58 @@ def synth_lstm_state_dict(dataset="mot", seed=318):
     }
 
 
+
+
+# --------------------------------------------------------------------------
+# a heat map shaped like a TRAINED detector's (tests + bench.py's peaked gate stream)
+# --------------------------------------------------------------------------
+def peaked_head(sd, H, W, nblobs, seed=11, classes=1):
+    """A final feature map and hm-head weights that give a heat map like a trained CenterNet's: `nblobs` Gaussian bumps
+    with distinct amplitudes (peak logits spread over [-2, 6]) on the prior_bias = -4.6 background (base_model.py:91-92,
+    opts.py:151), plus low-level feature noise.  `classes` > 1: blob b belongs to class b % classes; class c reads its own
+    group of the 64 feature channels and of the 256 hidden channels, so every class map is a blob map of its own.
+    -> (feat [1,64,h,w], state_dict with the hm head replaced)."""
+    g = torch.Generator().manual_seed(seed)
+    h, w = H // 4, W // 4
+    rows = max(1, int((nblobs * h / w) ** 0.5))
+    cols = -(-nblobs // rows)
+    ch, cw = h // rows, w // cols
+    assert ch >= 8 and cw >= 8, "blobs too dense for this map"
+    amp = torch.linspace(2.6, 10.6, nblobs)[torch.randperm(nblobs, generator=g)]       # peak logit = -4.6 + amp
+    amp = amp + (torch.rand(nblobs, generator=g) - 0.5) * 0.02
+    yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    bump = torch.zeros(classes, h, w)
+    for b in range(nblobs):
+        r, c = divmod(b, cols)
+        cy = r * ch + 3 + int(torch.randint(0, ch - 6, (1,), generator=g))
+        cx = c * cw + 3 + int(torch.randint(0, cw - 6, (1,), generator=g))
+        sig = 1.2 + 0.6 * float(torch.rand(1, generator=g))
+        bump[b % classes] += amp[b] * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sig * sig))
+    sd2 = dict(sd)
+    if classes == 1:
+        v = torch.rand(64, generator=g) + 0.2
+        v = v / v.norm()
+        feat = (bump[0][None] * v[:, None, None] + 0.02 * torch.rand(64, h, w, generator=g)).unsqueeze(0)
+        u = torch.rand(256, generator=g) + 0.5
+        w0 = torch.randn(256, 64, 3, 3, generator=g) * 0.01
+        w0[:, :, 1, 1] += u[:, None] * v[None, :]                     # the centre tap reads the blob direction
+        w2 = (torch.rand(1, 256, 1, 1, generator=g) + 0.5)
+        w2 = w2 / float((w2.view(-1) * u).sum())                      # so that logit ~= -4.6 + bump
+    else:
+        fc, hc = 64 // classes, 256 // classes                       # feature / hidden channels per class
+        v = torch.zeros(classes, 64)
+        u = torch.zeros(classes, 256)
+        for c in range(classes):
+            vc = torch.rand(fc, generator=g) + 0.2
+            v[c, c * fc:(c + 1) * fc] = vc / vc.norm()
+            u[c, c * hc:(c + 1) * hc] = torch.rand(hc, generator=g) + 0.5
+        feat = (torch.einsum("chw,cf->fhw", bump, v) + 0.02 * torch.rand(64, h, w, generator=g)).unsqueeze(0)
+        w0 = torch.randn(256, 64, 3, 3, generator=g) * 0.01
+        w0[:, :, 1, 1] += torch.einsum("cj,cf->jf", u, v)
+        w2 = torch.zeros(classes, 256, 1, 1)
+        for c in range(classes):
+            wc = torch.rand(hc, generator=g) + 0.5
+            w2[c, c * hc:(c + 1) * hc, 0, 0] = wc / float((wc * u[c, c * hc:(c + 1) * hc]).sum())
+    sd2["hm.0.weight"], sd2["hm.0.bias"] = w0, torch.zeros(256)
+    sd2["hm.2.weight"], sd2["hm.2.bias"] = w2, torch.full((classes,), -4.6)
+    return feat, sd2

@@ -1101,37 +1101,9 @@ def compare_topk_with_oracle(plan, out, K, logit_tol=2e-4, tie=1e-4, details=Non
 
 
 def peaked_head(sd, H, W, nblobs, seed=11):
-    """A final feature map and hm-head weights that give a heat map like a trained CenterNet's: `nblobs` Gaussian bumps
-    with distinct amplitudes (peak logits spread over [-2, 6]) on the prior_bias = -4.6 background (base_model.py:91-92,
-    opts.py:151), plus low-level feature noise.  -> (feat [1,64,h,w], state_dict with the hm head replaced)."""
-    g = torch.Generator().manual_seed(seed)
-    h, w = H // 4, W // 4
-    rows = max(1, int((nblobs * h / w) ** 0.5))
-    cols = -(-nblobs // rows)
-    ch, cw = h // rows, w // cols
-    assert ch >= 8 and cw >= 8, "blobs too dense for this map"
-    amp = torch.linspace(2.6, 10.6, nblobs)[torch.randperm(nblobs, generator=g)]       # peak logit = -4.6 + amp
-    amp = amp + (torch.rand(nblobs, generator=g) - 0.5) * 0.02
-    yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
-    bump = torch.zeros(h, w)
-    for b in range(nblobs):
-        r, c = divmod(b, cols)
-        cy = r * ch + 3 + int(torch.randint(0, ch - 6, (1,), generator=g))
-        cx = c * cw + 3 + int(torch.randint(0, cw - 6, (1,), generator=g))
-        sig = 1.2 + 0.6 * float(torch.rand(1, generator=g))
-        bump += amp[b] * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sig * sig))
-    v = torch.rand(64, generator=g) + 0.2
-    v = v / v.norm()
-    feat = (bump[None] * v[:, None, None] + 0.02 * torch.rand(64, h, w, generator=g)).unsqueeze(0)
-    sd2 = dict(sd)
-    u = torch.rand(256, generator=g) + 0.5
-    w0 = torch.randn(256, 64, 3, 3, generator=g) * 0.01
-    w0[:, :, 1, 1] += u[:, None] * v[None, :]                     # the centre tap reads the blob direction
-    w2 = (torch.rand(1, 256, 1, 1, generator=g) + 0.5)
-    w2 = w2 / float((w2.view(-1) * u).sum())                      # so that logit ~= -4.6 + bump
-    sd2["hm.0.weight"], sd2["hm.0.bias"] = w0, torch.zeros(256)
-    sd2["hm.2.weight"], sd2["hm.2.bias"] = w2, torch.full((1,), -4.6)
-    return feat, sd2
+    """deft_amd.synth.peaked_head (shared with bench.py's peaked gate stream): a trained-shaped heat map."""
+    from deft_amd.synth import peaked_head as ph
+    return ph(sd, H, W, nblobs, seed)
 
 
 def check_peaked_heatmap(lib, device, H, W, K=100, nblobs=140, seed=11):

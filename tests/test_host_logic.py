@@ -131,3 +131,72 @@ def test_embed_group_cache_keeps_captured_entries():
     assert keys[0][2] == 1 and afe._egroups[keys[0]] is first
     assert len(keys) == engine.AfePlan.EGROUP_CACHE + 1
     assert [k[2] for k in keys[1:]] == list(range(2 + 2 * engine.AfePlan.EGROUP_CACHE, 2 + 3 * engine.AfePlan.EGROUP_CACHE))
+
+
+# ---- bench.py's parity gate: what "decidable" means, checked on the oracle's own decode (no GPU) ----
+def _decode(logit, K):
+    import deft_oracle as O
+    C, h, w = logit.shape
+    z = torch.zeros(1, 2, h, w)
+    od = O.generic_decode(O.sigmoid_output({"hm": logit[None].clone(), "reg": z, "wh": z}), K=K)
+    return (od["clses"][0].long() * h * w + od["inds"][0].long()).tolist()
+
+
+def test_gate_margin_guarantees_the_ordered_topk():
+    """bench.oracle_margin: every heat map within margin / 2 of the oracle's decodes to the same ordered (class, index) list; and a map further
+    away than that CAN decode differently, but then only inside bench.tie_class_ok's class."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    g = torch.Generator().manual_seed(0)
+    flips = 0
+    for t in range(24):
+        C = (1, 3, 10)[t % 3]
+        logit = torch.randn(C, 20, 28, generator=g) - 2
+        K = 15
+        m = bench.oracle_margin(logit, K)
+        ok = _decode(logit, K)
+        for r in range(4):
+            pert = logit + (torch.rand(logit.shape, generator=g) * 2 - 1) * (m / 2 * 0.999)
+            assert _decode(pert, K) == ok
+        e = 0.02                                             # a cross-implementation error far above the margin: lists differ, inside the tie class
+        pert = logit + (torch.rand(logit.shape, generator=g) * 2 - 1) * e
+        gk = _decode(pert, K)
+        flips += gk != ok
+        assert bench.tie_class_ok(logit, gk, ok, 2 * e)
+    assert flips >= 3                                        # (the class check was exercised on real differences)
+
+
+def test_gate_tie_class_rejects_a_wrong_list():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    g = torch.Generator().manual_seed(1)
+    logit = torch.randn(1, 20, 28, generator=g) - 2
+    K = 15
+    ok = _decode(logit, K)
+    assert bench.tie_class_ok(logit, ok, ok, 1e-6)
+    sw = list(ok); sw[0], sw[5] = sw[5], sw[0]               # two clearly different scores swapped
+    assert not bench.tie_class_ok(logit, sw, ok, 1e-4)
+    flat = logit.reshape(-1)
+    low = int(torch.argmin(flat))                            # a pixel that is nowhere near the top K
+    bad = list(ok); bad[-1] = low
+    assert not bench.tie_class_ok(logit, bad, ok, 1e-4)
+    assert not bench.tie_class_ok(logit, ok[:-1] + [ok[0]], ok, 1e-4)      # a repeated key
+
+
+def test_peaked_head_classes():
+    """deft_amd.synth.peaked_head with several classes: every class map is a blob map, the K best peaks are well separated (what bench.py's peaked
+    gate stream relies on)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    import deft_oracle as O
+    from deft_amd.synth import peaked_head
+    for ds, H, W in (("kitti_tracking", 96, 320), ("nuscenes", 112, 200), ("mot", 128, 160)):
+        C = O.HEADS[ds]["hm"]
+        feat, sd2 = peaked_head(O.synth_state_dict(ds), H * 2, W * 2, 60, seed=12, classes=C)
+        with torch.no_grad():
+            out = {"hm": O.head_forward(feat, sd2, "hm")}
+        assert out["hm"].shape[1] == C
+        assert bench.oracle_margin(out["hm"][0], 40) >= 1e-3
