@@ -471,7 +471,8 @@ def parity_gate(cfg, wl, frames=None, tol=1e-3, outs=None, first=0, lib=None, de
     dec, dec_rep = [], None
     images2, placed = decidable_inputs(cfg, wl, first) if frames is None and decidable else (None, {})
     if images2 is not None:
-        outs2 = wl["step"](images2)                                     # (a collective step: the other ranks run it in gate_follow)
+        wl["step"](images2)                                             # twice: frame 0's history is the PREVIOUS step's last frames (the ring is in
+        outs2 = wl["step"](images2)                                     # steady state on these inputs, as the raw stream's is on the timed ones)
         torch.cuda.synchronize()
         dec = [look("decidable", images2, outs2, f) for f in sorted(placed)]
         for r in dec:

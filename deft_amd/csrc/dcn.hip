@@ -22,6 +22,8 @@
 // Sampling rule (upstream dmcn_im2col_bilinear / modulated_deformable_im2col_gpu_kernel, restated in oracle/dcn_scalar.py):
 //   h_im = oy - 1 + r + dy, w_im likewise; zero outside (-1, H) x (-1, W); four-corner bilinear with every corner outside the map
 //   dropped; the value times sigmoid(mask).
+#include <cstdlib>
+
 #include "common.h"
 
 typedef deft_f32x16 f32x16;
@@ -87,6 +89,50 @@ __device__ __forceinline__ unsigned dcnp_cvt_pk(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     const bf16x2 p = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, p);
+}
+
+// Sampling record of (output pixel (oy, ox), tap): the four corner weights x sigmoid(mask) x DEFT_ASCALE and the corner address.  Near (all four
+// corners inside the patch of margin R): c = LDS byte address, inside patch buffer 0, of the lane's first 16 bytes (plane 2 g) of the BASE pixel b;
+// the corners are b, b + 1, b + PW, b + PW + 1 with the weights w1..w4 (a corner clamped at the map border is folded away: the base moves one
+// pixel / line back and the weight of the dropped corner -- zero -- takes its place), so every corner read is `c + immediate`.  Far: c = bit 31 |
+// global pixel of the clamped top-left corner << 2 | bit 0: the right-hand corners are one pixel on | bit 1: the lower corners one line on; weights
+// in corner order.  (Branch-free: selects instead of nested ifs -- the nine records are 1/7 of the kernel's time at Cin = 64.)
+template <int DP_R>
+__device__ __forceinline__ void dcnp_record(const DeftGemmDesc& p, const f32x4 (&om)[7], const int tap, const int oy, const int ox, const bool rowok, const int img,
+                                    const int py0, const int px0, const int g, float& w1, float& w2, float& w3, float& w4, unsigned& c) {
+    constexpr int DP_PH = DP_PH_(DP_R), DP_PW = DP_PW_(DP_R), DP_PLANE = DP_PLANE_(DP_R);
+    // (branch-free: selects instead of nested ifs -- the nine records are 1/7 of the kernel's time at Cin = 64)
+    const float dy = om[(2 * tap) >> 2][(2 * tap) & 3], dx = om[(2 * tap + 1) >> 2][(2 * tap + 1) & 3];
+    const float ml = om[(18 + tap) >> 2][(18 + tap) & 3];
+    const int r = tap / 3, s = tap - 3 * r;
+    const float h_raw = (float)(oy - 1 + r) + dy, w_raw = (float)(ox - 1 + s) + dx;
+    const bool inside = rowok && h_raw > -1.f && w_raw > -1.f && h_raw < (float)p.H && w_raw < (float)p.W;
+    const float h_im = inside ? h_raw : 0.f, w_im = inside ? w_raw : 0.f;
+    const float hl = floorf(h_im), wl = floorf(w_im);
+    const float lh = h_im - hl, lw = w_im - wl;
+    const float hh = 1.f - lh, hw_ = 1.f - lw;
+    const int h_low = (int)hl, w_low = (int)wl;
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float mask = inside ? DEFT_FAST_RCP(1.f + expf(-ml)) * DEFT_ASCALE : 0.f;     // (the operand scale of the split rides on the corner weights: exact, a power of two)
+    const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
+    w1 = (t_ok && l_ok) ? hh * hw_ * mask : 0.f;
+    w2 = (t_ok && r_ok) ? hh * lw * mask : 0.f;
+    w3 = (b_ok && l_ok) ? lh * hw_ * mask : 0.f;
+    w4 = (b_ok && r_ok) ? lh * lw * mask : 0.f;
+    // h_low in [-1, H-1], w_low in [-1, W-1]: clamp the four corners into the map (a clamped corner has weight 0)
+    const int hl_c = h_low < 0 ? 0 : h_low, wl_c = w_low < 0 ? 0 : w_low;
+    const int hh_c = h_high > p.H - 1 ? p.H - 1 : h_high, wh_c = w_high > p.W - 1 ? p.W - 1 : w_high;
+    const int fr = wh_c - wl_c, fd = hh_c - hl_c;
+    const int bpy = hl_c - (1 - fd) - py0, bpx = wl_c - (1 - fr) - px0;          // base pixel of the near form
+    const bool near = !inside || (bpy >= 0 && bpy + 1 < DP_PH && bpx >= 0 && bpx + 1 < DP_PW);
+    if (near) {          // (weights only: selects)
+        if (!fr) { w2 += w1; w1 = 0.f; w4 += w3; w3 = 0.f; }                   // (one of each pair is zero)
+        if (!fd) { w3 += w1; w1 = 0.f; w4 += w2; w2 = 0.f; }
+    }
+    // (an unused record reads patch pixels 0, 1, PW, PW + 1 with weight 0)
+    const unsigned c_near = (unsigned)(g * 2 * DP_PLANE) + (inside ? (unsigned)((bpy * DP_PW + bpx) * 16) : 0u);
+    const unsigned c_far = 0x80000000u | (unsigned)((img + hl_c * p.W + wl_c) << 2) | (unsigned)(fr | (fd << 1));
+    c = near ? c_near : c_far;
 }
 
 // DEFORM = false: the same structure as a PLAIN 3x3 / stride 1 / pad 1 convolution on an fp32 input (the DCN's own conv_offset_mask layer,
@@ -226,38 +272,9 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
                 rc[tap] = (unsigned)(g * 2 * DP_PLANE) + (unsigned)((((oy - ty0) + r) * DP_PW + (ox - tx0) + s) * 16);
                 continue;
             }
-            // (branch-free: selects instead of nested ifs -- the nine records are 1/7 of the kernel's time at Cin = 64)
-            const float dy = om[(2 * tap) >> 2][(2 * tap) & 3], dx = om[(2 * tap + 1) >> 2][(2 * tap + 1) & 3];
-            const float ml = om[(18 + tap) >> 2][(18 + tap) & 3];
-            const int r = tap / 3, s = tap - 3 * r;
-            const float h_raw = (float)(oy - 1 + r) + dy, w_raw = (float)(ox - 1 + s) + dx;
-            const bool inside = rowok && h_raw > -1.f && w_raw > -1.f && h_raw < (float)p.H && w_raw < (float)p.W;
-            const float h_im = inside ? h_raw : 0.f, w_im = inside ? w_raw : 0.f;
-            const float hl = floorf(h_im), wl = floorf(w_im);
-            const float lh = h_im - hl, lw = w_im - wl;
-            const float hh = 1.f - lh, hw_ = 1.f - lw;
-            const int h_low = (int)hl, w_low = (int)wl;
-            const int h_high = h_low + 1, w_high = w_low + 1;
-            const float mask = inside ? DEFT_FAST_RCP(1.f + expf(-ml)) * DEFT_ASCALE : 0.f;     // (the operand scale of the split rides on the corner weights: exact, a power of two)
-            const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
-            float w1 = (t_ok && l_ok) ? hh * hw_ * mask : 0.f;
-            float w2 = (t_ok && r_ok) ? hh * lw * mask : 0.f;
-            float w3 = (b_ok && l_ok) ? lh * hw_ * mask : 0.f;
-            float w4 = (b_ok && r_ok) ? lh * lw * mask : 0.f;
-            // h_low in [-1, H-1], w_low in [-1, W-1]: clamp the four corners into the map (a clamped corner has weight 0)
-            const int hl_c = h_low < 0 ? 0 : h_low, wl_c = w_low < 0 ? 0 : w_low;
-            const int hh_c = h_high > p.H - 1 ? p.H - 1 : h_high, wh_c = w_high > p.W - 1 ? p.W - 1 : w_high;
-            const int fr = wh_c - wl_c, fd = hh_c - hl_c;
-            const int bpy = hl_c - (1 - fd) - py0, bpx = wl_c - (1 - fr) - px0;          // base pixel of the near form
-            const bool near = !inside || (bpy >= 0 && bpy + 1 < DP_PH && bpx >= 0 && bpx + 1 < DP_PW);
-            if (near) {          // (weights only: selects)
-                if (!fr) { w2 += w1; w1 = 0.f; w4 += w3; w3 = 0.f; }                   // (one of each pair is zero)
-                if (!fd) { w3 += w1; w1 = 0.f; w4 += w2; w2 = 0.f; }
-            }
-            // (an unused record reads patch pixels 0, 1, PW, PW + 1 with weight 0)
-            const unsigned c_near = (unsigned)(g * 2 * DP_PLANE) + (inside ? (unsigned)((bpy * DP_PW + bpx) * 16) : 0u);
-            const unsigned c_far = 0x80000000u | (unsigned)((img + hl_c * p.W + wl_c) << 2) | (unsigned)(fr | (fd << 1));
-            const unsigned c = near ? c_near : c_far;
+            float w1, w2, w3, w4;
+            unsigned c;
+            dcnp_record<DP_R>(p, om, tap, oy, ox, rowok, img, py0, px0, g, w1, w2, w3, w4, c);
             rw0[tap] = w1; rw1[tap] = w2; rw2[tap] = w3; rw3[tap] = w4;
             rc[tap] = c;
         }
@@ -442,6 +459,331 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
     });
 }
 
+// ---- Producer / consumer form of the 64-column tile (round 6; two fp16 pieces only) --------------------------------------------------------
+// What the counters of dcn_patch_kernel<2, 3, true> say (profiles/r6_dcn_counters.md: matrix pipe 0.20 busy, VALU ~0.4, LDS array 0.31, every wave
+// 36 % of its life issuing, two waves per SIMD): nothing is saturated -- one in-order wave does gather -> blend -> split -> MFMA -> weight DMA ->
+// fragment reads in sequence, and two such waves per SIMD do not cover each other's latencies.  Here the SAME work of a workgroup (8 x 16 pixels,
+// 64 columns, the same patch / weight images, the same arithmetic in the same order: bit-identical results) is split over EIGHT waves:
+//   producers (waves 4-7): hold the nine sampling records of their lane's row, gather the corners of the NEXT chunk from the LDS patch (far
+//     samples: global loads), blend, split into the two fp16 pieces and WRITE their A fragment -- 16 B per piece and lane -- into an LDS stage,
+//     in the lane-linear layout [piece][k group][row] the matrix instruction reads it in (conflict-free for both sides);
+//   consumers (waves 0-3): issue every LDS-DMA of the workgroup (weights three chunks ahead, the next block's patch), read the A fragment of
+//     their 32 rows (two ds_read_b128) and the B fragments, and run the six MFMAs of the chunk -- nothing else.
+// One workgroup barrier per chunk hands stage (kc & 1) over: the producers write A(kc + 1) while the consumers multiply A(kc).  Both roles fit
+// 128 VGPRs, so a CU holds two workgroups = FOUR waves per SIMD (one producer and one consumer of each): four instruction streams of different
+// kinds (VALU / LDS on one side, MFMA / DMA on the other) instead of two identical ones.  LDS: 2 x 24 KB patch + 3 x 4 KB weights + 2 x 8 KB
+// A = 76 KB.
+#if DEFT_PIECES == 2
+#ifndef DCNPC_R
+#define DCNPC_R 3
+#endif
+#define DPC_ABLK (DEFT_NP * 2 * 128 * 16)              // one A stage: [piece][k group][128 rows][8 halves]
+// Measurement builds only (tools/build_variant.sh ... -DDCNPC_ABL=<bits>; WRONG RESULTS by construction): what each part of a step costs.
+// 1 no far path | 2 no corner reads | 4 no blend + split | 8 no A write | 16 no MFMAs | 32 no DMA in the loop | 64 no A read
+#ifndef DCNPC_ABL
+#define DCNPC_ABL 0
+#endif
+// Scheduling pins of the producer step (no instruction is emitted).  DCNPC_PIN(b): the four blended values exist HERE and no memory operation moves
+// across this point -- the next chunk's corner reads go into the registers the blend has just released (hoisted above it they would need 16 more
+// registers per half: spills at 128).  DCNPC_ARRIVED(v): the four corner vectors are consumed no earlier than HERE -- without it the compiler
+// software-pipelines the blend of a chunk ABOVE the barrier of the step that issued its reads, with a vmcnt(0) wait for the far lanes' global loads
+// (a full L2 round trip) in front of every barrier.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DCNPC_PIN(b)                                                     \
+    do {                                                                 \
+        asm volatile("" : "+v"(b));                                      \
+        asm volatile("" ::: "memory");                                   \
+    } while (0)
+#define DCNPC_ARRIVED(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]))
+#else
+#define DCNPC_PIN(b) ((void)(b))
+#define DCNPC_ARRIVED(v) ((void)(v))
+#endif
+
+template <int DP_R>
+constexpr int dcnpc_lds_bytes() {
+    constexpr int loop = 2 * DP_PBUF_(DP_R) + 3 * DP_WBLK + 2 * DPC_ABLK;
+    constexpr int tile = 128 * (64 + 4) * 4;
+    return loop > tile ? loop : tile;
+}
+
+template <int DP_R>
+__global__ __launch_bounds__(512, 4) void dcn_pc_kernel(DeftGemmDesc p, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int DP_PW = DP_PW_(DP_R), DP_NPIX = DP_NPIX_(DP_R), DP_PARTS = DP_PARTS_(DP_R), DP_PLANE = DP_PLANE_(DP_R), DP_PBUF = DP_PBUF_(DP_R);
+    constexpr int TN = 2, BN = 64;
+    constexpr int NBP = DEFT_NP * 2;                   // weight DMA pieces (1 KB) per chunk: one per consumer wave
+    constexpr int BSTAGE = DP_WBLK;
+    static_assert(NBP == 4, "one weight piece per consumer wave and chunk");
+    constexpr int PT = 6;                              // the next block's patch pieces go out during taps 0 .. PT - 1 (a piece has two steps to land;
+                                                       // the producers read the block's first chunk during tap PT + 1 of the block before)
+    static_assert(DP_PARTS <= PT, "at most one patch piece per consumer wave and step");
+
+    DEFT_DYN_LDS(char, smem);
+    char* const patch = smem;                          // [2 buffers][4 planes][DP_PARTS * 64 pixels][16 B]
+    char* const Bd = smem + 2 * DP_PBUF;               // [3 stages][BSTAGE]
+    char* const Ad = Bd + 3 * BSTAGE;                  // [2 stages][DPC_ABLK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w4 = wave & 3;                           // the 32 rows (two tile rows) this wave produces / consumes
+    const bool producer = wave >= 4;
+    const int g = lane >> 5;
+
+    int bid = blockIdx.x;                              // XCD-aware, bijective workgroup remap (as dcn_patch_kernel)
+    {
+        const int nwg = p.N * tiles_x * tiles_y * ntiles;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = bid % ntiles;
+    int t = bid / ntiles;
+    const int tpi = tiles_x * tiles_y;
+    const int n = t / tpi;
+    t -= n * tpi;
+    const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    const int ty0 = tyi * DP_TH, tx0 = txi * DP_TW, n0 = nt * BN;
+    const int py0 = ty0 - 1 - DP_R, px0 = tx0 - 1 - DP_R;
+    const int img = n * p.H * p.W;
+    const int ncb = p.Cin >> 4, nchunks = ncb * 9;
+    const int arow = ((g * 128) + w4 * 32 + (lane & 31)) * 16;      // this lane's 16 bytes inside a piece of an A stage (+ piece * 4096)
+
+    f32x16 acc[1][TN];
+
+    if (producer) {
+        // ================================================= producers =================================================
+        int trow, tx;
+        dcnp_row_to_pixel(lane & 31, trow, tx);
+        const int oy = ty0 + 2 * w4 + trow, ox = tx0 + tx;
+        const bool rowok = oy < p.H && ox < p.W;
+        f32x4 om[7];
+        {
+            const float* omp = p.x2 + (size_t)(rowok ? img + oy * p.W + ox : 0) * p.ldom;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) om[q] = *(const f32x4*)(omp + 4 * q);
+        }
+        const deft_rsrc_t rx = deft_make_rsrc(p.x);
+        float rw0[9], rw1[9], rw2[9], rw3[9];
+        unsigned rc[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) dcnp_record<DP_R>(p, om, tap, oy, ox, rowok, img, py0, px0, g, rw0[tap], rw1[tap], rw2[tap], rw3[tap], rc[tap]);
+        const unsigned far_x = (unsigned)p.ldx * 4u, far_y = (unsigned)(p.W * p.ldx) * 4u;
+
+        // corner values of one (row, tap, 16-channel block), HALF h of the lane's 8 channels (plane 2 g + h): v[corner].  Every lane reads the patch
+        // (a far lane some valid address); the far lanes then load their corners from global memory into the same registers (see dcn_patch_kernel).
+        auto gather_half = [&](unsigned c, int bufoff, int cb, int h, f32x4 (&v)[4]) {
+            const bool far = !(DCNPC_ABL & 1) && (c & 0x80000000u) != 0u;
+            if (!(DCNPC_ABL & 2)) {
+                const char* const a = patch + bufoff + h * DP_PLANE + (((c & 0x80000000u) != 0u) ? (unsigned)(g * 2 * DP_PLANE) : c);
+                v[0] = *(const f32x4*)(a);
+                v[1] = *(const f32x4*)(a + 16);
+                v[2] = *(const f32x4*)(a + DP_PW * 16);
+                v[3] = *(const f32x4*)(a + DP_PW * 16 + 16);
+            }
+            if (far) {
+                const unsigned o1 = ((c & 0x7fffffffu) >> 2) * far_x + (unsigned)(cb * 64 + g * 32 + h * 16);
+                const unsigned o2 = o1 + ((c & 1u) ? far_x : 0u);
+                const unsigned dyb = (c & 2u) ? far_y : 0u;
+                v[0] = deft_buffer_load_x4(rx, o1);
+                v[1] = deft_buffer_load_x4(rx, o2);
+                v[2] = deft_buffer_load_x4(rx, o1 + dyb);
+                v[3] = deft_buffer_load_x4(rx, o2 + dyb);
+            }
+        };
+        auto blend_half = [&](const f32x4 (&v)[4], float w0, float w1, float w2, float w3) -> f32x4 {
+            f32x4 b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = fmaf(w3, v[3][e], fmaf(w2, v[2][e], fmaf(w1, v[1][e], w0 * v[0][e])));
+            return b;
+        };
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        f32x4 va[4], vb[4];                            // the chunk in flight: corners of half 0 / half 1
+        // blend + split the chunk in (va, vb) with the weights of `tap`, write it to A stage `stage`; as soon as a half is blended its registers
+        // take the corner reads of the chunk after (tap `gtap` of block `gcb`, patch buffer offset `gbuf`), if there is one
+        auto produce = [&](int tap, int stage, bool more, int gtap, int gbuf, int gcb) {
+            // (the blend of a half is FINISHED before its registers are handed to the next chunk's reads: the scheduler would otherwise hoist the
+            // reads above the blend -- 16 more live registers per half, spills at the 128 the four-waves-per-SIMD occupancy allows)
+            DCNPC_ARRIVED(va);
+            f32x4 b0 = (DCNPC_ABL & 4) ? va[0] : blend_half(va, rw0[tap], rw1[tap], rw2[tap], rw3[tap]);
+            DCNPC_PIN(b0);
+            if (more) gather_half(rc[gtap], gbuf, gcb, 0, va);
+            DCNPC_ARRIVED(vb);
+            f32x4 b1 = (DCNPC_ABL & 4) ? vb[0] : blend_half(vb, rw0[tap], rw1[tap], rw2[tap], rw3[tap]);
+            DCNPC_PIN(b1);
+            if (more) gather_half(rc[gtap], gbuf, gcb, 1, vb);
+            unsigned h0, h1, h2, h3, m0, m1, m2, m3;
+            if (DCNPC_ABL & 4) {
+                h0 = __float_as_uint(b0[0]); h1 = __float_as_uint(b0[1]); h2 = __float_as_uint(b0[2]); h3 = __float_as_uint(b0[3]);
+                m0 = __float_as_uint(b1[0]); m1 = __float_as_uint(b1[1]); m2 = __float_as_uint(b1[2]); m3 = __float_as_uint(b1[3]);
+            } else {
+                deft_split2_pair(b0[0], b0[1], h0, m0);
+                deft_split2_pair(b0[2], b0[3], h1, m1);
+                deft_split2_pair(b1[0], b1[1], h2, m2);
+                deft_split2_pair(b1[2], b1[3], h3, m3);
+            }
+            char* const ap = Ad + stage * DPC_ABLK + arow;
+            if (!(DCNPC_ABL & 8)) {
+                *(u32x4*)(ap) = u32x4{h0, h1, h2, h3};
+                *(u32x4*)(ap + 4096) = u32x4{m0, m1, m2, m3};
+            } else {
+                asm volatile("" :: "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(m0), "v"(m1), "v"(m2), "v"(m3));
+            }
+        };
+
+        DEFT_PIPE_BARRIER_ONLY();                      // P0: the first patch has landed (the consumers waited for it)
+        gather_half(rc[0], 0, 0, 0, va);
+        gather_half(rc[0], 0, 0, 1, vb);
+        produce(0, 0, true, 1, 0, 0);                  // A(0) -> stage 0; corner reads of chunk 1 (it exists: Cin >= 32)
+        for (int cb2 = 0; cb2 < ncb; cb2 += 2) {
+            const bool lastpair = cb2 + 2 >= ncb;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int cb = cb2 + half;
+                    const bool last_blk = half == 1 && lastpair;
+                    const int ntap = (tap + 1) % 9;                                  // chunk kc + 1: blended and written in this step
+                    const int gtap = (tap + 2) % 9, gblk = (tap + 2) / 9;          // chunk kc + 2: its corner reads are issued in this step
+                    const bool more = !(tap == 8 && last_blk);                       // is there a chunk kc + 1?
+                    const bool moreg = !(tap + 2 >= 9 && last_blk);                  // ... a chunk kc + 2?
+                    DEFT_PIPE_BARRIER_ONLY();          // barrier kc: A(kc) is in its stage (this wave's writes have been acknowledged: lgkmcnt(0))
+                    if (more) produce(ntap, (half * 9 + tap + 1) & 1, moreg, gtap, ((half + gblk) & 1) * DP_PBUF, cb + gblk);
+                }
+            }
+        }
+    } else {
+        // ================================================= consumers =================================================
+        const deft_rsrc_t rx = deft_make_rsrc(p.x);
+        const deft_rsrc_t rw = deft_make_rsrc(p.w3);
+        unsigned pv[DP_PARTS];                         // patch DMA sources: lane l deposits channel group `w4` of patch pixel 64 part + l
+#pragma unroll
+        for (int i = 0; i < DP_PARTS; ++i) {
+            const int pp = i * 64 + lane;
+            const int py = pp / DP_PW, px = pp - py * DP_PW;
+            const int gy = py0 + py, gx = px0 + px;
+            const bool ok = pp < DP_NPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            pv[i] = ok ? (unsigned)((img + gy * p.W + gx) * p.ldx * 4) : DEFT_OOB;
+        }
+        const unsigned vB = (unsigned)((n0 >> 6) * nchunks * DP_WBLK + lane * 16);
+        auto issue_b = [&](int kc, int st) {           // weight piece w4 (of NBP = 4) of chunk kc into stage st
+            deft_buffer_load_lds_x4s(rw, Bd + st * BSTAGE + w4 * 1024, vB, (unsigned)kc * (unsigned)DP_WBLK + (unsigned)w4 * 1024u);
+        };
+        auto issue_patch = [&](int cb, int buf, int part) {      // plane w4 of block cb
+            deft_buffer_load_lds_x4s(rx, patch + buf * DP_PBUF + w4 * DP_PLANE + part * 1024, pv[part], (unsigned)(cb * 64 + w4 * 16));
+        };
+        auto wait_vm = [&](int n_) {
+            switch (n_) {
+                case 0: DEFT_WAIT_VM(0); break;
+                case 1: DEFT_WAIT_VM(1); break;
+                default: DEFT_WAIT_VM(2); break;
+            }
+        };
+        auto np_of = [](int tap) { return (tap < PT ? (DP_PARTS * (tap + 1) / PT) - (DP_PARTS * tap / PT) : 0); };      // patch pieces issued at this tap
+        issue_b(0, 0);
+        if (nchunks > 1) issue_b(1, 1);
+        if (nchunks > 2) issue_b(2, 2);
+#pragma unroll
+        for (int i = 0; i < DP_PARTS; ++i) issue_patch(0, 0, i);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+        const int brow = (lane & 31) * 16 + g * 1024;
+        pcx8 pb[2][TN][DEFT_NP];
+        auto read_b = [&](int st, pcx8 (&o)[TN][DEFT_NP]) {
+            const char* const bs = Bd + st * BSTAGE + brow;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < DEFT_NP; ++q) o[j][q] = *(const pcx8*)(bs + (j & 1) * 512 + q * 2048);
+        };
+        DEFT_WAIT_VM(0);
+        DEFT_PIPE_BARRIER_ONLY();                      // P0: patch 0 and the first three weight chunks are in LDS
+        read_b(0, pb[0]);
+        for (int cb2 = 0; cb2 < ncb; cb2 += 2) {
+            const bool lastpair = cb2 + 2 >= ncb;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int cb = cb2 + half, kc = cb * 9 + tap;
+                    const int st = tap % 3;                                // = kc % 3
+                    const int cur = (half * 9 + tap) & 1;                  // = kc & 1: the A stage and the B register set of this step
+                    const bool last_blk = half == 1 && lastpair;
+                    const bool more = !(tap == 8 && last_blk);
+                    // ---- wait + barrier kc: what this wave issued up to two steps ago has landed (the pieces of ONE step ago may still fly) ----
+                    {
+                        const int pt = tap == 0 ? 8 : tap - 1;             // the previous step's tap; it is in the last block iff this one is and tap > 0
+                        if (tap > 0 && last_blk) wait_vm(pt < 6 ? 1 : 0);
+                        else wait_vm(1 + np_of(pt));
+                        DEFT_PIPE_BARRIER_ONLY();
+                    }
+                    pcx8 pa[DEFT_NP];
+                    if (!(DCNPC_ABL & 64) || kc == 0) {
+                        const char* const ap = Ad + cur * DPC_ABLK + arow;
+#pragma unroll
+                        for (int q = 0; q < DEFT_NP; ++q) pa[q] = *(const pcx8*)(ap + q * 4096);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < DEFT_NP; ++q) pa[q] = pb[cur][0][q];
+                    }
+                    // weights three chunks ahead into the stage whose fragments every consumer read one step ago; the next block's patch
+                    if (!(DCNPC_ABL & 32) && (tap < 6 || !last_blk)) issue_b(kc + 3, st);
+                    if (!(DCNPC_ABL & 32) && !last_blk) {
+#pragma unroll
+                        for (int i = DP_PARTS * tap / PT; i < (tap < PT ? DP_PARTS * (tap + 1) / PT : 0); ++i) issue_patch(cb + 1, half ^ 1, i);
+                    }
+                    if (more) read_b((tap + 1) % 3, pb[cur ^ 1]);
+#pragma unroll
+                    for (int q = 0; q < ((DCNPC_ABL & 16) ? 1 : DEFT_NPROD); ++q) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[0][j] = deft_mfma_pc(pa[deft_qa(q)], pb[cur][j][deft_qb(q)], acc[0][j]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                                   // E0: nobody reads the stages any more, no DMA in flight
+
+    // ---- epilogue through LDS (common.h): the consumers park their accumulators, all eight waves store ----
+    float* const T = (float*)smem;
+    if (!producer) deft_epilogue_stage<1, TN>(T, BN + 4, acc, w4, 0, lane, p, n0);
+    DEFT_PIPE_BARRIER_ONLY();
+    deft_epilogue_rows<128, BN, 512>(T, p, n0, tid, [&](int R) -> long long {
+        int tr, txx;
+        dcnp_row_to_pixel(R & 31, tr, txx);
+        const int y = ty0 + 2 * (R >> 5) + tr, x = tx0 + txx;
+        return (y < p.H && x < p.W) ? (long long)(img + y * p.W + x) : -1;
+    });
+}
+
+template <int R>
+static int launch_dcnpc(const DeftGemmDesc& d, hipStream_t s) {
+    constexpr int lds = dcnpc_lds_bytes<R>();
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)dcn_pc_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        DEFT_CHECK(e == hipSuccess, -101, "dcn_pc: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
+        done = true;
+    }
+    const int tiles_x = deft_cdiv(d.W, DP_TW), tiles_y = deft_cdiv(d.H, DP_TH), ntiles = deft_cdiv(d.Cout, 64);
+    const long long nwg = (long long)d.N * tiles_x * tiles_y * ntiles;
+    DEFT_CHECK(nwg < (1ll << 31), -71, "deft_dcn_v2_nhwc: too many tiles");
+    hipLaunchKernelGGL((dcn_pc_kernel<R>), dim3((unsigned)nwg), dim3(512), lds, s, d, tiles_x, tiles_y, ntiles);
+    DEFT_CHECK_LAUNCH("dcn_pc");
+    return 0;
+}
+
+// Which form the 64-column tiles run on when the descriptor leaves it open (tile bits 26 / 27): the one-role kernel unless DEFT_DCN_PC=1 --
+// measured on MI355X (profiles/r6_dcn_producer_consumer.md) the producer / consumer form is 6 - 12 % SLOWER on the bench's layer shapes.
+static bool dcnpc_enabled() {
+    static const bool on = [] { const char* e = getenv("DEFT_DCN_PC"); return e && e[0] == '1'; }();
+    return on;
+}
+#endif
+
 template <int TN, int R, bool DEFORM = true>
 static int launch_dcnp(const DeftGemmDesc& d, hipStream_t s) {
     constexpr int lds = dcnp_lds_bytes<TN, R>();
@@ -473,6 +815,9 @@ int deft_dcnp_dispatch(const DeftGemmDesc* d, hipStream_t s) {
     DEFT_CHECK(bn == 64 || bn == 128, -75, "deft_dcn_v2_nhwc: the patch form has 64- and 128-column tiles (tile & 0xffff = %d)", bn);
     // (the weight image has ceil(Cout / 128) * 128 rows: no n-tile reaches past it)
     // margin: as many pixels as still leave two workgroups per CU (DCNP_R2 / DCNP_R4; MI355X A/B of round 5: profiles/r5_dcn_margin_ab.log)
+#if DEFT_PIECES == 2
+    if (bn == 64 && !(d->tile & (1 << 27)) && ((d->tile & (1 << 26)) || dcnpc_enabled())) return launch_dcnpc<DCNPC_R>(*d, s);      // producer / consumer waves (round 6)
+#endif
     return bn == 128 ? launch_dcnp<4, DCNP_R4>(*d, s) : launch_dcnp<2, DCNP_R2>(*d, s);
 }
 

@@ -45,7 +45,9 @@ typedef struct DeftGemmDesc {
                                      Pre-split kernels (x3): bit 29 = 3 LDS stages, bit 30 = ONE stage;
                                      halo form: (TH<<16)|BN, bit 28 = tiles are 16 pixels wide (TH x 16),
                                      bit 29 = one tap per weight stage.  deft_dcn_v2_nhwc, patch form (p3_kernel = 2):
-                                     64 / 128 = output channels per workgroup */
+                                     64 / 128 = output channels per workgroup; bit 26 puts a 64-column launch on the
+                                     producer / consumer form (dcn_pc_kernel), bit 27 on the one-role kernel (dcn_patch_kernel)
+                                     -- same bits either way; neither: the library's choice (env DEFT_DCN_PC) */
     /* pair, batched form (Tper > 0): rows are (c, t, j) with c = m / (Tper*Q) the current
      * frame, t its history row, j its object; U' row = u0 + c*du + t, V' row = v0 + c*dv + j.
      * Tper == 0: rows are (t, j), U' row = t, V' row = j.                                   */

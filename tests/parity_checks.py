@@ -214,7 +214,7 @@ def _deform_tiled(plan, p, xv, tile):
     d = plan._gemms[-1][2]          # the dcn descriptor
     d.tile, d.splitk = tile, 0
     if d.p3_kernel == 2:
-        assert (tile >> 16) == 0 and (tile & 0xffff) in (64, 128), "patch form: tile = output channels per workgroup"
+        assert (tile >> 16) in (0, 1 << 10, 1 << 11) and (tile & 0xffff) in (64, 128), "patch form: tile = output channels per workgroup (| 1 << 26 / 27: kernel form)"
         return out
     if engine.SPLITK:
         plan._plan_splitk("deft_dcn_v2_nhwc", d)     # the split factor and workspace follow the tile
@@ -249,6 +249,37 @@ def check_dcn_golden(lib, device, name, patch):
     err = maxabs(out.to_nchw(), y)
     assert err <= 2e-5 * max(1.0, float(y.abs().max())), ("dcn golden", name, patch, err)
     return err
+
+
+def check_dcn_pc_identical(lib, device, N, H, W, Ci, Co=64, seed=0, big_offsets=False):
+    """The producer / consumer form of the 64-column DCN tile (dcn_pc_kernel, round 6) against the one-role kernel it replaces
+    (dcn_patch_kernel<2>, DeftGemmDesc.tile bit 27): the same patch, records, blend, split and product order -- the SAME BITS."""
+    saved = engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW
+    engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW = True, 0, 1e9, 0
+    try:
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(N, Ci, H, W, generator=g)
+        sd = {"d.conv.weight": torch.randn(Co, Ci, 3, 3, generator=g) * (1.0 / (Ci * 9) ** 0.5), "d.conv.bias": torch.randn(Co, generator=g) * 0.1,
+              "d.conv.conv_offset_mask.weight": torch.randn(27, Ci, 3, 3, generator=g) * ((2.0 if big_offsets else 0.5) / (Ci * 9) ** 0.5),
+              "d.conv.conv_offset_mask.bias": torch.randn(27, generator=g) * (3.0 if big_offsets else 0.5), "d.actf.0.weight": torch.rand(Co, generator=g) + 0.5,
+              "d.actf.0.bias": torch.randn(Co, generator=g) * 0.2, "d.actf.0.running_mean": torch.randn(Co, generator=g) * 0.2,
+              "d.actf.0.running_var": torch.rand(Co, generator=g) + 0.5}
+        outs = []
+        for tile in (64 | (1 << 26), 64 | (1 << 27)):
+            plan = engine.DlaSegPlan.__new__(engine.DlaSegPlan)
+            engine._Plan.__init__(plan, device, lib)
+            plan.sd = sd; plan._wcache = {}
+            xv = plan.alloc(N, H, W, Ci)
+            fill_view(xv, x)
+            out = _deform_tiled(plan, "d", xv, tile)
+            assert plan._gemms[-1][2].p3_kernel == 2
+            plan.run()
+            outs.append(out.to_nchw().cpu().clone())
+        assert torch.equal(outs[0], outs[1]), ("dcn producer/consumer vs one-role kernel", float((outs[0] - outs[1]).abs().max()))
+        ref = O.deform_conv(x, sd, "d")
+        assert maxabs(outs[0], ref) <= 5e-5 * max(1.0, float(ref.abs().max()))
+    finally:
+        engine.DCN_PATCH, engine.DCN_PATCH_MIN_TILES, engine.DCN_PATCH_WASTE, engine.OFFSET_FP32_MIN_HW = saved
 
 
 def check_dcn_patch_batch_invariance(lib, device, H, W, Ci, Co, N=4, reps=3, seed=0):

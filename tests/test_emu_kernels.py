@@ -68,6 +68,13 @@ def test_dcn_golden_vectors(emu_lib, name, patch):
     pc.check_dcn_golden(emu_lib, "cpu", name, patch)
 
 
+@pytest.mark.parametrize("args", [(1, 7, 9, 64), (2, 9, 19, 32), (1, 17, 35, 128)])
+def test_dcn_producer_consumer_identical(emu_lib, args):
+    """dcn_pc_kernel (8 waves: producers gather + blend + split into LDS, consumers multiply) == dcn_patch_kernel<2>, bit for bit."""
+    for big in (False, True):
+        pc.check_dcn_pc_identical(emu_lib, "cpu", *args, big_offsets=big, seed=5)
+
+
 def test_dcn_patch_batch_invariance(emu_lib):
     pc.check_dcn_patch_batch_invariance(emu_lib, "cpu", 9, 18, 64, 64, N=3, reps=2)
 
@@ -399,6 +406,11 @@ def test_late_dma_dcn_patch(late_dma, args):
     """The patch form's LDS-DMA pipeline (patch per 16-channel block, double-buffered weight chunks) under late delivery."""
     for big in (False, True):
         pc.check_dcn(late_dma, "cpu", *args, big_offsets=big, patch=True)
+
+
+def test_late_dma_dcn_producer_consumer(late_dma):
+    for big in (False, True):
+        pc.check_dcn_pc_identical(late_dma, "cpu", 2, 9, 19, 64, big_offsets=big, seed=6)
 
 
 def test_late_dma_forward_every_presplit_kernel(late_dma):

@@ -87,6 +87,15 @@ def test_dcn_patch_batch_invariance(gpu_lib, shape):
     pc.check_dcn_patch_batch_invariance(gpu_lib, "cuda", H, W, Ci, Co, N=N, reps=5)
 
 
+@pytest.mark.parametrize("args", [(1, 7, 9, 64), (2, 19, 34, 128), (16, 152, 272, 64), (32, 76, 136, 128), (64, 38, 68, 256)])
+def test_dcn_producer_consumer_identical(gpu_lib, args):
+    """Round 6: the producer / consumer form of the 64-column DCN tile (dcn_pc_kernel: eight waves, A fragments handed over through LDS,
+    one barrier per chunk) against the one-role kernel (dcn_patch_kernel<2>, tile bit 27) -- bit for bit, small and at the bench's launch
+    sizes (several generations of workgroups per CU), small and large offsets (the far lanes' global loads)."""
+    for big in (False, True):
+        pc.check_dcn_pc_identical(gpu_lib, "cuda", *args, big_offsets=big, seed=5)
+
+
 def test_dcn_big_offsets(gpu_lib):
     pc.check_dcn(gpu_lib, "cuda", 1, 6, 8, 64, 64, big_offsets=True, seed=3)
     pc.check_dcn(gpu_lib, "cuda", 1, 19, 34, 128, 64, big_offsets=True, seed=4)
