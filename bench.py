@@ -302,28 +302,50 @@ def tie_class_ok(logit, gk, ok, tau):
     return fine
 
 
-def _gate_frame(cfg, wl, images, outs, emb_dev, f):
-    """Frame f of a step of the timed plans (inputs `images`, affinity blocks `outs`, embeddings `emb_dev`) against the oracle:
-    (report dict, errors dict)."""
+def gate_snapshot(wl, outs):
+    """What the gate reads of a finished step of the timed plans, on the host: per frame the decoded (class, index) keys, scores, boxes and the dense
+    heat-map logits; the step's embeddings and affinity blocks."""
+    comp = wl["comp"]
+    torch.cuda.synchronize()
+    B = comp.emb.shape[0]
+    hw = None
+    snap = {"keys": [], "scores": [], "bboxes": [], "hm": [], "emb": comp.emb.detach().cpu().clone(), "outs": [o.detach().cpu().clone() for o in outs]}
+    for p in comp.plans:
+        hm = p.dense["hm"].to_nchw().cpu()
+        hw = hm.shape[2] * hm.shape[3]
+        for j in range(comp.sub):
+            snap["keys"].append((p.clses[j].cpu().long() * hw + p.inds[j].cpu().long()).tolist())
+            snap["scores"].append(p.scores[j].cpu().clone())
+            snap["bboxes"].append(p.bboxes[j].cpu().clone())
+            snap["hm"].append(hm[j].clone())
+    assert len(snap["keys"]) == B
+    return snap
+
+
+def _gate_frame(cfg, sd, images, snap, f, oracle=None):
+    """Frame f of a step of the timed plans (inputs `images`, device results `snap` = gate_snapshot) against the oracle: (report dict, errors
+    dict).  oracle: (out, maps, od) of the frame when the caller has it already (sweeps that compare several arithmetics on one oracle pass)."""
     import deft_oracle as O
-    comp, sd = wl["comp"], wl["sd"]
     H, W, nd, hist, ds = cfg["H"], cfg["W"], cfg["ndet"], cfg["hist"], cfg["dataset"]
     B = images.shape[0]
-    p, j = comp.plans[f // comp.sub], f % comp.sub
-    with torch.no_grad():
-        out, maps = O.dlaseg_forward(images[f:f + 1].cpu(), sd, ds)
-        od = O.generic_decode(O.sigmoid_output(out), K=KDET)
+    emb_dev = snap["emb"]
+    if oracle is None:
+        with torch.no_grad():
+            out, maps = O.dlaseg_forward(images[f:f + 1].cpu(), sd, ds)
+            od = O.generic_decode(O.sigmoid_output(out), K=KDET)
+    else:
+        out, maps, od = oracle
     logit = out["hm"][0]
     margin = oracle_margin(logit, KDET)                                  # from the oracle alone
     hw = logit.shape[1] * logit.shape[2]
-    gk = (p.clses[j].cpu().long() * hw + p.inds[j].cpu().long()).tolist()
+    gk = snap["keys"][f]
     ok = (od["clses"][0].long() * hw + od["inds"][0].long()).tolist()
-    e_hm = float((p.dense["hm"].to_nchw()[j].cpu() - logit).abs().max())
+    e_hm = float((snap["hm"][f] - logit).abs().max())
     opos = {k: n for n, k in enumerate(ok)}
     common = [(n, opos[k]) for n, k in enumerate(gk) if k in opos]
     gi = torch.tensor([n for n, _ in common], dtype=torch.long); oi = torch.tensor([n for _, n in common], dtype=torch.long)
-    e_s = float((p.scores[j].cpu()[gi] - od["scores"][0][oi]).abs().max())
-    e_b = float((p.bboxes[j].cpu()[gi] - od["bboxes"][0][oi]).abs().max())
+    e_s = float((snap["scores"][f][gi] - od["scores"][0][oi]).abs().max())
+    e_b = float((snap["bboxes"][f][gi] - od["bboxes"][0][oi]).abs().max())
     equal = gk == ok
     # differences, if any: only what a map within e_hm of the oracle's could decode to (tau = 2 e_hm; e_hm itself is bounded by the gate)
     ties = True if equal else tie_class_ok(logit, gk, ok, 2.0 * e_hm + 1e-6)
@@ -336,7 +358,7 @@ def _gate_frame(cfg, wl, images, outs, emb_dev, f):
     gi = torch.tensor([n for n, _ in pairs], dtype=torch.long); oi = torch.tensor([m for _, m in pairs], dtype=torch.long)
     e_e = float((emb_dev[f][gi] - emb_o[oi]).abs().max())
     # affinity block of the frame: history = the `hist` frames before it in the stream (the same frames every step)
-    e_a, blk = 0.0, outs[f].detach().cpu()
+    e_a, blk = 0.0, snap["outs"][f]
     with torch.no_grad():
         for hrow in range(hist):
             hf = (f - hist + hrow) % B
@@ -455,9 +477,12 @@ def parity_gate(cfg, wl, frames=None, tol=1e-3, outs=None, first=0, lib=None, de
            "checker": "oracle/deft_oracle.py (PyTorch-CPU restatement pinned to the reference modules)"}
     worst = {"score": 0.0, "bbox": 0.0, "embedding": 0.0, "affinity": 0.0, "hm_logit": 0.0}
 
+    snaps = {}
+
     def look(stream, imgs, outs_, f):
-        emb_dev = comp.emb.detach().cpu()                               # [B, nd, D] of the step just run
-        r, errs = _gate_frame(cfg, wl, imgs, outs_, emb_dev, f)
+        if stream not in snaps:
+            snaps[stream] = gate_snapshot(wl, outs_)                    # (of the step just run)
+        r, errs = _gate_frame(cfg, wl["sd"], imgs, snaps[stream], f)
         r["stream"] = stream
         rep["frames"].append(r)
         for k_, v_ in errs.items():
@@ -524,7 +549,7 @@ def roofline_of(wl, lib, rank, dt_step, config):
     lib.profile = None
     if rank != 0:
         return None, None
-    GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer", "deft_conv_direct")
+    GEMM = ("deft_conv2d_nhwc", "deft_conv2d_group", "deft_dcn_v2_nhwc", "deft_pair_layer", "deft_pair_mlp", "deft_conv_direct")
     rows = [(k, fl, e0.elapsed_time(e1), info, b, ceil) for (k, fl, e0, e1, info, b, ceil) in prof]
     gemm = [r for r in rows if r[0] in GEMM]
     gemm_ms = sum(r[2] for r in gemm)
@@ -577,7 +602,7 @@ def roofline_of(wl, lib, rank, dt_step, config):
             "serialized_achieved": round(ach, 3), "serialized_frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
             "traffic_bytes_per_step": tstep, "algorithmic_bytes_per_step_lower_bound": ALG_BYTES_PER_STEP.get(config),
             "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
-            "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel (conv, DCNv2, pair loaders; fp32 results)",
+            "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel / pair_mlp_kernel (conv, DCNv2, the fused pair MLP; fp32 results)",
             "peak_note": ("time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split kernels (" % (100.0 * split_ms / max(gemm_ms, 1e-9)))
                          + ("2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work: 3 bf16 pieces per operand, 6 bf16 MFMAs per fp32 product" if np_ == 3 else
                             "2500 / 3 = 833.3 TFLOP/s of fp32-equivalent work: 2 fp16 pieces per operand, 3 fp16 MFMAs per fp32 product")
@@ -813,7 +838,7 @@ def main():
             # (every frame of the ONE stream goes through rank 0's update in order): this, not the per-GPU step above, is config C's rate.
             if rank == 0 or world > 1:
                 from types import SimpleNamespace
-                from deft_amd.mot_tracker import Tracker2D
+                from deft_amd.array_tracker import Tracker2D
                 trk = None
                 if rank == 0:
                     trk = Tracker2D(SimpleNamespace(dataset=cfg["dataset"], track_buffer=30, max_object=100, lstm=False), SimpleNamespace(AFE=afe), h=H, w=W)
@@ -837,7 +862,7 @@ def main():
                 del stt
             del stc, dd, afe
         # ---- frame in -> tracks out on ONE stream: deft_amd.detector.Detector.run = process (hipGraph) -> vectorised
-        #      post-process -> deft_amd.mot_tracker.Tracker2D.update (embedding extraction, affinity chain against the stored frames,
+        #      post-process -> deft_amd.array_tracker.Tracker2D.update (embedding extraction, affinity chain against the stored frames,
         #      device-side similarity medians, batched Kalman gate, assignment, IoU stage), K detections per frame ----
         if args.config == "B" and world == 1:
             extras["end_to_end"] = end_to_end_fresh("B", dev, lib, local)
@@ -885,18 +910,17 @@ def main():
     # ---- the same step on the three-bf16-piece build of the same sources (six products per fp32 product: the arithmetic of rounds 1-4), in its
     #      own process: value + parity gate, so the line carries both arithmetics next to each other ----
     alt = None
-    alt_so = os.path.join(ROOT, "deft_amd", "lib", "libdeft_bf16x3.so")
     if (rank == 0 and world == 1 and not args.standin and not args.no_extras and args.config == "B" and getattr(lib, "pieces", 3) == 2
-            and os.path.exists(alt_so) and "DEFT_HIP_LIB" not in os.environ and "alt" not in skip):
+            and lib.twin() is not None and "DEFT_HIP_LIB" not in os.environ and "alt" not in skip):
         import subprocess
         torch.cuda.synchronize()
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", str(max(10, min(args.steps, 30))),
                             "--warmup", str(args.warmup), "--batch", str(B), "--streams", str(args.streams)] + (["--no-check"] if args.no_check else []),
-                           capture_output=True, text=True, env=dict(os.environ, DEFT_HIP_LIB=alt_so, DEFT_BENCH_OPS="bench_ops_bf16x3.json"), timeout=900)
+                           capture_output=True, text=True, env=dict(os.environ, DEFT_ARITH="bf16x3", DEFT_BENCH_OPS="bench_ops_bf16x3.json"), timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode == 0 and line:
             a_ = json.loads(line[-1])
-            alt = {"library": "libdeft_bf16x3.so (DEFT_PIECES=3)", "contraction": a_["config"]["contraction"], "value": a_["value"], "ms_per_step": a_["ms_per_step"],
+            alt = {"library": "the `_p3` entry points of the same libdeft_hip.so (DEFT_ARITH=bf16x3)", "contraction": a_["config"]["contraction"], "value": a_["value"], "ms_per_step": a_["ms_per_step"],
                    "roofline_frac": a_["roofline"]["frac"], "parity": a_["config"].get("parity")}
         else:
             alt = {"error": (r.stderr or r.stdout)[-300:]}
@@ -1036,7 +1060,7 @@ def end_to_end(name, dev, lib, local, ne=100):
     `Detector.track_stream` reads the stream ahead: the next frames' network pass runs on a second set of plan buffers while the host associates this
     frame (Detector.run's lookahead: one frame per pass, and E2E_PER_PASS frames per pass -- the batch-1 launch list is latency-bound)."""
     from types import SimpleNamespace
-    from deft_amd import detector as FD, engine, integrate, mot_tracker as MT, synth, tracker as DT
+    from deft_amd import detector as FD, engine, integrate, array_tracker as MT, synth, tracker as DT
     from deft_amd.postprocess import NUSCENES_TRACKING_NAMES
     cfg, e = CONFIGS[name], E2E[name]
     H, W, ds = cfg["H"], cfg["W"], cfg["dataset"]

@@ -34,7 +34,7 @@ mot / kitti_tracking / nuscenes x Kalman / LSTM and requires identical ids, flag
   * LSTM: no Kalman predict; fuse_motion uses the "gaussian" distance, which is identically zero on the 2-D position-only path unless
     the track has >= 300 observations (then Mahalanobis on the predicted box with np.cov of its observations, matching.py:339-366);
     the IoU stage uses the LSTM's predicted box (prediction_at_frame_tlbr, float32 arithmetic like the reference's arrays);
-  * ids come from the process-wide counter `mot_tracker.TrackIds` (basetrack.py:18, 40-42).
+  * ids come from the process-wide counter `kalman.TrackIds` (basetrack.py:18, 40-42).
 """
 import ctypes as C
 
@@ -43,7 +43,8 @@ import torch
 
 from . import association as A
 from . import tracker as DT
-from .kalman import TrackIds, kf_multi_predict, kf_multi_update, _SP, _SV
+from .kalman import (NEW, TRACKED, LOST, REMOVED, TrackIds, Node, kf_initiate, kf_multi_predict, kf_multi_update,  # noqa: F401
+                     tlbr_to_tlwh, tlwh_to_xyah, _F, _H, _SP, _SV)
 
 TRACKED, REMOVED = 1, 3                         # basetrack.py:11-15 (New = 0 and Lost = 2 never occur in a pool)
 
@@ -94,6 +95,15 @@ class _Columns(object):
         for k in self.a:
             self.a[k] = self.a[k][idx]
         self.n = len(self.a["tid"])
+
+
+def _finite_sim(sim):
+    """The similarity matrix is where the embedding / affinity chain (AfePlan: the same split arithmetic as the backbone, no heat map in between)
+    lands on the host: a non-finite entry means an operand left the two-fp16-piece range.  The native cascade would treat such pairs as gated --
+    silent non-matches and identity switches; raise instead (Detector.run moves to the range-free arithmetic)."""
+    if sim is not None and not np.isfinite(sim).all():
+        raise FloatingPointError("non-finite track / detection similarity: an operand of the embedding / affinity chain left the range of the "
+                                 "two-fp16-piece arithmetic (|x| >= 4094, csrc/common.h); run on the three-bf16-piece entry points (DEFT_ARITH=bf16x3)")
 
 
 class ArrayTracker(object):
@@ -372,6 +382,7 @@ class ArrayTracker(object):
         mt, md, lost, new_d, cnt = out[:k], out[k:2 * k], out[2 * k:2 * k + T], out[2 * k + T:2 * k + T + N], out[2 * k + T + N:]
         sim = sim_wait(raw=True) if sim_wait is not None else None     # everything above is host work the device round trip hides behind
         self._device_done()
+        _finite_sim(sim)
         if sim is not None:
             assert sim.dtype == np.float32 and sim.shape == (T, N + 1) and sim.flags.c_contiguous
         ptr = lambda a: C.c_void_p(a.ctypes.data if a.size else 0)
@@ -408,6 +419,7 @@ class ArrayTracker(object):
         mt, md, lost, new_d, cnt = out[:k], out[k:2 * k], out[2 * k:2 * k + T], out[2 * k + T:2 * k + T + N], out[2 * k + T + N:]
         sim = sim_wait(raw=True) if sim_wait is not None else None
         self._device_done()
+        _finite_sim(sim)
         if sim is not None:
             assert sim.dtype == np.float32 and sim.shape == (T, N + 1) and sim.flags.c_contiguous
         ptr = lambda a: C.c_void_p(a.ctypes.data if a.size else 0)
@@ -432,7 +444,12 @@ class ArrayTracker(object):
             self._undo(self._begun)
         rec = self.recorder
         snap = (rec.all_frame_index, dict(rec.all_features), dict(rec.all_boxes), dict(rec.all_similarity), rec._dev)
-        self._begun = self._first_half(results, FeatureMaps, ddd_boxes, depths_by_class, pre, feats)
+        try:
+            self._begun = self._first_half(results, FeatureMaps, ddd_boxes, depths_by_class, pre, feats)
+        except Exception:
+            self._undo({"snap": snap})                 # the recorder may hold the frame already: the next update() must not find it half recorded
+            self._begun = None
+            raise
         self._begun["snap"] = snap
 
     def _undo(self, b):

@@ -378,7 +378,7 @@ double assign_limited(const double* cost, int n_rows, int n_cols, double cost_li
 extern "C" int deft_lapjv(const double* cost, int n_rows, int n_cols, double cost_limit, int* x, int* y, double* total) {
     DEFT_CHECK(n_rows >= 0 && n_cols >= 0 && (n_rows == 0 || n_cols == 0 || cost != nullptr) && x != nullptr && y != nullptr, -90,
                "deft_lapjv: null pointer or negative size");
-    DEFT_CHECK(n_rows + n_cols <= 4096, -91, "deft_lapjv: %d x %d is beyond what the tracker's association builds", n_rows, n_cols);
+    DEFT_CHECK((long long)n_rows * (long long)n_cols < (1ll << 31), -91, "deft_lapjv: %d x %d overflows the 32-bit cost index", n_rows, n_cols);
     for (int i = 0; i < n_rows; ++i) x[i] = -1;
     for (int j = 0; j < n_cols; ++j) y[j] = -1;
     if (total) *total = 0.0;
@@ -431,7 +431,7 @@ extern "C" int deft_associate_2d(const float* sim, int ld, int T, int N, const d
                                  const double* meas2, double gate_thr, double lambda_, double w_gate, int second_stage,
                                  const unsigned char* iou_ok, const double* trk_tlbr, const double* det_tlbr, double thr_embed, double thr_iou,
                                  int* match_t, int* match_d, int* n_match, int* lost_t, int* n_lost, int* new_d, int* n_new) {
-    DEFT_CHECK(T >= 0 && N >= 0 && T + N <= 4096 && ld >= N, -93, "deft_associate_2d: T=%d N=%d ld=%d", T, N, ld);
+    DEFT_CHECK(T >= 0 && N >= 0 && (long long)T * (long long)(N + 1) < (1ll << 31) && ld >= N, -93, "deft_associate_2d: T=%d N=%d ld=%d", T, N, ld);
     DEFT_CHECK(n_match && n_lost && n_new && (T == 0 || (mean2 && chol && gated && iou_ok && trk_tlbr && lost_t)) &&
                (N == 0 || (meas2 && det_tlbr && new_d)) && (T == 0 || N == 0 || (sim && match_t && match_d)), -93, "deft_associate_2d: null pointer");
     int nm = 0;
@@ -521,7 +521,7 @@ extern "C" int deft_associate_ddd(const float* sim, int ld, int T, int N, int st
                                   const double* det_ddd, const double* depth, int metric, double gate_floor, double lambda_, double w_gate,
                                   const unsigned char* iou_ok, const double* trk_tlbr, const double* det_tlbr, double thr_3d, double thr_embed,
                                   double thr_iou, int* match_t, int* match_d, int* n_match, int* lost_t, int* n_lost, int* new_d, int* n_new) {
-    DEFT_CHECK(T >= 0 && N >= 0 && T + N <= 4096 && ld >= N, -93, "deft_associate_ddd: T=%d N=%d ld=%d", T, N, ld);
+    DEFT_CHECK(T >= 0 && N >= 0 && (long long)T * (long long)(N + 1) < (1ll << 31) && ld >= N, -93, "deft_associate_ddd: T=%d N=%d ld=%d", T, N, ld);
     DEFT_CHECK(n_match && n_lost && n_new && (T == 0 || (recent && trk_ddd && depth && iou_ok && trk_tlbr && lost_t)) &&
                (N == 0 || (det_ddd && det_tlbr && new_d)) && (T == 0 || N == 0 || (sim && match_t && match_d)), -93, "deft_associate_ddd: null pointer");
     int nm = 0;

@@ -94,7 +94,10 @@ __device__ __forceinline__ deft_f32x16 deft_mfma_pc(const pcx8 a, const pcx8 b, 
 // number) and rounds ONCE to fp16 into one half of the destination: the same bits as `(_Float16)(x - (float)(_Float16)x)`.  hipcc's own code
 // for that expression is 9-10 instructions per pair inside the kernels (separate conversions, v_cvt_f32_f16 + v_sub, canonicalising v_max);
 // tools/probe/f16_split_asm.hip checks these sequences against the C++ expression on the hardware, bit for bit.  `sc` (a power of two) is
-// folded into the same instructions.  (Outputs feed LDS / global stores or, a K step later, matrix instructions: no asm-to-MFMA adjacency.)
+// folded into the same instructions.  (Outputs feed LDS / global stores or, a K step later, matrix instructions: no asm-to-MFMA adjacency --
+// and that is a REQUIREMENT, not a nicety: v_fma_mixhi_f16 writes half a register, and a matrix instruction that reads the register within a
+// few instructions sees the stale half; the compiler inserts no wait states for inline asm.  Found in round 6 in csrc/pairmlp.hip, which
+// therefore splits with the C++ expression; profiles/r6_asm_split_mfma_hazard.md.)
 #ifndef DEFT_F16_SPLIT_HOOK    /* the unit-test SIMT emulator pre-defines this hook with the C++ expression */
 __device__ __forceinline__ void deft_split2_pair(float x0, float x1, unsigned& h, unsigned& m) {
 #if defined(__HIP_DEVICE_COMPILE__)

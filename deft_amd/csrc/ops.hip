@@ -807,13 +807,15 @@ __global__ __launch_bounds__(256) void affinity_finish_kernel(const int* __restr
 
 extern "C" int deft_affinity_finish(const float* h4, int ldh, int C4, const float* w5, float b5,
                                     const int* row_start, int F, int T, int Q, int max_object, float* out, void* stream) {
-    DEFT_CHECK(h4 && w5 && row_start && out, -1, "deft_affinity_finish: null pointer");
+    DEFT_CHECK((h4 == nullptr || w5) && row_start && out, -1, "deft_affinity_finish: null pointer");
     DEFT_CHECK(Q > 0 && Q <= AF_MAXOBJ && max_object <= AF_MAXOBJ && Q <= max_object && (C4 & 3) == 0 && (ldh & 3) == 0, -2,
                "deft_affinity_finish: Q=%d max_object=%d must be <= %d", Q, max_object, AF_MAXOBJ);
     if (F <= 0) return 0;
     DEFT_CHECK(T > 0 && (long long)T * Q < (1ll << 31), -3, "deft_affinity_finish: T=%d history rows in total (= row_start[F])", T);
-    hipLaunchKernelGGL(affinity_pairs_kernel, dim3(deft_cdiv((long long)T * Q, 64)), dim3(256), 0, (hipStream_t)stream, h4, ldh, C4, w5, b5, T * Q, Q, out);
-    DEFT_CHECK_LAUNCH("affinity_pairs");
+    if (h4 != nullptr) {                                             // (h4 == NULL: deft_pair_mlp has left the relu'd logits at their places in `out`)
+        hipLaunchKernelGGL(affinity_pairs_kernel, dim3(deft_cdiv((long long)T * Q, 64)), dim3(256), 0, (hipStream_t)stream, h4, ldh, C4, w5, b5, T * Q, Q, out);
+        DEFT_CHECK_LAUNCH("affinity_pairs");
+    }
     hipLaunchKernelGGL(affinity_finish_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, row_start, Q, max_object, out);
     DEFT_CHECK_LAUNCH("affinity_finish");
     return 0;

@@ -56,10 +56,16 @@ def _flag_finite(plan, d, lib):
 
 
 def _check_finite(dets):
+    """Raises FloatingPointError when the frame's heat map, or any decoded float field (scores, boxes, the regression heads at the peaks: they run the
+    same split arithmetic), is not finite.  Detector.process / run catch it ONCE per detector: the frame is re-run on the three-bf16-piece entry
+    points of the same library (no range limit) and the detector stays there (Detector._switch_to_safe)."""
     f = dets.pop("_finite", None)
-    if f is not None and not bool(np.all(f)):
-        raise FloatingPointError("non-finite heat map: an activation left the range of the two-fp16-piece arithmetic (|x| >= 4094, csrc/common.h) -- "
-                                 "run this model on the three-bf16-piece build: DEFT_HIP_LIB=<repo>/deft_amd/lib/libdeft_bf16x3.so")
+    bad = f is not None and not bool(np.all(f))
+    if not bad:
+        bad = any(v.dtype.kind == "f" and not np.isfinite(v).all() for v in dets.values())
+    if bad:
+        raise FloatingPointError("non-finite heat map or detection record: an activation left the range of the two-fp16-piece arithmetic (|x| >= 4094, "
+                                 "csrc/common.h); the three-bf16-piece entry points of the same library have no range limit (DEFT_ARITH=bf16x3)")
     return dets
 
 
@@ -82,6 +88,7 @@ class Detector(object):
         self.opt = opt
         self.device = torch.device("cuda" if getattr(opt, "gpus", [0])[0] >= 0 else "cpu")
         self.lib = hiplib.get_lib()            # the plans below refuse a CPU device with the HIP library (no CPU path)
+        self.arith = "fp16x2" if getattr(self.lib, "pieces", 3) == 2 else "bf16x3"
         self.sd = state_dict
         self.dataset = opt.dataset
         self.K = getattr(opt, "K", 100)
@@ -126,7 +133,41 @@ class Detector(object):
             self._plans[key] = p
         return self._plans[key]
 
+    arith = None      # "fp16x2" / "bf16x3": which entry points of the library this detector's plans run on (set in __init__)
+
+    def _switch_to_safe(self, why):
+        """An activation left the range of the two-fp16-piece arithmetic: move this detector -- plans, graphs, lookahead slots, the embedding /
+        affinity plan the tracker shares -- to the three-bf16-piece entry points of the SAME library (hiplib.HipLib.twin(): six matrix instructions
+        per fp32 product instead of three, no range limit, ~25 % slower) for the rest of its life.  Returns False when there is nothing to switch
+        to (the library carries one arithmetic, or this detector is on the range-free one already)."""
+        twin = self.lib.twin() if hasattr(self.lib, "twin") else None
+        if twin is None:
+            return False
+        import warnings
+        warnings.warn("deft_amd: %s -- this detector continues on the three-bf16-piece arithmetic (no range limit)" % why, RuntimeWarning)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self._drop_ahead()
+        self._ahead, self._plans, self._graphs = {}, {}, {}
+        self._launch_next = self._peeked = self._fm_ready = None
+        self.lib = twin
+        new = engine.AfePlan(self.sd, getattr(self.opt, "max_object", 100), self.device, twin)
+        self.afe.__dict__.clear()                      # in place: the tracker (model.AFE.plan) holds this object
+        self.afe.__dict__.update(new.__dict__)
+        self.arith = "bf16x3"
+        return True
+
     def process(self, images, pre_images=None, pre_hms=None, pre_inds=None, return_time=False):
+        """detector.py:530-551 (see _process_once).  A frame whose activations leave the two-fp16-piece range is re-run on the range-free
+        arithmetic (_switch_to_safe) instead of raising."""
+        try:
+            return self._process_once(images, pre_images, pre_hms, pre_inds, return_time)
+        except FloatingPointError as e:
+            if not self._switch_to_safe(str(e)):
+                raise
+            return self._process_once(images, pre_images, pre_hms, pre_inds, return_time)
+
+    def _process_once(self, images, pre_images=None, pre_hms=None, pre_inds=None, return_time=False):
         """detector.py:530-551.  images [N,3,H,W] fp32.  Returns (output, dets, FeatureMaps):
         output = {"hm": dense sigmoid'ed map as an NHWC View}, dets = generic_decode's dict as
         numpy (one D2H), FeatureMaps = the 13 NHWC Views consumed by AFE (tracker.py:826)."""
@@ -254,6 +295,19 @@ class Detector(object):
         return meta
 
     def run(self, image_or_path_or_tensor, meta={}, image_info=None, nms=True, prefetch=None):
+        """detector.py:112-344 (see _run_once).  A frame whose network pass leaves the two-fp16-piece range raises inside the detection stage,
+        before the tracker has seen it: the detector moves to the range-free arithmetic (_switch_to_safe: queued lookahead passes are dropped)
+        and the frame is run again -- the video goes on.  An overflow found in the TRACKER's stage (embedding / affinity chain: array_tracker
+        checks the similarity matrix) also moves the detector over, but that frame's association has begun: the error is passed on."""
+        st = {"tracker": False}
+        try:
+            return self._run_once(image_or_path_or_tensor, meta, image_info, nms, prefetch, st)
+        except FloatingPointError as e:
+            if not self._switch_to_safe(str(e)) or st["tracker"]:
+                raise
+            return self._run_once(image_or_path_or_tensor, meta, image_info, nms, prefetch, st)
+
+    def _run_once(self, image_or_path_or_tensor, meta={}, image_info=None, nms=True, prefetch=None, _stage=None):
         """detector.py:112-344 -- same argument forms, same return value (`Tracker.update`'s online targets; the post-processed
         `results` when no tracker is set), same stage timers (self.times: load / pre / net / dec / post / merge / track / tot):
           * numpy uint8 HWC frame (cv2 channel order): warp + normalise + layout ON THE DEVICE (deft_preprocess_u8, fix_res mode),
@@ -335,9 +389,11 @@ class Detector(object):
             t_post = time.time()
             results = self.merge_outputs([result])
         t_merge = time.time()
+        if _stage is not None:
+            _stage["tracker"] = True                    # from here on the tracker's state moves with the frame
         if getattr(opt, "public_det", False) and pre_processed:
             results = image_or_path_or_tensor["meta"]["cur_dets"]                     # detector.py:190-196
-        # the lookahead pass of the NEXT frame (prefetch=): a tracker that says when its device work is over (mot_tracker.Tracker2D:
+        # the lookahead pass of the NEXT frame (prefetch=): a tracker that says when its device work is over (array_tracker.Tracker2D:
         # after the similarity medians, ~40 % into update()) gets it queued at that point, so the pass overlaps the host-only rest of the
         # association instead of competing with the tracker's own launches; any other tracker gets it queued up front
         nxt, self._launch_next = getattr(self, "_launch_next", None), None

@@ -236,6 +236,58 @@ def scale_weight_rows(w, scale, cout):
     return w2.contiguous(), torch.ldexp(sc, -k[:cout]).contiguous()
 
 
+PAIR_MLP = _os.environ.get("DEFT_PAIR_MLP", "1") != "0"       # the affinity estimator's pair MLP as ONE launch (csrc/pairmlp.hip) instead of the four-launch chain
+
+
+def _pieces_of(w, np_):
+    """The NP 16-bit pieces of an fp32 matrix, as the kernels form them (common.h deft_split, round-to-nearest each): [NP, ...] int16 views."""
+    dt = torch.float16 if np_ == 2 else torch.bfloat16
+    out, r = [], w.float()
+    for _ in range(np_):
+        h = r.to(dt)
+        out.append(h.view(torch.int16))
+        r = r - h.float()
+    return torch.stack(out, 0)
+
+
+def pair_mlp_image(W2, W3, W4, np_):
+    """The weight image of deft_pair_mlp (csrc/pairmlp.hip): 21 chunks of 16 * np_ fragments; a fragment is what ONE matrix instruction's A
+    operand reads -- 64 lanes x 8 halves of one piece: lane l = output channel 32 ot + (l & 31) of channel tile ot, k group g = l >> 5,
+    element i.  W2 [256, 512], W3 [128, 256], W4 [64, 128] fp32 (row-scaled already when np_ == 2).
+      layer 2 (chunks 0-15, k step s of chunk ci): k = 16 (2 ci + s) + 8 g + i;
+      layers 3 / 4 (chunks 16-19: two 32-channel k tiles each; chunk 20: four): k step s of input tile kt, k = 32 kt + c(s, g, i) with
+      c(s, g, i) = (i & 3) + 8 (2 s + (i >> 2)) + 4 g -- the channel the accumulator of the layer before holds in register 8 s + i of k group g.
+    -> int16 tensor [21 * 16 * np_ * 512]."""
+    lane = torch.arange(64)
+    o, g = lane & 31, lane >> 5
+    i = torch.arange(8)
+    frags = []
+
+    def add(W, ot, kcols):          # kcols [64 lanes, 8]: the column of W each (lane, element) reads
+        rows = (32 * ot + o).view(64, 1).expand(64, 8)
+        vals = W[rows, kcols]                                        # [64, 8] fp32
+        pc = _pieces_of(vals, np_)                                   # [np_, 64, 8]
+        for q in range(np_):
+            frags.append(pc[q].reshape(-1))
+    for ci in range(16):
+        for s_ in range(2):
+            for ot in range(8):
+                add(W2, ot, (16 * (2 * ci + s_) + 8 * g).view(64, 1) + i.view(1, 8))
+    perm = lambda s_: ((i & 3) + 8 * (2 * s_ + (i >> 2))).view(1, 8) + (4 * g).view(64, 1)
+    for c3 in range(4):
+        for kk in range(2):
+            for s_ in range(2):
+                for ot in range(4):
+                    add(W3, ot, 32 * (2 * c3 + kk) + perm(s_))
+    for kt in range(4):
+        for s_ in range(2):
+            for ot in range(2):
+                add(W4, ot, 32 * kt + perm(s_))
+    img = torch.cat(frags)
+    assert img.numel() == 21 * 16 * np_ * 512
+    return img
+
+
 class _P3Out:
     """A producer's optional P3 (three bf16 pieces) output: written only if some pre-split conv reads it (`used`)."""
 
@@ -687,10 +739,10 @@ class _Plan:
         (`deft_gemm_plan`); the plan owns ONE workspace + ticket array shared by all its launches (they are
         ordered on the plan's stream), sized for the largest."""
         tile, S, wsf, wst = C.c_int(), C.c_int(), C.c_longlong(), C.c_int()
-        rc = self.lib.cdll.deft_gemm_plan(C.byref(desc), 0 if entry == "deft_conv2d_nhwc" else 1, C.byref(tile), C.byref(S),
+        rc = self.lib._fn["deft_gemm_plan"](C.byref(desc), 0 if entry == "deft_conv2d_nhwc" else 1, C.byref(tile), C.byref(S),
                                           C.byref(wsf), C.byref(wst))
         if rc != 0:
-            raise hiplib.DeftHipError("deft_gemm_plan failed (%d): %s" % (rc, self.lib.cdll.deft_last_error().decode()))
+            raise hiplib.DeftHipError("deft_gemm_plan failed (%d): %s" % (rc, self.lib.last_error()))
         if S.value <= 1:
             return
         desc.tile, desc.splitk = tile.value, S.value
@@ -881,7 +933,7 @@ class _Plan:
         out = self.alloc(x.N, OH, OW, Cout)
         key = (w_packed.data_ptr(), "direct")
         if key not in self._w3:
-            nb = self.lib.cdll.deft_direct_weight_bytes(KH, KH, x.C, Cout)
+            nb = self.lib._fn["deft_direct_weight_bytes"](KH, KH, x.C, Cout)
             assert nb > 0
             w3 = torch.empty(nb, dtype=torch.uint8, device=self.device)
             self._by_ptr.setdefault(w_packed.data_ptr(), w_packed)
@@ -1289,6 +1341,40 @@ class AfePlan(_Plan):
             self.layers.append((self.dev(wp), K, w.shape[0], self.dev(scale) if scale is not None else None, self.dev(shift)))
         self.w5 = self.dev(sd["AFE.final_net.11.weight"].float().reshape(-1))
         self.b5 = float(sd["AFE.final_net.11.bias"].float().item())
+        self._pair_mlp = None
+        if PAIR_MLP and PREC == 1 and "deft_pair_mlp" in self.lib._fn:
+            # the three matrix layers of the pair MLP as ONE weight image (pair_mlp_image) + per-channel scale / shift (BatchNorm and bias
+            # folded; two-piece builds: rows scaled into fp16 range, the inverse folded into the scale -- weight_row_shift, as _Plan.prescale)
+            Ws, scs, shs = [], [], []
+            for i, bn in ((3, True), (6, True), (9, False)):
+                w = sd["AFE.final_net.%d.weight" % i].float().reshape(sd["AFE.final_net.%d.weight" % i].shape[0], -1)
+                bias = sd["AFE.final_net.%d.bias" % i].float()
+                if bn:
+                    al, be = _bn_fold(sd, "AFE.final_net.%d" % (i + 1))
+                    sc, sh = al.float(), (bias * al + be).float()
+                else:
+                    sc, sh = torch.ones_like(bias), bias
+                if self.np == 2:
+                    k = weight_row_shift(w)
+                    w, sc = torch.ldexp(w, k.view(-1, 1)), torch.ldexp(sc, -k)
+                Ws.append(w); scs.append(sc.contiguous()); shs.append(sh.contiguous())
+            assert [tuple(w.shape) for w in Ws] == [(256, 512), (128, 256), (64, 128)], "deft_pair_mlp is the 512-256-128-64-1 net of AFE.py:331-347"
+            img = pair_mlp_image(Ws[0], Ws[1], Ws[2], self.np)
+            assert img.numel() * 2 == self.lib._fn["deft_pair_mlp_image_bytes"]()
+            self._pair_mlp = {"img": self.dev(img), "s": [self.dev(x) for x in scs], "t": [self.dev(x) for x in shs]}
+
+    def _pair_mlp_launch(self, U, V, M, Q, out, batched=None):
+        """deft_pair_mlp: U' / V' [rows, 512] -> relu'd logits at out[(m / Q) * (Q + 1) + m % Q]."""
+        pm = self._pair_mlp
+        d = hiplib.PairMlpDesc()
+        d.U, d.V, d.wimg = U.data_ptr(), V.data_ptr(), pm["img"].data_ptr()
+        d.s2, d.t2, d.s3, d.t3, d.s4, d.t4 = (pm["s"][0].data_ptr(), pm["t"][0].data_ptr(), pm["s"][1].data_ptr(), pm["t"][1].data_ptr(),
+                                              pm["s"][2].data_ptr(), pm["t"][2].data_ptr())
+        d.w5, d.out, d.b5 = self.w5.data_ptr(), out if isinstance(out, int) else out.data_ptr(), self.b5
+        d.ldu, d.M, d.Q = 512, M, Q
+        if batched is not None:
+            d.Tper, d.u0, d.du, d.v0, d.dv = batched
+        self.lib.call("deft_pair_mlp", C.byref(d), self._stream())
 
     def _embed_group(self, fmaps, Nf, ndet):
         """Per (feature-map buffers, Nf, ndet): the 13 sparse-row conv descriptors (host + device
@@ -1464,6 +1550,12 @@ class AfePlan(_Plan):
         V = self._work("V", Q * 512).view(Q, 512)
         self._lin(xh, T, Kd, Kd, self.Ua, Kd, 512, None, None, False, U, 512)
         self._lin(xc, Q, Kd, Kd, self.Vb, Kd, 512, None, self.cb, False, V, 512)
+        out = torch.empty(T, Q + 1, dtype=torch.float32, device=dev)
+        rs = self._staged_ints(starts)                # (pinned staging: a pageable torch.tensor(..., device=) is a blocking copy behind the whole chain)
+        if self._pair_mlp is not None:
+            self._pair_mlp_launch(U, V, M, Q, out)    # layers 2-5 in one launch: the logits land in `out`
+            self.lib.call("deft_affinity_finish", None, c4, c4, None, C.c_float(0.0), ptr(rs), len(hist), T, Q, self.max_object, ptr(out), self._stream())
+            return out, starts
         h2 = self._work("h2", M * c2).view(M, c2)
         d = GemmDesc()
         d.x = U.data_ptr(); d.x2 = V.data_ptr(); d.w = w2.data_ptr()
@@ -1481,8 +1573,6 @@ class AfePlan(_Plan):
         self._lin(h2, M, c2, c2, w3, w3.shape[1], c3, s3, t3, True, h3, c3)
         h4 = self._work("h4", M * c4).view(M, c4)
         self._lin(h3, M, c3, c3, w4, w4.shape[1], c4, s4, t4, True, h4, c4)
-        out = torch.empty(T, Q + 1, dtype=torch.float32, device=dev)
-        rs = self._staged_ints(starts)                # (pinned staging: a pageable torch.tensor(..., device=) is a blocking copy behind the whole chain)
         self.lib.call("deft_affinity_finish", ptr(h4), c4, c4, ptr(self.w5), C.c_float(self.b5), ptr(rs), len(hist), T, Q,
                       self.max_object, ptr(out), self._stream())
         return out, starts
@@ -1498,13 +1588,15 @@ class AfePlan(_Plan):
         assert ring.is_contiguous() and D == self.D and D == self.Kd and g0 - hist >= 0 and g0 + Bc <= R
         assert K <= self.max_object
         (w2, K2, c2, s2, t2), (w3, K3, c3, s3, t3), (w4, K4, c4, s4, t4) = self.layers
-        CH = max(1, min(Bc, ((1 << 29) - 1) // (hist * K * K * max(c2, 512))))
+        fused = self._pair_mlp is not None
+        # (the fused launch keeps the per-pair intermediates in registers: no h2 / h3 / h4 buffers, no 2 GiB-per-tensor limit on a chain)
+        CH = max(1, min(Bc, ((1 << 31) - 1) // (hist * K * (K + 1)))) if fused else max(1, min(Bc, ((1 << 29) - 1) // (hist * K * K * max(c2, 512))))
         key = (R, K, Bc, hist)
         if not hasattr(self, "_ring"):
             self._ring = {}
         if key not in self._ring:
             dev = self.device
-            Mc = CH * hist * K * K
+            Mc = 1 if fused else CH * hist * K * K
             buf = {"U": torch.empty(R * K, 512, dtype=torch.float32, device=dev),
                    "V": torch.empty(R * K, 512, dtype=torch.float32, device=dev),
                    "h2": torch.empty(Mc, c2, dtype=torch.float32, device=dev),
@@ -1519,6 +1611,12 @@ class AfePlan(_Plan):
         for c0 in range(0, Bc, CH):
             nc = min(CH, Bc - c0)
             M = nc * hist * K * K
+            if self._pair_mlp is not None:
+                o_ptr = b["out"].data_ptr() + 4 * c0 * hist * K * (K + 1)
+                self._pair_mlp_launch(b["U"], b["V"], M, K, o_ptr, batched=(hist * K, (g0 + c0 - hist) * K, K, (g0 + c0) * K, K))
+                self.lib.call("deft_affinity_finish", None, c4, c4, None, C.c_float(0.0), ptr(b["rs"]), nc * hist, nc * hist * K, K, self.max_object,
+                              C.c_void_p(o_ptr), self._stream())
+                continue
             d = GemmDesc()
             d.x = b["U"].data_ptr(); d.x2 = b["V"].data_ptr(); d.w = w2.data_ptr()
             d.scale = s2.data_ptr(); d.shift = t2.data_ptr(); d.res = None; d.y = b["h2"].data_ptr()

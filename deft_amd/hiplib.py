@@ -38,6 +38,13 @@ class GemmDesc(C.Structure):
     ]
 
 
+class PairMlpDesc(C.Structure):
+    """Mirror of DeftPairMlp (include/deft_hip.h)."""
+    _fields_ = [("U", c_fp), ("V", c_fp), ("wimg", c_fp), ("s2", c_fp), ("t2", c_fp), ("s3", c_fp), ("t3", c_fp), ("s4", c_fp), ("t4", c_fp),
+                ("w5", c_fp), ("out", c_fp), ("b5", C.c_float), ("ldu", C.c_int), ("M", C.c_int), ("Q", C.c_int),
+                ("Tper", C.c_int), ("u0", C.c_int), ("du", C.c_int), ("v0", C.c_int), ("dv", C.c_int)]
+
+
 _SIGS = {
     "deft_version": (C.c_int, []),
     "deft_pieces": (C.c_int, []),
@@ -46,6 +53,8 @@ _SIGS = {
     "deft_conv2d_group": (C.c_int, [C.POINTER(GemmDesc), c_fp, C.c_int, c_fp]),
     "deft_dcn_v2_nhwc": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "deft_pair_layer": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "deft_pair_mlp": (C.c_int, [C.POINTER(PairMlpDesc), c_fp]),
+    "deft_pair_mlp_image_bytes": (C.c_int, []),
     "deft_nchw_to_nhwc": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
     "deft_nhwc_to_nchw": (C.c_int, [c_fp, c_fp] + [C.c_int] * 5 + [c_fp]),
     "deft_preprocess_u8": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
@@ -84,34 +93,60 @@ _SIGS = {
                                     c_fp, c_fp, c_fp, C.c_double, C.c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class DeftHipError(RuntimeError):
     pass
 
 
+TWIN_SUFFIX = "_p3"       # deft_amd/build.py: every entry point of the device-code sources exists a second time, compiled with three bf16 pieces
+
+
 class HipLib:
-    def __init__(self, path):
+    """One arithmetic of one shared object.  libdeft_hip.so carries two (include/deft_hip.h): the entry points `name` (two fp16 pieces per operand:
+    three matrix instructions per fp32 product, activations |x| < 4094) and their twins `name_p3` (three bf16 pieces: six products, no range
+    limit).  `HipLib(path)` binds the first set, `.twin()` the second -- same library, same process; piece buffers, weight images and plans belong
+    to ONE of them (the piece formats differ), so the choice is made per plan (engine._Plan(lib=...))."""
+
+    def __init__(self, path, suffix="", cdll=None):
         if not os.path.exists(path):
             raise DeftHipError(
                 "HIP extension missing: %s -- run `python -m deft_amd.build` "
                 "(hipcc --offload-arch=gfx950); deft_amd has no CPU fallback" % path)
         self.path = path
-        self.cdll = C.CDLL(path)
+        self.suffix = suffix
+        self.cdll = C.CDLL(path) if cdll is None else cdll
         self._fn = {}
         for name, (res, args) in _SIGS.items():
-            fn = getattr(self.cdll, name)          # AttributeError if a symbol is not exported
+            fn = getattr(self.cdll, name + suffix, None) if suffix else None
+            if fn is None:
+                fn = getattr(self.cdll, name)      # AttributeError if a symbol is not exported (host-only helpers have no twin)
             fn.restype = res
             fn.argtypes = args
             self._fn[name] = fn
         # a build whose kernels run on host memory (the unit-test build of the same sources) exports this marker
         self.host_pointers = hasattr(self.cdll, "deft_host_pointers")
-        v = self.cdll.deft_version()
+        v = self._fn["deft_version"]()
         if v != ABI_VERSION:
             raise DeftHipError("libdeft_hip ABI version %d, expected %d -- rebuild: python -m deft_amd.build" % (v, ABI_VERSION))
-        # operand pieces of the split arithmetic of this build: 3 = bf16 x 3 (six products), 2 = fp16 x 2 (three products); sizes the piece buffers
-        self.pieces = int(self.cdll.deft_pieces())
+        # operand pieces of the split arithmetic of this set: 3 = bf16 x 3 (six products), 2 = fp16 x 2 (three products); sizes the piece buffers
+        self.pieces = int(self._fn["deft_pieces"]())
+        self._twin = None
+
+    @property
+    def has_twin(self):
+        return not self.suffix and hasattr(self.cdll, "deft_pieces" + TWIN_SUFFIX)
+
+    def twin(self):
+        """The three-bf16-piece entry points of the same library (None when this set is already range-free or the library carries one set)."""
+        if self._twin is None and self.has_twin and self.pieces == 2:
+            self._twin = HipLib(self.path, TWIN_SUFFIX, self.cdll)
+            assert self._twin.pieces == 3
+        return self._twin
+
+    def last_error(self):
+        return self._fn["deft_last_error"]().decode()
 
     profile = None      # set to a list to record (entry, algorithmic_flops, event0, event1, shape, algorithmic_bytes) per call
 
@@ -122,7 +157,7 @@ class HipLib:
             e0.record()
         rc = self._fn[name](*args)
         if rc != 0:
-            raise DeftHipError("%s failed (%d): %s" % (name, rc, self.cdll.deft_last_error().decode()))
+            raise DeftHipError("%s failed (%d): %s" % (name + self.suffix, rc, self.last_error()))
         if prof is not None:
             e1.record()
             fl, info, nbytes = 0.0, "", 0.0
@@ -139,6 +174,12 @@ class HipLib:
                 fl = sum(2.0 * ds[i].M * ds[i].Cout * ds[i].Ktot for i in range(args[2]))
                 nbytes = sum(alg_bytes(ds[i]) for i in range(args[2]))
                 info = "group of %d" % args[2]
+            elif name == "deft_pair_mlp":
+                d = args[0]._obj
+                fl = 2.0 * d.M * (512 * 256 + 256 * 128 + 128 * 64 + 64)
+                nbytes = 4.0 * (d.M + 2.0 * (d.M // max(d.Q, 1) + d.Q) * 512) + 672.0 * 1024
+                ceil = 2500.0 / (6 if self.pieces == 3 else 3)
+                info = "M=%d pair MLP 512-256-128-64-1 fused split" % d.M
             elif name in ("deft_conv2d_nhwc", "deft_dcn_v2_nhwc", "deft_pair_layer", "deft_conv_direct"):
                 d = args[0]._obj
                 fl = 2.0 * d.M * (d.flop_n if d.flop_n else d.Cout) * (d.flop_k if d.flop_k else d.Ktot)
@@ -165,7 +206,7 @@ class HipLib:
             if name == "deft_pair_layer":
                 return True                                  # 128 x 128 or 128 x 64
             t, s, wf, wt = C.c_int(), C.c_int(), C.c_longlong(), C.c_int()
-            if self.cdll.deft_gemm_plan(C.byref(d), 0 if name == "deft_conv2d_nhwc" else 1, C.byref(t), C.byref(s), C.byref(wf), C.byref(wt)) != 0:
+            if self._fn["deft_gemm_plan"](C.byref(d), 0 if name == "deft_conv2d_nhwc" else 1, C.byref(t), C.byref(s), C.byref(wf), C.byref(wt)) != 0:
                 return False
             tile = t.value
         return (tile & 0xffff) >= 64 and not (tile >> 29) & 1
@@ -189,6 +230,8 @@ def get_lib():
             # the unit-test build of the kernels (the SIMT emulator under tests/) runs on host memory: never a product path -- tests hand it over
             # explicitly (hiplib.load / the `lib=` arguments), an environment variable alone must not select it
             raise DeftHipError("%s is the host-memory test build of the kernels, not libdeft_hip.so (deft_amd has no CPU path)" % lib.path)
+        if os.environ.get("DEFT_ARITH", "") == "bf16x3" and lib.twin() is not None:
+            lib = lib.twin()                    # the whole process on the three-bf16-piece entry points (A/B runs, bench.py's side line)
         _lib = lib
         if not lib.host_pointers:
             import atexit

@@ -188,7 +188,7 @@ class ShardedStream:
             self.replay = ReplayAFE(getattr(afe, "plan", None), getattr(afe, "host_copy", True))
             tracker.model.AFE = self.replay
             if hasattr(tracker, "lazy_blocks"):
-                tracker.lazy_blocks = False          # (mot_tracker.Tracker2D) the gathered blocks cover EVERY stored frame: nothing to skip
+                tracker.lazy_blocks = False          # (array_tracker.Tracker2D) the gathered blocks cover EVERY stored frame: nothing to skip
         self.bytes_gathered = 0
 
     # -- (A) frame-local: detection rows + embeddings of the detections the tracker will build ------------------------

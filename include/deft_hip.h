@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 11
+#define DEFT_ABI_VERSION 12
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -80,7 +80,7 @@ typedef struct DeftGemmDesc {
      * accumulation.  NP = 2 (this library): two fp16 pieces (operand to 2^-24 relative inside the fp16 range, csrc/common.h),
      * three v_mfma_f32_32x32x16_f16 products -- 16/3 of the fp32 MFMA rate; the CALLER scales every weight row by a power of two
      * into fp16 range and folds the inverse into `scale` (deft_amd.engine.scale_weight_rows), the kernels scale the activations
-     * by 2^4 themselves.  NP = 3 (libdeft_bf16x3.so, the same sources with -DDEFT_PIECES=3): three bf16 pieces (exact), six
+     * by 2^4 themselves.  NP = 3 (the `_p3` twin of every entry point, see deft_pieces): three bf16 pieces (exact), six
      * v_mfma_f32_32x32x16_bf16 products (all terms down to 2^-24 relative) -- 16/6 of the fp32 MFMA rate, no scaling.
      * Honoured by the tiles with one wave per output sub-tile, BN >= 64 and the 1-stage loop (the 128x32 / 64x32 /
      * 32x32 tiles and the 2-stage form stay on the fp32 instruction: measured no faster there). */
@@ -135,6 +135,14 @@ int deft_version(void);
    pieces * 2 bytes per element.  With 2 pieces the host scales every weight row by a power of two (deft_amd/engine.py weight_row_shift). */
 int deft_pieces(void);
 const char* deft_last_error(void);
+/* BOTH ARITHMETICS IN ONE LIBRARY (round 6).  Every entry point `deft_X` declared in this header whose source holds device code (everything but
+ * the host-side association helpers deft_lapjv / deft_iou3d_matrix / deft_associate_* / deft_kf_*) exists a second time as `deft_X_p3` with the
+ * SAME signature: the same source compiled with three bf16 pieces per operand (deft_pieces_p3() == 3; six matrix instructions per fp32 product,
+ * no range limit on the activations).  Piece buffers (x3 / y3 / w3), weight images and error strings (deft_last_error_p3) belong to ONE of
+ * the two sets -- a caller picks per plan (all launches that exchange piece buffers from the same set).  The Python host builds its plans on
+ * the `deft_X` set and moves a detector to the `_p3` set when a frame's activations leave the fp16 range (deft_amd/detector.py
+ * Detector._switch_to_safe, deft_amd/hiplib.py HipLib.twin); DEFT_ARITH=bf16x3 starts there.  (Build: deft_amd/build.py links the
+ * -DDEFT_PIECES=3 objects with every symbol they define renamed by llvm-objcopy.) */
 
 /* Conv2d (+folded BatchNorm, +residual, +ReLU) as an FP32-MFMA implicit GEMM.
  * Replaces every nn.Conv2d/BatchNorm2d/ReLU triple of DLA-34 and the heads:
@@ -163,6 +171,28 @@ int deft_dcn_v2_nhwc(const DeftGemmDesc* d, void* stream);
  * Replaces AFE_module.forward_stacker2 + the first two blocks of forward_final
  * (AFE.py:190-213) without materialising the [1,832,100,100] tensor. */
 int deft_pair_layer(const DeftGemmDesc* d, void* stream);
+
+/* The WHOLE pair MLP of the affinity estimator in one launch (csrc/pairmlp.hip): AFE_module.forward_stacker2 +
+ * forward_final (AFE.py:190-213) from the separable first layer's U' / V' rows to the relu'd logit of every pair at its place in the
+ * affinity block -- replaces deft_pair_layer + two deft_conv2d_nhwc + phase 1 of deft_affinity_finish; the 448 intermediate floats per pair
+ * stay in registers.  Pair row m = (t, j) = (m / Q, m % Q) (Tper > 0: the batched rows of deft_pair_layer); out[(m / Q) * (Q + 1) + m % Q]
+ * = relu(w5 . h4 + b5); call deft_affinity_finish(h4 = NULL, ...) on `out` afterwards for the dual softmax.
+ * wimg: the weight image of deft_amd.engine.pair_mlp_image (deft_pair_mlp_image_bytes() bytes: 21 chunks of 16 x NP KB, the columns of
+ * W3 / W4 permuted to the accumulator layout of the layer before); s / t: per-channel scale / shift of layers 2, 3, 4 (BatchNorm and bias
+ * folded; with two fp16 pieces the inverse of the weight rows' power-of-two scale folded into s, like DeftGemmDesc.scale). */
+typedef struct DeftPairMlp {
+    const float* U;               /* [rows][ldu] history side of layer 1, fp32                */
+    const float* V;               /* [rows][ldu] current side (bias included)                 */
+    const void* wimg;
+    const float *s2, *t2, *s3, *t3, *s4, *t4;      /* [256] [256] [128] [128] [64] [64]       */
+    const float* w5;              /* [64]                                                     */
+    float* out;
+    float b5;
+    int ldu, M, Q;
+    int Tper, u0, du, v0, dv;     /* as DeftGemmDesc (deft_pair_layer)                        */
+} DeftPairMlp;
+int deft_pair_mlp(const DeftPairMlp* d, void* stream);
+int deft_pair_mlp_image_bytes(void);
 
 /* [N,C,H,W] -> NHWC with channel padding to ld (zeros), and back.  Boundary
  * adapters for detector.py:150 (images) and for handing FeatureMaps out as NCHW. */
@@ -264,7 +294,8 @@ int deft_embed_blend(const float* tmp, const float* bw, const int* map_out, int 
  * history object counts (device array; T = row_start[F] is also passed by value; every frame's count must be <= max_object <=
  * 112 -- a frame that violates it gets NaN rows, the kernel cannot report an error); out [T][Q+1].  The softmaxes subtract their
  * maximum like F.softmax (finite for any logit).  Two launches:
- * all T*Q pairs in parallel, then one block per history frame for the softmaxes (in place on `out`). */
+ * all T*Q pairs in parallel, then one block per history frame for the softmaxes (in place on `out`).  h4 == NULL: the relu'd logits are
+ * in `out` already (deft_pair_mlp) -- only the second launch runs. */
 int deft_affinity_finish(const float* h4, int ldh, int C4, const float* w5, float b5,
                          const int* row_start, int F, int T, int Q, int max_object,
                          float* out, void* stream);

@@ -76,7 +76,7 @@ def main():
             why = "%s: %s" % (type(e).__name__, e)        # 2-D tracker (identical tracks to the reference's, tests/test_mot_tracker.py)
             sys.argv = sys.argv if sys.argv[0] != "test.py" else [__file__]
             from types import SimpleNamespace
-            from deft_amd.mot_tracker import Tracker2D
+            from deft_amd.array_tracker import Tracker2D
             tracker = Tracker2D(SimpleNamespace(dataset="mot", track_buffer=30, max_object=100, lstm=False), SimpleNamespace(AFE=model.AFE), h=H, w=W)
     mk = lambda trk, coll: ShardedStream(detect, model.AFE, model.AFE.plan.D, tracker=trk, dataset="mot", kmax=100, img_h=H, img_w=W, batch=1, device=dev,
                                          force_collective=coll, snapshot=lambda tg: [(int(t.track_id), [float(v) for v in t.tlwh]) for t in tg])

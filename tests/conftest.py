@@ -35,7 +35,7 @@ def emu_lib():
     import subprocess
     from deft_amd import hiplib
     so = os.path.join(ROOT, "tests", "hipemu", "_build", "libdeft_emu.so")
-    srcs = [os.path.join(ROOT, "deft_amd", "csrc", f) for f in ("igemm.hip", "igemm3.hip", "dcn.hip", "direct.hip", "ops.hip", "assoc.hip", "common.h")]
+    srcs = [os.path.join(ROOT, "deft_amd", "csrc", f) for f in ("igemm.hip", "igemm3.hip", "dcn.hip", "direct.hip", "ops.hip", "pairmlp.hip", "assoc.hip", "common.h")]
     srcs += [os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "deft_hip.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh")])

@@ -119,6 +119,14 @@ def test_lstm(emu_lib, dataset):
     pc.check_lstm(emu_lib, "cpu", dataset)
 
 
+def test_pair_mlp_fused(emu_lib, monkeypatch):
+    """The pair MLP as ONE launch, both arithmetics of the library; the persistent workgroups' walk over row tiles (grid capped at 2 for
+    5 tiles: the weight stream runs on across tiles)."""
+    monkeypatch.setenv("DEFT_PAIR_MLP_GRID", "2")
+    pc.check_pair_mlp(emu_lib, "cpu", shapes=((5, 12, 1, 9), (100, 37, 20)), Q=(7, 8))
+    pc.check_pair_mlp(emu_lib.twin(), "cpu", shapes=((3, 4),), Q=(5,), ring=False)
+
+
 def test_affinity(emu_lib):
     import deft_oracle as O
     pc.check_affinity(emu_lib, "cpu", O.synth_state_dict("mot"), golden_tag="mot_128x160")
@@ -408,6 +416,10 @@ def test_late_dma_dcn_patch(late_dma, args):
         pc.check_dcn(late_dma, "cpu", *args, big_offsets=big, patch=True)
 
 
+def test_late_dma_pair_mlp(late_dma):
+    pc.check_pair_mlp(late_dma, "cpu", shapes=((100, 100, 37),), Q=(100,), ring=False)
+
+
 def test_late_dma_dcn_producer_consumer(late_dma):
     for big in (False, True):
         pc.check_dcn_pc_identical(late_dma, "cpu", 2, 9, 19, 64, big_offsets=big, seed=6)
@@ -503,23 +515,18 @@ def test_tracks_against_reference_trace(emu_lib, tag):
     pc.check_tracks_against_reference_trace(emu_lib, "cpu", tag)
 
 
-def test_out_of_range_activation_is_an_error_not_an_empty_frame(emu_lib, monkeypatch):
-    """The two-fp16-piece arithmetic carries activations of |x| < 4094 (csrc/common.h).  Beyond that an operand is +-inf and the heat map NaN --
-    and a NaN map has no peaks: without a check the frame would come back EMPTY.  The fused Detector carries one more field per frame (is
-    every heat-map logit finite?) and raises; a normal frame passes, and so does the same out-of-range frame on a three-bf16-piece build
-    (no range limit) -- checked on the hardware builds by the same function through `lib.pieces`."""
-    from types import SimpleNamespace
-    import deft_oracle as O
-    from deft_amd import detector as FD, hiplib
+def test_out_of_range_activation_is_rerun_on_the_range_free_arithmetic(emu_lib, monkeypatch):
+    from deft_amd import hiplib
     monkeypatch.setattr(hiplib, "_lib", emu_lib)
-    opt = SimpleNamespace(dataset="mot", K=8, max_object=100, gpus=[-1], hip_graphs=False, depth_scale=1.0, flip_test=False)
-    fd = FD.Detector(opt, O.synth_state_dict("mot"))
-    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(2))
-    _, dets, _ = fd.process(x)
-    assert "_finite" not in dets and np.isfinite(dets["scores"]).all() and float(dets["scores"][0, 0]) > 0
-    if emu_lib.pieces == 2:
-        with pytest.raises(FloatingPointError, match="two-fp16-piece"):
-            fd.process(x * 3.0e4)
-    else:
-        _, dets, _ = fd.process(x * 3.0e4)
-        assert np.isfinite(dets["scores"]).all()
+    pc.check_out_of_range_fallback(emu_lib, -1)
+
+
+def test_non_finite_similarity_is_an_error():
+    """the embedding / affinity chain has no heat map behind it -- its overflow shows in the similarity matrix, which the
+    native cascade would read as gated pairs.  array_tracker checks it where it lands on the host."""
+    from deft_amd import array_tracker as AT
+    AT._finite_sim(None)
+    AT._finite_sim(np.ones((3, 4), np.float32))
+    bad = np.ones((3, 4), np.float32); bad[1, 2] = np.nan
+    with pytest.raises(FloatingPointError, match="similarity"):
+        AT._finite_sim(bad)

@@ -1,4 +1,4 @@
-"""-m "not gpu" (build container: needs /root/reference): deft_amd.mot_tracker.Tracker2D -- the 2-D tracking loop as arrays, on the
+"""-m "not gpu" (build container: needs /root/reference): deft_amd.array_tracker.Tracker2D -- the 2-D tracking loop as arrays, on the
 device forms -- against the REFERENCE's own `Tracker` frame by frame: same track ids, same boxes, same activation flags, over a
 scene with births, a two-frame occlusion, an empty frame, a crossing pair and tracks that age out.  The embedding / affinity side is
 a cheap deterministic stand-in (so the association logic is what is compared); tests/test_reference_detector.py and the GPU replay
@@ -103,7 +103,7 @@ def _log(targets):
 
 @pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
 def test_tracker2d_matches_reference_tracker(emu_lib, dataset):
-    from deft_amd import mot_tracker as MT
+    from deft_amd import array_tracker as MT
     nframes = 40
     opt, ref = _reference(dataset, types.SimpleNamespace(AFE=FakeAFE()))
     MT.TrackIds.count = 0
@@ -130,7 +130,7 @@ def test_kalman_batch_forms_match_reference_filter():
     """kf_initiate / kf_multi_predict / kf_multi_update against utils/tracking_utils/kalman_filter.py (its per-track Cholesky update)."""
     _reference("mot", types.SimpleNamespace(AFE=FakeAFE()))
     from utils.tracking_utils.kalman_filter import KalmanFilter
-    from deft_amd import mot_tracker as MT
+    from deft_amd import array_tracker as MT
     kf = KalmanFilter()
     g = np.random.default_rng(0)
     meas = np.stack([g.uniform(10, 500, 9), g.uniform(10, 300, 9), g.uniform(0.3, 0.6, 9), g.uniform(40, 200, 9)], 1)
@@ -177,7 +177,7 @@ def test_lazy_affinity_blocks_change_nothing(emu_lib):
     """Tracker2D.lazy_blocks: the new frame is scored only against the stored frames that hold one of the pool's selected nodes (the
     reference scores all of them, tracker.py:76-90, and reads a few).  A crowded random scene with drop-outs and re-finds: identical
     outputs frame by frame with and without, and the lazy run really asked for fewer blocks."""
-    from deft_amd import mot_tracker as MT
+    from deft_amd import array_tracker as MT
     opt = types.SimpleNamespace(dataset="mot", track_buffer=30, max_object=100, lstm=False)
     g = np.random.RandomState(5)
     base = np.concatenate([g.rand(30, 2) * np.array([170.0, 90.0]), g.rand(30, 2) * 8 + 10], 1)
@@ -217,7 +217,7 @@ def test_native_association_equals_the_numpy_stages(emu_lib, dataset):
     """ArrayTracker.native_assoc: the cascade of a frame through deft_associate_2d + deft_kf_predict / deft_kf_update (one host call each) against the
     numpy stages (which the reference-tracker tests above pin) on the crowded random scene with drop-outs and re-finds: the same tracks in the same
     order frame by frame (ids, activation, length, score identical; boxes to 1e-9: the native Kalman update sums in another order than BLAS)."""
-    from deft_amd import mot_tracker as MT
+    from deft_amd import array_tracker as MT
     opt = types.SimpleNamespace(dataset=dataset, track_buffer=30, max_object=100, lstm=False)
     g = np.random.RandomState(11)
     base = np.concatenate([g.rand(30, 2) * np.array([170.0, 90.0]), g.rand(30, 2) * 8 + 10], 1)
@@ -259,7 +259,7 @@ def test_begin_ahead_changes_nothing(emu_lib, dataset):
     """ArrayTracker.begin(results, FeatureMaps): the device half of the NEXT frame queued behind update(k).  Same tracks as plain update() calls when
     every frame is begun ahead; and a begin() for a frame that never comes (update() is handed another frame's detections) is taken back -- the
     recorder's stored frames, evicted entries included (a stream longer than its 50-frame window), are what they were."""
-    from deft_amd import mot_tracker as MT
+    from deft_amd import array_tracker as MT
     opt = types.SimpleNamespace(dataset=dataset, track_buffer=30, max_object=100, lstm=False)
     nframes = 64
     frames = [[dict(r) for r in _scene(t % 24, dataset)] for t in range(nframes)]
@@ -352,7 +352,7 @@ def _reference_lstm(dataset, model, lstm, lsd):
 
 
 def _mine(opt, emu_lib, lsd):
-    from deft_amd import integrate, mot_tracker as MT, tracker as DT
+    from deft_amd import integrate, array_tracker as MT, tracker as DT
     MT.TrackIds.count = 0
     afe = FakeAFE()
     afe.plan = types.SimpleNamespace(lib=emu_lib, _stream=lambda: None)
@@ -402,7 +402,7 @@ def test_lstm_gate_with_300_observations_matches_fuse_motion(emu_lib):
     """matching.fuse_motion's branch for LSTM tracks with >= 300 observations (matching.py:342-353: Mahalanobis on the predicted box with
     np.cov of the observations): the tracker's running scatter against np.cov, and its gate against deft_amd.association.fuse_motion
     (pinned to the reference by tests/golden/association.npz)."""
-    from deft_amd import association as A, mot_tracker as MT
+    from deft_amd import association as A, array_tracker as MT
     g = np.random.RandomState(4)
     T, n = 6, 320
     obs = g.randn(T, n, 4) * np.array([30, 20, 0.05, 10]) + np.array([300, 200, 0.5, 80])

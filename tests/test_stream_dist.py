@@ -205,7 +205,7 @@ def test_stream_with_real_kernels_matches_level0_loop(emu_lib):
             got += st.step([x])
         assert got == level0 and sum(len(f) for _, f in level0) > 0
         # the repository's own 2-D tracker on the association rank (what run_stream.py uses where the reference tree is absent): same tracks
-        from deft_amd import mot_tracker as MT
+        from deft_amd import array_tracker as MT
         model.AFE = afe0
         MT.TrackIds.count = 0
         trk3 = MT.Tracker2D(types.SimpleNamespace(dataset="mot", track_buffer=30, max_object=100, lstm=False), types.SimpleNamespace(AFE=model.AFE),

@@ -5,7 +5,7 @@
   track similarity D2H of the frame's affinity blocks + per-track numpy medians (tracker.py:219-252, 663-688)
                    vs `deft_amd.tracker.get_similarity` (deft_track_similarity; only [T, N+1] comes back).
 
-  tracker update   deft_amd.mot_tracker.Tracker2D.update (the 2-D association loop on the device forms) over a synthetic scene of
+  tracker update   deft_amd.array_tracker.Tracker2D.update (the 2-D association loop on the device forms) over a synthetic scene of
                    `tracks` objects with the recorder full (`stored` frames): total per frame, and inside it the embedding extraction,
                    FeatureRecorder.update (the affinity chain), get_similarity, fuse_motion, lapjv, bbox_overlaps, the batched Kalman
                    steps, and the remaining per-track Python.
@@ -38,7 +38,7 @@ def timeit(fn, reps):
 def tracker_update_split(T, R, dev, H=608, W=1088, nframes=40):
     """Tracker2D.update on T drifting objects (every object detected every frame -> T tracks x T detections), real embedding /
     affinity kernels on random FeatureMaps of the config-B shapes, recorder filled with R frames before timing."""
-    from deft_amd import association as A, mot_tracker as MT, hiplib
+    from deft_amd import association as A, array_tracker as MT, hiplib
     from deft_amd.engine import View
     sd = synth.synth_state_dict("mot")
     lib = hiplib.get_lib()

@@ -7,8 +7,9 @@ python -m deft_amd.build > /dev/null
 EXTRA=""; [ "$SRC" = "dcn.hip" ] && EXTRA="-fno-slp-vectorize"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops $EXTRA "$@" -c deft_amd/csrc/$SRC -o /tmp/variant_$NAME.o
 OBJS=""
-for f in igemm.hip igemm3.hip dcn.hip direct.hip ops.hip assoc.hip; do
+for f in igemm.hip igemm3.hip dcn.hip direct.hip ops.hip pairmlp.hip assoc.hip; do
     if [ "$f" = "$SRC" ]; then OBJS="$OBJS /tmp/variant_$NAME.o"; else OBJS="$OBJS deft_amd/lib/obj/$f.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o deft_amd/lib/libdeft_$NAME.so $OBJS
+# (the three-bf16-piece twins of the product library ride along unchanged: deft_amd/build.py)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o deft_amd/lib/libdeft_$NAME.so $OBJS $(ls deft_amd/lib/obj_twin/*.o)
 echo deft_amd/lib/libdeft_$NAME.so

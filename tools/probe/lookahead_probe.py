@@ -4,7 +4,7 @@ import numpy as np, torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from types import SimpleNamespace
-from deft_amd import detector as FD, synth, integrate, mot_tracker as MT, hiplib
+from deft_amd import detector as FD, synth, integrate, array_tracker as MT, hiplib
 sd = dict(synth.synth_state_dict("mot"))
 sd["ltrb_amodal.2.weight"] = sd["ltrb_amodal.2.weight"] * 0.05
 sd["ltrb_amodal.2.bias"] = torch.tensor([-5.0, -8.0, 5.0, 8.0])
