@@ -281,10 +281,15 @@ def oracle_margin(logit, K):
 
 
 def tie_class_ok(logit, gk, ok, tau):
-    """Is the device's ordered key list `gk` one that SOME heat map within tau / 2 of the oracle's `logit` decodes to?  (Necessary conditions, each
-    decided on the oracle's map alone: every reported key could be a kept peak and could reach the top K; the order is non-increasing up to tau; every
-    oracle key the device does not report could have been suppressed or pushed out.)  This is what two correct fp32 implementations whose logits
-    differ by e = tau / 2 can disagree about -- and nothing else."""
+    """Is the device's ordered key list `gk` one that SOME heat map within tau / 2 of the oracle's `logit` decodes to?  Necessary conditions, each
+    decided on the oracle's map alone:
+      (a) every reported key could be a kept peak there (it is within tau of its strongest 3x3 neighbour, or above it);
+      (b) the reported order is non-increasing in the oracle's logits up to tau;
+      (c) every PEAK of the oracle's map that is not reported and lies more than tau above the lowest reported key could have been suppressed
+          (it is within tau of its strongest neighbour) -- otherwise it would outrank that key on any map within tau / 2.
+    (Not: "every new key is within tau of the oracle's K-th score" -- when a near-tie merges two oracle peaks into one on the device, the list is
+    one peak short and the oracle's (K + 1)-th moves up legitimately, however far below the K-th it scores.)  This is what two correct fp32
+    implementations whose logits differ by e = tau / 2 can disagree about -- and nothing else."""
     import torch.nn.functional as F
     C, h, w = logit.shape
     if len(set(gk)) != len(gk) or len(gk) != len(ok):
@@ -293,12 +298,13 @@ def tie_class_ok(logit, gk, ok, tau):
     nb8 = F.unfold(pad, 3).view(C, 9, h * w)
     nbx = torch.cat([nb8[:, :4], nb8[:, 5:]], 1).max(1).values.reshape(-1)
     flat = logit.reshape(-1)
-    kth = float(flat[ok[-1]])
     g = torch.tensor(gk, dtype=torch.long)
-    fine = bool((flat[g] >= nbx[g] - tau).all()) and bool((flat[g] >= kth - tau).all())
-    fine = fine and bool((flat[g][:-1] >= flat[g][1:] - tau).all())
-    for k in set(ok) - set(gk):
-        fine = fine and (float(flat[k]) <= kth + tau or float(flat[k] - nbx[k]) <= tau)
+    fine = bool((flat[g] >= nbx[g] - tau).all())                                        # (a)
+    fine = fine and bool((flat[g][:-1] >= flat[g][1:] - tau).all())                     # (b)
+    vmin = float(flat[g].min())
+    cand = (flat >= nbx) & (flat > vmin + tau)                                          # (c): the oracle's peaks above the reported range ...
+    cand[g] = False                                                                     # ... that are not reported ...
+    fine = fine and bool(((flat - nbx)[cand] <= tau).all())                             # ... must be suppressible
     return fine
 
 

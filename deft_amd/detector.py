@@ -121,6 +121,11 @@ class Detector(object):
             self._plans[key]._gkey = key
         return self._plans[key]
 
+    def _minv(self, sh, sw, n=1):
+        """dst -> src matrices [n, 6] of the input warp for sh x sw frames in this detector's input mode (preprocess.input_geometry)."""
+        from . import preprocess as PR
+        return np.tile(PR.invert_affine(PR.input_geometry(self.opt, sh, sw)[0])[None], (n, 1))
+
     def _plan_u8(self, N, H, W, sh, sw):
         """The plan for uint8 HWC frames of sh x sw (run() on a camera frame): its OWN plan and graph key -- use_u8_input rewrites the
         plan's first launch for good, so sharing the fp32 plan of process() would make a later process() call on the same input size
@@ -128,7 +133,7 @@ class Detector(object):
         key = ("u8", N, H, W, sh, sw)
         if key not in self._plans:
             p = engine.DlaSegPlan(self.sd, N, H, W, self.dataset, K=self.K, device=self.device, lib=self.lib)
-            p.use_u8_input(sh, sw)
+            p.use_u8_input(sh, sw, minv=self._minv(sh, sw, N))
             p._gkey = key
             self._plans[key] = p
         return self._plans[key]
@@ -282,9 +287,11 @@ class Detector(object):
 
     # ---- frame in -> tracks out: Detector.run (detector.py:112-344) on the fused path ----------------------------------------
     def _meta_for(self, height, width, inp_h, inp_w, input_meta):
-        """The meta dict of Detector.pre_process in fix_res mode (detector.py:363-367, 395-415), without touching the pixels."""
+        """The meta dict of Detector.pre_process (detector.py:346-415: fix_short / fix_res / keep_res, preprocess.input_geometry), without
+        touching the pixels."""
         from . import preprocess as PR
-        M, c, s = PR.input_affine(height, width, inp_h, inp_w)
+        M, c, s, gh, gw = PR.input_geometry(self.opt, height, width)
+        assert (gh, gw) == (inp_h, inp_w)
         calib = np.array(input_meta["calib"], dtype=np.float32) if "calib" in input_meta else \
             np.array([[1200.0, 0, width / 2, 0], [0, 1200.0, height / 2, 0], [0, 0, 1, 0]], np.float32)      # _get_default_calib, detector.py:424-428
         meta = {"calib": calib, "c": c, "s": s, "height": height, "width": width, "out_height": inp_h // 4, "out_width": inp_w // 4,
@@ -345,8 +352,8 @@ class Detector(object):
         if not pre_processed:
             assert frame.dtype == np.uint8 and frame.ndim == 3 and frame.shape[2] == 3
             sh, sw = frame.shape[:2]
-            inp_h, inp_w = int(getattr(opt, "input_h", 0)), int(getattr(opt, "input_w", 0))
-            assert inp_h > 0 and inp_w > 0, "the device pre-processing is the fix_res mode (opt.input_h / input_w)"
+            from . import preprocess as PR
+            _, _, _, inp_h, inp_w = PR.input_geometry(opt, sh, sw)        # fix_short / fix_res / keep_res (detector.py:346-376)
             meta = self._meta_for(sh, sw, inp_h, inp_w, meta)
             akey = (inp_h, inp_w, sh, sw)
             if getattr(opt, "flip_test", False):
@@ -487,7 +494,7 @@ class Detector(object):
         def __init__(self, det, inp_h, inp_w, sh, sw, n=1):
             self.n = n
             self.plan = engine.DlaSegPlan(det.sd, n, inp_h, inp_w, det.dataset, K=det.K, device=det.device, lib=det.lib)
-            self.plan.use_u8_input(sh, sw)
+            self.plan.use_u8_input(sh, sw, minv=det._minv(sh, sw, n))
             cuda = det.device.type == "cuda"
             self.stage = torch.empty(n, sh, sw, 3, dtype=torch.uint8, pin_memory=cuda)
             self.stage_np = self.stage.numpy()

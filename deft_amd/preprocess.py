@@ -25,6 +25,49 @@ def input_affine(height, width, inp_h, inp_w):
     return np.linalg.solve(A, dst.astype(np.float64)).T, c, s
 
 
+def _affine(c, src_w, inp_h, inp_w):
+    """utils/image.get_affine_transform(c, s, 0, [inp_w, inp_h]) with src_w = s[0] (image.py:42-72): three point pairs, float64 solve."""
+    c = np.asarray(c, np.float32)
+    src = np.zeros((3, 2), np.float32); dst = np.zeros((3, 2), np.float32)
+    src[0] = c
+    src[1] = c + np.array([0.0, np.float32(src_w) * -0.5], np.float32)
+    dst[0] = [inp_w * 0.5, inp_h * 0.5]
+    dst[1] = np.array([inp_w * 0.5, inp_h * 0.5], np.float32) + np.array([0, inp_w * -0.5], np.float32)
+    for p in (src, dst):
+        d = p[0] - p[1]
+        p[2] = p[1] + np.array([-d[1], d[0]], np.float32)
+    A = np.concatenate([src.astype(np.float64), np.ones((3, 1))], 1)
+    return np.linalg.solve(A, dst.astype(np.float64)).T
+
+
+def input_geometry(opt, height, width):
+    """Detector._transform_scale + trans_input (detector.py:346-385) at test scale 1, for the three input modes of the reference:
+      fix_short > 0   the short side becomes opt.fix_short, the long side follows the aspect ratio rounded up to a multiple of 64;
+                      c = (w / 2, h / 2), s = (w, h);
+      fix_res         (the default: opts.py `fix_res = not keep_res`) opt.input_h x opt.input_w, c = (w / 2, h / 2), s = max(h, w);
+      keep_res        the frame's own size padded to a multiple of opt.pad + 1, c = (w // 2, h // 2), s = (inp_w, inp_h).
+    -> (trans_input 2x3 float64, c float32[2], s (float32 scalar or [2], as the reference keeps it in `meta`), inp_h, inp_w)."""
+    fix_short = int(getattr(opt, "fix_short", 0) or 0)
+    if fix_short > 0:
+        if height < width:
+            inp_h, inp_w = fix_short, (int(width / height * fix_short) + 63) // 64 * 64
+        else:
+            inp_h, inp_w = (int(height / width * fix_short) + 63) // 64 * 64, fix_short
+        c = np.array([width / 2, height / 2], dtype=np.float32)
+        s = np.array([width, height], dtype=np.float32)
+    elif getattr(opt, "fix_res", not getattr(opt, "keep_res", False)):
+        inp_h, inp_w = int(getattr(opt, "input_h", 0)), int(getattr(opt, "input_w", 0))
+        assert inp_h > 0 and inp_w > 0, "fix_res mode needs opt.input_h / opt.input_w"
+        M, c, s = input_affine(height, width, inp_h, inp_w)
+        return M, c, s, inp_h, inp_w
+    else:
+        pad = int(getattr(opt, "pad", 31))
+        inp_h, inp_w = (height | pad) + 1, (width | pad) + 1
+        c = np.array([width // 2, height // 2], dtype=np.float32)
+        s = np.array([inp_w, inp_h], dtype=np.float32)
+    return _affine(c, s[0], inp_h, inp_w), c, s, inp_h, inp_w
+
+
 def invert_affine(M):
     """The dst -> src matrix cv2.warpAffine computes from a forward matrix (imgwarp.cpp: D = 1/det, b = -A^-1 t), float64 [6]."""
     M = np.asarray(M, np.float64)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--no-tracker", action="store_true", help="exchange only (records + affinity blocks on every rank)")
     ap.add_argument("--host-detect", action="store_true", help="the round-2 detect path (NCHW adapter, host decode): for A/B")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
+    ap.add_argument("--tracks-out", default=None, help="rank 0: write every frame's tracks [(frame, [(id, tlwh)])] to this JSON file (tools/scale_check.sh compares N ranks with one)")
     args = ap.parse_args()
     H, W = [int(v) for v in args.size.split("x")]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,7 +85,7 @@ def main():
     ref = mk(None, False) if args.check else None
     if ref is not None:
         ref.collective, ref.world, ref.rank = False, 1, 0
-    ok, ntracks = True, 0
+    ok, ntracks, track_log = True, 0, []
     nsteps = args.frames // world
     nwarm = (args.warmup // world) if args.bench else 0
     frames = [torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(500 + t)).to(dev) for t in range(min(nsteps + nwarm, 24) * world)]
@@ -98,6 +99,8 @@ def main():
     for s in range(nwarm, nwarm + nsteps):
         out = st.step([fr(s)])
         ntracks += sum(len(tg) for _, tg in out)
+        if args.tracks_out and rank == 0:
+            track_log += [[int(f), [[int(i), [round(float(v), 4) for v in b]] for i, b in tg]] for f, tg in out]
         if ref is not None and world == 1:
             ref.step([fr(s)])
             ok &= torch.equal(st.all_rec, ref.all_rec) and torch.equal(st.all_blk, ref.all_blk)
@@ -133,6 +136,9 @@ def main():
         if args.out:
             os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
             json.dump(line, open(args.out, "w"), indent=1)
+        if args.tracks_out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.tracks_out)), exist_ok=True)
+            json.dump(track_log, open(args.tracks_out, "w"))
     if dist.is_initialized():
         dist.destroy_process_group()
     sys.exit(0 if ok else 1)

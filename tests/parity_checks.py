@@ -1549,7 +1549,7 @@ def check_fused_run_prefetch(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=9
         hiplib._lib = saved_lib
 
 
-def check_fused_run_u8(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=4):
+def check_fused_run_u8(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=4, mode="fix_res"):
     """deft_amd.detector.Detector.run on a raw uint8 frame (device pre-processing -> fused process -> vectorised post-process ->
     merge -> tracker hand-over) against the same stages fed by the host restatement of Detector.pre_process (oracle.preprocess_u8:
     the arithmetic deft_preprocess_u8 reproduces bit for bit): identical detections, and the tracker receives them with the
@@ -1562,6 +1562,11 @@ def check_fused_run_u8(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=4):
     try:
         opt = SimpleNamespace(dataset="mot", K=K, max_object=100, gpus=[0 if device != "cpu" else -1], hip_graphs=True, depth_scale=1.0,
                               input_h=H, input_w=W, out_thresh=-1.0, test_scales=[1.0], flip_test=False, public_det=False)
+        if mode == "fix_short":                          # detector.py:355-362: the short side becomes fix_short, the long side a multiple of 64
+            opt.fix_short, opt.input_h, opt.input_w = H, 0, 0
+        elif mode == "keep_res":                         # detector.py:368-372: the frame's own size padded to a multiple of pad + 1
+            opt.fix_short, opt.fix_res, opt.pad, opt.input_h, opt.input_w = 0, False, 31, 0, 0
+        M, c, s, H, W = PR.input_geometry(opt, sh, sw)   # (fix_res: H, W as given)
         det = Detector(opt, sd)
         calls = []
 
@@ -1577,7 +1582,6 @@ def check_fused_run_u8(lib, device, sh=45, sw=80, H=64, W=96, K=12, seed=4):
             out = det.run(frame)
             assert out == ["tracks of %d detections" % K] and calls[-1] == (K, 13)
             got = det.last_results
-            M, c, s = PR.input_affine(sh, sw, H, W)
             images = O.preprocess_u8(frame, M, W, H, PR.MEAN, PR.STD)                       # [1, 3, H, W] float32, the reference's pre_process
             det2 = Detector(opt, sd)
             _, dets, _ = det2.process(images)

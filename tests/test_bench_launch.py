@@ -44,3 +44,15 @@ def test_bench_one_rank_standin_has_no_collective():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["distributed"]["collectives_per_step"] == 0 and out["distributed"]["backend"] is None
+
+
+def test_bench_config_E_two_replicas_no_collective():
+    """BASELINE configs[4] (nuScenes: one camera stream per GPU) as two ranks: independent replicas inside the process group -- no collective in
+    the step, the line says so (tools/scale_check.sh asserts the same of the RCCL run)."""
+    r = _run(["--gpus", "2", "--config", "E", "--standin", "--steps", "3", "--warmup", "1", "--batch", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["distributed"]["ranks"] == 2 and out["distributed"]["backend"] == "gloo"
+    assert out["distributed"]["collectives_per_step"] == 0 and out["distributed"]["bytes_gathered_per_step_per_rank"] == 0
+    assert "replicas" in out["config"]["parallelism"] and out["config"]["config"] == "E"
+    assert abs(out["value"] - 3 * 4 * 2 / (out["ms_per_step"] * 3e-3)) / out["value"] < 0.02        # whole-job frames/s over both replicas

@@ -621,8 +621,9 @@ def test_device_detect_record(gpu_lib, dataset):
     pc.check_device_detect(gpu_lib, "cuda", dataset, H=128, W=160, K=100, first_n=30)
 
 
-def test_fused_detector_run_on_uint8_frames(gpu_lib):
-    pc.check_fused_run_u8(gpu_lib, "cuda", sh=270, sw=480, H=128, W=160, K=50)
+@pytest.mark.parametrize("mode", ["fix_res", "fix_short", "keep_res"])
+def test_fused_detector_run_on_uint8_frames(gpu_lib, mode):
+    pc.check_fused_run_u8(gpu_lib, "cuda", sh=270, sw=480, H=128, W=160, K=50, mode=mode)
 
 
 def test_fused_run_with_lookahead(gpu_lib):

@@ -1,6 +1,8 @@
 """-m "not gpu": host-side logic of the seam objects that needs no reference checkout: the motion-model
 seam's constructor/caching and `gating_distance` (kalman_filter_lstm.py:80-102), node selection of the track
 similarity (tracker.py:219-252), slot management of the motion bank."""
+import os
+import sys
 from types import SimpleNamespace
 
 import numpy as np
@@ -185,6 +187,32 @@ def test_gate_tie_class_rejects_a_wrong_list():
     assert not bench.tie_class_ok(logit, ok[:-1] + [ok[0]], ok, 1e-4)      # a repeated key
 
 
+def test_gate_tie_class_accepts_a_merged_peak():
+    """Two oracle peaks A, B with the pixel C between them a hair below both: an implementation whose logits are 1e-4 away may find C on top,
+    report ONE peak where the oracle has two, and take the oracle's (K + 1)-th detection in -- however far below the K-th it scores.  That list is
+    inside the tie class; a list that takes some other low pixel in is not."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    g = torch.Generator().manual_seed(4)
+    logit = torch.full((1, 12, 40), -9.0)
+    vals = torch.linspace(3.0, 1.0, 12)
+    cols = list(range(2, 38, 3))                               # 12 isolated peaks on row 2 ...
+    for v, c in zip(vals, cols):
+        logit[0, 2, c] = v
+    logit[0, 8, 10], logit[0, 8, 11], logit[0, 8, 12] = 5.0, 5.0 - 4e-5, 5.0 - 2e-5      # ... and A, C, B on row 8
+    K = 10
+    ok = _decode(logit, K)
+    A, Cc, B = 8 * 40 + 10, 8 * 40 + 11, 8 * 40 + 12
+    assert ok[0] == A and ok[1] == B                           # the oracle keeps A and B (+ the 8 best of row 2)
+    dev = logit.clone(); dev[0, 8, 11] += 1e-4                 # the device sees C on top: one peak instead of two
+    gk = _decode(dev, K)
+    assert Cc in gk and A not in gk and B not in gk and gk[-1] == 2 * 40 + cols[8]        # the oracle's 11-th detection moved in, 0.18 below the 10-th
+    assert bench.tie_class_ok(logit, gk, ok, 2.5e-4)
+    bad = list(gk); bad[-1] = 2 * 40 + cols[10]                # a list that skips the oracle's next detection for a lower one
+    assert not bench.tie_class_ok(logit, bad, ok, 2.5e-4)
+
+
 def test_peaked_head_classes():
     """deft_amd.synth.peaked_head with several classes: every class map is a blob map, the K best peaks are well separated (what bench.py's peaked
     gate stream relies on)."""
@@ -200,3 +228,37 @@ def test_peaked_head_classes():
             out = {"hm": O.head_forward(feat, sd2, "hm")}
         assert out["hm"].shape[1] == C
         assert bench.oracle_margin(out["hm"][0], 40) >= 1e-3
+
+
+def test_input_geometry_modes():
+    """preprocess.input_geometry: the three input modes of Detector._transform_scale (detector.py:346-376).  Sizes by hand; and, where the
+    reference tree is present, (c, s, inp size, trans_input) against the reference's own _transform_scale + get_affine_transform."""
+    from deft_amd import preprocess as PR
+    o = SimpleNamespace(fix_short=0, fix_res=True, input_h=608, input_w=1088, pad=31)
+    M, c, s, ih, iw = PR.input_geometry(o, 1080, 1920)
+    assert (ih, iw) == (608, 1088) and float(s) == 1920.0 and c.tolist() == [960.0, 540.0]
+    M, c, s, ih, iw = PR.input_geometry(SimpleNamespace(fix_short=512, fix_res=True, input_h=608, input_w=1088, pad=31), 1080, 1920)
+    assert (ih, iw) == (512, 960) and s.tolist() == [1920.0, 1080.0]            # int(1920 / 1080 * 512) = 910 -> 960
+    M, c, s, ih, iw = PR.input_geometry(SimpleNamespace(fix_short=0, fix_res=False, input_h=0, input_w=0, pad=31), 375, 1242)
+    assert (ih, iw) == (384, 1248) and s.tolist() == [1248.0, 384.0] and c.tolist() == [621.0, 187.0]
+    if not os.path.isdir("/root/reference/src/lib"):
+        return
+    import ref_import, ref_shims, make_golden as MG
+    ref_shims.install(); ref_import.install_stubs(MG.OracleDCN); ref_shims.install_detector_stubs()
+    import cv2
+    cv2.resize = lambda im, size: im                                        # (scale 1: the identity)
+    argv, sys.argv = sys.argv, ["test.py", "tracking"]
+    try:
+        from detector import Detector as RefDetector
+        from utils.image import get_affine_transform
+    finally:
+        sys.argv = argv
+    for h, w in ((1080, 1920), (375, 1242), (900, 1600), (480, 640), (640, 480)):
+        for o in (SimpleNamespace(fix_short=0, fix_res=True, input_h=608, input_w=1088, pad=31), SimpleNamespace(fix_short=512, fix_res=True, input_h=0, input_w=0, pad=31),
+                  SimpleNamespace(fix_short=0, fix_res=False, input_h=0, input_w=0, pad=31)):
+            img = np.zeros((h, w, 3), np.uint8)
+            _, rc, rs, riw, rih, _, _ = RefDetector._transform_scale(SimpleNamespace(opt=o), img)
+            rM = get_affine_transform(rc, rs, 0, [riw, rih])
+            M, c, s, ih, iw = PR.input_geometry(o, h, w)
+            assert (ih, iw) == (rih, riw) and np.array_equal(np.asarray(c), np.asarray(rc)) and np.array_equal(np.asarray(s), np.asarray(rs))
+            assert np.abs(M - rM).max() <= 1e-12
