@@ -156,9 +156,18 @@ class Detector(object):
         self._ahead, self._plans, self._graphs = {}, {}, {}
         self._launch_next = self._peeked = self._fm_ready = None
         self.lib = twin
-        new = engine.AfePlan(self.sd, getattr(self.opt, "max_object", 100), self.device, twin)
-        self.afe.__dict__.clear()                      # in place: the tracker (model.AFE.plan) holds this object
-        self.afe.__dict__.update(new.__dict__)
+        def move(plan):                                # in place: whoever holds the plan object keeps it
+            if getattr(plan, "lib", None) is not None and plan.lib is not twin and getattr(plan.lib, "pieces", 3) == 2:
+                new = engine.AfePlan(self.sd, plan.max_object, self.device, twin, align_corners=plan.align_corners)
+                plan.__dict__.clear()
+                plan.__dict__.update(new.__dict__)
+        move(self.afe)
+        # the trackers' own embedding / affinity plans (model.AFE.plan: integrate.AfeSeam builds one per model) run the same split arithmetic
+        trks = list(self.tracker.values()) if isinstance(self.tracker, dict) else ([self.tracker] if self.tracker is not None else [])
+        for t in trks:
+            plan = getattr(getattr(getattr(t, "model", None), "AFE", None), "plan", None)
+            if isinstance(plan, engine.AfePlan):
+                move(plan)
         self.arith = "bf16x3"
         return True
 

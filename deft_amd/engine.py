@@ -1596,14 +1596,14 @@ class AfePlan(_Plan):
             self._ring = {}
         if key not in self._ring:
             dev = self.device
-            Mc = 1 if fused else CH * hist * K * K
+            Mc = CH * hist * K * K
             buf = {"U": torch.empty(R * K, 512, dtype=torch.float32, device=dev),
                    "V": torch.empty(R * K, 512, dtype=torch.float32, device=dev),
-                   "h2": torch.empty(Mc, c2, dtype=torch.float32, device=dev),
-                   "h3": torch.empty(Mc, c3, dtype=torch.float32, device=dev),
-                   "h4": torch.empty(Mc, c4, dtype=torch.float32, device=dev),
                    "out": torch.empty(Bc, hist * K, K + 1, dtype=torch.float32, device=dev),
                    "rs": torch.arange(0, CH * hist + 1, dtype=torch.int32, device=dev) * K}
+            if not fused:
+                buf.update({"h2": torch.empty(Mc, c2, dtype=torch.float32, device=dev), "h3": torch.empty(Mc, c3, dtype=torch.float32, device=dev),
+                            "h4": torch.empty(Mc, c4, dtype=torch.float32, device=dev)})
             self._ring[key] = buf
         b = self._ring[key]
         self._lin(ring, R * K, D, D, self.Ua, self.Kd, 512, None, None, False, b["U"], 512)

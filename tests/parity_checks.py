@@ -1686,7 +1686,7 @@ class _BesideForeign:
 
 def check_co_residency_afe_lstm(lib, H=256, W=256, N=8, K=100, ndet=32, hist=4):
     """VERDICT r4: the product also overlaps the AfePlan chain (embedding extraction: deft_embed_rows / deft_conv2d_group / deft_embed_blend;
-    affinity: the U' / V' layer-1 products, deft_pair_layer, layers 3 - 4, deft_affinity_finish -- ring form and list form) and
+    affinity: the U' / V' layer-1 products, deft_pair_mlp (or deft_pair_layer + layers 3 - 4), deft_affinity_finish -- ring form and list form) and
     LstmPlan.motion_step / step with the NEXT step's detection on the other stream (pipeline.py cross-step overlap).  Each of those launches
     beside a foreign matrix-core launch (a 3x3 conv of another sub-batch plan), every output and every intermediate buffer bit for bit against
     the same chain run alone."""
@@ -1757,8 +1757,9 @@ def check_co_residency_afe_lstm(lib, H=256, W=256, N=8, K=100, ndet=32, hist=4):
                                                                                      co[k_].view(torch.uint8) if co[k_].dtype != torch.int32 else co[k_])}
     assert not bad, "launches of the AFE / LSTM chain differ beside a foreign matrix-core kernel: %s" % bad
     names = set(beside.calls)
-    for want in ("deft_embed_rows", "deft_conv2d_group", "deft_embed_blend", "deft_conv2d_nhwc", "deft_pair_layer", "deft_affinity_finish",
-                 "deft_motion_step", "deft_lstm_step"):
+    fused = "deft_pair_mlp" in names                         # (round 6: layers 2-5 of the pair MLP as one launch, engine.PAIR_MLP)
+    for want in ("deft_embed_rows", "deft_conv2d_group", "deft_embed_blend", "deft_conv2d_nhwc", "deft_pair_mlp" if fused else "deft_pair_layer",
+                 "deft_affinity_finish", "deft_motion_step", "deft_lstm_step"):
         assert want in names, "the chain never launched %s" % want
     return len(beside.calls), sorted(names)
 
@@ -1989,3 +1990,52 @@ def check_pair_mlp(lib, device, shapes=((5, 12, 1, 9), (100, 37)), Q=(7, 100), s
             ref = torch.cat([torch.from_numpy(O.afe_affinity(rg[t].cpu().unsqueeze(0), rg[3 + c].cpu().unsqueeze(0), sd, 100)) for t in range(3 + c - H, 3 + c)], 0)
             assert maxabs(a[c], ref) <= 1e-4, (c, maxabs(a[c], ref))
     return worst
+
+
+def check_graph_replay_survives_tracker_teardown(lib, device="cuda", H=96, W=160, K=20, frames=6):
+    """nothing a live hipGraph replays into may be freed by the tracker's teardown.  A fused Detector with a lookahead pass
+    in flight and captured graphs; its trackers are closed, the tracking reset (detector.py:677-686), the MotionBank slots handed back, the
+    Python garbage collected and the caching allocator emptied -- ON PURPOSE, several times, between frames; every frame must still come back
+    identical to a fresh detector's (which has never seen a teardown)."""
+    import gc
+    from types import SimpleNamespace
+    from deft_amd import hiplib, integrate, array_tracker as MT, tracker as DT
+    from deft_amd.detector import Detector
+    sd = O.synth_state_dict("mot")
+    saved_lib, hiplib._lib = hiplib._lib, lib
+    try:
+        opt = SimpleNamespace(dataset="mot", K=K, max_object=100, gpus=[0 if device != "cpu" else -1], hip_graphs=True, depth_scale=1.0, input_h=H, input_w=W,
+                              out_thresh=0.0, test_scales=[1.0], flip_test=False, public_det=False, track_buffer=30, lstm=True)
+
+        def make():
+            det = Detector(opt, sd)
+            model = SimpleNamespace(AFE=integrate.AfeSeam(sd, 100, device, lib))
+            model.motion = DT.MotionBank(engine.LstmPlan(O.synth_lstm_state_dict("mot"), device, lib))
+            det.set_tracker(MT.ArrayTracker(opt, model, h=H, w=W), factory=lambda o, h, w: MT.ArrayTracker(o, model, h=h, w=w))
+            return det
+        g = np.random.RandomState(3)
+        fr = [g.randint(0, 256, (H * 2, W * 2, 3)).astype(np.uint8) for _ in range(frames)]
+        snap = lambda tg: sorted((int(t.track_id), [round(float(v), 3) for v in t.tlwh]) for t in tg)
+        MT.TrackIds.count = 0
+        ref_det = make()
+        want = []
+        for k in range(frames):
+            if k == frames // 2:
+                ref_det.reset_tracking(opt)
+            want.append(snap(ref_det.run(fr[k], prefetch=fr[k + 1] if k + 1 < frames else None)))
+        MT.TrackIds.count = 0
+        det = make()
+        for k in range(frames):
+            if k == frames // 2:
+                det.reset_tracking(opt)                     # closes the old tracker (bank slots back), drops the queued lookahead pass
+            got = snap(det.run(fr[k], prefetch=fr[k + 1] if k + 1 < frames else None))
+            assert got == want[k], (k, got[:2], want[k][:2])
+            # teardown noise between frames: a throw-away tracker on the same model is built, used for nothing, closed and collected
+            t2 = MT.ArrayTracker(opt, det.tracker.model, h=H, w=W)
+            t2.close(); del t2
+            gc.collect()
+            if device != "cpu":
+                torch.cuda.synchronize(); torch.cuda.empty_cache()
+        return len(want)
+    finally:
+        hiplib._lib = saved_lib

@@ -780,6 +780,12 @@ def test_bench_parity_gate_on_the_timed_plans(gpu_lib):
     assert out["n_gpus"] == 1 and out["config"]["frames_per_step_per_gpu"] == 32 and out["config"]["hip_streams"] == 2
 
 
+def test_graph_replay_survives_tracker_teardown(gpu_lib):
+    """parity_checks.check_graph_replay_survives_tracker_teardown: captured hipGraphs and queued lookahead passes against tracker close / reset /
+    garbage collection / allocator flushes between frames."""
+    assert pc.check_graph_replay_survives_tracker_teardown(gpu_lib, "cuda") == 6
+
+
 def test_pair_mlp_fused(gpu_lib):
     """deft_pair_mlp on the hardware: small shapes, the config sizes (5 x (100 x 100), 4 x (32 x 32)), the ring form, both arithmetics."""
     pc.check_pair_mlp(gpu_lib, "cuda", shapes=((5, 12, 1, 9), (100, 100, 100, 100, 100), (32, 32, 32, 32)), Q=(7, 100, 32))
