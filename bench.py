@@ -73,11 +73,12 @@ for _n, _c in CONFIGS.items():
     _c["name"] = _n
 
 
-def cpu_baseline(cfg, frames=5, threads=None):
+def cpu_baseline(cfg, frames=5, threads=None, all_cores=False):
     """kind=port: oracle/deft_oracle.py on the host cores (GPU not used): one full-size warm-up frame, then the median of
     `frames` timed frames of the same config.  threads: default min(host cpus, CPU_THREADS_CAP) -- ATen's CPU convs stop scaling (and thrash) far
-    below the GPU box's 256 hardware threads; the all-cores figure SURVEY 8(d) names (`torch.set_num_threads(os.cpu_count())`) is measured once
-    beside it (`all_cores`, fewer frames) so that the cap is a stated choice, not a hidden one."""
+    below the GPU box's 256 hardware threads.  The all-cores figure SURVEY 8(d) names (`torch.set_num_threads(os.cpu_count())`) was measured once
+    (profiles/r6_cpu_all_cores.json: 0.0051 frames/s at 256 threads -- 196 s per frame -- against 0.333 at 32) and is quoted in the line; measuring it
+    again costs ~10 minutes and is opt-in (`--cpu-all-cores`): the default run has to finish within minutes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import deft_oracle as O
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -115,7 +116,10 @@ def cpu_baseline(cfg, frames=5, threads=None):
            "kind_note": "the oracle restatement (pinned to the reference's modules, oracle/make_golden.py): the reference tree is absent on the GPU box",
            "sample": "1 full-size warm-up + median of %d frames of %dx%d (DLA-34+DCNv2+decode+embed(%d)+%dx(%dx%d) affinity%s), %d threads"
                      % (len(t_all), W, H, nd, hist, nd, nd, " + %d LSTM steps" % nd if lsd is not None else "", torch.get_num_threads())}
-    if threads is None and ncpu > CPU_THREADS_CAP:                      # the all-cores figure, once: 1 warm-up + 2 frames
+    if ncpu > CPU_THREADS_CAP and not all_cores:
+        rep["all_cores"] = {"measured_once": "profiles/r6_cpu_all_cores.json", "value": 0.0051, "cores": 256, "unit": "frames/s", "config": "B",
+                            "note": "torch.set_num_threads(256) on the round-6 GPU box: 196 s per frame (32 threads: 0.333 frames/s); --cpu-all-cores re-measures (~10 min)"}
+    if threads is None and ncpu > CPU_THREADS_CAP and all_cores:        # the all-cores figure: 1 warm-up + 2 frames (minutes per frame at 256 threads)
         torch.set_num_threads(ncpu)
         ta = []
         with torch.no_grad():
@@ -662,8 +666,8 @@ def side_config(name, args, dev, lib, rank):
     return out
 
 
-TRAFFIC_FILE = "r5_traffic.json"
-COUNTER_FILE = "r5_dominant_counters.json"
+TRAFFIC_FILE = "r6_traffic.json"
+COUNTER_FILE = "r6_dominant_counters.json"
 # SURVEY 8(d)'s lower bound of the HBM bytes one step has to move: every frame's image read once (4 B x 3 x H x W), the weights once per
 # step (85 MB), detections + embeddings + affinity blocks written once
 ALG_BYTES_PER_STEP = {"B": 32 * (608 * 1088 * 3 * 4 + 100 * 416 * 4 + 500 * 101 * 4) + 85_000_000}
@@ -689,11 +693,12 @@ def main():
     ap.add_argument("--standin", action="store_true",
                     help="TEST ONLY: CPU stand-in compute + gloo, to exercise the --gpus N launch path without GPUs; the line is marked invalid")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: print the cpu_baseline object of --config and exit (no GPU)")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="cpu_baseline: also time the oracle with torch.set_num_threads(os.cpu_count()) (~10 minutes on a 256-CPU host)")
     ap.add_argument("--e2e-only", default=None, choices=sorted(E2E), help="internal: print the end_to_end object of that config and exit")
     ap.add_argument("--e2e-frames", type=int, default=100)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(CONFIGS[args.config])), flush=True)
+        print(json.dumps(cpu_baseline(CONFIGS[args.config], all_cores=args.cpu_all_cores)), flush=True)
         return
     if args.e2e_only:
         from deft_amd import hiplib
@@ -937,8 +942,8 @@ def main():
         # one is visible -- AFE.py:104-108, image.py:410-412 -- and this process's HIP runtime threads would share the host cores)
         import subprocess
         env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config], capture_output=True, text=True,
-                           env=env, timeout=900)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config] + (["--cpu-all-cores"] if args.cpu_all_cores else []),
+                           capture_output=True, text=True, env=env, timeout=1800 if args.cpu_all_cores else 900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode == 0 and line:
             cpu = json.loads(line[-1])
