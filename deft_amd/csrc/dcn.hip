@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
 }
 
 // ---- Producer / consumer form of the 64-column tile (round 6; two fp16 pieces only) --------------------------------------------------------
-// What the counters of dcn_patch_kernel<2, 3, true> say (profiles/r6_dcn_counters.md: matrix pipe 0.20 busy, VALU ~0.4, LDS array 0.31, every wave
+// What the counters of dcn_patch_kernel<2, 3, true> say (profiles/r6_dcn_producer_consumer.md: matrix pipe 0.20 busy, VALU ~0.4, LDS array 0.31, every wave
 // 36 % of its life issuing, two waves per SIMD): nothing is saturated -- one in-order wave does gather -> blend -> split -> MFMA -> weight DMA ->
 // fragment reads in sequence, and two such waves per SIMD do not cover each other's latencies.  Here the SAME work of a workgroup (8 x 16 pixels,
 // 64 columns, the same patch / weight images, the same arithmetic in the same order: bit-identical results) is split over EIGHT waves:

@@ -43,10 +43,10 @@ if os.path.exists(st):
             break
         out.append("| `%s` | %s | %.2f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                     float(r["AverageNs"]) / 1e3, r["Percentage"]))
-    ig = [(int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(st)) if "igemm" in r["Name"] or "conv3h" in r["Name"] or "direct_conv" in r["Name"] or "dcn_patch" in r["Name"]]
+    ig = [(int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(st)) if any(t in r["Name"] for t in ("igemm", "conv3h", "direct_conv", "dcn_patch", "dcn_pc", "pair_mlp"))]
     if ig:
         out.append("")
-        out.append("All `igemm*` / `conv3h` / `direct_conv` / `dcn_patch` kernels together: %d launches, average %.1f us (compare `roofline.avg_launch_us` of the bench line; "
+        out.append("All `igemm*` / `conv3h` / `direct_conv` / `dcn_patch` / `pair_mlp` kernels together: %d launches, average %.1f us (compare `roofline.avg_launch_us` of the bench line; "
                    "this pass runs the launches serialised on one stream, like bench.py's per-launch HIP-event measurement)."
                    % (sum(c for c, _ in ig), sum(t for _, t in ig) / sum(c for c, _ in ig) / 1e3))
     out.append("")
@@ -102,14 +102,14 @@ if os.path.exists(fe) and os.path.exists(wr):
     out.append("")
 if os.path.exists(fe) and os.path.exists(wr):
     # dominant kernel family for bench.py's roofline.traffic: HBM bytes per launch, averaged over all igemm launches
-    fk = [k for k in pf if "igemm" in k or "conv3h" in k or "direct_conv" in k or "dcn_patch" in k]
+    fk = [k for k in pf if any(t in k for t in ("igemm", "conv3h", "direct_conv", "dcn_patch", "dcn_pc", "pair_mlp"))]
     nl = sum(nf[k] for k in fk)
     fetch = sum(pf[k]["FETCH_SIZE"] for k in fk) * 1024.0 * 2.0          # KiB -> B, gfx950 wide-stream correction x2
     write = sum(pw.get(k, {}).get("WRITE_SIZE", 0.0) for k in fk) * 1024.0
     # the whole step: every kernel's bytes over the number of steps the run made (two sub-batch plans per step: one layout kernel each)
     nsteps = max(1, sum(nf[k] for k in pf if "nchw_to_nhwc" in k or "preprocess_u8" in k) // 2)
     all_bytes = sum(v["FETCH_SIZE"] for v in pf.values()) * 1024.0 * 2.0 + sum(v.get("WRITE_SIZE", 0.0) for v in pw.values()) * 1024.0
-    json.dump({"kernel": "igemm* + conv3h + direct_conv + dcn_patch", "launches": nl, "fetch_bytes_per_launch": fetch / max(nl, 1), "write_bytes_per_launch": write / max(nl, 1),
+    json.dump({"kernel": "igemm* + conv3h + direct_conv + dcn_patch + pair_mlp", "launches": nl, "fetch_bytes_per_launch": fetch / max(nl, 1), "write_bytes_per_launch": write / max(nl, 1),
                "traffic_bytes_per_launch": (fetch + write) / max(nl, 1),
                "steps_in_the_run": nsteps, "traffic_bytes_per_step": all_bytes / nsteps,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof.sh), KiB units, FETCH_SIZE x2 per "
