@@ -18,17 +18,21 @@ A 512x512 + 32x128 affinity; D KITTI 1280x384 + 30x150 affinity + LSTM motion up
 per GPU (replicas: no collective) + 3-D LSTM motion update.
 
 Extra objects in the JSON line:
-  parity          the parity gate, in the same command and outside the timed region (--no-check skips it): the first and last frame of each sub-batch plan (0, 15, 16, 31) of the
-                  timed plan's own step (B frames per GPU on the sub-batch plans and HIP streams that `value` is measured on) against
-                  the oracle (oracle/deft_oracle.py as the CHECKER): ordered top-K (class, index), scores, boxes, embeddings and
-                  the [hist*N, N+1] affinity blocks of FramePipeline.step.
+  parity          the parity gate, in the same command and outside the timed region (--no-check skips it), on the timed plans' own configuration
+                  (B frames per GPU as sub-batch plans on their HIP streams), against the oracle (oracle/deft_oracle.py as the CHECKER) -- three
+                  streams (parity_gate): `raw` = first / last frame of each sub-batch plan of the timed step (0, 15, 16, 31): scores, boxes,
+                  embeddings, the [hist*N, N+1] affinity blocks of FramePipeline.step and the heat-map logits within tolerance, index differences
+                  only inside the oracle's own tie class (the strict verdict is reported as raw.pass); `decidable` = frames mined from the oracle
+                  alone for a well-conditioned top-K (tests/golden/gate_seeds.json) in the same slots: ordered (class, index) equality demanded;
+                  `peaked` = 32 trained-shaped heat maps through a twin of the timed sub-batch plan: ordered equality demanded outright.
+                  `pass` = all three; a compact copy lives in config.parity.
   configs         BASELINE configs A / D / E on the same GPU, compact (value, ms/step, roofline.frac, parity of frame 0).
-  roofline        the implicit-GEMM kernel family (conv / DCNv2 / pair launches of the step): algorithmic FLOPs
-                  (2*M*Cout*K per launch, no padding) / launch time (HIP events on the launch stream) against the
-                  TIME-WEIGHTED ceiling of the instructions each launch issues (bf16 dense / 6 = 416.7 TFLOP/s for
-                  the split-bf16 launches, 157.3 for the fp32-MFMA launches); the fp32-priced figure is kept as
-                  `frac_of_fp32_mfma_peak`.
-  cpu_baseline    the oracle (PyTorch-CPU restatement pinned against the reference modules) on this box's host cores:
+  roofline        the matrix-core kernel family (conv / DCNv2 / fused pair-MLP launches of the step): algorithmic FLOPs
+                  (2*M*Cout*K per launch, no padding) over the timed step, against the TIME-WEIGHTED ceiling of the
+                  instructions each launch issues (2500 / 3 = 833 TFLOP/s for two-fp16-piece launches, 2500 / 6 = 417 for
+                  three-bf16-piece ones, 157.3 for the fp32-MFMA launches); `dominant_kernel` = the shape with the largest share.
+  cpu_baseline    the oracle (PyTorch-CPU restatement pinned against the reference modules) on this box's host cores
+                  (min(cpus, 32) threads, stated; the all-cores figure is quoted from its one measurement):
                   one full-size warm-up frame, then the median of 5 timed frames.
   sustained       the same step loop continued until the GPU has been busy >= 5 s (not part of `value`).
   latency_mode    one frame per step per GPU, hipGraph replay (what every GPU runs in BASELINE configs[2] / [4]).

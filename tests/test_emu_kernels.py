@@ -419,7 +419,7 @@ def test_late_dma_dcn_patch(late_dma, args):
 
 
 def test_late_dma_pair_mlp(late_dma):
-    pc.check_pair_mlp(late_dma, "cpu", shapes=((100, 100, 37),), Q=(100,), ring=False)
+    pc.check_pair_mlp(late_dma, "cpu", shapes=((40, 31),), Q=(20,), ring=False)          # 6 row tiles, the weight ring under late delivery
 
 
 def test_late_dma_dcn_producer_consumer(late_dma):
