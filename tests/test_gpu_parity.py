@@ -769,7 +769,7 @@ def test_bench_parity_gate_on_the_timed_plans(gpu_lib):
     assert set(cp["max_err"]) == {"score", "bbox", "embedding", "affinity", "hm_logit"} and max(cp["max_err"].values()) <= 1e-3
     assert par["floats_within_tol"] and par["pass_up_to_roundoff_ties"], par
     assert par["max_err"]["affinity"] <= 1e-3 and par["max_err"]["embedding"] <= 1e-3 and par["max_err"]["bbox"] <= 1e-3
-    assert par["max_err"]["hm_logit"] <= par["margin_threshold"] / 2
+    assert par["max_err"]["hm_logit"] <= 2.5e-4
     for f in par["frames"]:
         assert f["common_detections"] >= 97 and f["embedding_rows_compared"] >= 97
     dec = par["decidable"]
@@ -804,6 +804,25 @@ def test_twin_arithmetic_forward_matches_oracle(gpu_lib):
     assert t is not None and t.pieces == 3
     plan, rep, _ = pc.check_forward(t, "cuda", "mot", 128, 160, golden_tag="mot_128x160", sd=O.synth_state_dict("mot"))
     assert plan.np == 3
+
+
+def test_float_errors_over_seeds_on_the_timed_plans(gpu_lib):
+    """the FLOAT errors (embedding, bbox, score, heat-map logit, affinity) of the device path against the oracle over input
+    seeds, on the timed plans' configuration (32 frames per step, 2 x 16 on two HIP streams), for BOTH arithmetics of the library on one oracle
+    pass (tools/probe/float_sweep.py; the 64 / 16 / 16 / 16-seed runs are profiles/r6_float_sweep_*.json).  Bars: the north-star 1e-3 on every
+    float, the gate's heat-map bound, and no index difference outside the oracle's tie class.  (The maxima over 64 seeds are 9.3e-4 / 1.4e-4:
+    the distance is fp32 summation order -- both arithmetics sit at the same level -- so the bar here is the stated one, not a tighter one.)"""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "float_sweep.py"), "A", "8"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for arith in ("fp16x2", "bf16x3"):
+        mx = rep[arith]["max"]
+        assert mx["embedding"] <= 1e-3 and mx["bbox"] <= 1e-3 and mx["score"] <= 1e-3 and mx["affinity"] <= 1e-3, (arith, mx)
+        assert mx["hm_logit"] <= 2.5e-4 and rep[arith]["frames_outside_tie_class"] == 0, (arith, mx)
+    assert rep["fp16x2"]["max"]["embedding"] <= 2.0 * rep["bf16x3"]["max"]["embedding"] + 1e-4          # the two arithmetics sit at the same level
 
 
 def test_launches_bit_exact_beside_another_kernel(gpu_lib):
