@@ -478,11 +478,8 @@ __global__ __launch_bounds__(256, DEFORM ? 2 : 3) void dcn_patch_kernel(DeftGemm
 #define DCNPC_R 3
 #endif
 #define DPC_ABLK (DEFT_NP * 2 * 128 * 16)              // one A stage: [piece][k group][128 rows][8 halves]
-// Measurement builds only (tools/build_variant.sh ... -DDCNPC_ABL=<bits>; WRONG RESULTS by construction): what each part of a step costs.
-// 1 no far path | 2 no corner reads | 4 no blend + split | 8 no A write | 16 no MFMAs | 32 no DMA in the loop | 64 no A read
-#ifndef DCNPC_ABL
-#define DCNPC_ABL 0
-#endif
+// (The ablation switches behind profiles/r6_dcn_producer_consumer.md -- no far path / corner reads / blend / A write / MFMAs / DMA / A read -- are kept as
+// profiles/r6_dcn_pc_ablation_switches.patch, not in this file.)
 // Scheduling pins of the producer step (no instruction is emitted).  DCNPC_PIN(b): the four blended values exist HERE and no memory operation moves
 // across this point -- the next chunk's corner reads go into the registers the blend has just released (hoisted above it they would need 16 more
 // registers per half: spills at 128).  DCNPC_ARRIVED(v): the four corner vectors are consumed no earlier than HERE -- without it the compiler
@@ -573,9 +570,9 @@ __global__ __launch_bounds__(512, 4) void dcn_pc_kernel(DeftGemmDesc p, int tile
         // corner values of one (row, tap, 16-channel block), HALF h of the lane's 8 channels (plane 2 g + h): v[corner].  Every lane reads the patch
         // (a far lane some valid address); the far lanes then load their corners from global memory into the same registers (see dcn_patch_kernel).
         auto gather_half = [&](unsigned c, int bufoff, int cb, int h, f32x4 (&v)[4]) {
-            const bool far = !(DCNPC_ABL & 1) && (c & 0x80000000u) != 0u;
-            if (!(DCNPC_ABL & 2)) {
-                const char* const a = patch + bufoff + h * DP_PLANE + (((c & 0x80000000u) != 0u) ? (unsigned)(g * 2 * DP_PLANE) : c);
+            const bool far = (c & 0x80000000u) != 0u;
+            {
+                const char* const a = patch + bufoff + h * DP_PLANE + (far ? (unsigned)(g * 2 * DP_PLANE) : c);
                 v[0] = *(const f32x4*)(a);
                 v[1] = *(const f32x4*)(a + 16);
                 v[2] = *(const f32x4*)(a + DP_PW * 16);
@@ -605,30 +602,21 @@ __global__ __launch_bounds__(512, 4) void dcn_pc_kernel(DeftGemmDesc p, int tile
             // (the blend of a half is FINISHED before its registers are handed to the next chunk's reads: the scheduler would otherwise hoist the
             // reads above the blend -- 16 more live registers per half, spills at the 128 the four-waves-per-SIMD occupancy allows)
             DCNPC_ARRIVED(va);
-            f32x4 b0 = (DCNPC_ABL & 4) ? va[0] : blend_half(va, rw0[tap], rw1[tap], rw2[tap], rw3[tap]);
+            f32x4 b0 = blend_half(va, rw0[tap], rw1[tap], rw2[tap], rw3[tap]);
             DCNPC_PIN(b0);
             if (more) gather_half(rc[gtap], gbuf, gcb, 0, va);
             DCNPC_ARRIVED(vb);
-            f32x4 b1 = (DCNPC_ABL & 4) ? vb[0] : blend_half(vb, rw0[tap], rw1[tap], rw2[tap], rw3[tap]);
+            f32x4 b1 = blend_half(vb, rw0[tap], rw1[tap], rw2[tap], rw3[tap]);
             DCNPC_PIN(b1);
             if (more) gather_half(rc[gtap], gbuf, gcb, 1, vb);
             unsigned h0, h1, h2, h3, m0, m1, m2, m3;
-            if (DCNPC_ABL & 4) {
-                h0 = __float_as_uint(b0[0]); h1 = __float_as_uint(b0[1]); h2 = __float_as_uint(b0[2]); h3 = __float_as_uint(b0[3]);
-                m0 = __float_as_uint(b1[0]); m1 = __float_as_uint(b1[1]); m2 = __float_as_uint(b1[2]); m3 = __float_as_uint(b1[3]);
-            } else {
-                deft_split2_pair(b0[0], b0[1], h0, m0);
-                deft_split2_pair(b0[2], b0[3], h1, m1);
-                deft_split2_pair(b1[0], b1[1], h2, m2);
-                deft_split2_pair(b1[2], b1[3], h3, m3);
-            }
+            deft_split2_pair(b0[0], b0[1], h0, m0);
+            deft_split2_pair(b0[2], b0[3], h1, m1);
+            deft_split2_pair(b1[0], b1[1], h2, m2);
+            deft_split2_pair(b1[2], b1[3], h3, m3);
             char* const ap = Ad + stage * DPC_ABLK + arow;
-            if (!(DCNPC_ABL & 8)) {
-                *(u32x4*)(ap) = u32x4{h0, h1, h2, h3};
-                *(u32x4*)(ap + 4096) = u32x4{m0, m1, m2, m3};
-            } else {
-                asm volatile("" :: "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(m0), "v"(m1), "v"(m2), "v"(m3));
-            }
+            *(u32x4*)(ap) = u32x4{h0, h1, h2, h3};
+            *(u32x4*)(ap + 4096) = u32x4{m0, m1, m2, m3};
         };
 
         DEFT_PIPE_BARRIER_ONLY();                      // P0: the first patch has landed (the consumers waited for it)
@@ -720,23 +708,20 @@ __global__ __launch_bounds__(512, 4) void dcn_pc_kernel(DeftGemmDesc p, int tile
                         DEFT_PIPE_BARRIER_ONLY();
                     }
                     pcx8 pa[DEFT_NP];
-                    if (!(DCNPC_ABL & 64) || kc == 0) {
+                    {
                         const char* const ap = Ad + cur * DPC_ABLK + arow;
 #pragma unroll
                         for (int q = 0; q < DEFT_NP; ++q) pa[q] = *(const pcx8*)(ap + q * 4096);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < DEFT_NP; ++q) pa[q] = pb[cur][0][q];
                     }
                     // weights three chunks ahead into the stage whose fragments every consumer read one step ago; the next block's patch
-                    if (!(DCNPC_ABL & 32) && (tap < 6 || !last_blk)) issue_b(kc + 3, st);
-                    if (!(DCNPC_ABL & 32) && !last_blk) {
+                    if (tap < 6 || !last_blk) issue_b(kc + 3, st);
+                    if (!last_blk) {
 #pragma unroll
                         for (int i = DP_PARTS * tap / PT; i < (tap < PT ? DP_PARTS * (tap + 1) / PT : 0); ++i) issue_patch(cb + 1, half ^ 1, i);
                     }
                     if (more) read_b((tap + 1) % 3, pb[cur ^ 1]);
 #pragma unroll
-                    for (int q = 0; q < ((DCNPC_ABL & 16) ? 1 : DEFT_NPROD); ++q) {
+                    for (int q = 0; q < DEFT_NPROD; ++q) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) acc[0][j] = deft_mfma_pc(pa[deft_qa(q)], pb[cur][j][deft_qb(q)], acc[0][j]);
                     }

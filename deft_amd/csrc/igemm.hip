@@ -26,14 +26,6 @@ typedef deft_f32x16 f32x16;
 
 enum { MODE_CONV = 0, MODE_DCN = 1, MODE_PAIR = 2 };
 
-// Bisection hooks of the round-4 packed-fp32 fault (profiles/r6_pkf32_bisect.md): wait states behind the sampling-record arithmetic (A) / behind the
-// four-corner blend (B) of MODE_DCN.  Empty in the product (which is built without packed fp32 VALU altogether, deft_amd/build.py).
-#ifndef DEFT_PKF32_PROBE_A
-#define DEFT_PKF32_PROBE_A do {} while (0)
-#endif
-#ifndef DEFT_PKF32_PROBE_B
-#define DEFT_PKF32_PROBE_B do {} while (0)
-#endif
 
 #define LDS_STRIDE 36
 #define ROW_INVALID (-(1 << 28))
@@ -229,7 +221,6 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                     o1 = (hl_c * p.W + wl_c) * (p.ldx * 4) | (wh_c - wl_c) | ((hh_c - hl_c) << 1);       // pixel stride is a multiple of 16 bytes
                 }
             }
-            DEFT_PKF32_PROBE_A;
             *(f32x4*)(prm + idx * 4) = f32x4{w1, w2, w3, w4};
             pof[idx] = o1;
         }
@@ -374,7 +365,6 @@ __device__ __forceinline__ void igemm_body(const DeftGemmDesc& p, int mtiles, in
                 v = s0[i];
             } else if (MODE == MODE_DCN) {      // (with PREC the operand scale DEFT_ASCALE is applied by deft_split below)
                 v = sw[i].x * s0[i] + sw[i].y * s1[i] + sw[i].z * s2[i] + sw[i].w * s3[i];
-                DEFT_PKF32_PROBE_B;
             } else {
                 const f32x4 t = s0[i] + s1[i];
                 v = f32x4{deft_relu(t.x), deft_relu(t.y), deft_relu(t.z), deft_relu(t.w)};
