@@ -88,6 +88,17 @@ class Detector(object):
         self.opt = opt
         self.device = torch.device("cuda" if getattr(opt, "gpus", [0])[0] >= 0 else "cpu")
         self.lib = hiplib.get_lib()            # the plans below refuse a CPU device with the HIP library (no CPU path)
+        # opt.deft_arith: "auto" (default) = two fp16 pieces, moving to the range-free three-bf16-piece entry points of the same library by itself when a
+        # frame overflows (_switch_to_safe); "bf16x3" = start there (a model whose activations are known to be large: tools/validate_checkpoint.py
+        # reports a checkpoint's largest activation against the fp16-piece range); "fp16x2" = never move (an overflow raises FloatingPointError)
+        want = getattr(opt, "deft_arith", "auto")
+        assert want in ("auto", "fp16x2", "bf16x3"), want
+        if want == "bf16x3" and getattr(self.lib, "pieces", 3) == 2:
+            twin = self.lib.twin()
+            if twin is None:
+                raise hiplib.DeftHipError("opt.deft_arith = 'bf16x3': this library carries no three-bf16-piece entry points")
+            self.lib = twin
+        self._arith_fixed = want == "fp16x2"
         self.arith = "fp16x2" if getattr(self.lib, "pieces", 3) == 2 else "bf16x3"
         self.sd = state_dict
         self.dataset = opt.dataset
@@ -145,7 +156,7 @@ class Detector(object):
         affinity plan the tracker shares -- to the three-bf16-piece entry points of the SAME library (hiplib.HipLib.twin(): six matrix instructions
         per fp32 product instead of three, no range limit, ~25 % slower) for the rest of its life.  Returns False when there is nothing to switch
         to (the library carries one arithmetic, or this detector is on the range-free one already)."""
-        twin = self.lib.twin() if hasattr(self.lib, "twin") else None
+        twin = self.lib.twin() if hasattr(self.lib, "twin") and not getattr(self, "_arith_fixed", False) else None
         if twin is None:
             return False
         import warnings

@@ -1959,6 +1959,20 @@ def check_out_of_range_fallback(lib, gpu):
         out2, _ = O.dlaseg_forward(x, sd, "mot")
     od2 = O.generic_decode(O.sigmoid_output(out2), K=8)
     assert np.array_equal(dets2["inds"][0], od2["inds"][0].numpy()) and np.abs(dets2["scores"][0] - od2["scores"][0].numpy()).max() <= 1e-4
+    # opt.deft_arith: "bf16x3" starts on the range-free entry points, "fp16x2" never leaves the two-piece ones (the overflow is an error again)
+    opt.deft_arith = "bf16x3"
+    f3 = FD.Detector(opt, sd)
+    assert f3.arith == "bf16x3" and f3.lib.pieces == 3
+    _, d3, _ = f3.process(x * 3.0e4)
+    assert np.abs(d3["scores"][0] - od["scores"][0].numpy()).max() <= 1e-3
+    opt.deft_arith = "fp16x2"
+    f2 = FD.Detector(opt, sd)
+    try:
+        f2.process(x * 3.0e4)
+        raise AssertionError("opt.deft_arith = 'fp16x2' must not fall back")
+    except FloatingPointError:
+        pass
+    assert f2.arith == "fp16x2"
     return fd
 
 
