@@ -193,6 +193,7 @@ def _parse_tile(spec):
 
 
 P3_IM2COL_TILE = _parse_tile(_os.environ.get("DEFT_P3_IM2COL_TILE", ""))
+P3_IM2COL_WIDE = _os.environ.get("DEFT_P3_IM2COL_WIDE", "1") != "0"      # 128 x 128 (two-stage) im2col tiles on the deep layers with enough tiles
 P3_STRIDE2 = _os.environ.get("DEFT_P3_STRIDE2", "0") == "1"      # tuning aid: stride-2 3x3 convs with Cin >= 64 on the im2col piece kernel
 P3H_TPI3 = 1 << 27         # halo tile flag: a filter row (three taps) per weight stage and barrier
 P3H_TPI3_64 = _os.environ.get("DEFT_P3H_TPI3_64", "0") == "1"      # tuning aid: the 64-column 8 x 16 tiles on three taps per interval
@@ -321,6 +322,11 @@ def p3_choice(KH, KW, stride, pad, Cin, Cout, H, W, M, korder):
     # the ONE-stage loop with several workgroups per CU (48 / 37 KB of LDS: 3 / 4 of them) beats the 2-stage ring with one 8-wave
     # workgroup on every shape (profiles/r2_bench_p3.log: 256->256 @38x68 179 vs 150 TFLOP/s, 64->64 @152x272 148 vs 120)
     tile = (_T(64, 128) if Cout >= 128 else _T(128, 64)) | P3_1STAGE
+    # round 6 (profiles/r6_im2col_tile_ab.log, two repetitions inside one call): the 128 x 128 tile on the TWO-stage ring -- half the weight
+    # traffic from L2 per output row -- is +0.7 % of the config-B step on the deep layers (256->256 @38x68, 512->512 @19x34) where it still
+    # leaves the launch enough tiles; the one-stage 64 x 128 tile (four workgroups per CU) otherwise
+    if Cout >= 128 and P3_IM2COL_WIDE and -(-M // 128) * -(-Cout // 128) >= P3_MIN_TILES:
+        tile = _T(128, 128)
     if P3_IM2COL_TILE and Cout >= 128:          # tuning aid: "BMxBN[:stages]" for the deep 128+-column layers
         tile = P3_IM2COL_TILE
     bm, bn = (tile >> 16) & 0x1fff, tile & 0xffff
