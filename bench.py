@@ -617,7 +617,7 @@ def roofline_of(wl, lib, rank, dt_step, config):
     roof = {"bound": "mfma", "achieved": round(pipe_ach, 3), "peak": round(peak_w, 1), "unit": "TFLOP/s",
             "frac": round(pipe_ach / peak_w, 4), "frac_basis": "algorithmic FLOPs of the step's matrix-core launches / the timed two-stream step",
             "serialized_achieved": round(ach, 3), "serialized_frac": round(ach / peak_w, 4), "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": tsrc,
-            "traffic_bytes_per_step": tstep, "algorithmic_bytes_per_step_lower_bound": ALG_BYTES_PER_STEP.get(config),
+            "traffic_bytes_per_step": tstep, "algorithmic_bytes_per_step_lower_bound": (images.shape[0] * ALG_BYTES_PER_FRAME[config] + 85_000_000) if config in ALG_BYTES_PER_FRAME else None,
             "algorithmic_bytes_per_launch": round(sum(r[4] for r in gemm) / max(1, n_launch)),
             "kernel": "matrix-core conv family: igemm_kernel / igemm3_kernel / conv3h_kernel / direct_conv_kernel / dcn_patch_kernel / pair_mlp_kernel (conv, DCNv2, the fused pair MLP; fp32 results)",
             "peak_note": ("time-weighted ceiling of the instructions issued: %.1f%% of the launch time on split kernels (" % (100.0 * split_ms / max(gemm_ms, 1e-9)))
@@ -677,7 +677,7 @@ TRAFFIC_FILE = "r6_traffic.json"
 COUNTER_FILE = "r6_dominant_counters.json"
 # SURVEY 8(d)'s lower bound of the HBM bytes one step has to move: every frame's image read once (4 B x 3 x H x W), the weights once per
 # step (85 MB), detections + embeddings + affinity blocks written once
-ALG_BYTES_PER_STEP = {"B": 32 * (608 * 1088 * 3 * 4 + 100 * 416 * 4 + 500 * 101 * 4) + 85_000_000}
+ALG_BYTES_PER_FRAME = {"B": 608 * 1088 * 3 * 4 + 100 * 416 * 4 + 500 * 101 * 4}       # image in, embeddings + affinity blocks out (+ 85 MB of weights per step)
 
 
 def main():
@@ -686,7 +686,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (round 6: 64 = two 32-frame sub-batch plans; 32 measured 1.8 % slower at B, "
+                                                             "5 - 8 % at A / D / E: profiles/r6_knob_ab.log)")
     ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle parity gate (profiling runs)")

@@ -749,10 +749,10 @@ def test_dataflow_schedule_bit_identical(gpu_lib, N, H, W):
 
 
 def test_bench_parity_gate_on_the_timed_plans(gpu_lib):
-    """The parity gate of BASELINE.md section 3 runs inside the bench command, on the plans the timed loop runs (32 frames per step as two
-    16-frame sub-batch plans on two HIP streams -- halo / patch / pre-split kernels, not the one-frame plan of the other full-size tests), and its
-    verdict is DECIDABLE: the raw frames 0, 15, 16, 31 (floats; index differences only inside the oracle's own tie class), the
-    mined well-conditioned frames in the same slots (ordered top-K equality demanded), the trained-shaped heat-map stream (ordered equality on all 32
+    """The parity gate of BASELINE.md section 3 runs inside the bench command, on the plans the timed loop runs (64 frames per step as two
+    32-frame sub-batch plans on two HIP streams -- halo / patch / pre-split kernels, not the one-frame plan of the other full-size tests), and its
+    verdict is DECIDABLE: the raw frames 0, 31, 32, 63 (floats; index differences only inside the oracle's own tie class), the
+    mined well-conditioned frames in the same slots (ordered top-K equality demanded), the trained-shaped heat-map stream (ordered equality on all 64
     frames) -- `pass` must be true, the strict verdict on the raw frames is reported beside it."""
     import json
     import subprocess
@@ -763,9 +763,9 @@ def test_bench_parity_gate_on_the_timed_plans(gpu_lib):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     par = out["parity"]
     rawf = [f for f in par["frames"] if f["stream"] == "raw"]
-    assert [f["frame"] for f in rawf] == [0, 15, 16, 31] and rawf[0]["affinity_block"] == [500, 101]
+    assert [f["frame"] for f in rawf] == [0, 31, 32, 63] and rawf[0]["affinity_block"] == [500, 101]
     cp = out["config"]["parity"]                     # the compact verdict where the driver keeps it
-    assert cp["frames"] == [0, 15, 16, 31] and cp["pass_up_to_roundoff_ties"] is True and cp["pass"] == par["pass"] and cp["error"] is None
+    assert cp["frames"] == [0, 31, 32, 63] and cp["pass_up_to_roundoff_ties"] is True and cp["pass"] == par["pass"] and cp["error"] is None
     assert set(cp["max_err"]) == {"score", "bbox", "embedding", "affinity", "hm_logit"} and max(cp["max_err"].values()) <= 1e-3
     assert par["floats_within_tol"] and par["pass_up_to_roundoff_ties"], par
     assert par["max_err"]["affinity"] <= 1e-3 and par["max_err"]["embedding"] <= 1e-3 and par["max_err"]["bbox"] <= 1e-3
@@ -774,10 +774,10 @@ def test_bench_parity_gate_on_the_timed_plans(gpu_lib):
         assert f["common_detections"] >= 97 and f["embedding_rows_compared"] >= 97
     dec = par["decidable"]
     assert dec["pass"] and dec["topk_ordered_equal"] and dec["every_plan_has_a_decidable_frame"] and len(dec["decidable_here"]) >= 2, dec
-    assert par["peaked"]["pass"] and par["peaked"]["frames"] == 32 and par["peaked"]["topk_ordered_equal"], par["peaked"]
+    assert par["peaked"]["pass"] and par["peaked"]["frames"] == 64 and par["peaked"]["topk_ordered_equal"], par["peaked"]
     assert par["pass"] is True and cp["raw"]["pass"] in (True, False) and cp["decidable"]["pass"] and cp["peaked"]["pass"]
     assert out["dtype"].startswith("f32 via ")
-    assert out["n_gpus"] == 1 and out["config"]["frames_per_step_per_gpu"] == 32 and out["config"]["hip_streams"] == 2
+    assert out["n_gpus"] == 1 and out["config"]["frames_per_step_per_gpu"] == 64 and out["config"]["hip_streams"] == 2
 
 
 def test_graph_replay_survives_tracker_teardown(gpu_lib):
