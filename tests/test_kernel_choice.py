@@ -17,10 +17,12 @@ def test_config_b_throughput_shapes():
     assert choice(128, 128, 76, 136) == ("halo", (8 << 16) | 128 | W16)          # 11 % padding instead of 18 %
     assert choice(128, 32, 76, 136) == ("halo", (8 << 16) | 32 | W16)
     assert choice(256, 32, 38, 68) == ("halo", (8 << 16) | 32 | W16)             # narrow convs: up to 30 % padding, from 384 tiles
-    kind, tile = choice(256, 256, 38, 68)                                        # 24 % padding: the one-stage im2col loop wins
+    kind, tile = choice(256, 256, 38, 68)                                        # 24 % halo padding: the im2col loop wins; round 6: 646 tiles of 128 x 128 remain
+    assert kind == "im2col" and tile == ((128 << 16) | 128)                      # -> the two-stage 128 x 128 tile (+1.1 % of the step, profiles/r6_im2col_tile_ab.log)
+    kind, tile = choice(512, 512, 19, 34)                                        # 324 tiles of 128 x 128: too few -> the one-stage 64 x 128 tile
     assert kind == "im2col" and tile == ((64 << 16) | 128 | engine.P3_1STAGE)
-    kind, tile = choice(512, 512, 19, 34)
-    assert kind == "im2col" and tile == ((64 << 16) | 128 | engine.P3_1STAGE)
+    kind, tile = choice(512, 512, 19, 34, N=32)                                  # the 32-frame sub-batch plans of bench.py's default step: 648 tiles
+    assert kind == "im2col" and tile == ((128 << 16) | 128)
     assert choice(512, 32, 19, 34) is None                                       # 144 tiles: the fp32-instruction split-K tile is faster
     assert choice(64, 128, 152, 272, stride=2) is None                           # stride 2 and 1x1: no gain from 6-byte pieces
     assert choice(448, 128, 76, 136, k=1) is None
