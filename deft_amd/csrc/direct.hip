@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void direct_conv_kernel(c
     // ---- stage the patch: fp32 NHWC -> three bf16 piece planes in LDS (zero outside the image) ----
     {
         const deft_rsrc_t rx = deft_make_rsrc(p.x);
+        const bool planar = CIN == 4 && (p.tile & DEFT_TILE_PLANAR) != 0;
         dc_f32x4 v[C::NI];
 #pragma unroll
         for (int i = 0; i < C::NI; ++i) {
@@ -86,6 +87,15 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void direct_conv_kernel(c
             const int py = px / C::PW, pxx = px - py * C::PW;
             const int iy = oy0 * STRIDE - p.pad + py, ix = ox0 * STRIDE - p.pad + pxx;
             const bool ok = it < C::ITEMS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            if (CIN == 4 && planar) {
+                // the image as the reference hands it over, [N, 3, H, W] planes (detector.py:150): three 4-byte reads per patch pixel,
+                // consecutive lanes on consecutive x -- what deft_nchw_to_nhwc would have written as (r, g, b, 0), without the pass
+                const size_t hw = (size_t)p.H * p.W;
+                const float* const xp = p.x + ((size_t)n * 3 * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0);
+                const float c0 = xp[0], c1 = xp[hw], c2 = xp[2 * hw];
+                v[i] = ok ? dc_f32x4{c0, c1, c2, 0.f} : dc_f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             const unsigned off = ok ? ((unsigned)((n * p.H + iy) * p.W + ix) * (unsigned)p.ldx + (unsigned)cq * 4u) * 4u : DEFT_OOB;
             v[i] = deft_buffer_load_x4(rx, off);
         }
@@ -221,7 +231,10 @@ extern "C" int deft_conv_direct(const DeftGemmDesc* d, void* stream) {
     DEFT_CHECK(d->Cout >= 1 && d->Cout <= 16 * d->stride && d->ldy >= d->Cout, -73, "deft_conv_direct: Cout=%d (at most 16 output channels per unit of stride), ldy=%d", d->Cout, d->ldy);
     DEFT_CHECK(d->res == nullptr && d->rowmap == nullptr && d->splitk <= 1 && d->y3 == nullptr && d->x3 == nullptr, -74,
                "deft_conv_direct: no residual / rowmap / split-K / P3 operands");
-    DEFT_CHECK((d->ldx & 3) == 0 && d->ldx >= d->Cin && (((size_t)d->x | (size_t)d->w3) & 15) == 0, -75, "deft_conv_direct: ldx %% 4, 16-byte aligned x / w3");
+    const bool planar = (d->tile & DEFT_TILE_PLANAR) != 0;
+    DEFT_CHECK(!planar || (d->Cin == 4 && d->KH == 7), -75, "deft_conv_direct: the planar ([N, 3, H, W]) input form is the 7x7 image layer's (Cin = 4)");
+    DEFT_CHECK(planar ? (((size_t)d->x & 3) == 0 && ((size_t)d->w3 & 15) == 0)
+                      : ((d->ldx & 3) == 0 && d->ldx >= d->Cin && (((size_t)d->x | (size_t)d->w3) & 15) == 0), -75, "deft_conv_direct: ldx %% 4, 16-byte aligned x / w3");
     DEFT_CHECK(d->M == d->N * d->OH * d->OW && (long long)d->N * d->H * d->W * d->ldx < (1ll << 29), -76, "deft_conv_direct: M mismatch or input exceeds 2 GiB");
     hipStream_t s = (hipStream_t)stream;
     if (d->KH == 3 && d->Cin == 16 && d->stride == 1) return launch_direct<3, 3, 16, 1>(*d, s);

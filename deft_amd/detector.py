@@ -201,7 +201,7 @@ class Detector(object):
             return self._process_flip(images, pre_inds, return_time)
         N, _, H, W = images.shape
         plan = self._plan(N, H, W)
-        assert plan.ops[0][0] == "deft_nchw_to_nhwc", "process() needs the fp32-input plan"
+        assert plan.input_kind == "fp32", "process() needs the fp32-input plan"
         images = images.to(self.device, non_blocking=True)
         key = plan._gkey
         if not self.hip_graphs or key not in self._graphs:
@@ -491,7 +491,7 @@ class Detector(object):
         """process() for a uint8 frame batch [N, sh, sw, 3] (host or device): the plan's first launch is deft_preprocess_u8."""
         import time
         key = plan._gkey
-        assert plan.ops[0][0] == "deft_preprocess_u8"
+        assert plan.input_kind == "u8"
         frames_u8 = frames_u8.to(self.device, non_blocking=True)
         if not self.hip_graphs or key not in self._graphs:
             plan.forward_u8(frames_u8)

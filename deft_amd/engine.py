@@ -209,6 +209,7 @@ P3_TILES = {0, _T(256, 128), _T(128, 256), _T(128, 128), _T(128, 128) | P3_3STAG
 # the two 16-channel full-resolution layers (base_layer 7x7, level0 3x3) on the patch-in-LDS kernel (csrc/direct.hip) instead of the
 # pixel-pair implicit GEMM on the fp32 MFMA instruction
 DIRECT = _os.environ.get("DEFT_DIRECT", "1") != "0"
+PLANAR = 1 << 25                                               # include/deft_hip.h DEFT_TILE_PLANAR: deft_conv_direct reads the [N, 3, H, W] image itself
 Y3_INLOOP = _os.environ.get("DEFT_Y3_INLOOP", "1") != "0"    # piece-form output from the in-loop kernel's epilogue (else deft_split_planes)
 FOLD = _os.environ.get("DEFT_FOLD", "1") != "0"       # heat-map head: the 1x1 conv folded into the epilogue of the 3x3 conv (DeftGemmDesc.fold_w)
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
@@ -963,6 +964,8 @@ class _Plan:
             self._by_ptr.setdefault(scale.data_ptr(), scale)
         self.prescale(d)                     # (two-piece builds: the image above was built from the row-scaled matrix; the scale compensates)
         self._keep.append(d)
+        if name == "base_layer":
+            self._base_desc = d
         lib, ref = self.lib, C.byref(d)
         self.add("deft_conv_direct", name, lambda: lib.call("deft_conv_direct", ref, self._stream()), 2.0 * d.M * Cout * KH * KH * true_cin,
                  reads=[x], writes=[out])
@@ -1004,7 +1007,9 @@ class DlaSegPlan(_Plan):
         lib = self.lib
         a = (ptr(self.image), C.c_void_p(x4.addr), N, 3, H, W, 4)
         self.add("deft_nchw_to_nhwc", "image", lambda: lib.call("deft_nchw_to_nhwc", *a, self._stream()), reads=[self.image], writes=[x4])
+        self._image_op = self.ops[0], self.io[0]
         self._build_base(x4)
+        self._read_image_planes(True)
         self._build_neck()
         self._build_heads(dense_heads)
         self.finalize_p3()
@@ -1250,13 +1255,36 @@ class DlaSegPlan(_Plan):
               self.reg_off.get("ltrb_amodal", -1), ptr(self.cts), ptr(self.bboxes), ptr(self.centers))
         self.add("deft_decode_boxes", "decode_boxes", lambda: lib.call("deft_decode_boxes", *d_, self._stream()))
 
+    def _read_image_planes(self, on):
+        """When the 7x7 image layer runs on deft_conv_direct, its patch loader reads the [N, 3, H, W] planes itself (DEFT_TILE_PLANAR) and the
+        plan's first launch -- the layout pass to 4-channel NHWC -- is dropped (slot 0 stays, as a no-launch placeholder, so that the op
+        numbering is the same for every input form); off = the NHWC buffer again (the uint8 path writes it)."""
+        if len(self.ops) < 2 or self.ops[1][:2] != ("deft_conv_direct", "base_layer"):
+            return
+        d = self._base_desc
+        if on:
+            d.x, d.tile = self.image.data_ptr(), d.tile | PLANAR
+            self.ops[0] = ("image_in_place", "image", lambda: 0, 0.0)
+            self.io[0] = ([], [])
+            self.io[1] = ([_region(self.image)], self.io[1][1])
+        else:
+            d.x, d.tile = self._x4.addr, d.tile & ~PLANAR
+            self.ops[0], self.io[0] = self._image_op
+            self.io[1] = ([_region(self._x4)], self.io[1][1])
+
+    @property
+    def input_kind(self):
+        """'fp32' (frames as [N, 3, H, W], detector.py:150) or 'u8' (camera frames, after use_u8_input)."""
+        return "u8" if self.ops[0][0] == "deft_preprocess_u8" else "fp32"
+
     # ---- public --------------------------------------------------------------
     def use_u8_input(self, sh, sw, minv=None):
         """Switch the plan's first launch from `deft_nchw_to_nhwc` (fp32 NCHW frames, detector.py:150) to `deft_preprocess_u8`:
         uint8 HWC frames [N, sh, sw, 3] are warped (Detector.pre_process' affine, fix_res mode), normalised and written straight
         into the network's input buffer.  minv: dst -> src matrices [N,6] float64 (default: the reference's for sh x sw frames)."""
         from . import preprocess as PR
-        assert self.ops[0][0] in ("deft_nchw_to_nhwc", "deft_preprocess_u8")
+        assert self.ops[0][0] in ("deft_nchw_to_nhwc", "image_in_place", "deft_preprocess_u8")
+        self._read_image_planes(False)
         if minv is None:
             M, _, _ = PR.input_affine(sh, sw, self.H, self.W)
             minv = np.tile(PR.invert_affine(M)[None], (self.N, 1))

@@ -47,7 +47,9 @@ typedef struct DeftGemmDesc {
                                      bit 29 = one tap per weight stage.  deft_dcn_v2_nhwc, patch form (p3_kernel = 2):
                                      64 / 128 = output channels per workgroup; bit 26 puts a 64-column launch on the
                                      producer / consumer form (dcn_pc_kernel), bit 27 on the one-role kernel (dcn_patch_kernel)
-                                     -- same bits either way; neither: the library's choice (env DEFT_DCN_PC) */
+                                     -- same bits either way; neither: the library's choice (env DEFT_DCN_PC).
+                                     deft_conv_direct, 7x7 image layer: DEFT_TILE_PLANAR = x is the image as [N, 3, H, W] fp32
+                                     planes (detector.py:150) instead of 4-channel NHWC -- no deft_nchw_to_nhwc pass in front */
     /* pair, batched form (Tper > 0): rows are (c, t, j) with c = m / (Tper*Q) the current
      * frame, t its history row, j its object; U' row = u0 + c*du + t, V' row = v0 + c*dv + j.
      * Tper == 0: rows are (t, j), U' row = t, V' row = j.                                   */
@@ -373,7 +375,10 @@ int deft_fold_finish(const float* part, int nparts, long long M, int C, int ldp,
  * per input element instead of one per output pixel and tap) and feeds v_mfma_f32_16x16x32_bf16 with shifted fragment reads:
  * six bf16 products per fp32 product, fp32 accumulation (the arithmetic of DeftGemmDesc.prec = 1; another summation order
  * than the implicit-GEMM kernels).  Uses x, w3, scale, shift, y, N, H, W, Cin, ldx, OH, OW, Cout, ldy, KH, KW, stride, pad,
- * M, relu of the descriptor; w3 = the fragment image of deft_split_weights_direct. */
+ * M, relu of the descriptor; w3 = the fragment image of deft_split_weights_direct.  With DEFT_TILE_PLANAR in `tile` (Cin = 4 only) x is
+ * the fp32 image in the reference's own layout, [N, 3, H, W] (ldx unused): the patch loader reads the three planes, bit-identical to
+ * deft_nchw_to_nhwc followed by the NHWC form. */
+#define DEFT_TILE_PLANAR (1 << 25)
 int deft_conv_direct(const DeftGemmDesc* d, void* stream);
 
 /* Packed fp32 weights [>= Cout rows][Kpad], k = (r*KW + s)*Cin + c (DeftGemmDesc.w order), -> the B-fragment image of

@@ -150,6 +150,32 @@ def check_conv_direct(lib, device, Ci, k, N=2, H=11, W=37, Co=16, relu=True, see
     return err
 
 
+def check_conv_direct_planar(lib, device, N=2, H=19, W=70, seed=5):
+    """The 7x7 image layer reading the [N, 3, H, W] planes itself (DeftGemmDesc.tile & DEFT_TILE_PLANAR) gives, bit for bit, what the
+    layout pass to 4-channel NHWC followed by the NHWC form gives -- on a map that is no multiple of the 8 x 32 tile."""
+    g = torch.Generator().manual_seed(seed)
+    plan = engine._Plan(device, lib)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(16, 3, 7, 7, generator=g) * (1.0 / 147 ** 0.5)
+    scale, shift = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g)
+    xv = plan.alloc(N, H, W, 4); fill_view(xv, x)
+    wp, K = engine.pack_conv_weight(w, 4)
+    a = plan.conv_direct("base_layer", xv, plan.dev(wp), K, 7, 3, 16, plan.dev(scale), plan.dev(shift), True, 3)
+    plan.run()
+    ref = a.to_nchw().cpu().clone()
+    d = plan._base_desc
+    img = plan.dev(x.contiguous())
+    d.x, d.tile = img.data_ptr(), d.tile | engine.PLANAR
+    a.buf.zero_()
+    plan.run()
+    got = a.to_nchw().cpu()
+    assert torch.equal(got, ref), ("planar image layer", float((got - ref).abs().max()))
+    import ctypes as C
+    d.Cin = 16                                         # the planar form is the image layer's alone: refused elsewhere
+    assert lib._fn["deft_conv_direct"](C.byref(d), None) == -75
+    d.Cin = 4
+
+
 def check_concat_conv(lib, device):
     """Root-style 1x1 conv reading a channel-concat buffer in place, output written
     into a channel slice of another buffer (dla.py:199-207)."""

@@ -42,6 +42,10 @@ def test_conv_direct(emu_lib, Ci, k, kw):
     pc.check_conv_direct(emu_lib, "cpu", Ci, k, **kw)
 
 
+def test_conv_direct_reads_the_image_planes(emu_lib):
+    pc.check_conv_direct_planar(emu_lib, "cpu")
+
+
 def test_concat_conv(emu_lib):
     pc.check_concat_conv(emu_lib, "cpu")
 

@@ -46,6 +46,11 @@ def test_conv_direct(gpu_lib, Ci, k, kw):
     pc.check_conv_direct(gpu_lib, "cuda", Ci, k, **kw)
 
 
+def test_conv_direct_reads_the_image_planes(gpu_lib):
+    pc.check_conv_direct_planar(gpu_lib, "cuda")
+    pc.check_conv_direct_planar(gpu_lib, "cuda", N=3, H=64, W=96, seed=6)
+
+
 @pytest.mark.parametrize("args", [(1, 9, 37, 64, 256, 1, "halo", 0), (2, 5, 33, 64, 256, 3, "halo", T(4, 128)), (1, 6, 40, 64, 128, 10, "halo", T(8, 64)),
                                   (1, 7, 19, 64, 256, 2, "im2col", T(64, 128) | (1 << 30)), (1, 6, 21, 64, 72, 1, "im2col", T(128, 64) | (1 << 30)),
                                   (2, 152, 272, 64, 256, 1, "halo", 0), (1, 152, 272, 64, 256, 10, "halo", 0)])

@@ -106,8 +106,9 @@ if os.path.exists(fe) and os.path.exists(wr):
     nl = sum(nf[k] for k in fk)
     fetch = sum(pf[k]["FETCH_SIZE"] for k in fk) * 1024.0 * 2.0          # KiB -> B, gfx950 wide-stream correction x2
     write = sum(pw.get(k, {}).get("WRITE_SIZE", 0.0) for k in fk) * 1024.0
-    # the whole step: every kernel's bytes over the number of steps the run made (two sub-batch plans per step: one layout kernel each)
-    nsteps = max(1, sum(nf[k] for k in pf if "nchw_to_nhwc" in k or "preprocess_u8" in k) // 2)
+    # the whole step: every kernel's bytes over the number of steps the run made (two sub-batch plans per step: one image-layer launch each)
+    first = [k for k in pf if "direct_conv_kernel<7" in k] or [k for k in pf if "nchw_to_nhwc" in k or "preprocess_u8" in k]      # one launch per sub-batch plan
+    nsteps = max(1, sum(nf[k] for k in first) // 2)
     all_bytes = sum(v["FETCH_SIZE"] for v in pf.values()) * 1024.0 * 2.0 + sum(v.get("WRITE_SIZE", 0.0) for v in pw.values()) * 1024.0
     json.dump({"kernel": "igemm* + conv3h + direct_conv + dcn_patch + pair_mlp", "launches": nl, "fetch_bytes_per_launch": fetch / max(nl, 1), "write_bytes_per_launch": write / max(nl, 1),
                "traffic_bytes_per_launch": (fetch + write) / max(nl, 1),
