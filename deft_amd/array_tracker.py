@@ -153,6 +153,7 @@ class ArrayTracker(object):
         self._pending = None                                  # ... and the motion step whose result has not been read back yet
         self.removed_ids = []
         self._begun = None                                    # begin(): the device half of the next frame, already queued
+        self._prepared = None                                 # prepare(): embeddings + affinity blocks of the frame AFTER that one, already queued
         self.lost_stracks = []
         self.classe = None
 
@@ -287,9 +288,7 @@ class ArrayTracker(object):
     def close(self):
         """End of a video: land the pending motion step and hand this tracker's MotionBank slots back (the bank is shared -- model.motion --
         by every tracker built on the model; without this its h / c / last tensors double with every sequence of an evaluation)."""
-        if self._begun is not None:
-            self._undo(self._begun)
-            self._begun = None
+        self._take_back()
         if self.use_lstm and self.bank is not None:
             try:
                 self._resolve()
@@ -442,17 +441,43 @@ class ArrayTracker(object):
         caller has them already (extract_together: one extraction for all classes)."""
         if self._begun is not None:
             self._undo(self._begun)
-        rec = self.recorder
-        snap = (rec.all_frame_index, dict(rec.all_features), dict(rec.all_boxes), dict(rec.all_similarity), rec._dev)
+        snap = self._snapshot()
         try:
             self._begun = self._first_half(results, FeatureMaps, ddd_boxes, depths_by_class, pre, feats)
         except Exception:
             self._undo({"snap": snap})                 # the recorder may hold the frame already: the next update() must not find it half recorded
             self._begun = None
             raise
-        self._begun["snap"] = snap
+        self._begun.setdefault("snap", snap)           # (a frame that was prepare()d: the recorder as it was BEFORE that)
+
+    def prepare(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None, pre=None, feats=None):
+        """One frame further ahead than begin(): the part of a frame's device half that does not even need the track table -- detections as arrays,
+        the embedding extraction and the affinity blocks (tracker.py:786-848; the pair MLP, by far the longest launch of a tracked frame) -- for the
+        frame AFTER the one that is begun, queued while that one is still waiting for its update().  The blocks are scored against a superset of
+        the stored frames the pool will read: the frames of the nodes today's table selects at that frame number, plus the begun frame itself (a
+        track the pending update() does not match keeps exactly that selection; one it matches selects the new node and a suffix of it).  With nothing begun this is
+        the first part of begin() for the next frame.  begin() / update() given the SAME `results` object continue from here; anything else takes
+        the work back.  Frames are prepared in stream order, one at a time."""
+        if self._prepared is not None:
+            self._undo(self._prepared)
+            self._prepared = None
+        snap = self._snapshot()
+        ahead = self._begun
+        try:
+            p = self._stage_a(self.frame_id + (2 if ahead is not None else 1), results, FeatureMaps, ddd_boxes, depths_by_class, pre, feats, ahead)
+        except Exception:
+            self._undo({"snap": snap})
+            raise
+        p["snap"] = snap
+        self._prepared = p
+
+    def _snapshot(self):
+        rec = self.recorder
+        return (rec.all_frame_index, dict(rec.all_features), dict(rec.all_boxes), dict(rec.all_similarity), rec._dev)
 
     def _undo(self, b):
+        """Take back what begin() / prepare() left in the recorder.  Undoing the begun frame also drops a frame prepared behind it (the older
+        snapshot knows neither)."""
         snap = b.get("snap")
         if snap is not None:
             rec = self.recorder
@@ -460,6 +485,16 @@ class ArrayTracker(object):
         w = b.get("sim_wait")
         if w is not None:
             w(raw=True)                                                # let the queued launches finish with the staging buffers they read
+        if b is not self._prepared:
+            self._prepared = None
+
+    def _take_back(self):
+        if self._begun is not None:
+            self._undo(self._begun)
+            self._begun = None
+        if self._prepared is not None:
+            self._undo(self._prepared)
+            self._prepared = None
 
     def detections_as_arrays(self, results, ddd_boxes=None, depths_by_class=None):
         """The frame's detections of this tracker as arrays (tracker.py:786-820): rows, boxes in the forms the stages read, and the embedding
@@ -512,27 +547,52 @@ class ArrayTracker(object):
             o += n
         return out
 
-    def _first_half(self, results, FeatureMaps, ddd_boxes, depths_by_class, pre=None, feats=None):
-        fid = self.frame_id + 1
-        c = self.cols
+    def _stage_a(self, fid, results, FeatureMaps, ddd_boxes, depths_by_class, pre=None, feats=None, ahead=None):
+        """Detections as arrays, embeddings, affinity blocks of frame `fid` (recorded).  ahead: the begun frame when `fid` is the one after it."""
         if pre is None or pre["results"] is not results:
             pre, feats = self.detections_as_arrays(results, ddd_boxes, depths_by_class), None
-        nd0, det_ddd, det_depth = pre["nd0"], pre["det_ddd"], pre["det_depth"]
-        tlwh, xyah, tlbr, dscore = pre["tlwh"], pre["xyah"], pre["tlbr"], pre["dscore"]
-        sel_all = self._selected_nodes(fid)
-        if nd0 > 0:
+        sel_all = None
+        if pre["nd0"] > 0:
             if feats is None:
                 if FeatureMaps[0].shape[0] == 2:                          # flip-test pair: the un-flipped frame's maps (tracker.py:821-825)
                     FeatureMaps = [fm[0].unsqueeze(0) for fm in FeatureMaps]
                 feats = self.model.AFE.forward_feature_extracter(FeatureMaps, pre["centers"])
-            needed = set(np.unique(sel_all[0][sel_all[2]]).tolist()) if self.lazy_blocks else None
+            needed = None
+            if self.lazy_blocks:
+                if ahead is None:
+                    sel_all = self._selected_nodes(fid)
+                    needed = set(np.unique(sel_all[0][sel_all[2]]).tolist())
+                else:
+                    # what update(ahead) can leave selected at `fid`: a track it does not match keeps its nodes (selection at `fid` on today's
+                    # table -- NOT the begun frame's selection: a node ageing out can take a track from "the last mm" back to "all mm + 1");
+                    # a track it matches selects the new node and a suffix of that
+                    sa = self._selected_nodes(fid)
+                    needed = set(np.unique(sa[0][sa[2]]).tolist()) | {int(ahead["fid"])}
             self.recorder.update(self.model, fid, feats.data, pre["org"], needed=needed)
+        return {"results": results, "fid": fid, "pre": pre, "sel_all": sel_all}
+
+    def _first_half(self, results, FeatureMaps, ddd_boxes, depths_by_class, pre=None, feats=None):
+        fid = self.frame_id + 1
+        c = self.cols
+        a, self._prepared = self._prepared, None
+        if a is not None and (a["results"] is not results or a["fid"] != fid):
+            self._undo(a)                                                 # prepared for a frame that is not the one that came
+            a = None
+        if a is None:
+            a = self._stage_a(fid, results, FeatureMaps, ddd_boxes, depths_by_class, pre, feats)
+        pre = a["pre"]
+        nd0, det_ddd, det_depth = pre["nd0"], pre["det_ddd"], pre["det_depth"]
+        tlwh, xyah, tlbr, dscore = pre["tlwh"], pre["xyah"], pre["tlbr"], pre["dscore"]
+        sel_all = a["sel_all"] if a["sel_all"] is not None else self._selected_nodes(fid)
         T0 = c.n
         # the similarity of EVERY pool row to the frame's detections, queued now and read after the host work that does not depend on it (prediction, motion
         # gate; nuScenes: the 3-D IoU stage, which only decides which of these rows the embedding stage keeps)
         sim_wait = self._similarity(fid, np.arange(T0), nd0, sel_all, defer=True) if (T0 and nd0) else None
-        return {"results": results, "fid": fid, "nd0": nd0, "sel_all": sel_all, "tlwh": tlwh, "xyah": xyah, "tlbr": tlbr, "dscore": dscore, "T0": T0,
-                "sim_wait": sim_wait, "det_ddd": det_ddd, "det_depth": det_depth}
+        b = {"results": results, "fid": fid, "nd0": nd0, "sel_all": sel_all, "tlwh": tlwh, "xyah": xyah, "tlbr": tlbr, "dscore": dscore, "T0": T0,
+             "sim_wait": sim_wait, "det_ddd": det_ddd, "det_depth": det_depth}
+        if "snap" in a:
+            b["snap"] = a["snap"]
+        return b
 
     def update(self, results, FeatureMaps, ddd_boxes=None, depths_by_class=None, ddd_org_boxes=None, submission=None, classe=None):
         """tracker.py:723-1056.  2-D: results = the frame's post-processed detections ({"bbox" tlbr, "score", "class"}).  nuScenes: results =

@@ -24,6 +24,7 @@ LOOKAHEAD_AT = _os.environ.get("DEFT_LOOKAHEAD_AT", "auto")
 # run() on a recorded stream: when the host already holds the NEXT frame's detections (same lookahead pass, or the other slot's finished pass), the
 # tracker's device half for that frame (ArrayTracker.begin) is queued right behind this frame's update().  "0": every frame's device half inside its own update()
 BEGIN_AHEAD = _os.environ.get("DEFT_BEGIN_AHEAD", "1") != "0"
+PREPARE_AHEAD = _os.environ.get("DEFT_PREPARE_AHEAD", "1") != "0"     # ... and the embeddings + affinity blocks of the frame after that (ArrayTracker.prepare)
 
 
 def _fetch(d):
@@ -357,7 +358,7 @@ class Detector(object):
         t_start = time.time()
         pre_processed, frame = False, None
         self._peek_src, meta_given = None, bool(meta)
-        peeked, self._peeked = getattr(self, "_peeked", None), None
+        known, self._peeked = getattr(self, "_peeked", None) or [], None       # [(frame, results)]: post-processed during earlier calls (_begin_next)
         if isinstance(image_or_path_or_tensor, np.ndarray):
             frame = image_or_path_or_tensor
         elif isinstance(image_or_path_or_tensor, str):
@@ -408,8 +409,9 @@ class Detector(object):
             t_pre = time.time()
             output, dets, t_fwd, fmaps = self.process(images, None, None, None, return_time=True)
         t_dec = time.time()
-        if peeked is not None and peeked[0] is frame and not meta_given:
-            results = peeked[1]                                        # post-processed one call ago (_begin_next): the tracker holds THIS list
+        mine = next((r for f, r in known if f is frame), None) if not meta_given else None
+        if mine is not None:
+            results = mine                                             # post-processed one or two calls ago (_begin_next): the tracker holds THIS list
             t_post = time.time()
         else:
             result = self.post_process(dets, meta, scale)
@@ -476,9 +478,9 @@ class Detector(object):
                     nxt()
             else:
                 targets = self.tracker.update(results, fmaps)                              # detector.py:340-342
-            if (BEGIN_AHEAD and self._peek_src is not None and per_class is None and self.tracker is not None and hasattr(self.tracker, "begin")
+            if (BEGIN_AHEAD and self._peek_src and per_class is None and self.tracker is not None and hasattr(self.tracker, "begin")
                     and not meta_given and not getattr(opt, "public_det", False)):
-                self._begin_next(meta, scale, prio)
+                self._begin_next(meta, scale, prio, known)
         if prio is not None:
             main.wait_stream(prio)
         t_end = time.time()
@@ -612,21 +614,32 @@ class Detector(object):
             o += cnt
         return dets
 
-    def _begin_next(self, meta, scale, prio):
-        """The NEXT frame's detections are already on the host (a later frame of the pass this frame came from, or the first frame of the other
-        slot's pass when that has finished): post-process them now and let the tracker queue its device half for them (ArrayTracker.begin) behind
-        this frame's update() -- the next run() call finds the embedding / affinity / similarity round trip under way instead of waiting for it."""
-        sl, j = self._peek_src
-        try:
-            dets = _check_finite(self._slot_dets(sl, j))
-        except FloatingPointError:
-            return                                                     # the next run() call raises it for its own frame
-        results = self.merge_outputs([self.post_process(dets, meta, scale)])
-        fmaps = sl.plan.fmaps if sl.n == 1 else [fm[j] for fm in sl.plan.fmaps]
-        if sl.done is not None:
-            (prio if prio is not None else torch.cuda.current_stream(self.device)).wait_event(sl.done)
-        self.tracker.begin(results, fmaps)
-        self._peeked = (sl.frames[j], results)
+    def _begin_next(self, meta, scale, prio, known=()):
+        """The detections of the NEXT frame(s) are already on the host (later frames of the pass this frame came from, or the first frames of the
+        other slot's pass when that has finished): post-process them now and let the tracker queue device work for them behind this frame's
+        update() -- the whole device half of the next frame (ArrayTracker.begin), and the embeddings + affinity blocks of the frame after it
+        (ArrayTracker.prepare: they do not need the track table, and the pair MLP is the longest launch of a tracked frame).  The next run()
+        call finds its embedding / affinity / similarity round trip finished instead of waiting for it.  known: [(frame, results)] post-processed
+        by an earlier call -- the tracker was handed THOSE lists."""
+        done = []
+        for i, (sl, j) in enumerate(self._peek_src):
+            frame = sl.frames[j]
+            results = next((r for f, r in known if f is frame), None)
+            if results is None:
+                try:
+                    dets = _check_finite(self._slot_dets(sl, j))
+                except FloatingPointError:
+                    break                                              # the run() call of that frame raises it
+                results = self.merge_outputs([self.post_process(dets, meta, scale)])
+            fmaps = sl.plan.fmaps if sl.n == 1 else [fm[j] for fm in sl.plan.fmaps]
+            if sl.done is not None:
+                (prio if prio is not None else torch.cuda.current_stream(self.device)).wait_event(sl.done)
+            if i == 0:
+                self.tracker.begin(results, fmaps)
+            else:
+                self.tracker.prepare(results, fmaps)
+            done.append((frame, results))
+        self._peeked = done
 
     def _process_ahead(self, akey, frame, prefetch):
         import time
@@ -661,12 +674,10 @@ class Detector(object):
             torch.cuda.current_stream(self.device).wait_event(cur.done)    # the tracker's launches read this slot's feature maps
         self._fm_ready = cur.done
         # whose detections the host holds next: the pass of this frame, or the other slot's when it has finished
-        if cur.frames is not None:
-            self._peek_src = (cur, cur.pos)
-        elif other.frames is not None and (other.done is None or other.done.query()):
-            self._peek_src = (other, other.pos)
-        else:
-            self._peek_src = None
+        nxt2 = [(cur, q) for q in range(cur.pos, len(cur.frames))] if cur.frames is not None else []
+        if len(nxt2) < 2 and other.frames is not None and (other.done is None or other.done.query()):
+            nxt2 += [(other, q) for q in range(other.pos, len(other.frames))]
+        self._peek_src = nxt2[:2 if PREPARE_AHEAD and hasattr(self.tracker, "prepare") else 1]
         t_fwd = time.time()
         self._launch_next = None
         if other.frames is None and len(upcoming) > left:              # the free slot takes the frames behind the ones this slot still holds

@@ -1847,6 +1847,8 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
             if dataset != "nuscenes":                   # ArrayTracker.begin: the next frame's device half queued behind this frame's update()
                 trk, begin = det.tracker, det.tracker.begin
                 trk.begin = lambda *a: (begun.append(lookahead), begin(*a))[1]
+                prepare = trk.prepare                   # ... and ArrayTracker.prepare: the embeddings + affinity blocks of the frame after that
+                trk.prepare = lambda *a: (prepared.append(lookahead), prepare(*a))[1]
             if lookahead == "pairs":                    # Detector.track_stream: the per-video loop with two frames per lookahead pass
                 outs = det.track_stream(iter(frames), image_infos=[info] * T, frames_per_pass=2)
             else:
@@ -1857,7 +1859,7 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
             launches = model.motion.launches if lstm else 0
             return log, launches
 
-        begun = []
+        begun, prepared = [], []
         serial, l0 = run(False)
         ahead, l1 = run(True)
         assert serial == ahead
@@ -1867,6 +1869,7 @@ def check_fused_run_array_tracker(lib, device, dataset, lstm, sh=45, sw=80, H=64
             assert l2 == l0 and len(two) == len(serial)
             if dataset != "nuscenes" and device == "cpu":   # (on the device: whenever the other slot's pass has finished by the time it is asked)
                 assert begun.count("pairs") >= (T - 1) // 2, begun      # at least the second frame of every full pass
+                assert prepared.count("pairs") >= (T - 2) // 2 - 1, prepared    # the frame behind it, whenever a finished pass holds it
             for fa, fb in zip(serial, two):
                 assert [x[:3] for x in fa] == [x[:3] for x in fb]
                 for x, y in zip(fa, fb):

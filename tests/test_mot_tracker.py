@@ -254,6 +254,50 @@ def test_native_association_equals_the_numpy_stages(emu_lib, dataset):
             assert np.abs(np.array(x[3]) - np.array(y[3])).max() <= 1e-9, (t, x, y)
 
 
+@pytest.mark.parametrize("dataset", ["mot", "nuscenes_2d_rule"])
+def test_prepare_ahead_covers_every_block_the_next_frame_reads(emu_lib, dataset):
+    """ArrayTracker.prepare scores frame k + 2 before update(k + 1) has run, against a SUPERSET of the stored frames that update will leave selected
+    (today's table evaluated at the later frame number, plus the begun frame).  A crowded scene with drop-outs of 2-8 frames and re-finds, long
+    enough for nodes to age out of the 50-frame window (the case where a track's selection GROWS back from "the last mm" to "all mm + 1"): no
+    KeyError for a missing block, and the same tracks as plain update() calls."""
+    from deft_amd import array_tracker as MT
+    opt = types.SimpleNamespace(dataset="mot", track_buffer=30 if dataset == "mot" else 240, max_object=100, lstm=False)
+    g = np.random.RandomState(23)
+    n = 24
+    base = np.concatenate([g.rand(n, 2) * np.array([170.0, 90.0]), g.rand(n, 2) * 8 + 10], 1)
+    vel = g.randn(n, 2) * 0.3
+    frames = []
+    for t in range(150):
+        rows = []
+        for i in range(n):
+            period, off, out = 9 + i, 3 * i, 2 + i % 7            # every object drops out for `out` frames once per `period` (+ one long absence)
+            if (t + off) % period < out or (i % 5 == 0 and 60 <= t < 60 + 40 + i):
+                continue
+            x, y = base[i, :2] + vel[i] * t
+            w, h = base[i, 2:]
+            rows.append({"score": float(0.6 + 0.01 * i), "class": 1, "bbox": np.array([x, y, x + w, y + h], np.float32)})
+        frames.append(rows)
+
+    def run(two):
+        MT.TrackIds.count = 0
+        afe = FakeAFE()
+        afe.plan = types.SimpleNamespace(lib=emu_lib, _stream=lambda: None)
+        trk = MT.Tracker2D(opt, types.SimpleNamespace(AFE=afe), h=H, w=W)
+        fm = [torch.zeros(1, 1, 1, 1)]
+        log = []
+        for t in range(len(frames)):
+            log.append(_log(trk.update(frames[t], fm)))
+            if two and t + 1 < len(frames):
+                trk.begin(frames[t + 1], fm)
+                if t + 2 < len(frames):
+                    trk.prepare(frames[t + 2], fm)
+        return log
+
+    plain = run(False)
+    assert run(True) == plain
+    assert sum(len(f) for f in plain) > 1500 and max(x[2] for f in plain for x in f) > 20
+
+
 @pytest.mark.parametrize("dataset", ["mot", "kitti_tracking"])
 def test_begin_ahead_changes_nothing(emu_lib, dataset):
     """ArrayTracker.begin(results, FeatureMaps): the device half of the NEXT frame queued behind update(k).  Same tracks as plain update() calls when
@@ -278,11 +322,27 @@ def test_begin_ahead_changes_nothing(emu_lib, dataset):
                 trk.begin(frames[t + 1], fm)
             elif mode == "wrong" and t + 1 < nframes:
                 trk.begin(wrong if t % 3 else frames[t + 1], fm)       # two of three announcements are for a frame that never comes
-        assert trk._begun is None
+            elif mode == "two" and t + 1 < nframes:                    # begin(k + 1) behind update(k), prepare(k + 2) behind that: Detector.run's order
+                trk.begin(frames[t + 1], fm)
+                if t + 2 < nframes:
+                    trk.prepare(frames[t + 2], fm)
+                    assert trk._prepared["fid"] == t + 3 and (not len(frames[t + 2]) or t + 3 in trk.recorder.all_features)
+            elif mode == "two_wrong" and t + 1 < nframes:              # ... with announcements that do not come true, at either distance
+                trk.begin(wrong if t % 4 == 1 else frames[t + 1], fm)
+                if t + 2 < nframes:
+                    trk.prepare(wrong if t % 4 == 2 else frames[t + 2], fm)
+                if t % 4 == 3 and t + 2 < nframes:
+                    trk.prepare(frames[t + 2], fm)                     # prepared twice: the first is taken back
+            elif mode == "prepare_only" and t + 1 < nframes:           # prepare() with nothing begun = the first part of the next frame's begin()
+                trk.prepare(frames[t + 1], fm)
+                if t % 2:
+                    trk.begin(frames[t + 1], fm)
+        assert trk._begun is None and trk._prepared is None
         return log, sorted(trk.recorder.all_features), trk.frame_id
 
     plain = run("plain")
     assert run("ahead") == plain and run("wrong") == plain
+    assert run("two") == plain and run("two_wrong") == plain and run("prepare_only") == plain
     assert sum(len(f) for f in plain[0]) > 200 and len(plain[1]) == 50 and plain[2] == nframes
 
 
