@@ -14,7 +14,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")[:60]
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:60]
 
 
 def counters(path):
