@@ -97,6 +97,12 @@ class _Columns(object):
         self.n = len(self.a["tid"])
 
 
+def _p(a):
+    """Host pointer of a C-contiguous numpy array (the native helpers take raw pointers)."""
+    assert a.flags["C_CONTIGUOUS"], "native helper needs a contiguous array"
+    return C.c_void_p(a.ctypes.data)
+
+
 def _finite_sim(sim):
     """The similarity matrix is where the embedding / affinity chain (AfePlan: the same split arithmetic as the backbone, no heat map in between)
     lands on the host: a non-finite entry means an operand left the two-fp16-piece range.  The native cascade would treat such pairs as gated --
@@ -198,6 +204,14 @@ class ArrayTracker(object):
         c = self.cols
         nf, ni, nn = c["nf"], c["ni"], c["nn"]
         T, L = nf.shape
+        lib = self._track_nodes_lib()
+        if lib is not None and T:                                      # the same rule in one host call (assoc.hip deft_track_nodes)
+            sel = np.empty((T, L), np.uint8)
+            rc = lib._fn["deft_track_nodes"](_p(nf), _p(ni), _p(nn), T, L, int(fid), self.mm, DT.max_track_node, _p(sel), None, None, None, None, 0,
+                                             None, None, None, None)
+            if rc != 0:
+                raise RuntimeError("deft_track_nodes failed (%d): %s" % (rc, lib.last_error()))
+            return nf, ni, sel.view(np.bool_)
         stored = np.minimum(nn, L)
         pos = np.arange(L)[None, :]
         have = pos >= (L - stored)[:, None]                            # nodes are right-aligned: the newest at column L - 1
@@ -206,6 +220,13 @@ class ArrayTracker(object):
         nsel = np.where(q <= self.mm + 1, q, self.mm)
         sel = pos >= (L - nsel)[:, None]
         return nf, ni, sel
+
+    def _track_nodes_lib(self):
+        """The library when the node selection / gather table run natively (native_assoc, and model.AFE.plan.lib is a bound HipLib)."""
+        if not self.native_assoc:
+            return None
+        lib = getattr(getattr(self.model.AFE, "plan", None), "lib", None)
+        return lib if lib is not None and "deft_track_nodes" in getattr(lib, "_fn", ()) else None
 
     def _similarity(self, fid, rows_idx, nd, sel_all, defer=False):
         """deft_amd.tracker.get_similarity on the node arrays: float64 [len(rows_idx), nd + 1].  defer: queue the launch and the copy back, return
@@ -217,7 +238,8 @@ class ArrayTracker(object):
         if T == 0:
             return np.array([])
         nf, ni, sel = sel_all
-        nf, ni, sel = nf[rows_idx], ni[rows_idx], sel[rows_idx]
+        if T != nf.shape[0] or (T and (rows_idx[0] != 0 or rows_idx[-1] != T - 1)):     # (begin() asks for every pool row: no gather then)
+            nf, ni, sel = nf[rows_idx], ni[rows_idx], sel[rows_idx]
         rec = self.recorder
         if rec._dev is None or rec._dev[0] != fid:
             if nd == 0 or not sel.any():
@@ -226,15 +248,55 @@ class ArrayTracker(object):
         _, sim, starts, index = rec._dev
         assert sim.shape[1] == nd + 1
         L = sel.shape[1]
+        plan = self.model.AFE.plan
+        dev = sim.device
+        n1 = T * L
+        need_in, need_out = 2 * n1 + T, T * (nd + 1)
+        pin = None
+        if dev.type == "cuda":                                         # pinned staging both ways: no pageable (= blocking) copies in the frame
+            pin = getattr(self, "_pin", None)
+            if pin is None or pin[0].numel() < need_in or pin[1].numel() < need_out:
+                pin = self._pin = (torch.empty(max(2048, 2 * need_in), dtype=torch.int32).pin_memory(),
+                                   torch.empty(max(32768, 2 * need_out), dtype=torch.float32).pin_memory())
+        lib = self._track_nodes_lib()
+        host = None
+        if lib is not None and sel is sel_all[2]:                      # every pool row (begin()): selection + table in ONE host call, written in place
+            arr = getattr(rec, "_dev_arrays", None)
+            if arr is None or arr[0] is not index:                     # the block table as arrays, once per recorded frame
+                st = np.asarray(starts, np.int64)
+                blk = np.fromiter((b for b, _ in index.values()), np.int64, len(index))
+                arr = rec._dev_arrays = (index, np.fromiter(index.keys(), np.int64, len(index)), np.ascontiguousarray(st[blk]),
+                                         np.ascontiguousarray(st[blk + 1] - st[blk]), np.fromiter((d for _, d in index.values()), np.float32, len(index)))
+            c = self.cols
+            if pin is not None:
+                base_h = pin[0].data_ptr()
+            else:
+                host = np.empty(need_in, np.int32)
+                base_h = host.ctypes.data
+            bad = C.c_longlong(0)
+            rc = lib._fn["deft_track_nodes"](_p(nf), _p(ni), _p(c["nn"]), T, L, int(fid), self.mm, DT.max_track_node, None, _p(arr[1]), _p(arr[2]),
+                                             _p(arr[3]), _p(arr[4]), len(index), C.c_void_p(base_h), C.c_void_p(base_h + 4 * n1),
+                                             C.c_void_p(base_h + 8 * n1), C.byref(bad))
+            if rc == -96:
+                raise KeyError(int(bad.value))                         # KeyError like the reference for a frame without a block
+            if rc == -97:
+                raise IndexError("node id outside its frame")
+            if rc != 0:
+                raise RuntimeError("deft_track_nodes failed (%d): %s" % (rc, lib.last_error()))
+            return self._similarity_launch(plan, sim, dev, pin, host, T, L, nd, n1, need_in, defer)
         rows = np.zeros((T, L), np.int32); scale = np.zeros((T, L), np.float32)
         cnt = sel.sum(1).astype(np.int32)
         if sel.any():
             f0, f1 = int(nf[sel].min()), int(nf[sel].max())
             # frame -> (first row of its block, its length, its decay): dense tables over the frames the selected nodes span
             st_t = np.zeros(f1 - f0 + 1, np.int64); ln_t = np.full(f1 - f0 + 1, -1, np.int64); dl_t = np.zeros(f1 - f0 + 1, np.float32)
-            for f, (blk, delta) in index.items():
-                if f0 <= f <= f1:
-                    st_t[f - f0], ln_t[f - f0], dl_t[f - f0] = starts[blk], starts[blk + 1] - starts[blk], delta
+            fr_k = np.fromiter(index.keys(), np.int64, len(index))
+            blk_k = np.fromiter((b for b, _ in index.values()), np.int64, len(index))
+            dl_k = np.fromiter((d for _, d in index.values()), np.float32, len(index))
+            inr = (fr_k >= f0) & (fr_k <= f1)
+            fr_k, blk_k = fr_k[inr] - f0, blk_k[inr]
+            st_k = np.asarray(starts, np.int64)
+            st_t[fr_k], ln_t[fr_k], dl_t[fr_k] = st_k[blk_k], st_k[blk_k + 1] - st_k[blk_k], dl_k[inr]
             fr = np.where(sel, nf - f0, 0)
             ln = ln_t[fr]
             if (sel & (ln < 0)).any():
@@ -245,17 +307,14 @@ class ArrayTracker(object):
             # reads (node_row[t][0 .. cnt - 1]; a median does not care about the order)
             rows = np.where(sel, st_t[fr] + ni, 0)[:, ::-1].astype(np.int32)
             scale = np.where(sel, dl_t[fr], np.float32(0))[:, ::-1].astype(np.float32)
-        plan = self.model.AFE.plan
-        dev = sim.device
-        n1 = T * L
         host = np.concatenate([rows.reshape(-1), scale.view(np.int32).reshape(-1), cnt])
-        if dev.type == "cuda":                                         # pinned staging both ways: no pageable (= blocking) copies in the frame
-            need_in, need_out = 2 * n1 + T, T * (nd + 1)
-            pin = getattr(self, "_pin", None)
-            if pin is None or pin[0].numel() < need_in or pin[1].numel() < need_out:
-                pin = self._pin = (torch.empty(max(2048, 2 * need_in), dtype=torch.int32).pin_memory(),
-                                   torch.empty(max(32768, 2 * need_out), dtype=torch.float32).pin_memory())
+        if pin is not None:
             pin[0][:need_in] = torch.from_numpy(host)
+        return self._similarity_launch(plan, sim, dev, pin, host, T, L, nd, n1, need_in, defer)
+
+    def _similarity_launch(self, plan, sim, dev, pin, host, T, L, nd, n1, need_in, defer):
+        """The gather table (pin[0][:need_in] on the device path, `host` otherwise: rows | scale | cnt) -> deft_track_similarity -> the copy back."""
+        if pin is not None:
             pack = pin[0][:need_in].to(dev, non_blocking=True)
         else:
             pack = torch.from_numpy(host)
@@ -504,6 +563,13 @@ class ArrayTracker(object):
             dets = np.array(results)
             det_ddd = np.array(ddd_boxes, dtype=np.float64).reshape(-1, 7) if len(dets) else np.zeros((0, 7))
             det_depth = np.array([d[0] for d in depths_by_class], dtype=np.float64) if len(dets) else np.zeros(0)
+        elif hasattr(results, "arrays") and results.arrays() is not None and "bbox" in results.arrays():
+            post = results.arrays()                                   # Detector.post_process' own arrays (postprocess.ResultList): no parsing back
+            bb, sc = np.asarray(post["bbox"], np.float32).reshape(-1, 4), np.asarray(post["score"], np.float32)
+            if self.dataset == "kitti_tracking":
+                m = np.asarray(post["class"]) == 2                     # tracker.py:790-797
+                bb, sc = bb[m], sc[m]
+            dets = np.concatenate([bb, sc[:, None]], 1)
         elif self.dataset == "kitti_tracking":
             dets = np.array([np.asarray(d["bbox"]).tolist() + [d["score"]] for d in results if d["class"] == 2], np.float32)     # tracker.py:790-797
         else:

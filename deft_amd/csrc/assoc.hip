@@ -703,6 +703,61 @@ extern "C" int deft_kf_update(double* mean, double* cov, const int* rows, int n,
     return 0;
 }
 
+// ---- which nodes a track's similarity medians over, and where their rows live ------------------------------------------------------------
+// STrack.get_similarity (tracker.py:221-248): the nodes younger than max_node frames; all of them while there are at most mm + 1, else the last
+// mm.  The pool keeps the last L = mm + 2 nodes of every track right-aligned (newest at column L - 1), so "young" nodes form a suffix and the
+// selection is the last nsel columns.  With a block table this also writes the gather table deft_track_similarity reads -- row of the node in
+// the stacked affinity blocks, its block's decay, newest node first -- straight into the caller's staging buffer: one host call instead of
+// ~30 numpy operations per frame (array_tracker.py _selected_nodes / _similarity, which stay as the cross-check).
+extern "C" int deft_track_nodes(const long long* nf, const long long* ni, const long long* nn, int T, int L, long long fid, int mm, int max_node,
+                                unsigned char* sel, const long long* blk_frame, const long long* blk_start, const long long* blk_len,
+                                const float* blk_delta, int nblk, int* rows, float* scale, int* cnt, long long* bad) {
+    DEFT_CHECK(T >= 0 && L >= 1 && mm >= 1 && (T == 0 || (nf && ni && nn)), -95, "deft_track_nodes: null pointer or bad size (T=%d L=%d mm=%d)", T, L, mm);
+    DEFT_CHECK(rows == nullptr || (scale && cnt && (nblk == 0 || (blk_frame && blk_start && blk_len && blk_delta))), -95,
+               "deft_track_nodes: the gather table needs rows, scale, cnt and the block table");
+    long long f0 = 0, f1 = -1;
+    std::vector<int> of;                                  // frame - f0 -> block, -1 = none
+    if (rows && nblk > 0) {
+        f0 = f1 = blk_frame[0];
+        for (int k = 1; k < nblk; ++k) { f0 = std::min(f0, blk_frame[k]); f1 = std::max(f1, blk_frame[k]); }
+        DEFT_CHECK(f1 - f0 < (1 << 20), -95, "deft_track_nodes: block frames span %lld", f1 - f0);
+        of.assign((size_t)(f1 - f0 + 1), -1);
+        for (int k = 0; k < nblk; ++k) of[(size_t)(blk_frame[k] - f0)] = k;
+    }
+    for (int t = 0; t < T; ++t) {
+        const long long* f = nf + (size_t)t * L;
+        const long long* id = ni + (size_t)t * L;
+        const int stored = (int)std::min<long long>(nn[t], L);
+        int q = 0;
+        for (int c = L - stored; c < L; ++c) q += (fid - f[c] < max_node) ? 1 : 0;
+        const int nsel = q <= mm + 1 ? q : mm;
+        if (sel)
+            for (int c = 0; c < L; ++c) sel[(size_t)t * L + c] = c >= L - nsel ? 1 : 0;
+        if (!rows) continue;
+        cnt[t] = nsel;
+        for (int c = 0; c < L - nsel; ++c) {               // (checked in column order: the first offender is the one numpy's row-major scan reports)
+            rows[(size_t)t * L + (L - 1 - c)] = 0;
+            scale[(size_t)t * L + (L - 1 - c)] = 0.f;
+        }
+        for (int c = L - nsel; c < L; ++c) {
+            const long long fr = f[c];
+            const int k = (fr >= f0 && fr <= f1) ? of[(size_t)(fr - f0)] : -1;
+            if (k < 0) {
+                if (bad) *bad = fr;
+                DEFT_CHECK(false, -96, "deft_track_nodes: no affinity block for frame %lld (track row %d)", fr, t);
+            }
+            if (id[c] < 0 || id[c] >= blk_len[k]) {
+                if (bad) *bad = fr;
+                DEFT_CHECK(false, -97, "deft_track_nodes: node id %lld outside its frame %lld (%lld rows)", id[c], fr, blk_len[k]);
+            }
+            rows[(size_t)t * L + (L - 1 - c)] = (int)(blk_start[k] + id[c]);
+            scale[(size_t)t * L + (L - 1 - c)] = blk_delta[k];
+        }
+    }
+    return 0;
+}
+
+
 extern "C" int deft_iou3d_matrix(const double* trk, int T, const double* det, int N, float* out) {
     DEFT_CHECK(T >= 0 && N >= 0 && (T == 0 || trk != nullptr) && (N == 0 || det != nullptr) && (T * N == 0 || out != nullptr), -92,
                "deft_iou3d_matrix: null pointer or negative size");

@@ -295,7 +295,15 @@ class Detector(object):
     def merge_outputs(self, detections):
         """detector.py:577-583 (single test scale)."""
         thr = getattr(self.opt, "out_thresh", 0.0)
-        return [d for d in detections[0] if d["score"] > thr]
+        det = detections[0]
+        post = det.arrays() if hasattr(det, "arrays") else None
+        if post is None:
+            return [d for d in det if d["score"] > thr]
+        from . import postprocess as PP
+        keep = post["score"] > thr                                         # the same rows, decided on the array the dicts were built from
+        out = PP.ResultList(det if keep.all() else [d for d, k in zip(det, keep.tolist()) if k])
+        out.post = post if keep.all() else {k: v[keep] for k, v in post.items()}
+        return out
 
     def nuscenes_targets(self, results, image_info, nms=True):
         """The nuScenes branch of Detector.run up to the tracker calls (detector.py:200-338): per tracking class the arguments of

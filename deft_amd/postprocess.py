@@ -108,10 +108,23 @@ def merge_outputs(post, out_thresh):
     return {k: v[keep] for k, v in post.items()}
 
 
+class ResultList(list):
+    """The reference's list of per-detection dicts, with the arrays it was built from riding along (`post`: the same rows in the same order, or
+    None) -- ArrayTracker.detections_as_arrays reads those instead of parsing 100 dicts back into the arrays they came from."""
+    __slots__ = ("post",)
+
+    def arrays(self):
+        """`post` if it still describes this list (nobody added or removed rows), else None."""
+        post = getattr(self, "post", None)
+        return post if post is not None and post["score"].shape[0] == len(self) else None
+
+
 def as_result_list(post):
     """The list of per-detection dicts `Tracker.update` / the result writers consume (test.py:220-258)."""
     n = post["score"].shape[0]
-    return [{k: (int(v[i]) if k == "class" else v[i]) for k, v in post.items()} for i in range(n)]
+    out = ResultList({k: (int(v[i]) if k == "class" else v[i]) for k, v in post.items()} for i in range(n))
+    out.post = post
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------

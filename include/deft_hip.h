@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 12
+#define DEFT_ABI_VERSION 13
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -434,6 +434,18 @@ int deft_associate_ddd(const float* sim, int ld, int T, int N, int stage0, const
  * HOST pointers, synchronous. */
 int deft_kf_predict(double* mean, double* cov, int T);
 int deft_kf_update(double* mean, double* cov, const int* rows, int n, const double* meas);
+
+/* Which nodes a track's similarity medians over (STrack.get_similarity, tracker.py:221-248) and where their rows live, for every pool row in one
+ * host call.  nf, ni [T][L] int64: frame and detection index of the last L = mm + 2 nodes of each track, right-aligned (newest at column L - 1);
+ * nn [T]: nodes the track ever had.  Selected: the nodes younger than max_node frames at frame `fid` -- all q of them while q <= mm + 1, else the
+ * last mm -- i.e. the last nsel columns.  sel [T][L] (optional): 1 for a selected node.  With rows != NULL also the gather table of
+ * deft_track_similarity: the block table (blk_frame / blk_start / blk_len [nblk] int64, blk_delta [nblk] float: the stored frame of each affinity
+ * block of the current frame, its first row in the stacked blocks, its row count, its decay -- FeatureRecorder.update, tracker.py:59-90) gives
+ * rows [T][L] = blk_start + ni, scale [T][L] = blk_delta, newest node first, zeros behind the cnt [T] = nsel selected ones.  -96: a selected node's
+ * frame has no block (the reference's KeyError), -97: its id is past the block (IndexError); *bad = that frame.  HOST pointers, synchronous. */
+int deft_track_nodes(const long long* nf, const long long* ni, const long long* nn, int T, int L, long long fid, int mm, int max_node,
+                     unsigned char* sel, const long long* blk_frame, const long long* blk_start, const long long* blk_len,
+                     const float* blk_delta, int nblk, int* rows, float* scale, int* cnt, long long* bad);
 
 #ifdef __cplusplus
 }

@@ -254,6 +254,69 @@ def test_native_association_equals_the_numpy_stages(emu_lib, dataset):
             assert np.abs(np.array(x[3]) - np.array(y[3])).max() <= 1e-9, (t, x, y)
 
 
+@pytest.mark.parametrize("mm", [4, 2])
+def test_native_node_selection_and_gather_table_equal_numpy(emu_lib, mm):
+    """deft_track_nodes (assoc.hip) against ArrayTracker's numpy restatement of STrack.get_similarity's node selection (tracker.py:221-248) and of
+    the gather table deft_track_similarity reads: random node tables with young / old / short histories -- the same mask, the same rows | scale |
+    cnt record bit for bit; a selected node whose frame has no block is the reference's KeyError(frame), an id past its block an IndexError, the
+    same offender as numpy's row-major scan reports."""
+    from deft_amd import array_tracker as MT
+    g = np.random.RandomState(5 + mm)
+    L, T, fid, F = mm + 2, 90, 200, 60
+
+    def tracker(native, nf, ni, nn, index, starts, nd):
+        t = MT.ArrayTracker.__new__(MT.ArrayTracker)
+        t.mm, t.native_assoc = mm, native
+        cols = {"nf": nf, "ni": ni, "nn": nn}
+        t.cols = types.SimpleNamespace(__getitem__=None)
+        t.cols = type("C", (), {"__getitem__": lambda s_, k: cols[k]})()
+        seen = []
+
+        def call(name, *a):                                   # deft_track_similarity: keep the gather table it was handed (rows | scale | cnt)
+            import ctypes as C
+            assert name == "deft_track_similarity"
+            seen.append(np.ctypeslib.as_array(C.cast(a[3].value, C.POINTER(C.c_int32)), (2 * T * L + T,)).copy())
+            return 0
+        lib = types.SimpleNamespace(_fn=emu_lib._fn, last_error=emu_lib.last_error, call=call)
+        t.model = types.SimpleNamespace(AFE=types.SimpleNamespace(plan=types.SimpleNamespace(lib=lib, _stream=lambda: None)))
+        t.recorder = types.SimpleNamespace(_dev=(fid, torch.zeros(int(starts[-1]), nd + 1), starts, index))
+        return t, seen
+
+    def record(t, seen, nd):
+        sel_all = t._selected_nodes(fid)
+        t._similarity(fid, np.arange(T), nd, sel_all)
+        return sel_all[2].copy(), seen[-1]
+
+    for trial in range(6):
+        nn = g.randint(0, 12, T).astype(np.int64)
+        nf = np.sort(g.randint(fid - F, fid, (T, L)), 1).astype(np.int64)
+        if trial % 2:
+            nf[:, -3:] = np.sort(g.randint(fid - 6, fid, (T, 3)), 1)                 # mostly young, some nodes just past max_track_node
+        blocks = sorted(set(nf.reshape(-1).tolist()))
+        lens = g.randint(1, 9, len(blocks))
+        starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        index = {f: (k, np.float32(0.5 + 0.01 * k)) for k, f in enumerate(blocks)}
+        ni = np.stack([[g.randint(0, lens[index[f][0]]) for f in row] for row in nf.tolist()]).astype(np.int64)
+        a, sa = tracker(True, nf, ni, nn, index, starts, 7)
+        b, sb = tracker(False, nf, ni, nn, index, starts, 7)
+        ma, ra = record(a, sa, 7)
+        mb, rb = record(b, sb, 7)
+        assert np.array_equal(ma, mb) and ma.dtype == mb.dtype == np.bool_ and np.array_equal(ra, rb), trial
+        assert ma.any() and not ma.all()
+        # a selected node whose frame has no block / whose id is past its block
+        tt, cc = np.argwhere(mb)[len(np.argwhere(mb)) // 2]
+        miss = dict(index); gone = int(nf[tt, cc]); del miss[gone]
+        for native in (True, False):
+            t_, s_ = tracker(native, nf, ni, nn, miss, starts, 7)
+            with pytest.raises(KeyError) as e:
+                record(t_, s_, 7)
+            assert e.value.args[0] == gone
+            ni2 = ni.copy(); ni2[tt, cc] = 99
+            t_, s_ = tracker(native, nf, ni2, nn, index, starts, 7)
+            with pytest.raises(IndexError):
+                record(t_, s_, 7)
+
+
 @pytest.mark.parametrize("dataset", ["mot", "nuscenes_2d_rule"])
 def test_prepare_ahead_covers_every_block_the_next_frame_reads(emu_lib, dataset):
     """ArrayTracker.prepare scores frame k + 2 before update(k + 1) has run, against a SUPERSET of the stored frames that update will leave selected

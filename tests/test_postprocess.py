@@ -146,3 +146,37 @@ def test_detector_mirror_post_process_methods():
     assert set(by_class) == set(__import__("deft_amd.postprocess", fromlist=["x"]).NUSCENES_TRACKING_NAMES)
     assert sum(len(v["results"]) for v in by_class.values()) > 0
     assert det.nuscenes_targets([], info)["car"]["results"] == []
+
+
+def test_result_list_arrays_equal_the_parsed_dicts():
+    """postprocess.ResultList: Detector.post_process' list of dicts carries the arrays it was built from, and ArrayTracker.detections_as_arrays
+    reads those -- the same rows as parsing the dicts back (the reference's own loop, tracker.py:786-797), through merge_outputs' score cut, for
+    the class filter of KITTI, and NOT once somebody has edited the list."""
+    from types import SimpleNamespace
+    from deft_amd.detector import Detector
+    import torch
+    from deft_amd import array_tracker as MT
+    g = np.random.RandomState(4)
+    n = 40
+    post = {"score": np.sort(g.rand(n).astype(np.float32))[::-1].copy(), "class": g.randint(1, 4, n).astype(np.int64),
+            "ct": g.rand(n, 2).astype(np.float32) * 100, "bbox": (g.rand(n, 4) * 300).astype(np.float32), "tracking": g.randn(n, 2).astype(np.float32)}
+    det = Detector.__new__(Detector)
+    det.opt = SimpleNamespace(out_thresh=0.3)
+    res = PP.as_result_list(post)
+    merged = det.merge_outputs([res])
+    assert isinstance(merged, PP.ResultList) and len(merged) == int((post["score"] > 0.3).sum()) < n and merged.arrays() is not None
+    assert all(a is b for a, b in zip(merged, res))                       # the same dict objects as the plain filter keeps
+    for dataset in ("mot", "kitti_tracking"):
+        trk = MT.ArrayTracker.__new__(MT.ArrayTracker)
+        trk.ddd, trk.dataset, trk.img_width, trk.img_height = False, dataset, 640.0, 480.0
+        fast = trk.detections_as_arrays(merged)
+        slow = trk.detections_as_arrays(list(merged))
+        assert fast["nd0"] == slow["nd0"] > 0
+        for k in ("tlwh", "xyah", "tlbr", "dscore", "org"):
+            assert np.array_equal(fast[k], slow[k]) and fast[k].dtype == slow[k].dtype, (dataset, k)
+        assert torch.equal(fast["centers"], slow["centers"])
+    merged.pop()                                                          # an edited list no longer matches its arrays: parsed again
+    assert merged.arrays() is None
+    assert trk.detections_as_arrays(merged)["nd0"] == trk.detections_as_arrays(list(merged))["nd0"]
+    empty = det.merge_outputs([PP.as_result_list({k: v[:0] for k, v in post.items()})])
+    assert trk.detections_as_arrays(empty)["nd0"] == 0
