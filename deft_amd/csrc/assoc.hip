@@ -23,6 +23,7 @@
 //    written out per pair in float64; the intersection polygon's area by the shoelace formula instead of scipy's ConvexHull.volume
 //    (the clipped polygon of two convex quadrilaterals is convex: same area up to round-off; a degenerate intersection -- fewer than
 //    three vertices -- has area 0 here where qhull raises).  Pinned against the reference's functions by tests/golden/iou_ddd.npz.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -699,6 +700,43 @@ extern "C" int deft_kf_update(double* mean, double* cov, const int* rows, int n,
                 for (int q = 0; q < 4; ++q) v += KS[i][q] * X[q][j];
                 P[8 * i + j] -= v;
             }
+    }
+    return 0;
+}
+
+// ---- greedy NMS of the nuScenes branch (utils/ddd_utils.py:178-245, called from detector.py:281-288 per tracking class) -----------------------
+// boxes [n][4] (x1, y1, x2, y2) and scores [n] in double; candidates = the top_k highest scores (stable ascending order, as numpy's stable
+// argsort -- torch.sort's order among equal scores is unspecified); repeatedly keep the best and drop what overlaps it by more than `overlap`
+// (IoU = inter / ((area_j - inter) + area_i), operation for operation as deft_amd.postprocess.greedy_nms, which stays as the cross-check; a NaN
+// ratio drops the box, as `nan <= overlap` is False there).  keep [n]: zero-initialised by the callee, kept indices in its first *count slots.
+extern "C" int deft_greedy_nms(const double* boxes, const double* scores, int n, double overlap, int top_k, long long* keep, int* count) {
+    DEFT_CHECK(n >= 0 && top_k >= 1 && keep && count && (n == 0 || (boxes && scores)), -98, "deft_greedy_nms: null pointer or bad size (n=%d top_k=%d)", n, top_k);
+    for (int i = 0; i < n; ++i) keep[i] = 0;
+    *count = 0;
+    if (n == 0) return 0;
+    std::vector<int> idx((size_t)n);
+    for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return scores[a] < scores[b]; });      // (NaN scores: unordered, like numpy's sort puts them last -- never produced upstream)
+    if (n > top_k) idx.erase(idx.begin(), idx.end() - top_k);
+    std::vector<double> area((size_t)n);
+    for (int i = 0; i < n; ++i) area[(size_t)i] = (boxes[4 * i + 2] - boxes[4 * i]) * (boxes[4 * i + 3] - boxes[4 * i + 1]);
+    while (!idx.empty()) {
+        const int i = idx.back();
+        keep[(*count)++] = i;
+        if (idx.size() == 1) break;
+        idx.pop_back();
+        size_t m = 0;
+        for (size_t q = 0; q < idx.size(); ++q) {
+            const int j = idx[q];
+            double w = std::min(boxes[4 * j + 2], boxes[4 * i + 2]) - std::max(boxes[4 * j], boxes[4 * i]);
+            double h = std::min(boxes[4 * j + 3], boxes[4 * i + 3]) - std::max(boxes[4 * j + 1], boxes[4 * i + 1]);
+            w = w < 0.0 ? 0.0 : w;
+            h = h < 0.0 ? 0.0 : h;
+            const double inter = w * h;
+            const double uni = (area[(size_t)j] - inter) + area[(size_t)i];
+            if (inter / uni <= overlap) idx[m++] = j;
+        }
+        idx.resize(m);
     }
     return 0;
 }

@@ -214,7 +214,7 @@ class Detector(object):
             if self._graphs[key] is None:
                 self._graphs[key] = plan.capture_graph()
             plan.image.copy_(images, non_blocking=True)
-            self._graphs[key].replay()
+            engine._Plan.replay_graph(self._graphs[key], self.device)
         d = plan.dets()
         if "dep" in d:      # _sigmoid_output, detector.py:491-493, applied at the K peaks
             d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
@@ -254,7 +254,7 @@ class Detector(object):
             if self._graphs[key] is None:
                 self._graphs[key] = plan.capture_graph()
             plan.image.copy_(images, non_blocking=True)
-            self._graphs[key].replay()
+            engine._Plan.replay_graph(self._graphs[key], self.device)
         out = {}
         for h, v in plan.dense.items():
             y = v.to_nchw()                                              # [2, C, h, w] (a device tensor)
@@ -309,10 +309,15 @@ class Detector(object):
         """The nuScenes branch of Detector.run up to the tracker calls (detector.py:200-338): per tracking class the arguments of
         `self.tracker[class_name].update(results, FeatureMaps, ddd_boxes=, depths_by_class=, ddd_org_boxes=, submission=, classe=)`."""
         from . import postprocess as PP
-        post = {k: np.stack([np.asarray(r[k]) for r in results]) if results else np.zeros((0,)) for k in ("score", "class", "bbox", "dim", "loc", "rot_y")}
+        keys = ("score", "class", "bbox", "dim", "loc", "rot_y")
+        arr = results.arrays() if hasattr(results, "arrays") else None
+        if arr is not None and all(k in arr for k in keys):                # post_process' own arrays (postprocess.ResultList): no parsing back
+            post = {k: arr[k] for k in keys}
+        else:
+            post = {k: np.stack([np.asarray(r[k]) for r in results]) if results else np.zeros((0,)) for k in keys}
         if not results:
             return {n: {"results": [], "ddd_boxes": [], "depths": [], "ddd_org_boxes": [], "submission": []} for n in PP.NUSCENES_TRACKING_NAMES}
-        return PP.nuscenes_frame(post, image_info, nms=nms)
+        return PP.nuscenes_frame(post, image_info, nms=nms, lib=getattr(self, "lib", None))
 
     # ---- frame in -> tracks out: Detector.run (detector.py:112-344) on the fused path ----------------------------------------
     def _meta_for(self, height, width, inp_h, inp_w, input_meta):
@@ -510,7 +515,7 @@ class Detector(object):
             if self._graphs[key] is None:
                 self._graphs[key] = plan.capture_graph()
             plan.image_u8.copy_(frames_u8, non_blocking=True)
-            self._graphs[key].replay()
+            engine._Plan.replay_graph(self._graphs[key], self.device)
         d = plan.dets()
         if "dep" in d:
             d["dep"] = (1.0 / (torch.sigmoid(d["dep"]) + 1e-6) - 1.0) * getattr(self.opt, "depth_scale", 1.0)
@@ -577,7 +582,7 @@ class Detector(object):
             for i, src in enumerate(srcs):
                 p.image_u8[i].copy_(src, non_blocking=True)
             if sl.graph is not None:
-                sl.graph.replay()
+                engine._Plan.replay_graph(sl.graph, self.device)
             else:
                 p.run()
                 sl.warm = True

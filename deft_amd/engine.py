@@ -213,10 +213,15 @@ PLANAR = 1 << 25                                               # include/deft_hi
 Y3_INLOOP = _os.environ.get("DEFT_Y3_INLOOP", "1") != "0"    # piece-form output from the in-loop kernel's epilogue (else deft_split_planes)
 FOLD = _os.environ.get("DEFT_FOLD", "1") != "0"       # heat-map head: the 1x1 conv folded into the epilogue of the 3x3 conv (DeftGemmDesc.fold_w)
 SPLITK = _os.environ.get("DEFT_SPLITK", "1") != "0"
-# launch lists of at most DATAFLOW_MAX_N frames run over this many HIP streams along their data dependencies (_Plan.build_schedule): one
-# frame per GPU leaves most of the chip idle in most launches, and DLA-34's up path has independent branches.  DEFT_DATAFLOW=1: one stream
-DATAFLOW = int(_os.environ.get("DEFT_DATAFLOW", "2"))
+# launch lists of at most DATAFLOW_MAX_N frames CAN run over this many HIP streams along their data dependencies (_Plan.build_schedule): one
+# frame per GPU leaves most of the chip idle in most launches, and DLA-34's up path has independent branches -- captured as a hipGraph that is a
+# graph with two parallel branches, 1.77 instead of 2.00 ms per frame in the one-frame latency mode.  OFF by default since round 6 (one stream,
+# one branch): ROCm 7.2's hipGraphLaunch walks off the end of an executable graph's internal stream list for graphs WITH parallel branches after
+# certain process histories (hip::Graph::UpdateStreams, a host segfault; profiles/r6_graph_replay_segfault.md -- moving the launch to another
+# stream does not avoid it).  DEFT_DATAFLOW=2 opts back in.
+DATAFLOW = int(_os.environ.get("DEFT_DATAFLOW", "1"))
 DATAFLOW_MAX_N = int(_os.environ.get("DEFT_DATAFLOW_MAX_N", "1"))
+REPLAY_STREAM = _os.environ.get("DEFT_REPLAY_STREAM", "0") != "0"      # 1: a hipGraph replay that would land on the NULL stream runs on a side stream (experiment)
 
 
 def weight_row_shift(w):
@@ -587,7 +592,19 @@ class _Plan:
         was_enabled = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(g, stream=torch.cuda.Stream(device=self.device)):
+            cap = torch.cuda.Stream(device=self.device)
+            if _os.environ.get("DEFT_DEBUG_CAPTURE") == "1":
+                import sys as _sys
+                side = [] if not self.sched or self.sched.get("streams") is None else [s_.cuda_stream for s_ in self.sched["streams"][1:]]
+                _sys.stderr.write("capture_graph: capture stream %#x, side streams %s, sched n=%s\n" % (cap.cuda_stream, [hex(v) for v in side], None if not self.sched else self.sched.get("n")))
+                if self.sched:
+                    import json as _json
+                    _Plan._dbg_n = getattr(_Plan, "_dbg_n", 0) + 1
+                    _os.makedirs("gpurun_out/r6x", exist_ok=True)
+                    _json.dump({"shape": [getattr(self, "N", None), getattr(self, "H", None), getattr(self, "W", None)], "kinds": [o[0] for o in self.ops],
+                                "names": [o[1] for o in self.ops], **{k: self.sched[k] for k in ("n", "where", "waits", "signals", "order")}},
+                               open("gpurun_out/r6x/sched_%02d.json" % _Plan._dbg_n, "w"))
+            with torch.cuda.graph(g, stream=cap):
                 self.run()
                 if then is not None:
                     then()
@@ -595,6 +612,25 @@ class _Plan:
             if was_enabled:
                 gc.enable()
         return g
+
+    @staticmethod
+    def replay_graph(g, device):
+        """g.replay(): the one place the package launches a captured hipGraph from.  (DEFT_REPLAY_STREAM=1: a replay that would land on the NULL
+        stream runs on a process-wide side stream instead -- the first workaround tried for the runtime fault described at DATAFLOW above; it
+        survives the first reproducer and dies in another, so it is off and graphs are captured without parallel branches instead.)"""
+        cur = torch.cuda.current_stream(device) if REPLAY_STREAM else None
+        if cur is None or cur.cuda_stream != 0:
+            g.replay()
+            return
+        rs = _Plan._replay_streams.get(device.index)
+        if rs is None:
+            rs = _Plan._replay_streams[device.index] = torch.cuda.Stream(device=device)
+        rs.wait_stream(cur)
+        with torch.cuda.stream(rs):
+            g.replay()
+        cur.wait_stream(rs)
+
+    _replay_streams = {}
 
     def _run_dataflow(self):
         sc = self.sched

@@ -89,13 +89,14 @@ _SIGS = {
                                      c_fp, c_fp, c_fp, C.c_double, C.c_double, C.c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "deft_kf_predict": (C.c_int, [c_fp, c_fp, C.c_int]),
     "deft_kf_update": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp]),
+    "deft_greedy_nms": (C.c_int, [c_fp, c_fp, C.c_int, C.c_double, C.c_int, c_fp, c_fp]),
     "deft_track_nodes": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int,
                                    c_fp, c_fp, c_fp, c_fp]),
     "deft_associate_2d": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_double, C.c_double, C.c_double, C.c_int,
                                     c_fp, c_fp, c_fp, C.c_double, C.c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class DeftHipError(RuntimeError):

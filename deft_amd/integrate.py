@@ -342,7 +342,7 @@ class DeftModel(object):
             if self._graphs[key] is None:
                 self._graphs[key] = plan.capture_graph()
             plan.image.copy_(images, non_blocking=True)
-            self._graphs[key].replay()
+            engine._Plan.replay_graph(self._graphs[key], self.device)
         s = hiplib.stream_ptr(self.device)
         out = {}
         for h, v in plan.dense.items():

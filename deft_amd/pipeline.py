@@ -98,7 +98,7 @@ class HipCompute:
         sl = slice(s_ * self.sub, (s_ + 1) * self.sub)
         if self.graphs is not None:
             (p.image_u8 if images.dtype == torch.uint8 else p.image).copy_(images[sl], non_blocking=True)
-            self.graphs[s_].replay()
+            engine._Plan.replay_graph(self.graphs[s_], self.device)
         else:
             p.forward_u8(images[sl]) if images.dtype == torch.uint8 else p.forward(images[sl])
             self.afe.extract(p.fmaps, p.centers if self.ndet == self.K else p.centers[:, :self.ndet], out=self.emb[sl])

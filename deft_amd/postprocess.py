@@ -174,13 +174,23 @@ def q_angle_axis(q):
 # ---------------------------------------------------------------------------------------------------------------------
 # greedy NMS (utils/ddd_utils.py:178-245) and the nuScenes branch of Detector.run
 # ---------------------------------------------------------------------------------------------------------------------
-def greedy_nms(boxes, scores, overlap=0.93, top_k=200):
+def greedy_nms(boxes, scores, overlap=0.93, top_k=200, lib=None):
     """-> (keep, count): `keep` is the reference's zero-initialised index vector of FULL length with the kept indices in its
-    first `count` slots (highest score first)."""
+    first `count` slots (highest score first).  lib: a bound HipLib -- the same loop as one native host call (assoc.hip deft_greedy_nms);
+    this numpy form stays as its cross-check."""
     boxes = np.asarray(boxes, np.float64).reshape(-1, 4); scores = np.asarray(scores, np.float64).reshape(-1)
     keep = np.zeros(scores.shape[0], np.int64)
     if boxes.size == 0:
         return keep, 0
+    if lib is not None and "deft_greedy_nms" in getattr(lib, "_fn", ()):
+        import ctypes as C
+        boxes, scores = np.ascontiguousarray(boxes), np.ascontiguousarray(scores)
+        cnt = C.c_int(0)
+        rc = lib._fn["deft_greedy_nms"](C.c_void_p(boxes.ctypes.data), C.c_void_p(scores.ctypes.data), scores.shape[0], float(overlap), int(top_k),
+                                        C.c_void_p(keep.ctypes.data), C.byref(cnt))
+        if rc != 0:
+            raise RuntimeError("deft_greedy_nms failed (%d): %s" % (rc, lib.last_error()))
+        return keep, int(cnt.value)
     x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
     area = (x2 - x1) * (y2 - y1)
     idx = np.argsort(scores, kind="stable")[-top_k:]               # ascending; torch.sort's order among equal scores is unspecified
@@ -199,7 +209,7 @@ def greedy_nms(boxes, scores, overlap=0.93, top_k=200):
     return keep, count
 
 
-def nuscenes_frame(post, image_info, nms=True):
+def nuscenes_frame(post, image_info, nms=True, lib=None):
     """The nuScenes branch of `Detector.run` (detector.py:200-338) on the merged post-processed detections `post`
     (arrays: score, class, bbox, dim, loc, rot_y).  image_info: trans_matrix [3|4 x 4], cs_record_rot / pose_record_rot
     (w,x,y,z), cs_record_trans / pose_record_trans.  -> {class_name: dict(results [m,5], ddd_boxes [m,7], depths [m,1],
@@ -238,7 +248,7 @@ def nuscenes_frame(post, image_info, nms=True):
         m = np.nonzero(ok & (names == name))[0]
         r = {"results": results[m], "ddd_boxes": ddd[m], "depths": depths[m], "ddd_org_boxes": org[m], "submission": sub[m]}
         if m.size > 0 and nms:
-            keep, _ = greedy_nms(r["results"][:, :4], r["results"][:, -1], overlap=0.7 if name in ("bus", "truck") else 0.8)
+            keep, _ = greedy_nms(r["results"][:, :4], r["results"][:, -1], overlap=0.7 if name in ("bus", "truck") else 0.8, lib=lib)
             k = sorted(set(keep.tolist()))                         # the reference ignores `count`: index 0 is always kept
             r = {key: v[k] for key, v in r.items()}
         out[name] = r

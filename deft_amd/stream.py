@@ -72,7 +72,7 @@ class DeviceDetect:
         if self.graph is None:
             self.graph = p.capture_graph()
         p.image.copy_(frame, non_blocking=True)
-        self.graph.replay()
+        type(p).replay_graph(self.graph, p.device)          # (engine._Plan.replay_graph: never on the NULL stream)
 
     def __call__(self, frame):
         p, K = self.plan, self.K

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DEFT_ABI_VERSION 13
+#define DEFT_ABI_VERSION 14
 
 /* ---- implicit-GEMM descriptor shared by the three contraction entry points ---- */
 typedef struct DeftGemmDesc {
@@ -434,6 +434,11 @@ int deft_associate_ddd(const float* sim, int ld, int T, int N, int stage0, const
  * HOST pointers, synchronous. */
 int deft_kf_predict(double* mean, double* cov, int T);
 int deft_kf_update(double* mean, double* cov, const int* rows, int n, const double* meas);
+
+/* Greedy NMS of the nuScenes branch (utils/ddd_utils.py:178-245; detector.py:281-288, per tracking class): boxes [n][4] tlbr, scores [n], double.
+ * The top_k best-scoring boxes are visited best first; a box is kept and every remaining one whose IoU with it exceeds `overlap` is dropped.
+ * keep [n] int64 (zeroed here): the kept indices in its first *count slots -- the reference's return value.  HOST pointers, synchronous. */
+int deft_greedy_nms(const double* boxes, const double* scores, int n, double overlap, int top_k, long long* keep, int* count);
 
 /* Which nodes a track's similarity medians over (STrack.get_similarity, tracker.py:221-248) and where their rows live, for every pool row in one
  * host call.  nf, ni [T][L] int64: frame and detection index of the last L = mm + 2 nodes of each track, right-aligned (newest at column L - 1);

@@ -48,3 +48,19 @@ def gpu_lib():
     from deft_amd import hiplib
     assert torch.cuda.is_available(), "-m gpu tests need a GPU"
     return hiplib.get_lib()      # raises loudly if libdeft_hip.so is missing
+
+
+@pytest.fixture(autouse=True)
+def _gc_experiment():
+    """tools/probe/r6_crash_bisect3.sh: DEFT_TEST_GC=each -> collect + synchronise after every test; =off -> no cyclic collection at all."""
+    mode = os.environ.get("DEFT_TEST_GC")
+    import gc
+    if mode == "off":
+        gc.disable()
+    yield
+    if mode == "each" and "torch" in sys.modules:
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.synchronize()

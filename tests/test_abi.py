@@ -26,9 +26,9 @@ def test_gfx950_library_exports_every_symbol():
     lib = hiplib.HipLib(so)                                # binds every symbol; raises if one is missing
     for name in _declared():
         assert hasattr(lib.cdll, name)
-    assert lib.cdll.deft_version() == hiplib.ABI_VERSION == 13
+    assert lib.cdll.deft_version() == hiplib.ABI_VERSION == 14
     # both arithmetics in the one library (include/deft_hip.h): every device-code entry point has its three-bf16-piece twin
-    host_only = {"deft_lapjv", "deft_iou3d_matrix", "deft_associate_ddd", "deft_associate_2d", "deft_kf_predict", "deft_kf_update", "deft_track_nodes"}
+    host_only = {"deft_lapjv", "deft_iou3d_matrix", "deft_associate_ddd", "deft_associate_2d", "deft_kf_predict", "deft_kf_update", "deft_track_nodes", "deft_greedy_nms"}
     for name in _declared():
         assert hasattr(lib.cdll, name + hiplib.TWIN_SUFFIX) != (name in host_only), name
     assert lib.pieces == 2 and lib.twin().pieces == 3 and lib.twin().cdll is lib.cdll

@@ -791,6 +791,31 @@ def test_graph_replay_survives_tracker_teardown(gpu_lib):
     assert pc.check_graph_replay_survives_tracker_teardown(gpu_lib, "cuda") == 6
 
 
+def test_captured_graphs_have_no_parallel_branch_by_default(gpu_lib):
+    """ROCm 7.2's hipGraphLaunch of a graph WITH parallel branches walks off the end of the executable graph's internal stream list after
+    certain process histories (hip::Graph::UpdateStreams: a host segfault; profiles/r6_graph_replay_segfault.md, reproducer
+    tools/probe/r6_crash_fix.sh).  The package therefore captures its launch lists on ONE stream unless DEFT_DATAFLOW=2 asks for the two-branch
+    schedule: a serial Detector.run loop captures a plan without a schedule, and its results are what the eager launch list gives."""
+    from types import SimpleNamespace
+    from deft_amd import engine
+    from deft_amd.detector import Detector
+    import numpy as np
+    assert engine.DATAFLOW == 1 and not engine.REPLAY_STREAM
+    sd = O.synth_state_dict("mot")
+    g = np.random.RandomState(2)
+    frames = [g.randint(0, 256, (120, 170, 3), dtype=np.uint8) for _ in range(4)]
+    out = {}
+    for graphs in (True, False):
+        opt = SimpleNamespace(dataset="mot", K=20, max_object=100, gpus=[0], hip_graphs=graphs, depth_scale=1.0, input_h=96, input_w=128, out_thresh=-1.0,
+                              test_scales=[1.0], flip_test=False, public_det=False)
+        det = Detector(opt, sd)
+        out[graphs] = [[(float(r["score"]), tuple(float(v) for v in r["bbox"])) for r in det.run(f)] for f in frames]
+        plans = list(det._plans.values())
+        assert len(plans) == 1 and plans[0].sched is None                    # no multi-stream schedule: the capture is one chain of kernel nodes
+        assert (sum(v is not None for v in det._graphs.values()) == 1) == graphs
+    assert out[True] == out[False]
+
+
 def test_pair_mlp_fused(gpu_lib):
     """deft_pair_mlp on the hardware: small shapes, the config sizes (5 x (100 x 100), 4 x (32 x 32)), the ring form, both arithmetics."""
     pc.check_pair_mlp(gpu_lib, "cuda", shapes=((5, 12, 1, 9), (100, 100, 100, 100, 100), (32, 32, 32, 32)), Q=(7, 100, 32))

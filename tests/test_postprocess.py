@@ -43,6 +43,28 @@ def test_greedy_nms_matches_reference_incl_the_keep_quirk():
     assert keep.shape == (0,) and count == 0
 
 
+def test_native_greedy_nms_equals_numpy_and_reference_vectors(emu_lib):
+    """deft_greedy_nms (assoc.hip, one host call per class) against the reference's golden vectors and against the numpy loop on random crowded
+    scenes: equal scores (stable order), boxes of zero area (a NaN ratio drops the box in both), more boxes than top_k."""
+    f = np.load(GOLD)
+    for case in range(4):
+        keep, count = PP.greedy_nms(f["nms%d_boxes" % case], f["nms%d_scores" % case], overlap=float(f["nms%d_overlap" % case]), lib=emu_lib)
+        assert count == int(f["nms%d_count" % case]) and np.array_equal(keep, f["nms%d_keep" % case])
+    g = np.random.RandomState(9)
+    for trial in range(40):
+        n = int(g.randint(1, 60))
+        xy = g.rand(n, 2) * 50
+        wh = g.rand(n, 2) * 30 * (g.rand(n, 1) > 0.1)                   # a tenth of the boxes degenerate
+        boxes = np.concatenate([xy, xy + wh], 1)
+        scores = np.round(g.rand(n), 1 if trial % 2 else 6)              # every other trial: many equal scores
+        for top_k in (200, 7):
+            a = PP.greedy_nms(boxes, scores, overlap=0.3 + 0.1 * (trial % 5), top_k=top_k, lib=emu_lib)
+            b = PP.greedy_nms(boxes, scores, overlap=0.3 + 0.1 * (trial % 5), top_k=top_k)
+            assert a[1] == b[1] and np.array_equal(a[0], b[0]), (trial, top_k)
+    keep, count = PP.greedy_nms(np.zeros((0, 4)), np.zeros(0), lib=emu_lib)
+    assert keep.shape == (0,) and count == 0
+
+
 def test_quaternion_helpers_against_scipy():
     g = np.random.RandomState(0)
     a = g.randn(20, 4); b = g.randn(20, 4)
@@ -143,6 +165,11 @@ def test_detector_mirror_post_process_methods():
     assert len(merged) == int((f["nusc_out_score"].reshape(-1) > 0.25).sum())
     info = {"trans_matrix": np.eye(3, 4), "cs_record_rot": [1, 0, 0, 0], "cs_record_trans": [0, 0, 0], "pose_record_rot": [1, 0, 0, 0], "pose_record_trans": [0, 0, 0]}
     by_class = det.nuscenes_targets(merged, info)
+    assert hasattr(merged, "arrays") and merged.arrays() is not None       # the arrays rode along: no parsing back ...
+    slow = det.nuscenes_targets(list(merged), info)                        # ... and the parsed form gives the same per-class arguments
+    for name in by_class:
+        for k in by_class[name]:
+            assert np.array_equal(np.asarray(by_class[name][k]), np.asarray(slow[name][k])), (name, k)
     assert set(by_class) == set(__import__("deft_amd.postprocess", fromlist=["x"]).NUSCENES_TRACKING_NAMES)
     assert sum(len(v["results"]) for v in by_class.values()) > 0
     assert det.nuscenes_targets([], info)["car"]["results"] == []
